@@ -1,0 +1,225 @@
+/*
+ * oracle/amo_ortho.cc -- TEST INFRASTRUCTURE ONLY (CPU oracle for
+ * ortho::OrthoBackwardGrid).
+ *
+ * CPU restatement of the reference's grid-based backward-projection
+ * orthomosaic:
+ *   OrthoBackwardGrid::process                         aerial_mapper_ortho/src/
+ *                                                      ortho-backward-grid.cc:223-239
+ *   OrthoBackwardGrid::updateOrthomosaicLayer          :42-126  (single thread)
+ *   OrthoBackwardGrid::updateOrthomosaicLayerMultiThreaded :128-221 (parFor)
+ *
+ * Per cell, images are folded in ascending index order; the running best
+ * elevation angle is the FLOAT layer value, re-read (widened to double) for
+ * every comparison, so the fold is order dependent and float-rounded exactly
+ * like the reference's  `if (alpha > layer_elevation_angle(x, y))`.
+ *
+ * PARITY UNPINNED: the reference has no tests or golden vectors, and the
+ * projection / pose / grid arithmetic lives in un-vendored dependencies
+ * (aslam_cv2, minkindr, grid_map_core, OpenCV Mat::at) restated in
+ * amo_compat.h.  Results of this file DEFINE parity for the ortho path.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "amo_compat.h"
+#include "amo_types.h"
+
+namespace amo {
+
+struct OrthoArgs {
+  amo_grid grid;
+  amo_camera cam;
+  std::vector<Pose> T_G_C;
+  const uint8_t* const* images;  // cv::Mat::data per image
+  const size_t* steps;           // cv::Mat::step per image (bytes per row)
+  int channels;                  // 1 (8UC1) or 3 (8UC3, OpenCV BGR order)
+  bool colored;                  // ortho::Settings::colored_ortho
+  const float* elevation;
+  float* elevation_angle;
+  float* observation_index;
+  float* num_observations;
+  float* ortho;
+  float* colored_ortho;
+  volatile int error;
+};
+
+// One cell of ortho-backward-grid.cc:144-211 (identical to :56-121).
+static void ortho_cell(OrthoArgs* a, int i, int j) {
+  const size_t at = static_cast<size_t>(i) +
+                    static_cast<size_t>(j) * static_cast<size_t>(a->grid.rows);
+  double px, py;
+  cell_position(a->grid, i, j, &px, &py);
+  const Vec3 landmark = {px, py, static_cast<double>(a->elevation[at])};
+
+  const size_t F = a->T_G_C.size();
+  for (size_t f = 0; f < F; ++f) {
+    const Vec3 C_p = transform(inverse(a->T_G_C[f]), landmark);
+    double u, v;
+    const ProjectionStatus st = project3(a->cam, C_p, &u, &v);
+    const bool visible = (u >= 0.0) && (v >= 0.0) &&
+                         (u < static_cast<double>(a->cam.width)) &&
+                         (v < static_cast<double>(a->cam.height)) &&
+                         (st != POINT_BEHIND_CAMERA) &&
+                         (st != PROJECTION_INVALID);
+    if (!visible) continue;
+
+    const double norm =
+        std::sqrt(C_p.x * C_p.x + C_p.y * C_p.y + C_p.z * C_p.z);
+    const double alpha = std::asin(std::fabs(C_p.z) / norm);
+    if (!(alpha > 0.0)) {  // CHECK(alpha > 0.0)
+      a->error = AMO_ERR_ALPHA_NONPOS;
+      return;
+    }
+    if (std::fabs(alpha) > a->elevation_angle[at]) {
+      a->elevation_angle[at] = static_cast<float>(std::fabs(alpha));
+      a->observation_index[at] = static_cast<float>(f);
+      a->num_observations[at] += a->num_observations[at];
+
+      // The reference re-projects here (same inputs, same result).
+      const int kp_y = std::min(static_cast<int>(std::round(v)),
+                                a->cam.height - 1);
+      const int kp_x = std::min(static_cast<int>(std::round(u)),
+                                a->cam.width - 1);
+      const uint8_t* row = a->images[f] + static_cast<size_t>(kp_y) * a->steps[f];
+      if (a->colored) {
+        // cv::Vec3b of an 8UC3 Mat = (B, G, R)
+        const uint8_t* px3 = row + static_cast<size_t>(kp_x) * 3u;
+        const float c0 = static_cast<float>(static_cast<float>(px3[2]) / 255.0);
+        const float c1 = static_cast<float>(static_cast<float>(px3[1]) / 255.0);
+        const float c2 = static_cast<float>(static_cast<float>(px3[0]) / 255.0);
+        a->colored_ortho[at] = color_vector_to_value(c0, c1, c2);
+      } else {
+        const double gray = row[kp_x];  // images[i].at<uchar>(kp_y, kp_x)
+        a->ortho[at] = static_cast<float>(gray);
+      }
+    }
+  }
+}
+
+template <typename F>
+static void par_for(size_t num_items, const F& fn, size_t num_threads) {
+  if (num_threads == 0) num_threads = 1;
+  const size_t per_block = static_cast<size_t>(
+      std::ceil(static_cast<double>(num_items) /
+                static_cast<double>(num_threads)));
+  if (per_block == 0) return;
+  const size_t num_blocks = static_cast<size_t>(std::ceil(
+      static_cast<double>(num_items) / static_cast<double>(per_block)));
+  std::vector<std::thread> threads;
+  for (size_t b = 0; b < num_blocks; ++b) {
+    const size_t lo = b * per_block;
+    const size_t hi = (lo + per_block < num_items) ? lo + per_block : num_items;
+    threads.push_back(std::thread([&fn, lo, hi]() { fn(lo, hi); }));
+  }
+  for (size_t b = 0; b < threads.size(); ++b) threads[b].join();
+}
+
+}  // namespace amo
+
+extern "C" {
+
+/*
+ * ortho::OrthoBackwardGrid::process(T_G_Bs, images, map).
+ *   T_G_B   F x 7 doubles (tx,ty,tz,qw,qx,qy,qz)
+ *   T_C_B   7 doubles, ncameras->get_T_C_B(0)
+ *   images  F pointers to 8UC1 (channels=1) or 8UC3/BGR (channels=3) rasters
+ *   layers  float32 column-major rows*cols, updated in place
+ */
+int amo_ortho_backward_process(
+    const amo_grid* grid, const amo_camera* cam, const double* T_G_B,
+    const double* T_C_B, const uint8_t* const* images, const size_t* steps,
+    int channels, size_t F, int colored, int multi_thread, int num_threads,
+    const float* elevation, float* elevation_angle, float* observation_index,
+    float* num_observations, float* ortho, float* colored_ortho) {
+  if (!grid || !cam || !T_G_B || !T_C_B || !images || !steps || F == 0)
+    return AMO_ERR_ARG;  // CHECK(!T_G_Bs.empty()), CHECK(map)
+  if (colored && channels != 3) return AMO_ERR_ARG;
+  if (!colored && channels != 1) return AMO_ERR_ARG;
+  if (!elevation || !elevation_angle || !observation_index ||
+      !num_observations || !ortho || !colored_ortho)
+    return AMO_ERR_ARG;
+
+  amo::OrthoArgs a;
+  a.grid = *grid;
+  a.cam = *cam;
+  // T_G_C = T_G_B * T_C_B^-1   (ortho-backward-grid.cc:230-233)
+  const amo::Pose T_B_C = amo::inverse(amo::pose_from7(T_C_B));
+  a.T_G_C.resize(F);
+  for (size_t f = 0; f < F; ++f)
+    a.T_G_C[f] = amo::compose(amo::pose_from7(T_G_B + 7 * f), T_B_C);
+  a.images = images;
+  a.steps = steps;
+  a.channels = channels;
+  a.colored = colored != 0;
+  a.elevation = elevation;
+  a.elevation_angle = elevation_angle;
+  a.observation_index = observation_index;
+  a.num_observations = num_observations;
+  a.ortho = ortho;
+  a.colored_ortho = colored_ortho;
+  a.error = AMO_OK;
+
+  const size_t cells =
+      static_cast<size_t>(grid->rows) * static_cast<size_t>(grid->cols);
+  auto range = [&](size_t lo, size_t hi) {
+    for (size_t lin = lo; lin < hi; ++lin) {
+      int i, j;
+      amo::linear_to_index(a.grid, lin, &i, &j);
+      amo::ortho_cell(&a, i, j);
+    }
+  };
+  if (multi_thread) {
+    size_t nt = num_threads > 0 ? static_cast<size_t>(num_threads)
+                                : std::thread::hardware_concurrency();
+    amo::par_for(cells, range, nt);
+  } else {
+    range(0, cells);
+  }
+  return a.error;
+}
+
+/* T_G_C = T_G_B * T_C_B^-1 for F poses (exposed so tests can check the GPU
+ * library's host-side pose composition against the oracle's). */
+void amo_compose_T_G_C(const double* T_G_B, const double* T_C_B, size_t F,
+                       double* T_G_C) {
+  const amo::Pose T_B_C = amo::inverse(amo::pose_from7(T_C_B));
+  for (size_t f = 0; f < F; ++f) {
+    const amo::Pose p = amo::compose(amo::pose_from7(T_G_B + 7 * f), T_B_C);
+    amo::pose_to7(p, T_G_C + 7 * f);
+  }
+}
+
+/* Project one landmark through one camera pose (for known-answer tests):
+ * out = {u, v, alpha, status, C_x, C_y, C_z}. */
+void amo_project_probe(const amo_camera* cam, const double* T_G_C7,
+                       const double* landmark, double* out) {
+  const amo::Pose T = amo::pose_from7(T_G_C7);
+  const amo::Vec3 L = {landmark[0], landmark[1], landmark[2]};
+  const amo::Vec3 C = amo::transform(amo::inverse(T), L);
+  double u, v;
+  const amo::ProjectionStatus st = amo::project3(*cam, C, &u, &v);
+  const double norm = std::sqrt(C.x * C.x + C.y * C.y + C.z * C.z);
+  out[0] = u;
+  out[1] = v;
+  out[2] = std::asin(std::fabs(C.z) / norm);
+  out[3] = static_cast<double>(st);
+  out[4] = C.x;
+  out[5] = C.y;
+  out[6] = C.z;
+}
+
+/* grid_map::colorVectorToValue over the reference's  byte/255.0 -> float
+ * chain, for one BGR pixel (known-answer test 8). */
+float amo_color_value_bgr(uint8_t b, uint8_t g, uint8_t r) {
+  const float c0 = static_cast<float>(static_cast<float>(r) / 255.0);
+  const float c1 = static_cast<float>(static_cast<float>(g) / 255.0);
+  const float c2 = static_cast<float>(static_cast<float>(b) / 255.0);
+  return amo::color_vector_to_value(c0, c1, c2);
+}
+
+}  // extern "C"

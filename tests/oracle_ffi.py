@@ -1,0 +1,199 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so, oracle/_ref/liboracle_ref.so).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by the product package aerial_mapper_amd.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+PORT_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "liboracle_ref.so")
+
+
+class Grid(C.Structure):
+    """amo_grid / amhip_grid_desc (identical layout)."""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32),
+                ("resolution", C.c_double),
+                ("length_x", C.c_double), ("length_y", C.c_double),
+                ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class Camera(C.Structure):
+    """amo_camera / amhip_camera (identical layout)."""
+    _fields_ = [("fu", C.c_double), ("fv", C.c_double),
+                ("cu", C.c_double), ("cv", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("distortion", C.c_int32), ("_pad", C.c_int32),
+                ("dist", C.c_double * 4)]
+
+
+DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = 0, 1, 2
+OK, ERR_ARG, ERR_EXACT_HIT, ERR_ALPHA_NONPOS = 0, 1, 2, 3
+
+
+def build(force=False):
+    """(Re)build the oracle libraries with oracle/Makefile (gcc only)."""
+    if force or not os.path.exists(PORT_SO):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "all"],
+                              stdout=subprocess.DEVNULL)
+
+
+def _bind(lib):
+    f64p = C.POINTER(C.c_double)
+    f32p = C.POINTER(C.c_float)
+    lib.amo_uses_vendored_nanoflann.restype = C.c_int
+    lib.amo_dsm_process.restype = C.c_int
+    lib.amo_dsm_process.argtypes = [
+        f64p, C.c_size_t, C.POINTER(Grid), C.c_int, C.c_double, C.c_double,
+        C.c_int, C.c_int, f32p, f64p]
+    lib.amo_dsm_radius_probe.restype = C.c_int
+    lib.amo_dsm_radius_probe.argtypes = [
+        f64p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int,
+        C.POINTER(C.c_int), f64p]
+    lib.amo_make_grid.restype = None
+    lib.amo_make_grid.argtypes = [C.c_double] * 5 + [C.POINTER(Grid)]
+    lib.amo_cell_position.restype = None
+    lib.amo_cell_position.argtypes = [C.POINTER(Grid), C.c_int, C.c_int, f64p, f64p]
+    lib.amo_ortho_backward_process.restype = C.c_int
+    lib.amo_ortho_backward_process.argtypes = [
+        C.POINTER(Grid), C.POINTER(Camera), f64p, f64p,
+        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t,
+        C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p]
+    lib.amo_compose_T_G_C.restype = None
+    lib.amo_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
+    lib.amo_project_probe.restype = None
+    lib.amo_project_probe.argtypes = [C.POINTER(Camera), f64p, f64p, f64p]
+    lib.amo_color_value_bgr.restype = C.c_float
+    lib.amo_color_value_bgr.argtypes = [C.c_uint8] * 3
+    return lib
+
+
+_libs = {}
+
+
+def lib(which="port"):
+    """which: 'port' (own kd-tree) or 'ref' (vendored nanoflann build)."""
+    if which not in _libs:
+        path = PORT_SO if which == "port" else REF_SO
+        if which == "port":
+            build()
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        _libs[which] = _bind(C.CDLL(path))
+    return _libs[which]
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def _f64(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def make_grid(length_x, length_y, resolution, pos_x=0.0, pos_y=0.0, which="port"):
+    g = Grid()
+    lib(which).amo_make_grid(length_x, length_y, resolution, pos_x, pos_y, C.byref(g))
+    return g
+
+
+def cell_position(g, i, j, which="port"):
+    x, y = C.c_double(), C.c_double()
+    lib(which).amo_cell_position(C.byref(g), i, j, C.byref(x), C.byref(y))
+    return x.value, y.value
+
+
+def new_layers(g):
+    """The 6 layers the hot path touches, initialised like
+    aerial-mapper-grid-map.cc:40-48 (column-major float32, shape (cols, rows)
+    in numpy C-order == Eigen (rows, cols) column-major)."""
+    shape = (g.cols, g.rows)
+    return {
+        "ortho": np.full(shape, 255.0, np.float32),
+        "elevation": np.full(shape, np.nan, np.float32),
+        "elevation_angle": np.zeros(shape, np.float32),
+        "num_observations": np.zeros(shape, np.float32),
+        "observation_index": np.full(shape, np.nan, np.float32),
+        "colored_ortho": np.full(shape, np.nan, np.float32),
+    }
+
+
+def dsm_process(xyz, g, radius_sq=1, center_easting=0.0, center_northing=0.0,
+                elevation=None, multi_thread=True, num_threads=0, which="port"):
+    """Returns (rc, elevation, (t_build, t_cells))."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    if elevation is None:
+        elevation = np.full((g.cols, g.rows), np.nan, np.float32)
+    assert elevation.dtype == np.float32 and elevation.flags.c_contiguous
+    t = np.zeros(2)
+    rc = lib(which).amo_dsm_process(
+        _f64(xyz), xyz.shape[0], C.byref(g), int(radius_sq),
+        center_easting, center_northing, int(bool(multi_thread)),
+        int(num_threads), _f32(elevation), _f64(t))
+    return rc, elevation, (t[0], t[1])
+
+
+def radius_probe(xyz, qx, qy, radius_sq, cap=4096, which="port"):
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    idx = np.zeros(cap, np.int32)
+    d2 = np.zeros(cap, np.float64)
+    n = lib(which).amo_dsm_radius_probe(
+        _f64(xyz), xyz.shape[0], qx, qy, radius_sq, cap,
+        idx.ctypes.data_as(C.POINTER(C.c_int)), _f64(d2))
+    k = min(n, cap)
+    return n, idx[:k].copy(), d2[:k].copy()
+
+
+def ortho_process(g, cam, T_G_B, T_C_B, images, layers, colored=False,
+                  multi_thread=True, num_threads=0, which="port"):
+    """images: list of uint8 arrays (H,W) or (H,W,3 BGR). layers updated in place."""
+    T_G_B = np.ascontiguousarray(T_G_B, np.float64).reshape(-1, 7)
+    T_C_B = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
+    F = T_G_B.shape[0]
+    assert len(images) == F
+    ch = 3 if colored else 1
+    ptrs = (C.c_void_p * F)()
+    steps = (C.c_size_t * F)()
+    keep = []
+    for k, im in enumerate(images):
+        assert im.dtype == np.uint8
+        assert im.strides[-1] == 1 and (im.ndim == 2 or im.strides[1] == 3)
+        keep.append(im)
+        ptrs[k] = im.ctypes.data
+        steps[k] = im.strides[0]
+    rc = lib(which).amo_ortho_backward_process(
+        C.byref(g), C.byref(cam), _f64(T_G_B), _f64(T_C_B), ptrs, steps, ch, F,
+        int(bool(colored)), int(bool(multi_thread)), int(num_threads),
+        _f32(layers["elevation"]), _f32(layers["elevation_angle"]),
+        _f32(layers["observation_index"]), _f32(layers["num_observations"]),
+        _f32(layers["ortho"]), _f32(layers["colored_ortho"]))
+    return rc
+
+
+def compose_T_G_C(T_G_B, T_C_B, which="port"):
+    T_G_B = np.ascontiguousarray(T_G_B, np.float64).reshape(-1, 7)
+    T_C_B = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
+    out = np.zeros_like(T_G_B)
+    lib(which).amo_compose_T_G_C(_f64(T_G_B), _f64(T_C_B), T_G_B.shape[0], _f64(out))
+    return out
+
+
+def project_probe(cam, T_G_C7, landmark, which="port"):
+    T = np.ascontiguousarray(T_G_C7, np.float64).reshape(7)
+    L = np.ascontiguousarray(landmark, np.float64).reshape(3)
+    out = np.zeros(7)
+    lib(which).amo_project_probe(C.byref(cam), _f64(T), _f64(L), _f64(out))
+    return dict(u=out[0], v=out[1], alpha=out[2], status=int(out[3]), C=out[4:7].copy())
+
+
+def color_value_bgr(b, g, r, which="port"):
+    return np.float32(lib(which).amo_color_value_bgr(b, g, r))
