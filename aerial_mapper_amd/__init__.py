@@ -1,0 +1,16 @@
+"""aerial_mapper_amd -- MI355X-native DSM rasterisation + grid-based orthomosaic.
+
+The hot path of ethz-asl/aerial_mapper (dsm::Dsm::process and
+ortho::OrthoBackwardGrid::process) as hand-written HIP kernels for gfx950 behind
+a C ABI (include/aerial_mapper_hip.h), with host-side mirrors of the reference's
+class API.  See DESIGN.md / INTEGRATION.md.
+"""
+from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,  # noqa: F401
+                      DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
+from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, NCamera,  # noqa: F401
+                     OrthoBackwardGrid, OrthoSettings, compose_T_G_C)
+
+__all__ = ["AerialGridMap", "GridMapSettings", "Dsm", "DsmSettings", "OrthoBackwardGrid",
+           "OrthoSettings", "NCamera", "compose_T_G_C", "AmhipError", "Camera", "GridDesc",
+           "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
+           "DIST_EQUIDISTANT"]

@@ -1,0 +1,97 @@
+"""Build libaerial_mapper_hip.so (hand-written HIP kernels + C ABI) for gfx950.
+
+Usage:  python -m aerial_mapper_amd.build [--force]
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build
+container; the resulting .so lives in-tree (aerial_mapper_amd/lib/) and travels
+to the GPU box with the repository snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libaerial_mapper_hip.so")
+SHIM_PATH = os.path.join(LIB_DIR, "libaerial_mapper_shim.so")
+
+HIP_SOURCES = ["amhip_api.hip", "amhip_dsm.hip", "amhip_ortho.hip"]
+HIP_HEADERS = ["amhip_common.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
+
+# -ffp-contract=off: every decision of the path (inside-radius test, image-box
+# test, pixel rounding, best-view comparison) must see the same doubles as the
+# reference's baseline-x86-64 build, i.e. no fused multiply-add unless written
+# explicitly with fma().
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_hip(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HIP_HEADERS]
+    if not force and not _stale(LIB_PATH, deps):
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+                                      "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def build_shim(force=False, verbose=False):
+    """The drop-in C++ classes (dsm::Dsm, ortho::OrthoBackwardGrid) over the C ABI,
+    compiled against the compat headers (the real grid_map / aslam / minkindr /
+    OpenCV are absent from this image)."""
+    cpp = os.path.join(PKG, "cpp")
+    srcs = [os.path.join(cpp, f) for f in sorted(os.listdir(cpp)) if f.endswith(".cc")] \
+        if os.path.isdir(cpp) else []
+    if not srcs:
+        return None
+    inc = os.path.join(ROOT, "include")
+    deps = list(srcs)
+    for base, _, files in os.walk(inc):
+        deps += [os.path.join(base, f) for f in files]
+    build_hip(force=False, verbose=verbose)
+    if not force and not _stale(SHIM_PATH, deps + [LIB_PATH]):
+        return SHIM_PATH
+    cxx = os.environ.get("CXX", "g++")
+    cmd = [cxx, "-O2", "-std=c++11", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+           "-Wall", "-I" + inc, "-o", SHIM_PATH] + srcs + \
+          ["-L" + LIB_DIR, "-laerial_mapper_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SHIM_PATH
+
+
+def build_all(force=False, verbose=False):
+    out = [build_hip(force, verbose)]
+    s = build_shim(force, verbose)
+    if s:
+        out.append(s)
+    return out
+
+
+if __name__ == "__main__":
+    force = "--force" in sys.argv
+    for p in build_all(force=force, verbose=True):
+        print("built", p)

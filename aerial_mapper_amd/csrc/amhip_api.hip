@@ -1,0 +1,716 @@
+// amhip_api.hip -- C ABI of libaerial_mapper_hip.so (see
+// include/aerial_mapper_hip.h): context, layers, parameter set-up, host
+// staging, timing.  Kernels live in amhip_dsm.hip / amhip_ortho.hip.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+
+#include "amhip_common.h"
+
+namespace amhip {
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+void set_last_error(const std::string& msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "HIP error %d (%s) in `%s` at %s:%d", (int)e,
+                hipGetErrorString(e), what, file, line);
+  set_last_error(buf);
+  return e == hipErrorOutOfMemory ? AMHIP_ERR_NOMEM : AMHIP_ERR_HIP;
+}
+
+static int arg_fail(const char* msg) {
+  set_last_error(msg);
+  return AMHIP_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// memory
+// ---------------------------------------------------------------------------
+int ensure_bytes(void** ptr, size_t* cap_bytes, size_t need_bytes) {
+  if (*cap_bytes >= need_bytes && *ptr) return AMHIP_OK;
+  if (*ptr) {
+    AMHIP_TRY(hipFree(*ptr));
+    *ptr = nullptr;
+    *cap_bytes = 0;
+  }
+  // grow by 1/8 so that slightly larger follow-up clouds do not reallocate
+  size_t want = need_bytes + need_bytes / 8 + 256;
+  hipError_t e = hipMalloc(ptr, want);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    want = need_bytes;
+    AMHIP_TRY(hipMalloc(ptr, want));
+  }
+  *cap_bytes = want;
+  return AMHIP_OK;
+}
+
+template <typename T>
+int ensure_capacity(T** ptr, size_t* cap, size_t need) {
+  size_t cap_bytes = *cap * sizeof(T);
+  void* p = *ptr;
+  const int rc = ensure_bytes(&p, &cap_bytes, need * sizeof(T));
+  *ptr = static_cast<T*>(p);
+  *cap = cap_bytes / sizeof(T);
+  return rc;
+}
+template int ensure_capacity<double>(double**, size_t*, size_t);
+template int ensure_capacity<uint32_t>(uint32_t**, size_t*, size_t);
+template int ensure_capacity<uint8_t>(uint8_t**, size_t*, size_t);
+template int ensure_capacity<FramePose>(FramePose**, size_t*, size_t);
+
+// ---------------------------------------------------------------------------
+// timing
+// ---------------------------------------------------------------------------
+ScopedTimer::ScopedTimer(Ctx* ctx, int slot) : c(ctx), on(ctx->timing) {
+  if (!on) return;
+  if (!c->free_regions.empty()) {
+    r = c->free_regions.back();
+    c->free_regions.pop_back();
+  } else {
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+      on = false;
+      return;
+    }
+  }
+  r.slot = slot;
+  (void)hipEventRecord(r.a, c->stream);
+}
+
+ScopedTimer::~ScopedTimer() {
+  if (!on) return;
+  (void)hipEventRecord(r.b, c->stream);
+  c->regions.push_back(r);
+}
+
+static void drain_timers(Ctx* c) {
+  for (TimedRegion& r : c->regions) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess &&
+        hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      c->slot_ms[r.slot] += ms;
+      c->slot_launches[r.slot] += 1;
+    }
+    c->free_regions.push_back(r);
+  }
+  c->regions.clear();
+}
+
+// ---------------------------------------------------------------------------
+// host-side pose math (minkindr; mirrors oracle/amo_compat.h)
+// ---------------------------------------------------------------------------
+struct H3 {
+  double x, y, z;
+};
+static H3 hcross(const H3& a, const H3& b) {
+  H3 r;
+  r.x = a.y * b.z - a.z * b.y;
+  r.y = a.z * b.x - a.x * b.z;
+  r.z = a.x * b.y - a.y * b.x;
+  return r;
+}
+static H3 hrotate(double qw, double qx, double qy, double qz, const H3& v) {
+  const H3 qv = {qx, qy, qz};
+  H3 uv = hcross(qv, v);
+  uv.x = uv.x + uv.x;
+  uv.y = uv.y + uv.y;
+  uv.z = uv.z + uv.z;
+  const H3 c2 = hcross(qv, uv);
+  H3 r;
+  r.x = (v.x + qw * uv.x) + c2.x;
+  r.y = (v.y + qw * uv.y) + c2.y;
+  r.z = (v.z + qw * uv.z) + c2.z;
+  return r;
+}
+
+HPose hpose_from7(const double* p) {
+  HPose r;
+  r.tx = p[0];
+  r.ty = p[1];
+  r.tz = p[2];
+  r.qw = p[3];
+  r.qx = p[4];
+  r.qy = p[5];
+  r.qz = p[6];
+  return r;
+}
+
+// inverse() = (q*, -(q* (x) t))
+HPose hpose_inverse(const HPose& T) {
+  HPose r;
+  r.qw = T.qw;
+  r.qx = -T.qx;
+  r.qy = -T.qy;
+  r.qz = -T.qz;
+  const H3 t = {T.tx, T.ty, T.tz};
+  const H3 rt = hrotate(r.qw, r.qx, r.qy, r.qz, t);
+  r.tx = -rt.x;
+  r.ty = -rt.y;
+  r.tz = -rt.z;
+  return r;
+}
+
+// A * B = (qA qB, tA + qA (x) tB)
+HPose hpose_compose(const HPose& A, const HPose& B) {
+  HPose r;
+  r.qw = A.qw * B.qw - A.qx * B.qx - A.qy * B.qy - A.qz * B.qz;
+  r.qx = A.qw * B.qx + A.qx * B.qw + A.qy * B.qz - A.qz * B.qy;
+  r.qy = A.qw * B.qy + A.qy * B.qw + A.qz * B.qx - A.qx * B.qz;
+  r.qz = A.qw * B.qz + A.qz * B.qw + A.qx * B.qy - A.qy * B.qx;
+  const H3 tb = {B.tx, B.ty, B.tz};
+  const H3 rt = hrotate(A.qw, A.qx, A.qy, A.qz, tb);
+  r.tx = A.tx + rt.x;
+  r.ty = A.ty + rt.y;
+  r.tz = A.tz + rt.z;
+  return r;
+}
+
+// ---------------------------------------------------------------------------
+// parameter set-up
+// ---------------------------------------------------------------------------
+static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
+  // getPosition: (mapPosition + (0.5*length - 0.5*resolution)) + resolution*(-i)
+  const double off_x = 0.5 * g.length_x - 0.5 * g.resolution;
+  const double off_y = 0.5 * g.length_y - 0.5 * g.resolution;
+  *bx = g.pos_x + off_x;
+  *by = g.pos_y + off_y;
+}
+
+static int make_dsm_params(const amhip_grid_desc& g, int radius_sq,
+                           double center_easting, double center_northing,
+                           DsmParams* out) {
+  DsmParams p;
+  std::memset(&p, 0, sizeof(p));
+  grid_bases(g, &p.base_x, &p.base_y);
+  p.res = g.resolution;
+  p.inv_res = 1.0 / g.resolution;
+  p.rows = g.rows;
+  p.cols = g.cols;
+  p.sub_x = center_northing;  // dsm.cc:42
+  p.sub_y = center_easting;   // dsm.cc:43
+
+  // Squared search radii in the order dsm.cc:127-144 tries them: the initial
+  // search with T = R, then lambda*R for lambda = 1, 1.1, 1.1^2, ... where
+  // lambda is updated by `lambda *= 1.1` and the loop stops once lambda*R > 7.
+  int n = 0;
+  p.T[n++] = static_cast<double>(radius_sq);
+  double lambda = 1.0;
+  for (;;) {
+    if (n >= kMaxLevels) return arg_fail("radius ladder too long");
+    p.T[n++] = lambda * radius_sq;
+    lambda *= 1.1;
+    if (lambda * radius_sq > 7.0) break;
+  }
+  p.nlevels = n;
+  double tmax = 0.0;
+  for (int k = 0; k < n; ++k) {
+    // a point within sqrt(T) of the centre of cell i lies in a cell whose index
+    // differs from i by at most floor(sqrt(T)/res + 0.5) (+ slack for rounding)
+    p.w[k] = static_cast<int>(
+        std::floor(std::sqrt(p.T[k]) / g.resolution + 0.5 + 1e-6));
+    if (p.T[k] > tmax) tmax = p.T[k];
+  }
+  int wmax = 0;
+  for (int k = 0; k < n; ++k)
+    if (p.w[k] > wmax) wmax = p.w[k];
+
+  // Bin edge: about half the first search radius (in cells), at least 1.
+  int B = p.w[0] / 2;
+  if (B < 1) B = 1;
+  p.B = B;
+  p.M = ((wmax + B - 1) / B) * B;
+  const long long ex = (long long)p.rows + 2LL * p.M;
+  const long long ey = (long long)p.cols + 2LL * p.M;
+  p.nbx = static_cast<int>((ex + B - 1) / B);
+  p.nby = static_cast<int>((ey + B - 1) / B);
+  const unsigned long long nbins =
+      (unsigned long long)p.nbx * (unsigned long long)p.nby;
+  if (nbins + 1 >= 0xFFFFFFFFull) return arg_fail("grid too large for 32-bit bin ids");
+  *out = p;
+  return AMHIP_OK;
+}
+
+static void normalize3(double* v) {
+  const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  v[0] /= n;
+  v[1] /= n;
+  v[2] /= n;
+}
+
+static void make_ortho_params(const amhip_grid_desc& g, const amhip_camera& cam,
+                              size_t F, size_t frame_stride, size_t row_step,
+                              int channels, int colored, OrthoParams* out) {
+  OrthoParams p;
+  std::memset(&p, 0, sizeof(p));
+  grid_bases(g, &p.base_x, &p.base_y);
+  p.res = g.resolution;
+  p.rows = g.rows;
+  p.cols = g.cols;
+  p.fu = cam.fu;
+  p.fv = cam.fv;
+  p.cu = cam.cu;
+  p.cv = cam.cv;
+  for (int k = 0; k < 4; ++k) p.dist[k] = cam.dist[k];
+  p.width = cam.width;
+  p.height = cam.height;
+  p.distortion = cam.distortion;
+  p.num_frames = static_cast<int>(F);
+  p.channels = channels;
+  p.colored = colored;
+  p.frame_stride = frame_stride;
+  p.row_step = row_step;
+  // Side planes of the undistorted pinhole frustum, camera frame, through the
+  // optical centre; a landmark with z > 0 projects into [0,W) x [0,H) only if
+  // it is on the inner side of all four.
+  p.cull = (cam.distortion == AMHIP_DIST_NONE && cam.fu > 0.0 && cam.fv > 0.0) ? 1 : 0;
+  if (p.cull) {
+    const double W = cam.width, H = cam.height;
+    double l[3] = {cam.fu, 0.0, cam.cu};          // u >= 0
+    double r[3] = {-cam.fu, 0.0, W - cam.cu};     // u <  W
+    double t[3] = {0.0, cam.fv, cam.cv};          // v >= 0
+    double b[3] = {0.0, -cam.fv, H - cam.cv};     // v <  H
+    normalize3(l);
+    normalize3(r);
+    normalize3(t);
+    normalize3(b);
+    for (int k = 0; k < 3; ++k) {
+      p.pl[0][k] = l[k];
+      p.pl[1][k] = r[k];
+      p.pl[2][k] = t[k];
+      p.pl[3][k] = b[k];
+    }
+  }
+  *out = p;
+}
+
+static float layer_init_value(int layer) {
+  // aerial-mapper-grid-map.cc:40-48
+  switch (layer) {
+    case AMHIP_LAYER_ORTHO:
+      return 255.0f;
+    case AMHIP_LAYER_ELEVATION_ANGLE:
+    case AMHIP_LAYER_NUM_OBSERVATIONS:
+      return 0.0f;
+    default:
+      return std::numeric_limits<float>::quiet_NaN();
+  }
+}
+
+static int use_device(Ctx* c) {
+  AMHIP_TRY(hipSetDevice(c->device));
+  return AMHIP_OK;
+}
+
+static int fetch_status(Ctx* c) {
+  // dev_err -> pinned mirror, then clear
+  AMHIP_TRY(hipMemcpyAsync(c->host_err, c->dev_err, sizeof(unsigned),
+                           hipMemcpyDeviceToHost, c->stream));
+  AMHIP_TRY(hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream));
+  AMHIP_TRY(hipStreamSynchronize(c->stream));
+  const unsigned e = *c->host_err;
+  if (e & kDevErrExactHit) {
+    set_last_error(
+        "a point coincides with a cell centre (reference: dsm.cc:165 "
+        "CHECK(distances[i] > 0.0))");
+    return AMHIP_ERR_EXACT_HIT;
+  }
+  if (e & kDevErrAlphaNonPos) {
+    set_last_error(
+        "observation angle alpha <= 0 (reference: ortho-backward-grid.cc:178 "
+        "CHECK(alpha > 0.0))");
+    return AMHIP_ERR_ALPHA_NONPOS;
+  }
+  return AMHIP_OK;
+}
+
+static bool valid_layer(int l) { return l >= 0 && l < AMHIP_NUM_LAYERS; }
+
+}  // namespace amhip
+
+using namespace amhip;
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int amhip_abi_version(void) { return AMHIP_ABI_VERSION; }
+
+const char* amhip_last_error(void) { return g_last_error.c_str(); }
+
+void amhip_make_grid(double length_x, double length_y, double resolution,
+                     double pos_x, double pos_y, amhip_grid_desc* out) {
+  if (!out) return;
+  out->rows = static_cast<int>(std::round(length_x / resolution));
+  out->cols = static_cast<int>(std::round(length_y / resolution));
+  out->resolution = resolution;
+  out->length_x = static_cast<double>(out->rows) * resolution;
+  out->length_y = static_cast<double>(out->cols) * resolution;
+  out->pos_x = pos_x;
+  out->pos_y = pos_y;
+}
+
+void amhip_cell_position(const amhip_grid_desc* grid, int i, int j, double* x,
+                         double* y) {
+  double bx, by;
+  grid_bases(*grid, &bx, &by);
+  if (x) *x = bx + grid->resolution * (-static_cast<double>(i));
+  if (y) *y = by + grid->resolution * (-static_cast<double>(j));
+}
+
+int amhip_ctx_create(const amhip_grid_desc* grid, int device, amhip_ctx** out) {
+  if (!grid || !out) return arg_fail("amhip_ctx_create: null argument");
+  if (grid->rows <= 0 || grid->cols <= 0 || !(grid->resolution > 0.0))
+    return arg_fail("amhip_ctx_create: empty grid");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    set_last_error("no HIP device visible (libaerial_mapper_hip needs a gfx950 GPU)");
+    return AMHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return arg_fail("amhip_ctx_create: bad device index");
+  amhip_ctx* h = new (std::nothrow) amhip_ctx();
+  if (!h) return AMHIP_ERR_NOMEM;
+  Ctx* c = &h->impl;
+  c->grid = *grid;
+  c->device = device;
+  c->cells = static_cast<size_t>(grid->rows) * static_cast<size_t>(grid->cols);
+  int rc = AMHIP_OK;
+  do {
+    if ((rc = use_device(c))) break;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+      rc = hip_fail(hipGetLastError(), "hipStreamCreate", __FILE__, __LINE__);
+      break;
+    }
+    c->stream = c->own_stream;
+    hipError_t e = hipSuccess;
+    for (int l = 0; l < AMHIP_NUM_LAYERS && e == hipSuccess; ++l)
+      e = hipMalloc(reinterpret_cast<void**>(&c->layers[l]), c->cells * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_err), sizeof(unsigned));
+    if (e == hipSuccess)
+      e = hipHostMalloc(reinterpret_cast<void**>(&c->host_err), sizeof(unsigned), 0);
+    if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "context allocation", __FILE__, __LINE__);
+      break;
+    }
+    rc = amhip_layers_reset(h);
+  } while (0);
+  if (rc != AMHIP_OK) {
+    const std::string keep = g_last_error;
+    amhip_ctx_destroy(h);
+    set_last_error(keep);
+    return rc;
+  }
+  *out = h;
+  return AMHIP_OK;
+}
+
+void amhip_ctx_destroy(amhip_ctx* h) {
+  if (!h) return;
+  Ctx* c = &h->impl;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drain_timers(c);
+  for (TimedRegion& r : c->free_regions) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+    if (c->layers[l]) (void)hipFree(c->layers[l]);
+  void* bufs[] = {c->dev_err, c->sorted,       c->rank,        c->bin_start,
+                  c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (c->host_err) (void)hipHostFree(c->host_err);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete h;
+}
+
+int amhip_ctx_set_stream(amhip_ctx* h, void* hip_stream) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  AMHIP_TRY(hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return AMHIP_OK;
+}
+
+int amhip_ctx_synchronize(amhip_ctx* h) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  return fetch_status(c);
+}
+
+int amhip_layers_reset(amhip_ctx* h) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+    if ((rc = launch_fill(c, c->layers[l], c->cells, layer_init_value(l)))) return rc;
+  return AMHIP_OK;
+}
+
+int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
+  if (!h || !host || !valid_layer(layer)) return arg_fail("amhip_layer_upload: bad argument");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  AMHIP_TRY(hipMemcpyAsync(c->layers[layer], host, c->cells * sizeof(float),
+                           hipMemcpyHostToDevice, c->stream));
+  AMHIP_TRY(hipStreamSynchronize(c->stream));
+  return AMHIP_OK;
+}
+
+int amhip_layer_download(amhip_ctx* h, int layer, float* host) {
+  if (!h || !host || !valid_layer(layer)) return arg_fail("amhip_layer_download: bad argument");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  AMHIP_TRY(hipMemcpyAsync(host, c->layers[layer], c->cells * sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
+  AMHIP_TRY(hipStreamSynchronize(c->stream));
+  return AMHIP_OK;
+}
+
+void* amhip_layer_device_ptr(amhip_ctx* h, int layer) {
+  if (!h || !valid_layer(layer)) return nullptr;
+  return h->impl.layers[layer];
+}
+
+// ---- DSM ------------------------------------------------------------------
+
+int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
+                          int radius_sq, double center_easting,
+                          double center_northing) {
+  if (!h) return arg_fail("null context");  // CHECK(map), dsm.cc:194
+  if (n == 0) return AMHIP_OK;               // empty cloud: warning + return
+  if (!dev_xyz) return arg_fail("amhip_dsm_process_dev: null point pointer");
+  if (radius_sq <= 0)
+    return arg_fail("interpolation_radius must be >= 1 (the reference loops forever on 0)");
+  if (n >= 0x7FFFFFFFull)
+    return arg_fail("more than 2^31-1 points (the reference indexes results with int)");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  DsmParams p;
+  if ((rc = make_dsm_params(c->grid, radius_sq, center_easting, center_northing, &p)))
+    return rc;
+  return dsm_run(c, dev_xyz, n, p);
+}
+
+int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
+                      int radius_sq, double center_easting,
+                      double center_northing, float* elevation) {
+  if (!h) return arg_fail("null context");
+  if (n == 0) return AMHIP_OK;
+  if (!host_xyz || !elevation) return arg_fail("amhip_dsm_process: null buffer");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
+  AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ELEVATION], elevation,
+                           c->cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  if ((rc = amhip_dsm_process_dev(h, c->stage_points, n, radius_sq, center_easting,
+                                  center_northing)))
+    return rc;
+  AMHIP_TRY(hipMemcpyAsync(elevation, c->layers[AMHIP_LAYER_ELEVATION],
+                           c->cells * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return fetch_status(c);
+}
+
+// ---- ortho ----------------------------------------------------------------
+
+void amhip_compose_T_G_C(const double* T_G_B, const double* T_C_B, size_t F,
+                         double* T_G_C) {
+  const HPose T_B_C = hpose_inverse(hpose_from7(T_C_B));
+  for (size_t f = 0; f < F; ++f) {
+    const HPose p = hpose_compose(hpose_from7(T_G_B + 7 * f), T_B_C);
+    double* o = T_G_C + 7 * f;
+    o[0] = p.tx;
+    o[1] = p.ty;
+    o[2] = p.tz;
+    o[3] = p.qw;
+    o[4] = p.qx;
+    o[5] = p.qy;
+    o[6] = p.qz;
+  }
+}
+
+int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
+                                     const double* host_T_G_C, size_t F,
+                                     const uint8_t* dev_frames,
+                                     size_t frame_stride, size_t row_step,
+                                     int channels, int colored) {
+  if (!h || !cam) return arg_fail("null context / camera");
+  if (F == 0 || !host_T_G_C) return arg_fail("empty pose list (CHECK(!T_G_Bs.empty()))");
+  if (!dev_frames) return arg_fail("null frame pointer");
+  if (colored ? channels != 3 : channels != 1)
+    return arg_fail("colored_ortho needs 8UC3 frames, gray needs 8UC1");
+  if (cam->width <= 0 || cam->height <= 0) return arg_fail("bad image size");
+  if (row_step < (size_t)cam->width * (size_t)channels ||
+      frame_stride < row_step * (size_t)cam->height)
+    return arg_fail("frame strides smaller than the image");
+  if (F >= (1u << 24)) return arg_fail("too many frames for a float observation_index");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if ((rc = ensure_capacity(&c->frame_poses, &c->frame_pose_cap, F))) return rc;
+
+  // T_C_G[f] = T_G_C[f].inverse()  (ortho-backward-grid.cc:157-158; the
+  // reference recomputes it per cell and frame, the value is the same)
+  std::vector<FramePose> inv(F);
+  for (size_t f = 0; f < F; ++f) {
+    const HPose T = hpose_inverse(hpose_from7(host_T_G_C + 7 * f));
+    inv[f].qw = T.qw;
+    inv[f].qx = T.qx;
+    inv[f].qy = T.qy;
+    inv[f].qz = T.qz;
+    inv[f].tx = T.tx;
+    inv[f].ty = T.ty;
+    inv[f].tz = T.tz;
+    inv[f]._pad = 0.0;
+  }
+  // pageable source: hipMemcpyAsync returns once it has been staged
+  AMHIP_TRY(hipMemcpyAsync(c->frame_poses, inv.data(), F * sizeof(FramePose),
+                           hipMemcpyHostToDevice, c->stream));
+
+  OrthoParams p;
+  make_ortho_params(c->grid, *cam, F, frame_stride, row_step, channels, colored, &p);
+  return ortho_run(c, p, c->frame_poses, dev_frames);
+}
+
+int amhip_ortho_backward_process(
+    amhip_ctx* h, const amhip_camera* cam, const double* host_T_G_C, size_t F,
+    const uint8_t* const* images, const size_t* steps, int channels,
+    int colored, const float* elevation, float* elevation_angle,
+    float* observation_index, float* num_observations, float* ortho,
+    float* colored_ortho) {
+  if (!h || !cam) return arg_fail("null context / camera");
+  if (F == 0 || !host_T_G_C || !images || !steps)
+    return arg_fail("empty pose / image list (CHECK(!T_G_Bs.empty()))");
+  if (cam->width <= 0 || cam->height <= 0) return arg_fail("bad image size");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  const size_t bytes = c->cells * sizeof(float);
+  const float* ups[AMHIP_NUM_LAYERS] = {ortho,           elevation,
+                                        elevation_angle, num_observations,
+                                        observation_index, colored_ortho};
+  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+    if (ups[l])
+      AMHIP_TRY(hipMemcpyAsync(c->layers[l], ups[l], bytes, hipMemcpyHostToDevice,
+                               c->stream));
+  // stage the frames densely: [F][H][W*channels]
+  const size_t row = (size_t)cam->width * (size_t)channels;
+  const size_t frame = row * (size_t)cam->height;
+  if ((rc = ensure_capacity(&c->stage_frames, &c->stage_frames_cap, frame * F))) return rc;
+  for (size_t f = 0; f < F; ++f) {
+    if (!images[f]) return arg_fail("null image");
+    if (steps[f] < row) return arg_fail("image step smaller than a row");
+    AMHIP_TRY(hipMemcpy2DAsync(c->stage_frames + f * frame, row, images[f], steps[f],
+                               row, (size_t)cam->height, hipMemcpyHostToDevice,
+                               c->stream));
+  }
+  if ((rc = amhip_ortho_backward_process_dev(h, cam, host_T_G_C, F, c->stage_frames,
+                                             frame, row, channels, colored)))
+    return rc;
+  float* downs[AMHIP_NUM_LAYERS] = {ortho,           nullptr,
+                                    elevation_angle, num_observations,
+                                    observation_index, colored_ortho};
+  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+    if (downs[l])
+      AMHIP_TRY(hipMemcpyAsync(downs[l], c->layers[l], bytes, hipMemcpyDeviceToHost,
+                               c->stream));
+  return fetch_status(c);
+}
+
+// ---- measurement ------------------------------------------------------------
+
+int amhip_ctx_enable_timing(amhip_ctx* h, int on) {
+  if (!h) return arg_fail("null context");
+  h->impl.timing = on != 0;
+  return AMHIP_OK;
+}
+
+int amhip_ctx_timing_reset(amhip_ctx* h) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  drain_timers(c);
+  for (int k = 0; k < AMHIP_NUM_KERNELS; ++k) {
+    c->slot_ms[k] = 0.0;
+    c->slot_launches[k] = 0;
+  }
+  return AMHIP_OK;
+}
+
+int amhip_ctx_kernel_time(amhip_ctx* h, int kernel, double* total_ms,
+                          int64_t* launches) {
+  if (!h || kernel < 0 || kernel >= AMHIP_NUM_KERNELS) return arg_fail("bad kernel slot");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  drain_timers(c);
+  if (total_ms) *total_ms = c->slot_ms[kernel];
+  if (launches) *launches = c->slot_launches[kernel];
+  return AMHIP_OK;
+}
+
+const char* amhip_kernel_name(int kernel) {
+  switch (kernel) {
+    case AMHIP_K_DSM_BIN_COUNT:
+      return "k_dsm_bin_count";
+    case AMHIP_K_DSM_SCAN:
+      return "k_scan_partials+k_scan_top+k_scan_final";
+    case AMHIP_K_DSM_SCATTER:
+      return "k_dsm_scatter";
+    case AMHIP_K_DSM_GATHER:
+      return "k_dsm_gather";
+    case AMHIP_K_ORTHO:
+      return "k_ortho_backward";
+    case AMHIP_K_MISC:
+      return "memset/fill";
+    default:
+      return "?";
+  }
+}
+
+int amhip_ctx_dsm_stats(amhip_ctx* h, int64_t* points_binned, int64_t* num_bins,
+                        int32_t* bin_cells) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if (points_binned) {
+    *points_binned = 0;
+    if (c->bin_start && c->last_num_bins > 0) {
+      uint32_t total = 0;
+      AMHIP_TRY(hipMemcpyAsync(&total, c->bin_start + c->last_num_bins,
+                               sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      AMHIP_TRY(hipStreamSynchronize(c->stream));
+      *points_binned = total;
+    }
+  }
+  if (num_bins) *num_bins = c->last_num_bins;
+  if (bin_cells) *bin_cells = c->last_bin_cells;
+  return AMHIP_OK;
+}
+
+}  // extern "C"

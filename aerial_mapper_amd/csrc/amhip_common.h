@@ -1,0 +1,166 @@
+// amhip_common.h -- internal declarations shared by the HIP translation units
+// of libaerial_mapper_hip.so (gfx950 only; not part of the public C ABI).
+#ifndef AMHIP_COMMON_H_
+#define AMHIP_COMMON_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "aerial_mapper_hip.h"
+
+namespace amhip {
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+void set_last_error(const std::string& msg);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define AMHIP_TRY(expr)                                                  \
+  do {                                                                   \
+    hipError_t _e = (expr);                                              \
+    if (_e != hipSuccess) return ::amhip::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// device-side constants
+// ---------------------------------------------------------------------------
+constexpr int kMaxLevels = 24;  // radius ladder: R, then lambda_k * R (<= 22 for R = 1)
+
+// Geometry + search parameters of one DSM call, passed by value to kernels.
+struct DsmParams {
+  // grid_map_core getPosition: x_i = base_x + res * (-(double)i)
+  double base_x, base_y, res;
+  int rows, cols;
+  // dsm.cc:42-43: px = p.x - center_northing, py = p.y - center_easting
+  double sub_x, sub_y;
+  // binning: bins of B x B cells, grid extended by M cells on every side
+  double inv_res;
+  int B, M, nbx, nby;
+  // radius ladder (squared radii, exactly the doubles dsm.cc:127-144 uses)
+  int nlevels;
+  double T[kMaxLevels];
+  int w[kMaxLevels];  // conservative window half-width in cells for T[k]
+};
+
+// Per-frame inverse pose T_C_G = T_G_C^-1 (minkindr inverse()).
+struct FramePose {
+  double qw, qx, qy, qz;
+  double tx, ty, tz;
+  double _pad;
+};
+
+struct OrthoParams {
+  double base_x, base_y, res;
+  int rows, cols;
+  // camera
+  double fu, fv, cu, cv;
+  double dist[4];
+  int width, height, distortion;
+  // frames
+  int num_frames;
+  int channels, colored;
+  size_t frame_stride, row_step;
+  // frustum side planes in the camera frame (unit normals, inside = n.p >= 0),
+  // only valid when distortion == NONE
+  double pl[4][3];
+  int cull;
+};
+
+// Device error word bits (sticky until amhip_ctx_synchronize).
+enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u };
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct TimedRegion {
+  hipEvent_t a, b;
+  int slot;
+};
+
+struct Ctx {
+  amhip_grid_desc grid;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  size_t cells = 0;
+
+  float* layers[AMHIP_NUM_LAYERS] = {nullptr, nullptr, nullptr,
+                                     nullptr, nullptr, nullptr};
+  unsigned* dev_err = nullptr;   // device error word
+  unsigned* host_err = nullptr;  // pinned mirror
+
+  // DSM workspaces (grow on demand)
+  double* sorted = nullptr;      // 3 doubles per binned point (px, py, z)
+  size_t sorted_cap = 0;         // in points
+  uint32_t* rank = nullptr;      // per input point: rank inside its bin
+  size_t rank_cap = 0;
+  uint32_t* bin_start = nullptr; // nbins + 1 (+ scan partials behind it)
+  size_t bin_cap = 0;
+  uint32_t* scan_partials = nullptr;
+  size_t partial_cap = 0;
+  double* stage_points = nullptr;  // H2D staging of host clouds
+  size_t stage_points_cap = 0;
+
+  // ortho workspaces
+  FramePose* frame_poses = nullptr;
+  size_t frame_pose_cap = 0;
+  uint8_t* stage_frames = nullptr;
+  size_t stage_frames_cap = 0;
+
+  // stats of the last DSM call
+  int64_t last_points_binned = 0;
+  int64_t last_num_bins = 0;
+  int32_t last_bin_cells = 0;
+
+  // timing
+  bool timing = false;
+  std::vector<TimedRegion> regions;
+  std::vector<TimedRegion> free_regions;
+  double slot_ms[AMHIP_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
+  int64_t slot_launches[AMHIP_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
+};
+
+// RAII-less helper: bracket a launch sequence with events when timing is on.
+struct ScopedTimer {
+  Ctx* c;
+  TimedRegion r;
+  bool on;
+  ScopedTimer(Ctx* ctx, int slot);
+  ~ScopedTimer();
+};
+
+template <typename T>
+int ensure_capacity(T** ptr, size_t* cap, size_t need);
+
+int ensure_bytes(void** ptr, size_t* cap_bytes, size_t need_bytes);
+
+// ---------------------------------------------------------------------------
+// launchers (defined in amhip_dsm.hip / amhip_ortho.hip)
+// ---------------------------------------------------------------------------
+int launch_fill(Ctx* c, float* dst, size_t n, float value);
+int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p);
+int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
+              const uint8_t* dev_frames);
+
+// host-side restatements of the external pose math (minkindr), used to build
+// T_G_C and T_C_G; kept in one place so the composition and the per-cell
+// transform agree operation for operation.
+struct HPose {
+  double qw, qx, qy, qz, tx, ty, tz;
+};
+HPose hpose_from7(const double* p);
+HPose hpose_inverse(const HPose& T);
+HPose hpose_compose(const HPose& A, const HPose& B);
+
+}  // namespace amhip
+
+struct amhip_ctx {
+  amhip::Ctx impl;
+};
+
+#endif  // AMHIP_COMMON_H_

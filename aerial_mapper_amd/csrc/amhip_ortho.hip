@@ -1,0 +1,321 @@
+// amhip_ortho.hip -- grid-based backward-projection orthomosaic on MI355X.
+//
+// Replaces ortho::OrthoBackwardGrid::updateOrthomosaicLayerMultiThreaded
+// (aerial_mapper_ortho/src/ortho-backward-grid.cc:128-221): for every cell the
+// centre (x, y, elevation) is projected into every frame in ascending frame
+// order, the most-nadir view wins (strict `>` against the FLOAT-rounded
+// running maximum, which makes the fold order dependent) and the nearest
+// pixel of the winning frame is sampled.
+//
+// One workgroup owns a tile of 64 x kTileJ cells.  It first reduces the
+// tile's elevation range, then culls the frames against the tile's bounding
+// sphere with the four side planes of the (undistorted pinhole) frustum --
+// conservative, so a culled frame can not be visible from any cell of the
+// tile and skipping it does not change the fold -- and finally every lane
+// folds the surviving frames, in ascending order, for its cells.  The
+// reference brute-forces all F frames per cell; with ~4x overlap only a
+// handful survive per tile.
+//
+// All per-pair arithmetic is the oracle's (oracle/amo_compat.h), operation
+// for operation, in double without fused multiply-add (-ffp-contract=off):
+// minkindr transform of the landmark, aslam pinhole project3 (+ radtan /
+// equidistant distortion), asin(|z| / ||p||).
+#include "amhip_common.h"
+
+namespace amhip {
+
+constexpr int kTileI = 64;
+constexpr int kTileJ = 16;
+constexpr int kOrthoThreads = 256;
+constexpr int kCellsPerLane = kTileJ / (kOrthoThreads / 64);  // 4
+constexpr int kChunk = 1024;  // frames culled per pass
+
+struct V3 {
+  double x, y, z;
+};
+
+__device__ __forceinline__ V3 cross3(const V3& a, const V3& b) {
+  V3 r;
+  r.x = a.y * b.z - a.z * b.y;
+  r.y = a.z * b.x - a.x * b.z;
+  r.z = a.x * b.y - a.y * b.x;
+  return r;
+}
+
+// Eigen::Quaternion::_transformVector followed by the translation
+// (kindr::minimal::QuatTransformation::transform).
+__device__ __forceinline__ V3 transform_point(const FramePose& T, const V3& v) {
+  const V3 qv = {T.qx, T.qy, T.qz};
+  V3 uv = cross3(qv, v);
+  uv.x = uv.x + uv.x;
+  uv.y = uv.y + uv.y;
+  uv.z = uv.z + uv.z;
+  const V3 c2 = cross3(qv, uv);
+  V3 r;
+  r.x = (v.x + T.qw * uv.x) + c2.x;
+  r.y = (v.y + T.qw * uv.y) + c2.y;
+  r.z = (v.z + T.qw * uv.z) + c2.z;
+  r.x = r.x + T.tx;
+  r.y = r.y + T.ty;
+  r.z = r.z + T.tz;
+  return r;
+}
+
+__device__ __forceinline__ void distort_point(const OrthoParams& p, double* px,
+                                              double* py) {
+  double x = *px, y = *py;
+  if (p.distortion == AMHIP_DIST_RADTAN) {
+    const double k1 = p.dist[0], k2 = p.dist[1], p1 = p.dist[2], p2 = p.dist[3];
+    const double mx2 = x * x;
+    const double my2 = y * y;
+    const double mxy = x * y;
+    const double rho2 = mx2 + my2;
+    const double rad = k1 * rho2 + k2 * rho2 * rho2;
+    const double nx = x + (x * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2));
+    const double ny = y + (y * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2));
+    x = nx;
+    y = ny;
+  } else if (p.distortion == AMHIP_DIST_EQUIDISTANT) {
+    const double r = sqrt(x * x + y * y);
+    const double theta = atan(r);
+    const double th2 = theta * theta;
+    const double th4 = th2 * th2;
+    const double th6 = th4 * th2;
+    const double th8 = th4 * th4;
+    const double thetad =
+        theta * (1.0 + p.dist[0] * th2 + p.dist[1] * th4 + p.dist[2] * th6 +
+                 p.dist[3] * th8);
+    const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+    x = x * scaling;
+    y = y * scaling;
+  }
+  *px = x;
+  *py = y;
+}
+
+// aslam::PinholeCamera::project3 + the visibility test of
+// ortho-backward-grid.cc:164-171.
+__device__ __forceinline__ bool project_visible(const OrthoParams& p,
+                                                const V3& c, double* u,
+                                                double* v) {
+  const double rz = 1.0 / c.z;
+  double kx = c.x * rz;
+  double ky = c.y * rz;
+  if (p.distortion != AMHIP_DIST_NONE) distort_point(p, &kx, &ky);
+  *u = p.fu * kx + p.cu;
+  *v = p.fv * ky + p.cv;
+  const bool in_box = (*u >= 0.0) && (*v >= 0.0) && (*u < (double)p.width) &&
+                      (*v < (double)p.height);
+  // status not in {POINT_BEHIND_CAMERA, PROJECTION_INVALID} <=> z > 1e-10
+  return in_box && (c.z > 1e-10);
+}
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+__global__ void __launch_bounds__(kOrthoThreads)
+k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
+                 const uint8_t* __restrict__ frames,
+                 const float* __restrict__ elevation,
+                 float* __restrict__ elevation_angle,
+                 float* __restrict__ observation_index,
+                 float* __restrict__ num_observations,
+                 float* __restrict__ out_layer, unsigned* __restrict__ dev_err) {
+  __shared__ float s_red[2 * (kOrthoThreads / 64)];
+  __shared__ int s_cand[kChunk];
+  __shared__ int s_wave_cnt[kOrthoThreads / 64];
+
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  const int i = blockIdx.x * kTileI + lane;
+  const int j0 = blockIdx.y * kTileJ;
+  const bool i_ok = i < p.rows;
+
+  // ---- phase A: this lane's cells + tile elevation range -------------------
+  float elev[kCellsPerLane];
+  float zmin = __builtin_huge_valf(), zmax = -__builtin_huge_valf();
+#pragma unroll
+  for (int c = 0; c < kCellsPerLane; ++c) {
+    const int j = j0 + wid + c * (kOrthoThreads / 64);
+    float e = __builtin_nanf("");
+    if (i_ok && j < p.cols) e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
+    elev[c] = e;
+    if (e == e) {  // NaN elevation can never be visible
+      zmin = fminf(zmin, e);
+      zmax = fmaxf(zmax, e);
+    }
+  }
+  zmin = wave_min_f(zmin);
+  zmax = wave_max_f(zmax);
+  if (lane == 0) {
+    s_red[wid] = zmin;
+    s_red[kOrthoThreads / 64 + wid] = zmax;
+  }
+  __syncthreads();
+  zmin = s_red[0];
+  zmax = s_red[kOrthoThreads / 64];
+#pragma unroll
+  for (int w = 1; w < kOrthoThreads / 64; ++w) {
+    zmin = fminf(zmin, s_red[w]);
+    zmax = fmaxf(zmax, s_red[kOrthoThreads / 64 + w]);
+  }
+  if (!(zmin <= zmax)) return;  // no finite elevation in this tile
+
+  // bounding sphere of the tile's landmarks (cell centres x elevation range)
+  const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
+  const int j_hi = min(j0 + kTileJ, p.cols) - 1;
+  const double xa = p.base_x + p.res * (-(double)(blockIdx.x * kTileI));
+  const double xb = p.base_x + p.res * (-(double)i_hi);
+  const double ya = p.base_y + p.res * (-(double)j0);
+  const double yb = p.base_y + p.res * (-(double)j_hi);
+  const V3 centre = {0.5 * (xa + xb), 0.5 * (ya + yb),
+                     0.5 * ((double)zmin + (double)zmax)};
+  const double hx = 0.5 * fabs(xa - xb), hy = 0.5 * fabs(ya - yb),
+               hz = 0.5 * ((double)zmax - (double)zmin);
+  // generous slack: the cull only has to be conservative
+  const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6;
+
+  // ---- per-lane fold state ---------------------------------------------------
+  const double lx = p.base_x + p.res * (-(double)i);
+  float best[kCellsPerLane];
+  int best_f[kCellsPerLane];
+  int best_u[kCellsPerLane];
+  int best_v[kCellsPerLane];
+  int accepted[kCellsPerLane];
+  bool bad_alpha = false;
+#pragma unroll
+  for (int c = 0; c < kCellsPerLane; ++c) {
+    const int j = j0 + wid + c * (kOrthoThreads / 64);
+    best[c] = 0.0f;
+    if (i_ok && j < p.cols)
+      best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
+    best_f[c] = -1;
+    best_u[c] = 0;
+    best_v[c] = 0;
+    accepted[c] = 0;
+  }
+
+  for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
+    // ---- phase B: cull this chunk of frames, keep ascending order -----------
+    const int chunk_n = min(kChunk, p.num_frames - chunk0);
+    int ncand = 0;  // same value in every thread of the block
+    for (int r = 0; r < chunk_n; r += kOrthoThreads) {
+      const int f = chunk0 + r + (int)threadIdx.x;
+      bool keep = false;
+      if (f < chunk0 + chunk_n) {
+        keep = true;
+        if (p.cull) {
+          const FramePose T = poses[f];
+          const V3 cc = transform_point(T, centre);
+          if (cc.z < -radius) keep = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double d =
+                p.pl[k][0] * cc.x + p.pl[k][1] * cc.y + p.pl[k][2] * cc.z;
+            if (d < -radius) keep = false;
+          }
+        }
+      }
+      const unsigned long long m = __ballot(keep);
+      const int before = __popcll(m & ((1ull << lane) - 1ull));
+      __syncthreads();  // previous round's readers of s_wave_cnt are done
+      if (lane == 0) s_wave_cnt[wid] = __popcll(m);
+      __syncthreads();
+      int base = ncand, tot = 0;
+#pragma unroll
+      for (int w = 0; w < kOrthoThreads / 64; ++w) {
+        const int cw = s_wave_cnt[w];
+        if (w < wid) base += cw;
+        tot += cw;
+      }
+      if (keep) s_cand[base + before] = f;
+      ncand += tot;
+    }
+    __syncthreads();  // s_cand complete
+
+    // ---- phase C: fold the candidates, ascending -----------------------------
+    if (i_ok) {
+      for (int k = 0; k < ncand; ++k) {
+        const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
+        const FramePose T = poses[f];
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c) {
+          const int j = j0 + wid + c * (kOrthoThreads / 64);
+          const double ly = p.base_y + p.res * (-(double)j);
+          const V3 landmark = {lx, ly, (double)elev[c]};
+          const V3 cp = transform_point(T, landmark);
+          double u, v;
+          if (!project_visible(p, cp, &u, &v)) continue;
+          const double norm = sqrt(cp.x * cp.x + cp.y * cp.y + cp.z * cp.z);
+          const double alpha = asin(fabs(cp.z) / norm);
+          if (!(alpha > 0.0)) bad_alpha = true;  // CHECK(alpha > 0.0)
+          if (alpha > (double)best[c]) {
+            best[c] = (float)alpha;
+            best_f[c] = f;
+            accepted[c]++;
+            best_v[c] = min((int)round(v), p.height - 1);
+            best_u[c] = min((int)round(u), p.width - 1);
+          }
+        }
+      }
+    }
+    __syncthreads();  // everyone is done with s_cand before the next chunk
+  }
+
+  if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
+
+  // ---- write back ------------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < kCellsPerLane; ++c) {
+    const int j = j0 + wid + c * (kOrthoThreads / 64);
+    if (!(i_ok && j < p.cols) || accepted[c] == 0) continue;
+    const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+    elevation_angle[at] = best[c];
+    observation_index[at] = (float)best_f[c];
+    // layer_num_observations(x, y) += layer_num_observations(x, y), once per
+    // accepted update (ortho-backward-grid.cc:183): doubles the stored value.
+    float nobs = num_observations[at];
+    if (nobs != 0.0f) {
+      for (int n = 0; n < accepted[c]; ++n) nobs += nobs;
+      num_observations[at] = nobs;
+    }
+    const uint8_t* px = frames + (size_t)best_f[c] * p.frame_stride +
+                        (size_t)best_v[c] * p.row_step;
+    if (p.colored) {
+      // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B
+      px += (size_t)best_u[c] * 3u;
+      const unsigned bits = ((unsigned)px[2] << 16) | ((unsigned)px[1] << 8) |
+                            (unsigned)px[0];
+      out_layer[at] = __uint_as_float(bits);
+    } else {
+      out_layer[at] = (float)px[best_u[c]];
+    }
+  }
+}
+
+int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
+              const uint8_t* dev_frames) {
+  ScopedTimer t(c, AMHIP_K_ORTHO);
+  dim3 grid((unsigned)((p.rows + kTileI - 1) / kTileI),
+            (unsigned)((p.cols + kTileJ - 1) / kTileJ));
+  float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
+                         : c->layers[AMHIP_LAYER_ORTHO];
+  hipLaunchKernelGGL(k_ortho_backward, grid, dim3(kOrthoThreads), 0, c->stream,
+                     p, dev_poses, dev_frames,
+                     c->layers[AMHIP_LAYER_ELEVATION],
+                     c->layers[AMHIP_LAYER_ELEVATION_ANGLE],
+                     c->layers[AMHIP_LAYER_OBSERVATION_INDEX],
+                     c->layers[AMHIP_LAYER_NUM_OBSERVATIONS], out, c->dev_err);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+}  // namespace amhip

@@ -1,0 +1,149 @@
+"""ctypes binding of libaerial_mapper_hip.so (include/aerial_mapper_hip.h).
+
+There is NO CPU fallback: if the library is missing this module raises, and if
+no gfx950 device is visible `Context()` raises.  (The CPU oracle under oracle/
+is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "lib", "libaerial_mapper_hip.so")
+
+ABI_VERSION = 1
+
+# amhip_status
+OK, ERR_ARG, ERR_EXACT_HIT, ERR_ALPHA_NONPOS, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = range(7)
+STATUS_NAMES = {OK: "AMHIP_OK", ERR_ARG: "AMHIP_ERR_ARG", ERR_EXACT_HIT: "AMHIP_ERR_EXACT_HIT",
+                ERR_ALPHA_NONPOS: "AMHIP_ERR_ALPHA_NONPOS", ERR_HIP: "AMHIP_ERR_HIP",
+                ERR_NO_DEVICE: "AMHIP_ERR_NO_DEVICE", ERR_NOMEM: "AMHIP_ERR_NOMEM"}
+
+# amhip_layer
+(LAYER_ORTHO, LAYER_ELEVATION, LAYER_ELEVATION_ANGLE, LAYER_NUM_OBSERVATIONS,
+ LAYER_OBSERVATION_INDEX, LAYER_COLORED_ORTHO) = range(6)
+NUM_LAYERS = 6
+LAYER_NAMES = ["ortho", "elevation", "elevation_angle", "num_observations",
+               "observation_index", "colored_ortho"]
+
+# amhip_kernel
+(K_DSM_BIN_COUNT, K_DSM_SCAN, K_DSM_SCATTER, K_DSM_GATHER, K_ORTHO, K_MISC) = range(6)
+NUM_KERNELS = 6
+
+DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = 0, 1, 2
+
+# every symbol include/aerial_mapper_hip.h declares
+EXPORTS = [
+    "amhip_abi_version", "amhip_last_error", "amhip_make_grid", "amhip_cell_position",
+    "amhip_ctx_create", "amhip_ctx_destroy", "amhip_ctx_set_stream", "amhip_ctx_synchronize",
+    "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
+    "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
+    "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
+    "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
+    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
+]
+
+
+class GridDesc(C.Structure):
+    """amhip_grid_desc"""
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32),
+                ("resolution", C.c_double),
+                ("length_x", C.c_double), ("length_y", C.c_double),
+                ("pos_x", C.c_double), ("pos_y", C.c_double)]
+
+
+class Camera(C.Structure):
+    """amhip_camera"""
+    _fields_ = [("fu", C.c_double), ("fv", C.c_double),
+                ("cu", C.c_double), ("cv", C.c_double),
+                ("width", C.c_int32), ("height", C.c_int32),
+                ("distortion", C.c_int32), ("_pad", C.c_int32),
+                ("dist", C.c_double * 4)]
+
+
+class AmhipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(status, status), message))
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: run `python -m aerial_mapper_amd.build` "
+            "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, f64p, f32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
+    gp, cp = C.POINTER(GridDesc), C.POINTER(Camera)
+    lib.amhip_abi_version.restype = C.c_int
+    lib.amhip_last_error.restype = C.c_char_p
+    lib.amhip_make_grid.restype = None
+    lib.amhip_make_grid.argtypes = [C.c_double] * 5 + [gp]
+    lib.amhip_cell_position.restype = None
+    lib.amhip_cell_position.argtypes = [gp, C.c_int, C.c_int, f64p, f64p]
+    lib.amhip_ctx_create.argtypes = [gp, C.c_int, C.POINTER(vp)]
+    lib.amhip_ctx_destroy.restype = None
+    lib.amhip_ctx_destroy.argtypes = [vp]
+    lib.amhip_ctx_set_stream.argtypes = [vp, vp]
+    lib.amhip_ctx_synchronize.argtypes = [vp]
+    lib.amhip_layers_reset.argtypes = [vp]
+    lib.amhip_layer_upload.argtypes = [vp, C.c_int, vp]
+    lib.amhip_layer_download.argtypes = [vp, C.c_int, vp]
+    lib.amhip_layer_device_ptr.restype = vp
+    lib.amhip_layer_device_ptr.argtypes = [vp, C.c_int]
+    lib.amhip_dsm_process_dev.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double]
+    lib.amhip_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
+    lib.amhip_compose_T_G_C.restype = None
+    lib.amhip_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
+    lib.amhip_ortho_backward_process_dev.argtypes = [
+        vp, cp, f64p, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
+    lib.amhip_ortho_backward_process.argtypes = [
+        vp, cp, f64p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+        vp, vp, vp, vp, vp, vp]
+    lib.amhip_ctx_enable_timing.argtypes = [vp, C.c_int]
+    lib.amhip_ctx_timing_reset.argtypes = [vp]
+    lib.amhip_ctx_kernel_time.argtypes = [vp, C.c_int, f64p, C.POINTER(C.c_int64)]
+    lib.amhip_kernel_name.restype = C.c_char_p
+    lib.amhip_kernel_name.argtypes = [C.c_int]
+    lib.amhip_ctx_dsm_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                        C.POINTER(C.c_int32)]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("amhip_abi_version",):
+            pass
+    if lib.amhip_abi_version() != ABI_VERSION:
+        raise ImportError("libaerial_mapper_hip.so ABI %d != expected %d"
+                          % (lib.amhip_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().amhip_last_error().decode("utf-8", "replace")
+
+
+def check(status):
+    if status != OK:
+        raise AmhipError(status, last_error())
+    return status
+
+
+def make_grid(length_x, length_y, resolution, pos_x=0.0, pos_y=0.0):
+    """grid_map_core setGeometry as called by AerialGridMap::initialize
+    (Length(delta_easting, delta_northing), resolution, Position(center_easting,
+    center_northing))."""
+    g = GridDesc()
+    load().amhip_make_grid(length_x, length_y, resolution, pos_x, pos_y, C.byref(g))
+    return g
+
+
+def cell_position(g, i, j):
+    x, y = C.c_double(), C.c_double()
+    load().amhip_cell_position(C.byref(g), i, j, C.byref(x), C.byref(y))
+    return x.value, y.value

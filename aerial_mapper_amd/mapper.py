@@ -1,0 +1,313 @@
+"""Host-side mirror of the reference's class API for the hot path, over the C ABI.
+
+  grid_map::AerialGridMap   aerial_mapper_grid_map/include/aerial-mapper-grid-map/
+                            aerial-mapper-grid-map.h:23-54
+  dsm::Settings / dsm::Dsm  aerial_mapper_dsm/include/aerial-mapper-dsm/dsm.h:25-42
+  ortho::Settings / ortho::OrthoBackwardGrid
+                            aerial_mapper_ortho/include/aerial-mapper-ortho/
+                            ortho-backward-grid.h:32-50
+
+Same names, argument meaning and error behaviour (a failed reference CHECK
+surfaces as AmhipError instead of abort()).  The C++ drop-in classes live under
+include/aerial-mapper-dsm/ and include/aerial-mapper-ortho/; this Python layer
+exists so the parity tests and bench.py can drive the very same C ABI.
+
+The layers stay resident in HBM between calls (what the reference keeps in the
+GridMap's matrices); `AerialGridMap.get()` downloads one for publishing.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hip_lib as L
+
+
+class GridMapSettings(object):
+    """grid_map::Settings (aerial-mapper-grid-map.h:23-29)."""
+
+    def __init__(self, center_easting=0.0, center_northing=0.0, delta_easting=0.0,
+                 delta_northing=0.0, resolution=1.0):
+        self.center_easting = center_easting
+        self.center_northing = center_northing
+        self.delta_easting = delta_easting
+        self.delta_northing = delta_northing
+        self.resolution = resolution
+
+
+class AerialGridMap(object):
+    """grid_map::AerialGridMap: geometry + the layers, device resident."""
+
+    def __init__(self, settings, device=0):
+        self.settings = settings
+        lib = L.load()
+        self.grid = L.make_grid(settings.delta_easting, settings.delta_northing,
+                                settings.resolution, settings.center_easting,
+                                settings.center_northing)
+        h = C.c_void_p()
+        L.check(lib.amhip_ctx_create(C.byref(self.grid), int(device), C.byref(h)))
+        self._h = h
+        self._lib = lib
+        self.device = int(device)
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.amhip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- geometry ---------------------------------------------------------
+    @property
+    def rows(self):
+        return self.grid.rows
+
+    @property
+    def cols(self):
+        return self.grid.cols
+
+    @property
+    def num_cells(self):
+        return self.grid.rows * self.grid.cols
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- layers -----------------------------------------------------------
+    @staticmethod
+    def _layer_id(layer):
+        return L.LAYER_NAMES.index(layer) if isinstance(layer, str) else int(layer)
+
+    def get(self, layer):
+        """Download a layer: float32 array of shape (cols, rows) -- numpy C order
+        of an Eigen column-major (rows, cols) matrix, so a[j, i] == layer(i, j)."""
+        out = np.empty((self.grid.cols, self.grid.rows), np.float32)
+        L.check(self._lib.amhip_layer_download(self._h, self._layer_id(layer),
+                                               out.ctypes.data))
+        return out
+
+    def set(self, layer, values):
+        a = np.ascontiguousarray(values, np.float32)
+        assert a.shape == (self.grid.cols, self.grid.rows), a.shape
+        L.check(self._lib.amhip_layer_upload(self._h, self._layer_id(layer), a.ctypes.data))
+
+    def device_ptr(self, layer):
+        return self._lib.amhip_layer_device_ptr(self._h, self._layer_id(layer))
+
+    def as_torch(self, layer):
+        """Zero-copy torch view (cols, rows) of a device-resident layer."""
+        import torch
+        ptr = self.device_ptr(layer)
+        n = self.num_cells
+
+        class _Holder(object):
+            pass
+
+        holder = _Holder()
+        holder.__cuda_array_interface__ = {
+            "shape": (self.grid.cols, self.grid.rows), "typestr": "<f4",
+            "data": (int(ptr), False), "version": 2}
+        holder._keepalive = self
+        assert n > 0
+        return torch.as_tensor(holder, device="cuda:%d" % self.device)
+
+    def reset(self):
+        """AerialGridMap::initialize() constants."""
+        L.check(self._lib.amhip_layers_reset(self._h))
+
+    # -- stream / sync / timing ------------------------------------------
+    def set_stream(self, stream_handle):
+        L.check(self._lib.amhip_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def synchronize(self):
+        """Waits for the GPU and raises if a device-side CHECK fired."""
+        L.check(self._lib.amhip_ctx_synchronize(self._h))
+
+    def enable_timing(self, on=True):
+        L.check(self._lib.amhip_ctx_enable_timing(self._h, int(bool(on))))
+
+    def timing_reset(self):
+        L.check(self._lib.amhip_ctx_timing_reset(self._h))
+
+    def kernel_times(self):
+        """{kernel name: (total_ms, launches)} since the last timing_reset()."""
+        out = {}
+        for k in range(L.NUM_KERNELS):
+            ms, n = C.c_double(), C.c_int64()
+            L.check(self._lib.amhip_ctx_kernel_time(self._h, k, C.byref(ms), C.byref(n)))
+            out[self._lib.amhip_kernel_name(k).decode()] = (ms.value, n.value)
+        return out
+
+    def dsm_stats(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
+        L.check(self._lib.amhip_ctx_dsm_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"points_binned": a.value, "num_bins": b.value, "bin_cells": c.value}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class DsmSettings(object):
+    """dsm::Settings (dsm.h:25-32).  interpolation_radius is an int holding the
+    SQUARED search radius (it is handed to nanoflann's RadiusResultSet as is)."""
+
+    def __init__(self, interpolation_radius=1, adaptive_interpolation=False,
+                 center_easting=0.0, center_northing=0.0, use_multi_threads=True):
+        self.interpolation_radius = int(interpolation_radius)
+        self.adaptive_interpolation = adaptive_interpolation  # unused by the reference too
+        self.center_easting = center_easting
+        self.center_northing = center_northing
+        self.use_multi_threads = use_multi_threads  # both reference variants give one result
+
+
+class Dsm(object):
+    """dsm::Dsm."""
+
+    def __init__(self, settings, map):
+        if map is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(map) (dsm.cc:22)")
+        self.settings = settings
+
+    def process(self, point_cloud, map, sync=True):
+        """point_cloud: (N,3) float64 numpy array (host path, like the reference)
+        or a CUDA torch tensor (device-resident path).  Updates map's
+        'elevation' layer."""
+        if map is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(map) (dsm.cc:194)")
+        s = self.settings
+        lib = L.load()
+        if _is_torch(point_cloud):
+            assert point_cloud.is_cuda and point_cloud.dtype.is_floating_point
+            assert point_cloud.element_size() == 8 and point_cloud.is_contiguous()
+            n = point_cloud.numel() // 3
+            L.check(lib.amhip_dsm_process_dev(
+                map.handle, C.c_void_p(point_cloud.data_ptr()), n,
+                s.interpolation_radius, s.center_easting, s.center_northing))
+            if sync:
+                map.synchronize()
+            return
+        pts = np.ascontiguousarray(point_cloud, np.float64).reshape(-1, 3)
+        if pts.shape[0] == 0:
+            return  # "Passed empty point cloud to DSM module" (dsm.cc:189-192)
+        elev = map.get("elevation")
+        L.check(lib.amhip_dsm_process(map.handle, pts.ctypes.data, pts.shape[0],
+                                      s.interpolation_radius, s.center_easting,
+                                      s.center_northing, elev.ctypes.data))
+        # `elev` is what the reference would have left in the host GridMap; the
+        # device copy is identical.
+
+
+class OrthoSettings(object):
+    """ortho::Settings (ortho-backward-grid.h:32-41); only colored_ortho and
+    use_multi_threads influence the result."""
+
+    def __init__(self, show_orthomosaic_opencv=True, save_orthomosaic_jpg=True,
+                 orthomosaic_jpg_filename="", orthomosaic_elevation_m=0.0,
+                 use_digital_elevation_map=True, colored_ortho=False,
+                 use_multi_threads=True):
+        self.show_orthomosaic_opencv = show_orthomosaic_opencv
+        self.save_orthomosaic_jpg = save_orthomosaic_jpg
+        self.orthomosaic_jpg_filename = orthomosaic_jpg_filename
+        self.orthomosaic_elevation_m = orthomosaic_elevation_m
+        self.use_digital_elevation_map = use_digital_elevation_map
+        self.colored_ortho = colored_ortho
+        self.use_multi_threads = use_multi_threads
+
+
+class NCamera(object):
+    """What the hot path reads from aslam::NCamera: camera 0's pinhole model
+    and T_C_B(0) (7 doubles tx,ty,tz,qw,qx,qy,qz)."""
+
+    def __init__(self, fu, fv, cu, cv, width, height, distortion=L.DIST_NONE,
+                 dist=(0.0, 0.0, 0.0, 0.0), T_C_B=(0, 0, 0, 1, 0, 0, 0)):
+        self.camera = L.Camera()
+        self.camera.fu, self.camera.fv, self.camera.cu, self.camera.cv = fu, fv, cu, cv
+        self.camera.width, self.camera.height = int(width), int(height)
+        self.camera.distortion = int(distortion)
+        for k in range(4):
+            self.camera.dist[k] = float(dist[k])
+        self.T_C_B = np.asarray(T_C_B, np.float64).reshape(7).copy()
+
+
+def compose_T_G_C(T_G_Bs, T_C_B):
+    """T_G_C[i] = T_G_B[i] * T_C_B^-1 (ortho-backward-grid.cc:230-233)."""
+    T = np.ascontiguousarray(T_G_Bs, np.float64).reshape(-1, 7)
+    tcb = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
+    out = np.empty_like(T)
+    f64p = C.POINTER(C.c_double)
+    L.load().amhip_compose_T_G_C(T.ctypes.data_as(f64p), tcb.ctypes.data_as(f64p),
+                                 T.shape[0], out.ctypes.data_as(f64p))
+    return out
+
+
+class OrthoBackwardGrid(object):
+    """ortho::OrthoBackwardGrid."""
+
+    def __init__(self, ncameras, settings, map=None):
+        if ncameras is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(ncameras_) (ortho-backward-grid.cc:27)")
+        if settings.use_multi_threads and map is None:
+            # the reference dereferences the null map here (ortho-backward-grid.cc:34)
+            raise L.AmhipError(L.ERR_ARG, "map must not be null")
+        self.ncameras = ncameras
+        self.settings = settings
+
+    def process(self, T_G_Bs, images, map, sync=True):
+        """T_G_Bs: (F,7).  images: list of numpy uint8 rasters ((H,W) gray or
+        (H,W,3) BGR) for the host path, or one CUDA torch uint8 tensor
+        (F,H,W[,3]) for the device-resident path."""
+        T_G_Bs = np.ascontiguousarray(T_G_Bs, np.float64).reshape(-1, 7)
+        F = T_G_Bs.shape[0]
+        if F == 0:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(!T_G_Bs.empty())")
+        if len(images) != F:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(T_G_Bs.size() == images.size())")
+        if map is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(map)")
+        lib = L.load()
+        cam = self.ncameras.camera
+        colored = bool(self.settings.colored_ortho)
+        T_G_C = compose_T_G_C(T_G_Bs, self.ncameras.T_C_B)
+        f64p = C.POINTER(C.c_double)
+        if _is_torch(images):
+            assert images.is_cuda and images.is_contiguous() and images.element_size() == 1
+            ch = 3 if images.dim() == 4 else 1
+            row = cam.width * ch
+            frame = row * cam.height
+            assert images.shape[1] == cam.height and images.shape[2] == cam.width
+            L.check(lib.amhip_ortho_backward_process_dev(
+                map.handle, C.byref(cam), T_G_C.ctypes.data_as(f64p), F,
+                C.c_void_p(images.data_ptr()), frame, row, ch, int(colored)))
+            if sync:
+                map.synchronize()
+            return
+        ch = 3 if colored else 1
+        ptrs = (C.c_void_p * F)()
+        steps = (C.c_size_t * F)()
+        keep = []
+        for k, im in enumerate(images):
+            im = np.asarray(im)
+            if im.dtype != np.uint8 or im.strides[-1] != 1 or \
+                    (im.ndim == 3 and (im.shape[2] != 3 or im.strides[1] != 3)):
+                im = np.ascontiguousarray(im, np.uint8)
+            if (im.ndim == 3) != colored:
+                raise L.AmhipError(L.ERR_ARG, "colored_ortho needs 8UC3 frames, gray needs 8UC1")
+            keep.append(im)
+            ptrs[k] = im.ctypes.data
+            steps[k] = im.strides[0]
+        # layers are already device resident: pass NULL for all of them
+        L.check(lib.amhip_ortho_backward_process(
+            map.handle, C.byref(cam), T_G_C.ctypes.data_as(f64p), F, ptrs, steps, ch,
+            int(colored), None, None, None, None, None, None))

@@ -82,12 +82,14 @@ def _axis_angle(axis, ang):
 
 
 def make_lawnmower_poses(num_frames, half_extent, altitude, seed,
-                         tilt_deg=5.0, center=(0.0, 0.0), lines=None):
+                         tilt_deg=5.0, center=(0.0, 0.0), lines=None,
+                         yaw_offset=math.pi / 2.0):
     """Nadir-looking lawn-mower flight over [-half_extent, half_extent]^2.
 
-    Camera convention (pinhole, z forward): a level camera flying along +x has
-    R_G_C = Rz(yaw) * Rx(pi), i.e. optical axis pointing at -z (down).  Roll
-    and pitch ~ U(-tilt, tilt) degrees are applied in the camera frame.
+    Camera convention (pinhole, z forward): a level camera has
+    R_G_C = Rz(yaw + yaw_offset) * Rx(pi), i.e. optical axis pointing at -z
+    (down); with the default yaw_offset the long image side lies across track.
+    Roll and pitch ~ U(-tilt, tilt) degrees are applied in the camera frame.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     if lines is None:
@@ -104,7 +106,7 @@ def make_lawnmower_poses(num_frames, half_extent, altitude, seed,
             frac = (s + 0.5) / per_line
             x = (-half_extent + frac * 2.0 * half_extent) * (1.0 if forward else -1.0)
             yaw = 0.0 if forward else math.pi
-            q = _axis_angle((0.0, 0.0, 1.0), yaw)
+            q = _axis_angle((0.0, 0.0, 1.0), yaw + yaw_offset)
             q = _qmul(q, _axis_angle((1.0, 0.0, 0.0), math.pi))
             roll = math.radians(rng.uniform(-tilt_deg, tilt_deg))
             pitch = math.radians(rng.uniform(-tilt_deg, tilt_deg))

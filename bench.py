@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py -- DSM + backward-grid orthomosaic throughput on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch of synthetic input that is
+already resident in HBM:  AerialGridMap::initialize() (layer reset) ->
+dsm::Dsm::process (point cloud -> elevation) -> ortho::OrthoBackwardGrid::process
+(249 frames -> most-nadir view per cell).  Metric = BASELINE.json's
+"Mcells/s (DSM+ortho)": grid cells finished per second, whole job.
+
+Workload at N = 1 (default `cfg3`, BASELINE.json configs[2] = configs[1]'s DSM
++ the ortho layer): 50 M points -> 10 000 x 10 000 cells @ 0.25 m, 249 frames
+1920x1080 8UC1.  With N ranks every rank owns one such tile of a larger survey
+(weak scaling, no data-path collective: cells are independent once a rank
+holds the points within the last fallback radius of its tile, which the
+synthetic generator hands it directly).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description) with
+two extra objects: `roofline` (dominant kernel, algorithmic bytes / measured
+HIP-event time, vs 8 TB/s HBM) and `cpu_baseline` (the CPU oracle timed on a
+bounded sample of the same workload on this box's host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    # name: (cells per side, resolution, points, frames, W, H)
+    "cfg3": dict(side=10000, res=0.25, points=50_000_000, frames=249, W=1920, H=1080,
+                 f=1400.0, altitude=700.0,
+                 desc="50M pts -> 10000x10000 @0.25m DSM (radius_sq=1) + OrthoBackwardGrid, "
+                      "249 frames 1920x1080 8UC1"),
+    "cfg2": dict(side=10000, res=0.25, points=50_000_000, frames=0, W=1920, H=1080,
+                 f=1400.0, altitude=700.0,
+                 desc="50M pts -> 10000x10000 @0.25m DSM only (radius_sq=1)"),
+    "small": dict(side=2000, res=0.25, points=2_000_000, frames=24, W=1920, H=1080,
+                  f=1400.0, altitude=700.0,
+                  desc="2M pts -> 2000x2000 @0.25m DSM + ortho, 24 frames (smoke-size)"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-side", type=int, default=1000,
+                    help="cells per side of the sub-tile the CPU oracle is timed on")
+    ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
+    """Time the CPU oracle (oracle/_ref = vendored nanoflann, else the port) on a
+    corner sub-tile of this rank's workload and check GPU parity on it."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    which = "ref" if O.have_ref() else "port"
+    side, res = wl["side"], wl["res"]
+    s = min(args.cpu_sample_side, side)
+    L = side * res
+    # sub-tile = cells [0,s) x [0,s) of the big grid: its cell centres are
+    # x_i = base_x - res*i with base_x = cx + L/2 - res/2 (all dyadic here)
+    sub_len = s * res
+    sub_cx = tile_center[0] + L / 2.0 - sub_len / 2.0
+    sub_cy = tile_center[1] + L / 2.0 - sub_len / 2.0
+    g = O.make_grid(sub_len, sub_len, res, sub_cx, sub_cy, which=which)
+    assert g.rows == s and g.cols == s
+    halo = 3.0
+    x, y = pts_dev[:, 0], pts_dev[:, 1]
+    keep = (x > sub_cx - sub_len / 2 - halo) & (x < sub_cx + sub_len / 2 + halo) & \
+           (y > sub_cy - sub_len / 2 - halo) & (y < sub_cy + sub_len / 2 + halo)
+    sub_pts = pts_dev[keep].cpu().numpy()
+    t0 = time.time()
+    rc, elev, (t_build, t_cells) = O.dsm_process(sub_pts, g, 1, 0.0, 0.0, which=which)
+    assert rc == 0
+    t_dsm = time.time() - t0
+    t_ortho = 0.0
+    layers = O.new_layers(g)
+    layers["elevation"] = elev
+    F = wl["frames"]
+    if F:
+        frames_host = [f for f in frames_dev.cpu().numpy()]
+        cam = O.Camera()
+        cam.fu, cam.fv, cam.cu, cam.cv = ncam.camera.fu, ncam.camera.fv, ncam.camera.cu, ncam.camera.cv
+        cam.width, cam.height = ncam.camera.width, ncam.camera.height
+        t0 = time.time()
+        rc = O.ortho_process(g, cam, poses, ncam.T_C_B, frames_host, layers,
+                             colored=args.colored, which=which)
+        assert rc == 0
+        t_ortho = time.time() - t0
+    # parity of the GPU result on the same cells
+    gpu_elev = map_.get("elevation")[:s, :s]
+    ok = ~np.isnan(elev)
+    parity = {"cells": int(s * s),
+              "dsm_nan_pattern_equal": bool(np.array_equal(np.isnan(gpu_elev), ~ok)),
+              "dsm_max_abs_err_m": float(np.abs(gpu_elev[ok].astype(np.float64) - elev[ok]).max())
+              if ok.any() else 0.0}
+    if F:
+        for name in ("observation_index", "colored_ortho" if args.colored else "ortho"):
+            a = map_.get(name)[:s, :s]
+            b = layers[name]
+            eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            parity[name + "_mismatch_cells"] = int((~eq).sum())
+    total = t_dsm + t_ortho
+    cores = os.cpu_count() or 1
+    return {"value": round(s * s / total / 1e6, 4), "unit": "Mcells/s", "cores": cores,
+            "kind": "reference" if which == "ref" else "port",
+            "sample": "%dx%d-cell corner sub-tile of the workload (%d pts incl. 3 m halo, "
+                      "all %d frames brute force); kd-tree build %.2fs (1 thread) + cell loop "
+                      "%.2fs + ortho %.2fs, std::thread x hardware_concurrency like "
+                      "utils::parFor" % (s, s, sub_pts.shape[0], F, t_build, t_cells, t_ortho),
+            "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}, parity
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import synth
+
+    wl = WORKLOADS[args.workload]
+    side, res = wl["side"], wl["res"]
+    L = side * res
+    # rank r owns tile r of a 1 x N strip of tiles (weak scaling)
+    tile_center = (rank * L, 0.0)
+    st = A.GridMapSettings(tile_center[0], tile_center[1], L, L, res)
+    m = A.AerialGridMap(st, device=local_rank)
+    m.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # inputs, generated in HBM (synthetic, seeded): the tile's points + 4 m halo
+    pts = synth.make_points_torch(wl["points"], L / 2.0 + 4.0, 43 + rank, dev, center=tile_center)
+    F = wl["frames"]
+    ch = 3 if args.colored else 1
+    frames = poses = ncam = mosaic = None
+    if F:
+        frames = synth.make_frames_torch(F, wl["H"], wl["W"], ch, 44 + rank, dev)
+        poses = synth.make_lawnmower_poses(F, L / 2.0, wl["altitude"], 44 + rank,
+                                           tilt_deg=5.0, center=tile_center)
+        ncam = A.NCamera(wl["f"], wl["f"], (wl["W"] - 1) / 2.0, (wl["H"] - 1) / 2.0,
+                         wl["W"], wl["H"])
+        mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=args.colored), m)
+    dsm = A.Dsm(A.DsmSettings(interpolation_radius=1), m)
+
+    def step():
+        m.reset()
+        dsm.process(pts, m, sync=False)
+        if F:
+            mosaic.process(poses, frames, m, sync=False)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    m.synchronize()  # also surfaces device-side CHECK failures
+    m.enable_timing(True)
+    m.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    m.synchronize()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ktimes = m.kernel_times()
+    m.enable_timing(False)
+
+    cells = side * side
+    value = world * cells * args.steps / dt / 1e6
+
+    if rank == 0:
+        N = wl["points"]
+        b_dsm = 24.0 * N + 4.0 * cells
+        b_ortho = (20.0 * cells + F * wl["W"] * wl["H"] * ch + 56.0 * F) if F else 0.0
+        alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho,
+                     "k_dsm_bin_count": 24.0 * N, "k_dsm_scatter": 48.0 * N}
+        kern = {}
+        for name, (ms, n) in ktimes.items():
+            if n:
+                per_step = ms / args.steps
+                kern[name] = {"ms_per_step": round(per_step, 4), "launches_per_step": n / args.steps}
+        dom = max((k for k in kern if k in alg_bytes and alg_bytes[k] > 0),
+                  key=lambda k: kern[k]["ms_per_step"])
+        dom_ms = kern[dom]["ms_per_step"] / kern[dom]["launches_per_step"]
+        achieved = alg_bytes[dom] / (dom_ms * 1e-3) / 1e9
+        total_alg = b_dsm + b_ortho
+        out = {
+            "metric": "Mcells/s (DSM+ortho)" if F else "Mcells/s (DSM)",
+            "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload + ": " + wl["desc"],
+                       "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
+                       "step": "layers reset + Dsm::process + OrthoBackwardGrid::process, "
+                               "inputs resident in HBM",
+                       "parallelism": "tile-per-gpu x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes[dom],
+                         "kernel_ms": round(dom_ms, 4)},
+            "whole_step_hbm": {"algorithmic_bytes": total_alg,
+                               "achieved_GBs": round(total_alg / (dt / args.steps) / 1e9, 1),
+                               "frac": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            "kernels": kern,
+            "dsm_stats": m.dsm_stats(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
+                out["cpu_baseline"] = cb
+                out["parity_sample"] = parity
+            except Exception as e:  # the GPU number stands on its own
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,234 @@
+/*
+ * aerial_mapper_hip.h -- C ABI of libaerial_mapper_hip.so
+ *
+ * MI355X (gfx950) implementation of aerial_mapper's one data-parallel hot
+ * path: point cloud -> DSM rasterisation and the grid-based backward-projection
+ * orthomosaic.  The reference (ethz-asl/aerial_mapper) has no FFI layer; its
+ * boundary for this path is the C++ class API
+ *
+ *   dsm::Dsm::Dsm / Dsm::process
+ *       aerial_mapper_dsm/include/aerial-mapper-dsm/dsm.h:25-42
+ *       aerial_mapper_dsm/src/dsm.cc:20-34,186-201
+ *   ortho::OrthoBackwardGrid::OrthoBackwardGrid / ::process
+ *       aerial_mapper_ortho/include/aerial-mapper-ortho/ortho-backward-grid.h:32-50
+ *       aerial_mapper_ortho/src/ortho-backward-grid.cc:23-40,223-239
+ *   grid_map::AerialGridMap::initialize (layer set, geometry, init constants)
+ *       aerial_mapper_grid_map/src/aerial-mapper-grid-map.cc:23-49
+ *
+ * which the drop-in C++ classes under include/aerial-mapper-dsm/ and
+ * include/aerial-mapper-ortho/ implement on top of the entry points below
+ * (see INTEGRATION.md).  Everything here is extern "C", POD only: plain
+ * pointers, sizes and two small structs; no C++ / torch / HIP types.
+ *
+ * Conventions
+ *   - A layer is one grid_map::Matrix (Eigen::MatrixXf): float32, column-major,
+ *     rows*cols elements, element (i,j) at i + j*rows.  rows <-> index(0) <->
+ *     x/easting, cols <-> index(1) <-> y/northing.
+ *   - Points are AoS x,y,z doubles, 24 B apart: the memory layout of
+ *     AlignedType<std::vector, Eigen::Vector3d>::type (dsm.h:41).
+ *   - Poses are 7 doubles tx,ty,tz,qw,qx,qy,qz (Hamilton unit quaternion), the
+ *     components of kindr::minimal::QuatTransformation.
+ *   - Images are 8UC1 (gray) or 8UC3 (OpenCV BGR) rasters with a row step in
+ *     bytes (cv::Mat::data / cv::Mat::step).
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP
+ *     device allocations on the context's GPU (e.g. torch tensor data_ptr()).
+ *   - Every function returns an amhip_status (0 = ok) unless noted.  The
+ *     reference aborts through glog CHECK on precondition failures; the C++
+ *     shim turns a non-zero status back into that behaviour.
+ *   - One context serialises its own calls (the caller must not use one
+ *     context from two threads at once); different contexts are independent.
+ */
+#ifndef AERIAL_MAPPER_HIP_H_
+#define AERIAL_MAPPER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMHIP_ABI_VERSION 1
+
+typedef enum amhip_status {
+  AMHIP_OK = 0,
+  AMHIP_ERR_ARG = 1,          /* null / shape / mode error (reference: CHECK) */
+  AMHIP_ERR_EXACT_HIT = 2,    /* a point coincides with a cell centre:
+                                 dsm.cc:165 CHECK(distances[i] > 0.0)        */
+  AMHIP_ERR_ALPHA_NONPOS = 3, /* ortho-backward-grid.cc:178 CHECK(alpha > 0) */
+  AMHIP_ERR_HIP = 4,          /* HIP runtime failure, see amhip_last_error() */
+  AMHIP_ERR_NO_DEVICE = 5,    /* no usable gfx950 device                     */
+  AMHIP_ERR_NOMEM = 6
+} amhip_status;
+
+/* Geometry of the grid_map::GridMap the layers belong to
+ * (grid_map_core GridMap::setGeometry as called by
+ * aerial-mapper-grid-map.cc:30-33; startIndex is always 0 there). */
+typedef struct amhip_grid_desc {
+  int32_t rows;      /* getSize()(0) */
+  int32_t cols;      /* getSize()(1) */
+  double resolution; /* getResolution() */
+  double length_x;   /* getLength().x() = rows * resolution */
+  double length_y;   /* getLength().y() = cols * resolution */
+  double pos_x;      /* getPosition().x() (center_easting)  */
+  double pos_y;      /* getPosition().y() (center_northing) */
+} amhip_grid_desc;
+
+enum {
+  AMHIP_DIST_NONE = 0,
+  AMHIP_DIST_RADTAN = 1,      /* k1,k2,p1,p2 */
+  AMHIP_DIST_EQUIDISTANT = 2  /* k1,k2,k3,k4 */
+};
+
+/* aslam::PinholeCamera of ncameras->getCamera(0)
+ * (ortho-backward-grid.cc:46,131): intrinsics, image size, distortion. */
+typedef struct amhip_camera {
+  double fu, fv, cu, cv;
+  int32_t width;
+  int32_t height;
+  int32_t distortion; /* AMHIP_DIST_* */
+  int32_t _pad;
+  double dist[4];
+} amhip_camera;
+
+/* The layers of AerialGridMap the hot path reads or writes
+ * (aerial-mapper-grid-map.cc:25-28). */
+typedef enum amhip_layer {
+  AMHIP_LAYER_ORTHO = 0,
+  AMHIP_LAYER_ELEVATION = 1,
+  AMHIP_LAYER_ELEVATION_ANGLE = 2,
+  AMHIP_LAYER_NUM_OBSERVATIONS = 3,
+  AMHIP_LAYER_OBSERVATION_INDEX = 4,
+  AMHIP_LAYER_COLORED_ORTHO = 5,
+  AMHIP_NUM_LAYERS = 6
+} amhip_layer;
+
+typedef struct amhip_ctx amhip_ctx; /* opaque: GPU, stream, layers, workspaces */
+
+/* ---- library / context ---------------------------------------------------*/
+
+int amhip_abi_version(void);
+
+/* Message of the last failing call on this thread ("" if none). */
+const char* amhip_last_error(void);
+
+/* grid_map_core GridMap::setGeometry: size = (int)round(length/resolution),
+ * length := size*resolution.  Pure host helper. */
+void amhip_make_grid(double length_x, double length_y, double resolution,
+                     double pos_x, double pos_y, amhip_grid_desc* out);
+
+/* grid_map_core GridMap::getPosition(index): centre of cell (i,j). */
+void amhip_cell_position(const amhip_grid_desc* grid, int i, int j, double* x,
+                         double* y);
+
+/* Replaces the per-cell bookkeeping of dsm.cc:24-33 and
+ * ortho-backward-grid.cc:30-39 (the GPU needs only the geometry).  Allocates
+ * the six layers on GPU `device` and sets them to AerialGridMap::initialize()'s
+ * constants (ortho 255, elevation NaN, elevation_angle 0, num_observations 0,
+ * observation_index NaN, colored_ortho NaN). */
+int amhip_ctx_create(const amhip_grid_desc* grid, int device, amhip_ctx** out);
+void amhip_ctx_destroy(amhip_ctx* ctx);
+
+/* Run the context's kernels on an existing HIP stream (hipStream_t passed as
+ * void*; NULL = back to the context's own stream). */
+int amhip_ctx_set_stream(amhip_ctx* ctx, void* hip_stream);
+
+/* Wait for everything enqueued on the context and return the sticky status
+ * of the device-side CHECKs (EXACT_HIT / ALPHA_NONPOS) or HIP errors since
+ * the last synchronize; the status is then cleared. */
+int amhip_ctx_synchronize(amhip_ctx* ctx);
+
+/* ---- layers (device resident; persist across process() calls like the
+ *      GridMap's matrices do in incremental mode,
+ *      main-ortho-backward-grid-incremental.cc:153-162) --------------------*/
+
+int amhip_layers_reset(amhip_ctx* ctx); /* AerialGridMap::initialize() values */
+int amhip_layer_upload(amhip_ctx* ctx, int layer, const float* host);
+int amhip_layer_download(amhip_ctx* ctx, int layer, float* host);
+/* Device address of a layer (rows*cols floats) or NULL. */
+void* amhip_layer_device_ptr(amhip_ctx* ctx, int layer);
+
+/* ---- DSM: dsm::Dsm::process (dsm.cc:186-201) ----------------------------*/
+
+/* Asynchronous, device-resident form.  dev_xyz: n points on the context's
+ * GPU.  Updates the context's ELEVATION layer exactly where the reference
+ * would (cells with no point inside the last fallback radius stay untouched).
+ * n == 0 is the reference's soft no-op.  radius_sq is
+ * dsm::Settings::interpolation_radius (an int holding the SQUARED search
+ * radius in m^2); center_* are dsm::Settings::center_easting/northing
+ * (note dsm.cc:42-43 subtracts center_northing from x and center_easting
+ * from y -- reproduced). */
+int amhip_dsm_process_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
+                          int radius_sq, double center_easting,
+                          double center_northing);
+
+/* Synchronous drop-in form on host buffers: uploads `elevation` (the map's
+ * current layer), copies the cloud to the GPU, runs the DSM, downloads the
+ * layer back into `elevation`, returns the final status. */
+int amhip_dsm_process(amhip_ctx* ctx, const double* host_xyz, size_t n,
+                      int radius_sq, double center_easting,
+                      double center_northing, float* elevation);
+
+/* ---- Ortho: ortho::OrthoBackwardGrid::process
+ *      (ortho-backward-grid.cc:223-239) ------------------------------------*/
+
+/* T_G_C[i] = T_G_B[i] * T_C_B^-1 (ortho-backward-grid.cc:230-233) with
+ * minkindr's composition / inverse.  Pure host helper (F poses of 7). */
+void amhip_compose_T_G_C(const double* T_G_B, const double* T_C_B, size_t F,
+                         double* T_G_C);
+
+/* Asynchronous, device-resident form.  host_T_G_C: F x 7 doubles on the host
+ * (small; copied).  dev_frames: F rasters on the GPU, frame f starts at
+ * dev_frames + f*frame_stride, rows are row_step bytes apart, `channels` is 1
+ * (8UC1) or 3 (8UC3 BGR).  colored = ortho::Settings::colored_ortho (needs
+ * channels == 3; gray needs channels == 1).  Reads the ELEVATION layer, folds
+ * the F frames in ascending order into ELEVATION_ANGLE / OBSERVATION_INDEX /
+ * NUM_OBSERVATIONS and ORTHO or COLORED_ORTHO of the context. */
+int amhip_ortho_backward_process_dev(amhip_ctx* ctx, const amhip_camera* cam,
+                                     const double* host_T_G_C, size_t F,
+                                     const uint8_t* dev_frames,
+                                     size_t frame_stride, size_t row_step,
+                                     int channels, int colored);
+
+/* Synchronous drop-in form on host buffers: uploads the six layers given
+ * (any may be NULL = keep the context's copy), stages the images on the GPU,
+ * runs the mosaic, downloads the five output layers that are non-NULL. */
+int amhip_ortho_backward_process(
+    amhip_ctx* ctx, const amhip_camera* cam, const double* host_T_G_C, size_t F,
+    const uint8_t* const* images, const size_t* steps, int channels,
+    int colored, const float* elevation, float* elevation_angle,
+    float* observation_index, float* num_observations, float* ortho,
+    float* colored_ortho);
+
+/* ---- measurement ----------------------------------------------------------*/
+
+/* Kernel slots for amhip_ctx_kernel_time(). */
+typedef enum amhip_kernel {
+  AMHIP_K_DSM_BIN_COUNT = 0, /* points -> bin histogram + rank            */
+  AMHIP_K_DSM_SCAN = 1,      /* exclusive scan of the histogram (3 launches) */
+  AMHIP_K_DSM_SCATTER = 2,   /* points -> bin-sorted order                 */
+  AMHIP_K_DSM_GATHER = 3,    /* per-cell radius search + IDW               */
+  AMHIP_K_ORTHO = 4,         /* per-tile frame cull + per-cell fold/sample */
+  AMHIP_K_MISC = 5,          /* memsets / small helpers                    */
+  AMHIP_NUM_KERNELS = 6
+} amhip_kernel;
+
+/* With timing enabled every launch is bracketed by hipEvents on the
+ * context's stream.  amhip_ctx_kernel_time() synchronises, then reports the
+ * accumulated milliseconds and launch count of one slot since the last
+ * amhip_ctx_timing_reset(). */
+int amhip_ctx_enable_timing(amhip_ctx* ctx, int on);
+int amhip_ctx_timing_reset(amhip_ctx* ctx);
+int amhip_ctx_kernel_time(amhip_ctx* ctx, int kernel, double* total_ms,
+                          int64_t* launches);
+const char* amhip_kernel_name(int kernel);
+
+/* Counters of the last amhip_dsm_process*: points kept after the bin-range
+ * filter, number of bins, bin edge in cells. */
+int amhip_ctx_dsm_stats(amhip_ctx* ctx, int64_t* points_binned,
+                        int64_t* num_bins, int32_t* bin_cells);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AERIAL_MAPPER_HIP_H_ */

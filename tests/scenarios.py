@@ -1,0 +1,60 @@
+"""Seeded small scenarios shared by the CPU and GPU test-suites."""
+import numpy as np
+
+import oracle_ffi as O
+from aerial_mapper_amd import synth
+
+
+def camera(width=192, height=108, f=140.0, distortion=O.DIST_NONE, dist=(0, 0, 0, 0)):
+    c = O.Camera()
+    c.fu = c.fv = f
+    c.cu = (width - 1) / 2.0
+    c.cv = (height - 1) / 2.0
+    c.width, c.height = width, height
+    c.distortion = distortion
+    for k in range(4):
+        c.dist[k] = float(dist[k])
+    return c
+
+
+class Scene(object):
+    """A DSM + ortho scenario: grid, cloud, camera, poses, frames."""
+
+    def __init__(self, length_x, length_y, res, n_points, seed, center=(0.0, 0.0),
+                 num_frames=12, cam=None, altitude=700.0, colored=False, tilt_deg=5.0,
+                 point_extent=None):
+        self.grid = O.make_grid(length_x, length_y, res, center[0], center[1])
+        half = max(length_x, length_y) / 2.0 + 4.0 if point_extent is None else point_extent
+        self.points = synth.make_points(n_points, half, seed, center=center)
+        self.cam = cam or camera()
+        self.colored = colored
+        self.poses = synth.make_lawnmower_poses(num_frames, 0.45 * min(length_x, length_y),
+                                                altitude, seed + 1, tilt_deg=tilt_deg,
+                                                center=center)
+        ch = 3 if colored else 1
+        fr = synth.make_frames(num_frames, self.cam.height, self.cam.width, ch, salt=seed % 7)
+        self.frames = [np.ascontiguousarray(fr[k]) for k in range(num_frames)]
+        self.T_C_B = synth.IDENTITY_POSE.copy()
+        self.center = center
+
+
+def assert_dsm_close(got, want, tol=1e-4):
+    """DSM parity: identical NaN pattern, heights within `tol` metres
+    (north_star: 1e-4 m).  Returns the fraction of bit-identical cells."""
+    assert got.shape == want.shape
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), "NaN pattern differs in %d cells" % int((gn != wn).sum())
+    ok = ~wn
+    if ok.any():
+        err = np.abs(got[ok].astype(np.float64) - want[ok].astype(np.float64)).max()
+        assert err <= tol, "max |dh| = %g m" % err
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (gn & wn)
+    return float(same.mean())
+
+
+def assert_layers_equal(got, want, names):
+    for n in names:
+        a, b = got[n], want[n]
+        eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert eq.all(), "layer %s differs in %d cells (first at %s)" % (
+            n, int((~eq).sum()), np.argwhere(~eq)[0])
