@@ -78,6 +78,15 @@ def load():
         raise ImportError(
             "%s is missing: run `python -m aerial_mapper_amd.build` "
             "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 /
+    # libhsa-runtime64.  If torch is importable, load it FIRST so that this
+    # library binds (by SONAME) to the runtime torch uses -- device pointers and
+    # streams are then shareable, and the second runtime that would otherwise
+    # come up blind ("No HIP GPUs are available") never exists.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, f64p, f32p = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
     gp, cp = C.POINTER(GridDesc), C.POINTER(Camera)
