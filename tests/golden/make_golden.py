@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz -- small input/output vectors of the hot path.
+
+The reference has no tests or fixtures of its own, so
+these are produced HERE by the strongest checker available in the build
+container: oracle/_ref/liboracle_ref.so = the reference's VENDORED nanoflann
+(kd-tree build + radius search, compiled from /root/reference where it lies)
+driven by the restated dsm.cc / ortho-backward-grid.cc loops.  The fixtures
+travel to the GPU box, where /root/reference does not exist.
+
+    python tests/golden/make_golden.py        (needs /root/reference)
+
+Inputs are stored verbatim (not as seeds) so the fixtures do not depend on
+numpy's generators staying bit-stable.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_ffi as O  # noqa: E402
+import scenarios as S  # noqa: E402
+from aerial_mapper_amd import synth  # noqa: E402
+
+WHICH = "ref"
+
+
+def grid_tuple(g):
+    return np.array([g.length_x, g.length_y, g.resolution, g.pos_x, g.pos_y], np.float64)
+
+
+def cam_tuple(c):
+    return np.array([c.fu, c.fv, c.cu, c.cv, c.width, c.height, c.distortion] + list(c.dist),
+                    np.float64)
+
+
+def dsm_case(name, length_x, length_y, res, n, seed, radius=1, ce=0.0, cn=0.0,
+             center=(0.0, 0.0), keep=None, extent=None, init=None):
+    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=WHICH)
+    half = (max(length_x, length_y) / 2.0 + 4.0) if extent is None else extent
+    pts = synth.make_points(n, half, seed, center=center)
+    if keep is not None:
+        pts = np.ascontiguousarray(pts[keep(pts)])
+    elev0 = None
+    if init is not None:
+        elev0 = init(g)
+    rc, elev, _ = O.dsm_process(pts, g, radius, ce, cn,
+                                elevation=None if elev0 is None else elev0.copy(), which=WHICH)
+    assert rc == O.OK, rc
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="dsm", grid=grid_tuple(g),
+                        points=pts, radius_sq=radius, center_easting=ce, center_northing=cn,
+                        elevation_init=np.zeros(0, np.float32) if elev0 is None else elev0,
+                        elevation=elev)
+    print("%-28s %4dx%-4d pts=%6d  NaN cells=%d" % (name, g.rows, g.cols, pts.shape[0],
+                                                   int(np.isnan(elev).sum())))
+
+
+def ortho_case(name, length_x, length_y, res, n, seed, num_frames, altitude, colored=False,
+               cam=None, batches=None, keep=None, nobs_init=0.0):
+    sc = S.Scene(length_x, length_y, res, n, seed, num_frames=num_frames, altitude=altitude,
+                 colored=colored, cam=cam or S.camera(96, 54, 70.0))
+    if keep is not None:
+        sc.points = np.ascontiguousarray(sc.points[keep(sc.points)])
+    rc, elev, _ = O.dsm_process(sc.points, sc.grid, which=WHICH)
+    assert rc == O.OK
+    layers = O.new_layers(sc.grid)
+    layers["elevation"] = elev
+    layers["num_observations"][:] = nobs_init
+    batches = batches or [(0, num_frames)]
+    for lo, hi in batches:
+        rc = O.ortho_process(sc.grid, sc.cam, sc.poses[lo:hi], sc.T_C_B, sc.frames[lo:hi], layers,
+                             colored=colored, which=WHICH)
+        assert rc == O.OK
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), kind="ortho", grid=grid_tuple(sc.grid),
+        camera=cam_tuple(sc.cam), T_G_B=sc.poses, T_C_B=sc.T_C_B, frames=np.stack(sc.frames),
+        colored=colored, batches=np.array(batches, np.int64), num_observations_init=nobs_init,
+        elevation=elev, elevation_angle=layers["elevation_angle"],
+        observation_index=layers["observation_index"],
+        num_observations=layers["num_observations"], ortho=layers["ortho"],
+        colored_ortho=layers["colored_ortho"])
+    cov = float((~np.isnan(layers["observation_index"])).mean())
+    print("%-28s %4dx%-4d F=%d coverage=%.3f" % (name, sc.grid.rows, sc.grid.cols, num_frames, cov))
+
+
+def main():
+    if not O.have_ref():
+        raise SystemExit("oracle/_ref/liboracle_ref.so missing: run `make -C oracle` where "
+                         "/root/reference exists")
+    assert O.lib("ref").amo_uses_vendored_nanoflann() == 1
+    dsm_case("dsm_sparse_1m", 70.0, 50.0, 1.0, 3800, 101)
+    dsm_case("dsm_dense_quarter", 16.0, 12.0, 0.25, 2600, 102, extent=10.0)
+    dsm_case("dsm_holes_ladder", 60.0, 40.0, 0.5, 700, 103)
+    dsm_case("dsm_left_half_only", 48.0, 36.0, 0.5, 5000, 104, keep=lambda p: p[:, 0] < -6.0)
+    dsm_case("dsm_radius3_offsets", 40.0, 30.0, 0.5, 4000, 105, radius=3, ce=5.5, cn=-2.25,
+             center=(5.5, -2.25), extent=32.0)
+    dsm_case("dsm_incremental_overwrite", 40.0, 30.0, 0.5, 900, 106,
+             keep=lambda p: p[:, 1] > 2.0,
+             init=lambda g: np.full((g.cols, g.rows), 123.5, np.float32))
+    cam_small = S.camera(96, 54, 70.0)
+    ortho_case("ortho_gray", 70.0, 50.0, 1.0, 9000, 201, 7, 470.0)
+    ortho_case("ortho_colored", 60.0, 44.0, 1.0, 7000, 202, 6, 470.0, colored=True)
+    ortho_case("ortho_incremental_3batches", 70.0, 50.0, 1.0, 9000, 203, 9, 470.0,
+               batches=[(0, 3), (3, 7), (7, 9)], nobs_init=0.75)
+    ortho_case("ortho_nan_elevation", 60.0, 44.0, 1.0, 2500, 204, 5, 480.0,
+               keep=lambda p: p[:, 0] < 4.0)
+    ortho_case("ortho_radtan", 50.0, 40.0, 1.0, 5000, 205, 5, 470.0,
+               cam=S.camera(96, 54, 70.0, O.DIST_RADTAN, (-0.28, 0.07, 2e-4, -1e-4)))
+    del cam_small
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,304 @@
+"""CPU tests of the oracle (no GPU): golden vectors, known-answer tests derived
+from the reference's code, own kd-tree vs the vendored
+nanoflann build."""
+import numpy as np
+import pytest
+
+import golden_io as G
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+F32 = np.float32
+
+
+# ---------------------------------------------------------------------------
+# golden vectors (generated with the vendored-nanoflann build)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", G.names("dsm"))
+def test_port_reproduces_golden_dsm_bitwise(name):
+    d = G.load(name)
+    g = G.grid_of(d)
+    init = d["elevation_init"]
+    elev0 = init.copy() if init.size else None
+    rc, elev, _ = O.dsm_process(d["points"], g, int(d["radius_sq"]), float(d["center_easting"]),
+                                float(d["center_northing"]), elevation=elev0)
+    assert rc == O.OK
+    assert G.bits_equal(elev, d["elevation"]).all()
+
+
+@pytest.mark.parametrize("name", G.names("ortho"))
+def test_port_reproduces_golden_ortho_bitwise(name):
+    d = G.load(name)
+    g, cam = G.grid_of(d), G.camera_of(d)
+    layers = O.new_layers(g)
+    layers["elevation"] = d["elevation"].copy()
+    layers["num_observations"][:] = float(d["num_observations_init"])
+    frames = [np.ascontiguousarray(f) for f in d["frames"]]
+    for lo, hi in d["batches"]:
+        rc = O.ortho_process(g, cam, d["T_G_B"][lo:hi], d["T_C_B"], frames[lo:hi], layers,
+                             colored=bool(d["colored"]))
+        assert rc == O.OK
+    for n in G.ORTHO_LAYERS:
+        assert G.bits_equal(layers[n], d[n]).all(), n
+
+
+# ---------------------------------------------------------------------------
+# own kd-tree == vendored nanoflann, bit for bit (only where _ref was built)
+# ---------------------------------------------------------------------------
+needs_ref = pytest.mark.skipif(not O.have_ref(), reason="oracle/_ref not built (no /root/reference)")
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,res,n", [(1, 1.0, 20000), (2, 0.5, 30000), (3, 0.25, 40000)])
+def test_port_equals_vendored_nanoflann(seed, res, n):
+    g = O.make_grid(90.0, 70.0, res)
+    pts = synth.make_points(n, 50.0, seed)
+    # duplicates and coordinate ties stress the three-way partition
+    pts[: n // 50, 0] = np.round(pts[: n // 50, 0])
+    pts[n // 50: n // 25] = pts[: n // 25 - n // 50] + (1e-3, 0.0, 0.0)
+    a = O.dsm_process(pts, g, which="port")
+    b = O.dsm_process(pts, g, which="ref")
+    assert a[0] == b[0] == O.OK
+    assert G.bits_equal(a[1], b[1]).all()
+
+
+@needs_ref
+def test_port_visits_neighbours_in_nanoflann_order():
+    pts = synth.make_points(5000, 30.0, 9)
+    for q in [(0.3, -4.1), (29.0, 29.5), (-31.0, 2.0), (100.0, 100.0)]:
+        n1, i1, d1 = O.radius_probe(pts, q[0], q[1], 6.25, which="port")
+        n2, i2, d2 = O.radius_probe(pts, q[0], q[1], 6.25, which="ref")
+        assert n1 == n2 and np.array_equal(i1, i2) and np.array_equal(d1, d2)
+
+
+# ---------------------------------------------------------------------------
+# known-answer tests derived from the reference's code
+# ---------------------------------------------------------------------------
+def _grid10():
+    g = O.make_grid(10.0, 8.0, 1.0)
+    assert (g.rows, g.cols) == (10, 8)
+    return g
+
+
+def _far_filler():
+    # keeps the kd-tree non-trivial without coming near the probed cells
+    return [[100.0 + k, 100.0, 5.0] for k in range(25)]
+
+
+def test_kat_geometry_and_iteration_order():
+    g = O.make_grid(10.2, 7.6, 0.5, 3.0, -2.0)   # size = round(length/res)
+    assert (g.rows, g.cols) == (20, 15)
+    assert g.length_x == 10.0 and g.length_y == 7.5
+    # x = cE + (Lx/2 - res/2) - res*i ; y = cN + (Ly/2 - res/2) - res*j
+    assert O.cell_position(g, 0, 0) == (3.0 + 5.0 - 0.25, -2.0 + 3.75 - 0.25)
+    assert O.cell_position(g, 19, 14) == (3.0 - 5.0 + 0.25, -2.0 - 3.75 + 0.25)
+
+
+def test_kat_single_thread_equals_multi_thread():
+    sc = S.Scene(60.0, 40.0, 0.5, 12000, seed=5)
+    a = O.dsm_process(sc.points, sc.grid, multi_thread=True)[1]
+    b = O.dsm_process(sc.points, sc.grid, multi_thread=False)[1]
+    c = O.dsm_process(sc.points, sc.grid, multi_thread=True, num_threads=3)[1]
+    assert G.bits_equal(a, b).all() and G.bits_equal(a, c).all()
+
+
+def test_kat_single_point_and_strict_radius():
+    g = _grid10()
+    cx, cy = O.cell_position(g, 4, 3)
+    # (2) one point at offset (0.3, 0.4): d2 = 0.25 < 1 -> cell = z exactly
+    pts = np.array([[cx + 0.3, cy + 0.4, 17.25]] + _far_filler())
+    rc, e, _ = O.dsm_process(pts, g)
+    assert rc == O.OK and e[3, 4] == F32(17.25)
+    # a point at distance exactly 1.0 is NOT inside T = 1 (strict <) but inside
+    # the lambda = 1.1 retry
+    pts = np.array([[cx + 1.0, cy, 33.0]] + _far_filler())
+    n, _, _ = O.radius_probe(pts, cx, cy, 1.0)
+    assert n == 0
+    rc, e, _ = O.dsm_process(pts, g)
+    assert e[3, 4] == F32(33.0)
+    # ... whereas a neighbour inside T = 1 wins over it: no fallback then
+    pts = np.array([[cx + 1.0, cy, 33.0], [cx - 0.5, cy, 10.0]] + _far_filler())
+    rc, e, _ = O.dsm_process(pts, g)
+    assert e[3, 4] == F32(10.0)
+
+
+def test_kat_idw_weights_are_inverse_squared_distance():
+    g = _grid10()
+    cx, cy = O.cell_position(g, 2, 5)
+    # (3) z=10 @ d2=0.25, z=20 @ d2=0.5 -> (10/0.25 + 20/0.5)/(1/0.25 + 1/0.5)
+    s = np.sqrt(0.5)
+    pts = np.array([[cx + 0.5, cy, 10.0], [cx, cy + s, 20.0]] + _far_filler())
+    rc, e, _ = O.dsm_process(pts, g)
+    d2b = (cy - (cy + s)) ** 2
+    want = (10.0 / 0.25 + 20.0 / d2b) / (1.0 / 0.25 + 1.0 / d2b)
+    assert rc == O.OK and e[5, 2] == F32(want)
+    assert abs(float(e[5, 2]) - 13.3333333) < 1e-5
+
+
+def test_kat_last_fallback_radius():
+    g = _grid10()
+    cx, cy = O.cell_position(g, 5, 4)
+    # (4) last threshold for R = 1 is 1.1^20 (computed by repeated *= 1.1)
+    lam, last = 1.0, None
+    while True:
+        last = lam * 1
+        lam *= 1.1
+        if lam * 1 > 7.0:
+            break
+    assert abs(last - 6.7275) < 1e-4
+    for d2, filled in ((6.72, True), (6.73, False)):
+        pts = np.array([[cx + np.sqrt(d2), cy, 50.0]] + _far_filler())
+        rc, e, _ = O.dsm_process(pts, g)
+        assert rc == O.OK
+        assert (not np.isnan(e[4, 5])) == filled, d2
+
+
+def test_kat_exact_hit_is_a_check_failure():
+    g = _grid10()
+    cx, cy = O.cell_position(g, 1, 1)
+    pts = np.array([[cx, cy, 5.0]] + _far_filler())
+    rc, _, _ = O.dsm_process(pts, g)
+    assert rc == O.ERR_EXACT_HIT
+
+
+def test_kat_empty_cloud_is_a_noop():
+    g = _grid10()
+    e0 = np.full((g.cols, g.rows), 7.0, F32)
+    rc, e, _ = O.dsm_process(np.zeros((0, 3)), g, elevation=e0.copy())
+    assert rc == O.OK and np.array_equal(e, e0)
+
+
+# ---- ortho ------------------------------------------------------------------
+
+
+def _nadir_pose(x, y, z):
+    # R_G_C = Rx(pi): camera x = world x, camera y = -world y, optical axis down
+    return np.array([x, y, z, 0.0, 1.0, 0.0, 0.0])
+
+
+def _flat(g, h=100.0):
+    L = O.new_layers(g)
+    L["elevation"][:] = h
+    return L
+
+
+def test_kat_nadir_view_angle_and_float_rounded_fold():
+    g = O.make_grid(9.0, 7.0, 1.0)
+    cam = S.camera(64, 48, 40.0)
+    cx, cy = O.cell_position(g, 4, 3)
+    L = _flat(g)
+    img = np.full((48, 64), 9, np.uint8)
+    # (5) cell under the principal point: alpha = pi/2 stored as float
+    rc = O.ortho_process(g, cam, [_nadir_pose(cx, cy, 130.0)], synth.IDENTITY_POSE, [img], L)
+    assert rc == O.OK
+    assert L["elevation_angle"][3, 4] == F32(np.pi / 2) == F32(1.5707964)
+    assert L["observation_index"][3, 4] == 0.0 and L["ortho"][3, 4] == 9.0
+    # a later frame whose alpha lies in (best_double, (double)(float)best] must
+    # NOT replace: float(pi/2) > pi/2, so an identical second view never wins
+    img2 = np.full((48, 64), 77, np.uint8)
+    rc = O.ortho_process(g, cam, [_nadir_pose(cx, cy, 130.0)], synth.IDENTITY_POSE, [img2], L)
+    assert L["ortho"][3, 4] == 9.0
+
+
+def test_kat_fold_is_order_dependent_and_index_is_per_batch():
+    g = O.make_grid(9.0, 7.0, 1.0)
+    cam = S.camera(64, 48, 40.0)
+    cx, cy = O.cell_position(g, 4, 3)
+    imgs = [np.full((48, 64), v, np.uint8) for v in (10, 20, 30)]
+    poses = [_nadir_pose(cx + 3.0, cy, 130.0), _nadir_pose(cx + 0.5, cy, 130.0),
+             _nadir_pose(cx + 1.5, cy, 130.0)]
+    L = _flat(g)
+    O.ortho_process(g, cam, poses, synth.IDENTITY_POSE, imgs, L)
+    assert L["observation_index"][3, 4] == 1.0 and L["ortho"][3, 4] == 20.0
+    # (9) second batch with lower angles leaves the cell untouched
+    keep = {k: v.copy() for k, v in L.items()}
+    O.ortho_process(g, cam, [poses[0], poses[2]], synth.IDENTITY_POSE, [imgs[0], imgs[2]], L)
+    assert L["ortho"][3, 4] == 20.0 and L["observation_index"][3, 4] == 1.0
+    assert G.bits_equal(L["elevation_angle"], keep["elevation_angle"]).all()
+    # ... and a better view in a later batch reports its index WITHIN that batch
+    O.ortho_process(g, cam, [poses[0], _nadir_pose(cx, cy, 130.0)], synth.IDENTITY_POSE,
+                    [imgs[0], imgs[2]], L)
+    assert L["observation_index"][3, 4] == 1.0 and L["ortho"][3, 4] == 30.0
+
+
+def test_kat_pixel_rounding_and_image_box():
+    cam = S.camera(64, 48, 40.0)
+    T = _nadir_pose(0.0, 0.0, 40.0)   # depth 40 -> 1 px per metre
+    # (6) u = W - 0.4 is visible, round() -> W, clamped to W - 1
+    u_target = 64 - 0.4
+    x = (u_target - cam.cu) * 40.0 / 40.0
+    r = O.project_probe(cam, T, [x, 0.0, 0.0])
+    assert abs(r["u"] - u_target) < 1e-9 and r["status"] == 0
+    assert int(round(r["u"])) == 64
+    # u = -0.2 is not visible even though round() -> 0
+    r = O.project_probe(cam, T, [(-0.2 - cam.cu), 0.0, 0.0])
+    assert abs(r["u"] + 0.2) < 1e-9 and r["status"] == 1
+    # behind the camera
+    r = O.project_probe(cam, T, [0.0, 0.0, 50.0])
+    assert r["status"] == 2
+    g = O.make_grid(80.0, 8.0, 1.0)
+    L = _flat(g, 0.0)
+    img = np.zeros((48, 64), np.uint8)
+    img[:, 63] = 200
+    img[:, 0] = 100
+    O.ortho_process(g, cam, [T], synth.IDENTITY_POSE, [img], L)
+    # cells whose u rounds to 64 sample column 63
+    xs = np.array([O.cell_position(g, i, 0)[0] for i in range(g.rows)])
+    us = xs + cam.cu
+    edge = np.where((us > 63.5) & (us < 64.0))[0]
+    for i in edge:
+        assert L["ortho"][4, i] == 200.0
+    outside = np.where(us < 0.0)[0]
+    assert outside.size and (L["ortho"][4, outside] == 255.0).all()
+
+
+def test_kat_nan_elevation_and_color_packing():
+    g = O.make_grid(9.0, 7.0, 1.0)
+    cam = S.camera(64, 48, 40.0)
+    cx, cy = O.cell_position(g, 4, 3)
+    L = _flat(g)
+    L["elevation"][3, 4] = np.nan
+    img = np.zeros((48, 64, 3), np.uint8)
+    img[..., 0], img[..., 1], img[..., 2] = 1, 2, 3   # B, G, R
+    rc = O.ortho_process(g, cam, [_nadir_pose(cx, cy, 130.0)], synth.IDENTITY_POSE, [img], L,
+                         colored=True)
+    assert rc == O.OK
+    # (7) NaN elevation -> untouched
+    assert np.isnan(L["colored_ortho"][3, 4]) and L["elevation_angle"][3, 4] == 0.0
+    assert np.isnan(L["observation_index"][3, 4])
+    # (8) BGR = (1,2,3) -> float bits 0x00030201; gray layer untouched
+    assert L["colored_ortho"][3, 5].view(np.uint32) == 0x00030201
+    assert (L["ortho"] == 255.0).all()
+    # the x255 truncation of the reference's byte/255.0 chain is exact for all bytes
+    for b in range(256):
+        v = O.color_value_bgr(b, 255 - b, (7 * b) & 255)
+        assert int(np.float32(v).view(np.uint32)) == (((7 * b) & 255) << 16) | ((255 - b) << 8) | b
+
+
+def test_kat_num_observations_plus_equals_itself():
+    g = O.make_grid(9.0, 7.0, 1.0)
+    cam = S.camera(64, 48, 40.0)
+    cx, cy = O.cell_position(g, 4, 3)
+    L = _flat(g)
+    img = np.zeros((48, 64), np.uint8)
+    O.ortho_process(g, cam, [_nadir_pose(cx, cy, 130.0)], synth.IDENTITY_POSE, [img], L)
+    assert (L["num_observations"] == 0.0).all()     # 0 += 0
+    L = _flat(g)
+    L["num_observations"][:] = 1.25
+    O.ortho_process(g, cam, [_nadir_pose(cx + 2, cy, 130.0), _nadir_pose(cx, cy, 130.0)],
+                    synth.IDENTITY_POSE, [img, img], L)
+    assert L["num_observations"][3, 4] == 5.0       # accepted twice: 1.25 * 4
+
+
+def test_kat_pose_composition():
+    rng = np.random.default_rng(3)
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    T_C_B = np.concatenate([[0.1, -0.2, 0.05], q])
+    T_G_B = np.array([[5.0, 6.0, 7.0, 1.0, 0.0, 0.0, 0.0]])
+    T_G_C = O.compose_T_G_C(T_G_B, T_C_B)[0]
+    # T_G_C * T_C_B == T_G_B: camera origin expressed in G
+    cam = S.camera()
+    r = O.project_probe(cam, T_G_C, T_G_C[:3])
+    assert np.allclose(r["C"], 0.0, atol=1e-12)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases (kernel trace and/or PMC passes).
+
+  python tools/rocprof_summary.py --trace DB [--fetch DB] [--write DB] [-o OUT.md]
+
+Prints per-kernel launch count / avg / min / max / total duration for the
+library's own kernels (amhip::*) and, when PMC passes are given, the
+FETCH_SIZE / WRITE_SIZE per launch.  FETCH_SIZE / WRITE_SIZE are reported by
+rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-B requests at 64 B, so the
+corrected read traffic of a wide streaming kernel is 2 x FETCH_SIZE
+(/opt/skills/guides/MI355X_MICROARCH.md, section HBM).
+"""
+import argparse
+import sqlite3
+import sys
+
+
+def short(name):
+    name = name.split("(")[0]
+    return name.replace("amhip::", "")
+
+
+def kernel_rows(db_path):
+    db = sqlite3.connect(db_path)
+    q = ("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
+         "from kernels where name like 'amhip::%' group by name order by 6 desc")
+    rows = list(db.execute(q))
+    tot = list(db.execute("select sum(end-start) from kernels"))[0][0]
+    return rows, tot
+
+
+def pmc_rows(db_path, counter):
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info(pmc_events)")]
+    name_col = "counter_name" if "counter_name" in cols else "pmc_name" if "pmc_name" in cols else None
+    if name_col is None:
+        raise SystemExit("unexpected pmc_events schema: %s" % cols)
+    val_col = "value" if "value" in cols else "counter_value"
+    kcol = "name" if "name" in cols else "kernel_name"
+    q = ("select {k}, count(*), avg(v), min(v), max(v) from (select {k}, dispatch_id, sum({v}) as v "
+         "from pmc_events where {n} = ? and {k} like 'amhip::%' group by {k}, dispatch_id) "
+         "group by {k}").format(k=kcol, v=val_col, n=name_col)
+    return {short(r[0]): r[1:] for r in db.execute(q, (counter,))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trace")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("-o", "--out")
+    ap.add_argument("--title", default="rocprofv3 summary")
+    a = ap.parse_args()
+    lines = ["# " + a.title, ""]
+    if a.trace:
+        rows, tot = kernel_rows(a.trace)
+        lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats`), library kernels only", "",
+                  "| kernel | launches | avg ms | min ms | max ms | total ms |", "|---|---|---|---|---|---|"]
+        for n, c, avg, mn, mx, s in rows:
+            lines.append("| %s | %d | %.4f | %.4f | %.4f | %.3f |" % (short(n), c, avg / 1e6, mn / 1e6, mx / 1e6, s / 1e6))
+        lines += ["", "(all kernels in the process incl. torch's input generators: %.3f ms)" % (tot / 1e6), ""]
+    for label, path, ctr in (("FETCH_SIZE", a.fetch, "FETCH_SIZE"), ("WRITE_SIZE", a.write, "WRITE_SIZE")):
+        if not path:
+            continue
+        rows = pmc_rows(path, ctr)
+        lines += ["## PMC pass: %s (KiB per launch, as reported)" % label, "",
+                  "| kernel | launches | avg KiB | min KiB | max KiB | avg MB | %s |" %
+                  ("2x avg MB (gfx950 read correction)" if ctr == "FETCH_SIZE" else "-"), "|---|---|---|---|---|---|---|"]
+        for k, (c, avg, mn, mx) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            mb = avg * 1024 / 1e6
+            lines.append("| %s | %d | %.0f | %.0f | %.0f | %.1f | %s |" %
+                         (k, c, avg, mn, mx, mb, ("%.1f" % (2 * mb)) if ctr == "FETCH_SIZE" else "-"))
+        lines.append("")
+    text = "\n".join(lines)
+    if a.out:
+        open(a.out, "w").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
