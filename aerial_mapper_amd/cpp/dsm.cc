@@ -1,0 +1,56 @@
+// dsm::Dsm over the C ABI (see include/aerial-mapper-dsm/dsm.h).
+#include "aerial-mapper-dsm/dsm.h"
+
+#include <cstdio>
+
+#include "shim_common.h"
+
+namespace dsm {
+
+Dsm::Dsm(const Settings& settings, grid_map::GridMap* map)
+    : settings_(settings), ctx_(nullptr), ctx_rows_(0), ctx_cols_(0) {
+  if (!map) amhip_shim::fatal("Dsm::Dsm", "CHECK(map)");
+  printParams();
+  // The reference builds a sample->cell-index table for every cell here
+  // (dsm.cc:24-33); the GPU path needs the geometry only.
+  ensureContext(*map);
+}
+
+Dsm::~Dsm() {
+  if (ctx_) amhip_ctx_destroy(ctx_);
+}
+
+void Dsm::ensureContext(const grid_map::GridMap& map) {
+  amhip_shim::ensure_context(&ctx_, &ctx_rows_, &ctx_cols_, ctx_geom_, map, "Dsm");
+}
+
+void Dsm::process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_cloud,
+                  grid_map::GridMap* map) {
+  if (point_cloud.empty()) {
+    std::fprintf(stderr, "[aerial_mapper_hip] WARNING Passed empty point cloud to DSM module\n");
+    return;
+  }
+  if (!map) amhip_shim::fatal("Dsm::process", "CHECK(map)");
+  ensureContext(*map);
+  static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double),
+                "point cloud must be contiguous x,y,z doubles");
+  const double* xyz = reinterpret_cast<const double*>(point_cloud.data());
+  grid_map::Matrix& elevation = (*map)["elevation"];
+  amhip_shim::check_status(
+      amhip_dsm_process(ctx_, xyz, point_cloud.size(), settings_.interpolation_radius,
+                        settings_.center_easting, settings_.center_northing, elevation.data()),
+      "Dsm::process");
+}
+
+void Dsm::printParams() {
+  std::fprintf(stderr,
+               "**************************************************\n"
+               "DSM parameters (MI355X / HIP):\n"
+               "  Interp. radius   %d\n  Adaptive interp. %d\n"
+               "  Center easting   %f\n  Center northing  %f\n"
+               "**************************************************\n",
+               settings_.interpolation_radius, (int)settings_.adaptive_interpolation,
+               settings_.center_easting, settings_.center_northing);
+}
+
+}  // namespace dsm

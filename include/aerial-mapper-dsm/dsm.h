@@ -1,0 +1,56 @@
+// dsm::Dsm on MI355X -- drop-in for the reference class
+// (aerial_mapper_dsm/include/aerial-mapper-dsm/dsm.h:25-42): same namespace,
+// Settings fields/defaults and public signatures, so
+// aerial_mapper_demos/src/dsm/main-dsm.cc:103-107 compiles against it
+// unchanged.  The kd-tree + per-cell loop of dsm.cc:36-184 run as HIP kernels
+// behind the C ABI (include/aerial_mapper_hip.h).
+#ifndef AERIAL_MAPPER_HIP_DSM_H_
+#define AERIAL_MAPPER_HIP_DSM_H_
+
+#include <vector>
+
+#include "aerial-mapper-deps.h"
+#include "aerial-mapper-utils/utils-nearest-neighbor.h"
+
+struct amhip_ctx;
+
+namespace dsm {
+
+struct Settings {
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+  // SQUARED search radius in m^2 (it is handed to nanoflann's RadiusResultSet
+  // as is); an int in the reference too.
+  int interpolation_radius = 1.0;
+  bool adaptive_interpolation = false;  // printed only, like the reference
+  double center_easting = 0.0;
+  double center_northing = 0.0;
+  bool use_multi_threads = true;  // both reference variants give one result
+};
+
+class Dsm {
+ public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+
+  Dsm(const Settings& settings, grid_map::GridMap* map);
+  ~Dsm();
+  Dsm(const Dsm&) = delete;
+  Dsm& operator=(const Dsm&) = delete;
+
+  // Reads the "elevation" layer of *map, overwrites every cell that finds a
+  // point within the (expanding) radius, leaves the others untouched.
+  void process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_cloud,
+               grid_map::GridMap* map);
+
+ private:
+  void ensureContext(const grid_map::GridMap& map);
+  void printParams();
+
+  Settings settings_;
+  amhip_ctx* ctx_;
+  int ctx_rows_, ctx_cols_;
+  double ctx_geom_[4];  // resolution, pos x, pos y, length x
+};
+
+}  // namespace dsm
+
+#endif  // AERIAL_MAPPER_HIP_DSM_H_

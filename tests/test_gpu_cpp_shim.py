@@ -1,0 +1,35 @@
+"""GPU: the drop-in C++ classes (dsm::Dsm, ortho::OrthoBackwardGrid) driven like
+the reference's demo, checked against the oracle by tests/cpp/shim_parity.cc."""
+import os
+import subprocess
+
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    from aerial_mapper_amd import build
+    build.build_all()
+    O.build()
+    out = str(tmp_path_factory.mktemp("shim") / "shim_parity")
+    lib = os.path.join(ROOT, "aerial_mapper_amd", "lib")
+    cmd = ["g++", "-O2", "-std=c++11", "-pthread", "-ffp-contract=off",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "oracle"),
+           os.path.join(ROOT, "tests", "cpp", "shim_parity.cc"), "-o", out,
+           "-L" + lib, "-laerial_mapper_shim", "-laerial_mapper_hip",
+           "-L" + os.path.join(ROOT, "oracle"), "-loracle",
+           "-Wl,-rpath," + lib, "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    subprocess.check_call(cmd)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["gray", "colored"])
+def test_cpp_dropin_classes_match_oracle(exe, mode):
+    r = subprocess.run([exe, mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    print(r.stdout.decode())
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
