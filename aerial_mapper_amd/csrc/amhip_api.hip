@@ -3,6 +3,7 @@
 // staging, timing.  Kernels live in amhip_dsm.hip / amhip_ortho.hip.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -222,9 +223,11 @@ static int make_dsm_params(const amhip_grid_desc& g, int radius_sq,
   for (int k = 0; k < n; ++k)
     if (p.w[k] > wmax) wmax = p.w[k];
 
-  // Bin edge: about half the first search radius (in cells), at least 1.
-  int B = p.w[0] / 2;
+  // Bin edge = the first search radius in cells: the LDS gather then needs
+  // exactly one ring of bins around a tile.
+  int B = p.w[0];
   if (B < 1) B = 1;
+  if (B > 8) B = 8;
   p.B = B;
   p.M = ((wmax + B - 1) / B) * B;
   const long long ex = (long long)p.rows + 2LL * p.M;
@@ -234,6 +237,40 @@ static int make_dsm_params(const amhip_grid_desc& g, int radius_sq,
   const unsigned long long nbins =
       (unsigned long long)p.nbx * (unsigned long long)p.nby;
   if (nbins + 1 >= 0xFFFFFFFFull) return arg_fail("grid too large for 32-bit bin ids");
+
+  // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
+  const int kTileI = 64, kTileJ = 32;
+  p.tiles_i = (p.rows + kTileI - 1) / kTileI;
+  p.tiles_j = (p.cols + kTileJ - 1) / kTileJ;
+  const int w0 = p.w[0];
+  p.lds_ok = (w0 >= 1 && w0 <= kMaxW0) ? 1 : 0;
+  if (p.lds_ok) {
+    // disc-shaped window: a point whose cell row differs by dj from the query's
+    // is at least (|dj| - 0.5) * res away in y; what is left of the radius
+    // bounds its column distance.
+    const double r2 = p.T[0] / (g.resolution * g.resolution);  // in cells^2
+    for (int dj = -w0; dj <= w0; ++dj) {
+      const double dy = std::fabs((double)dj) - 0.5 - 1e-6;
+      const double rem = dy > 0.0 ? r2 - dy * dy : r2;
+      int wr = rem > 0.0 ? static_cast<int>(std::floor(std::sqrt(rem) + 0.5 + 1e-6)) : 0;
+      if (wr > w0) wr = w0;
+      p.wr[dj + w0] = wr;
+    }
+    for (int r = 0; r <= 2 * w0 + 1; ++r) {
+      const int a = r <= 2 * w0 ? p.wr[r] : 0;
+      const int b = r >= 1 ? p.wr[r - 1] : 0;
+      p.wr2[r] = a > b ? a : b;
+    }
+    const int rw = kTileI + 2 * w0 + 2 * (B - 1);
+    const int rh = kTileJ + 2 * w0 + 2 * (B - 1);
+    p.lds_cells = rw * rh;
+    p.lds_cap = 2048;  // kMaxPtsPerThread * 256
+    const size_t bytes = ((size_t)p.lds_cap + 2) * 24 + ((size_t)p.lds_cells + 1) * 4 +
+                         (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;
+    p.lds_bytes = static_cast<unsigned>((bytes + 15) & ~size_t(15));
+    if (p.lds_bytes > 150 * 1024) p.lds_ok = 0;
+  }
+  p.dbg = std::getenv("AMHIP_DBG") ? std::atoi(std::getenv("AMHIP_DBG")) : 0;
   *out = p;
   return AMHIP_OK;
 }

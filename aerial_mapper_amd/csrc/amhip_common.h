@@ -30,6 +30,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // device-side constants
 // ---------------------------------------------------------------------------
 constexpr int kMaxLevels = 24;  // radius ladder: R, then lambda_k * R (<= 22 for R = 1)
+constexpr int kMaxW0 = 16;      // largest first-level window (cells) the LDS gather handles
 
 // Geometry + search parameters of one DSM call, passed by value to kernels.
 struct DsmParams {
@@ -45,6 +46,16 @@ struct DsmParams {
   int nlevels;
   double T[kMaxLevels];
   int w[kMaxLevels];  // conservative window half-width in cells for T[k]
+  // LDS-tiled gather (first level only): per window row dj in [-w0, w0] the
+  // half-width in cells of the disc of squared radius T[0]
+  int lds_ok;                 // 0 -> every tile takes the global-memory path
+  int wr[2 * kMaxW0 + 1];
+  int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
+  int lds_cap;                // points the tile's LDS image can hold
+  int lds_cells;              // cell-offset table entries reserved (+1 sentinel)
+  int tiles_i, tiles_j;
+  unsigned lds_bytes;
+  int dbg;                    // timing experiments only (AMHIP_DBG), 0 = off
 };
 
 // Per-frame inverse pose T_C_G = T_G_C^-1 (minkindr inverse()).

@@ -22,6 +22,8 @@
 //   k_dsm_gather      one lane per cell (64 consecutive rows of one column per
 //                     wave -> coalesced layer writes); radius search + IDW;
 //                     cells with an empty first search walk the ladder
+#include <cstdlib>
+
 #include "amhip_common.h"
 
 namespace amhip {
@@ -250,6 +252,20 @@ struct Accum {
   bool exact;
 };
 
+// One IDW term.  1/d2 through v_rcp_f64 + two Newton steps (relative error
+// ~1e-16; the accumulation order already differs from the kd-tree's, the
+// result is rounded to float afterwards and the parity bar is 1e-4 m).
+__device__ __forceinline__ void idw_add(double d2, double z, double* num,
+                                        double* den) {
+  double r = __builtin_amdgcn_rcp(d2);
+  double e = fma(-d2, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-d2, r, 1.0);
+  r = fma(r, e, r);
+  *num = fma(z, r, *num);
+  *den += r;
+}
+
 // Visit every binned point that can lie within the window of half-width w
 // cells around cell (i, j).  MODE 0: accumulate IDW over d2 < T.
 // MODE 1: track the minimum d2.
@@ -279,10 +295,7 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
       if (MODE == 0) {
         if (d2 < T) {  // RadiusResultSet::addPoint, strict (nanoflann.hpp:157)
           if (d2 > 0.0) {
-            const double z = sorted[3 * (size_t)k + 2];
-            const double wgt = 1.0 / d2;
-            acc->num = fma(z, wgt, acc->num);
-            acc->den += wgt;
+            idw_add(d2, sorted[3 * (size_t)k + 2], &acc->num, &acc->den);
           } else {
             acc->exact = true;  // dsm.cc:165 CHECK(distances[i] > 0.0)
           }
@@ -295,6 +308,64 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
   }
 }
 
+// Expanding-radius fallback for a cell whose first search (T[0]) was empty
+// (dsm.cc:133-144): the reference retries with T[1], T[2], ... until a search
+// returns something.  Equivalent: find the nearest point within the LAST
+// radius, pick the first level whose threshold exceeds its d2, gather with
+// that threshold.  Works on the global bin structure.
+__device__ __forceinline__ void cell_fallback_global(const DsmParams& p,
+                                                  const uint32_t* __restrict__ start,
+                                                  const double* __restrict__ sorted,
+                                                  int i, int j, double qx, double qy,
+                                                  float* __restrict__ elevation,
+                                                  unsigned* __restrict__ dev_err) {
+  if (p.nlevels <= 1) return;
+  Accum acc = {0.0, 0.0, 0u, false};
+  const int last = p.nlevels - 1;
+  double dmin = __builtin_huge_val();
+  scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
+  int level = -1;
+  for (int k = 1; k <= last; ++k) {
+    if (dmin < p.T[k]) {
+      level = k;
+      break;
+    }
+  }
+  if (level < 0) return;  // nothing within the last radius: cell untouched
+  scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
+  if (acc.exact) {
+    atomicOr(dev_err, kDevErrExactHit);
+    return;
+  }
+  if (acc.cnt > 0)
+    elevation[(size_t)i + (size_t)j * (size_t)p.rows] = (float)(acc.num / acc.den);
+}
+
+// Whole cell through the global bins (first level + fallback).
+__device__ __forceinline__ void cell_global(const DsmParams& p,
+                                            const uint32_t* __restrict__ start,
+                                            const double* __restrict__ sorted, int i,
+                                            int j, float* __restrict__ elevation,
+                                            unsigned* __restrict__ dev_err) {
+  // grid_map_core getPosition (oracle/amo_compat.h cell_position)
+  const double qx = p.base_x + p.res * (-(double)i);
+  const double qy = p.base_y + p.res * (-(double)j);
+  Accum acc = {0.0, 0.0, 0u, false};
+  double dmin = 0.0;
+  scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
+  if (acc.exact) {
+    atomicOr(dev_err, kDevErrExactHit);
+    return;
+  }
+  if (acc.cnt > 0) {
+    elevation[(size_t)i + (size_t)j * (size_t)p.rows] = (float)(acc.num / acc.den);
+    return;
+  }
+  cell_fallback_global(p, start, sorted, i, j, qx, qy, elevation, dev_err);
+}
+
+// Pure global-memory gather: used when the first-level window is too wide for
+// the LDS image (very fine grids).
 __global__ void __launch_bounds__(256)
 k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
              const double* __restrict__ sorted, float* __restrict__ elevation,
@@ -302,42 +373,308 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
+  cell_global(p, start, sorted, i, j, elevation, dev_err);
+}
 
-  // grid_map_core getPosition (oracle/amo_compat.h cell_position)
-  const double qx = p.base_x + p.res * (-(double)i);
-  const double qy = p.base_y + p.res * (-(double)j);
+// ---------------------------------------------------------------------------
+// LDS-tiled gather
+// ---------------------------------------------------------------------------
+// One workgroup owns a tile of 64 x 32 cells.  It copies every binned point
+// that can lie within the first search radius of any of its cells (the tile's
+// bins plus one ring) from HBM into LDS exactly once, re-bins them there at
+// CELL granularity (LDS atomics + scan), and then every lane walks, for each
+// of its 8 cells, the 2*w0+1 rows of the disc-shaped window: one contiguous
+// span of LDS points per row.  Cells whose first search is empty are queued
+// in LDS and finished by the fallback path on the global bins.
+constexpr int kTileI = 64;
+constexpr int kTileJ = 32;
+constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
-  Accum acc = {0.0, 0.0, 0u, false};
-  double dmin = 0.0;
-  scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
+template <int NT, int NR>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
+                   const double* __restrict__ sorted,
+                   float* __restrict__ elevation,
+                   unsigned* __restrict__ dev_err) {
+  constexpr int kWaves = NT / 64;
+  constexpr int kCellsPerLane = kTileJ / kWaves;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // [xy: cap+1 double2][z: cap+1 double (+pad)][cell offsets][rows][ctl][flags]
+  double2* s_xy = reinterpret_cast<double2*>(smem);
+  double* s_z = reinterpret_cast<double*>(smem + (size_t)(p.lds_cap + 1) * 16);
+  uint32_t* s_off = reinterpret_cast<uint32_t*>(smem + (size_t)(p.lds_cap + 2) * 24);
+  uint32_t* s_rowg = s_off + p.lds_cells + 1;        // global start of a region bin-row
+  uint32_t* s_rowp = s_rowg + kMaxRegionRows;        // prefix of the row lengths (+1)
+  uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;    // block-scan scratch
+  uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext
+  int* s_wr1 = reinterpret_cast<int*>(s_ctl + 4);     // p.wr  (per-lane row index)
+  int* s_wr2 = s_wr1 + 2 * kMaxW0 + 2;                // p.wr2
+  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_wr2 + 2 * kMaxW0 + 2);  // kTileI*kTileJ entries
 
-  if (acc.cnt == 0 && p.nlevels > 1) {
-    // Expanding-radius fallback (dsm.cc:133-144): the reference retries with
-    // T[1], T[2], ... until a search returns something.  Equivalent: find the
-    // nearest point within the LAST radius, pick the first level whose
-    // threshold exceeds its d2, gather with that threshold.
-    const int last = p.nlevels - 1;
-    dmin = __builtin_huge_val();
-    scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
-    int level = -1;
-    for (int k = 1; k <= last; ++k) {
-      if (dmin < p.T[k]) {
-        level = k;
-        break;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+
+  // XCD-aware tile order: consecutive tiles (which share halo points) go to
+  // the same XCD's L2.  Blocks are dealt round-robin to the 8 XCDs, so give
+  // XCD x the x-th contiguous chunk of the tile list (bijective for any count).
+  const int ntiles = p.tiles_i * p.tiles_j;
+  int tile;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, k = b >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int ti = tile % p.tiles_i;
+  const int tj = tile / p.tiles_i;
+  const int i0 = ti * kTileI;
+  const int j0 = tj * kTileJ;
+  const int i_hi = min(i0 + kTileI, p.rows) - 1;
+  const int j_hi = min(j0 + kTileJ, p.cols) - 1;
+  const int w0 = p.w[0];
+
+  // region of bins holding every first-level candidate of the tile
+  const int rbx0 = (i0 - w0 + p.M) / p.B;
+  const int rbx1 = (i_hi + w0 + p.M) / p.B;
+  const int rby0 = (j0 - w0 + p.M) / p.B;
+  const int rby1 = (j_hi + w0 + p.M) / p.B;
+  const int nrb = rby1 - rby0 + 1;
+  const int RW = (rbx1 - rbx0 + 1) * p.B;
+  const int RH = nrb * p.B;
+  const int ncell = RW * RH;
+  const int ox = rbx0 * p.B;  // region origin in M-shifted cell coordinates
+  const int oy = rby0 * p.B;
+
+  const bool geom_ok = nrb <= kMaxRegionRows && ncell <= p.lds_cells;
+  if (geom_ok && tid < nrb) {
+    const uint32_t* row = start + (size_t)(rby0 + tid) * p.nbx;
+    const uint32_t gs = row[rbx0];
+    s_rowg[tid] = gs;
+    s_rowp[tid + 1] = row[rbx1 + 1] - gs;
+  }
+  if (tid == NT - 1) {
+    // anything at all within the LAST fallback radius of the tile?
+    const int wl = p.w[p.nlevels - 1];
+    const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
+    const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
+    uint32_t tot = 0;
+    for (int by = ey0; by <= ey1; ++by) {
+      const uint32_t* row = start + (size_t)by * p.nbx;
+      tot += row[ex1 + 1] - row[ex0];
+    }
+    s_ctl[2] = tot;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    s_rowp[0] = 0;
+    if (geom_ok) {
+      for (int r = 0; r < nrb; ++r) {
+        run += s_rowp[r + 1];
+        s_rowp[r + 1] = run;
       }
     }
-    if (level > 0)
-      scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[level], p.T[level],
-                     &acc, &dmin);
+    s_ctl[0] = run;
+    s_ctl[1] = 0;
   }
+  __syncthreads();
+  const int np = (int)s_ctl[0];
+  if (s_ctl[2] == 0) return;  // empty neighbourhood: every cell stays untouched
 
-  if (acc.exact) {
-    atomicOr(dev_err, kDevErrExactHit);
+  const bool use_lds = geom_ok && np <= p.lds_cap;
+  if (p.dbg == 2) return;
+  if (!use_lds) {
+    // over-full tile (very dense / clustered cloud): global path for all cells
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
+      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, elevation, dev_err);
+    }
     return;
   }
-  if (acc.cnt > 0) {
-    const double h = acc.num / acc.den;
-    elevation[(size_t)i + (size_t)j * (size_t)p.rows] = (float)h;
+
+  // ---- stage + cell-bin the region's points in LDS --------------------------
+  // pass 1: count per cell (LDS atomics), remember (cell, rank) per point
+  for (int k = tid; k <= ncell; k += NT) s_off[k] = 0;
+  if (tid < 2 * kMaxW0 + 2) {
+    s_wr1[tid] = tid < 2 * kMaxW0 + 1 ? p.wr[tid] : 0;
+    s_wr2[tid] = p.wr2[tid];
+  }
+  __syncthreads();
+  constexpr int kMaxK = (2048 + NT - 1) / NT;  // lds_cap <= 2048
+  uint32_t pslot[kMaxK];                       // cell << 12 | rank  (rank < 4096)
+  uint32_t pglob[kMaxK];                       // index into `sorted`
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    const int idx = tid + k * NT;
+    pslot[k] = 0xFFFFFFFFu;
+    if (idx < np) {
+      int r = 0;
+      while (idx >= (int)s_rowp[r + 1]) ++r;
+      const uint32_t g = s_rowg[r] + (uint32_t)(idx - (int)s_rowp[r]);
+      pglob[k] = g;
+      const double px = sorted[3 * (size_t)g + 0];
+      const double py = sorted[3 * (size_t)g + 1];
+      // same arithmetic as point_bin(): the point's cell in shifted coordinates
+      const double cx = (p.base_x - px) * p.inv_res;
+      const double cy = (p.base_y - py) * p.inv_res;
+      int ix = (int)floor(cx + 0.5) + p.M;
+      int iy = (int)floor(cy + 0.5) + p.M;
+      ix = min(max(ix, 0), p.rows + 2 * p.M - 1) - ox;
+      iy = min(max(iy, 0), p.cols + 2 * p.M - 1) - oy;
+      ix = min(max(ix, 0), RW - 1);  // (always inside: the bins are aligned)
+      iy = min(max(iy, 0), RH - 1);
+      const uint32_t cell = (uint32_t)(iy * RW + ix);
+      pslot[k] = (cell << 12) | atomicAdd(&s_off[cell], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    // exclusive scan of the ncell counters, in place
+    const int per = (ncell + NT - 1) / NT;
+    const int lo = tid * per;
+    const int hi = min(lo + per, ncell);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_off[k];
+    unsigned total;
+    unsigned run = block_excl_scan<NT>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_off[k];
+      s_off[k] = run;
+      run += t;
+    }
+    if (tid == 0) s_off[ncell] = total;
+  }
+  __syncthreads();
+  // pass 2: re-read the points (L2 hits) and drop them into their sorted slot
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (pslot[k] != 0xFFFFFFFFu) {
+      const size_t g = pglob[k];
+      const double px = sorted[3 * g + 0];
+      const double py = sorted[3 * g + 1];
+      const double pz = sorted[3 * g + 2];
+      const uint32_t pos = s_off[pslot[k] >> 12] + (pslot[k] & 0xFFFu);
+      s_xy[pos] = make_double2(px, py);
+      s_z[pos] = pz;
+    }
+  }
+  __syncthreads();
+
+  if (p.dbg == 3) return;
+  // ---- gather: lane = row index i; the lane's cells are taken two at a time
+  // (columns j, j+1): every candidate read from LDS is tested against both,
+  // which halves the LDS traffic per test (the LDS pipe is shared by the CU's
+  // four SIMDs and would otherwise co-limit with the FP64 VALU work).
+  const int i = i0 + lane;
+  const double T0 = p.T[0];
+  const int nwin2 = 2 * w0 + 2;
+  if (i <= i_hi) {
+    const double qx = p.base_x + p.res * (-(double)i);
+    const int ci = i + p.M - ox;  // this cell's column in the region
+    for (int c = 0; c < kCellsPerLane; c += 2) {
+      const int jA = j0 + wid * kCellsPerLane + c;
+      if (jA > j_hi) break;
+      const bool haveB = (jA + 1 <= j_hi) && (c + 1 < kCellsPerLane);
+      const double qyA = p.base_y + p.res * (-(double)jA);
+      const double qyB = p.base_y + p.res * (-(double)(jA + 1));
+      const double TB = haveB ? T0 : -1.0;  // d2 < -1 never holds
+      const int cj = jA + p.M - oy;
+      // Division-free IDW: h = (sum z_i/d_i) / (sum 1/d_i) is kept as N/D with
+      //   N = sum_i z_i * prod_{j!=i} d_j,  D = sum_i prod_{j!=i} d_j,  P = prod_j d_j
+      // so a hit costs  N = N*d + z*P;  D = D*d + P;  P = P*d  (4 FP64 ops; the
+      // alternative v_rcp_f64 is a quarter-rate instruction: 17.7 vs 5.3 cycles,
+      // tools/ubench).  D > 0 <=> at least one hit;  P == 0 <=> some hit had
+      // d2 == 0 (dsm.cc:165 CHECK(distances[i] > 0.0)).  One division per cell.
+      double NA = 0.0, DA = 0.0, PA = 1.0, NB = 0.0, DB = 0.0, PB = 1.0;
+      // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B; it exists
+      // in the region whenever B does).  Two rows are walked per trip of the
+      // outer loop as ONE span (lanes wait for each other per trip, and the
+      // spread of a two-row candidate count is relatively smaller).
+      const int nrows = p.dbg == 1 ? 0 : (haveB ? nwin2 : nwin2 - 1);
+      const int* wtab = haveB ? p.wr2 : p.wr;
+      const uint32_t* orow = s_off + (cj - w0) * RW + ci;
+      for (int r = 0; r < nrows; r += 2) {
+        const int w1 = wtab[r];
+        const uint32_t s1 = orow[-w1];
+        const uint32_t len1 = orow[w1 + 1] - s1;
+        uint32_t s2 = 0, len2 = 0;
+        if (r + 1 < nrows) {
+          const int w2 = wtab[r + 1];
+          s2 = orow[RW - w2];
+          len2 = orow[RW + w2 + 1] - s2;
+        }
+        orow += 2 * RW;
+        const uint32_t tot = len1 + len2;
+        const uint32_t off2 = s2 - len1;
+        for (uint32_t t = 0; t < tot; ++t) {
+          const uint32_t k = t + (t < len1 ? s1 : off2);
+          const double2 xy = s_xy[k];
+          const double z = s_z[k];
+          // L2_Adaptor, size == 2 (nanoflann.hpp:319-322): 0 + dx*dx, + dy*dy
+          const double dx = qx - xy.x;
+          const double dx2 = dx * dx;
+          const double dyA = qyA - xy.y;
+          const double dyB = qyB - xy.y;
+          const double d2A = dx2 + dyA * dyA;
+          const double d2B = dx2 + dyB * dyB;
+          if (d2A < T0) {  // strict (nanoflann.hpp:157)
+            NA = fma(NA, d2A, z * PA);
+            DA = fma(DA, d2A, PA);
+            PA = PA * d2A;
+          }
+          if (d2B < TB) {
+            NB = fma(NB, d2B, z * PB);
+            DB = fma(DB, d2B, PB);
+            PB = PB * d2B;
+          }
+        }
+        // keep the running products inside the double range (exact scaling by
+        // powers of two; N, D, P share the factor so N/D is unaffected)
+        if (!(PA > 1e-100 && PA < 1e100) && PA != 0.0) {
+          const double sc = PA < 1.0 ? 0x1p+400 : 0x1p-400;
+          NA *= sc;
+          DA *= sc;
+          PA *= sc;
+        }
+        if (!(PB > 1e-100 && PB < 1e100) && PB != 0.0) {
+          const double sc = PB < 1.0 ? 0x1p+400 : 0x1p-400;
+          NB *= sc;
+          DB *= sc;
+          PB *= sc;
+        }
+      }
+      if (PA == 0.0 || (haveB && PB == 0.0)) {
+        atomicOr(dev_err, kDevErrExactHit);
+      } else {
+        if (DA > 0.0) {
+          elevation[(size_t)i + (size_t)jA * (size_t)p.rows] = (float)(NA / DA);
+        } else {
+          const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
+          s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c) * kTileI + lane);
+        }
+        if (haveB) {
+          if (DB > 0.0) {
+            elevation[(size_t)i + (size_t)(jA + 1) * (size_t)p.rows] = (float)(NB / DB);
+          } else {
+            const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
+            s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c + 1) * kTileI + lane);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- fallback ladder for the queued cells (dense over the workgroup) --------
+  const int nflag = (int)s_ctl[1];
+  for (int f = tid; f < nflag; f += NT) {
+    const int code = s_flag[f];
+    const int fi = i0 + (code % kTileI);
+    const int fj = j0 + (code / kTileI);
+    const double fqx = p.base_x + p.res * (-(double)fi);
+    const double fqy = p.base_y + p.res * (-(double)fj);
+    cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, elevation, dev_err);
   }
 }
 
@@ -393,10 +730,33 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
   }
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
-    dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
-    hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p,
-                       c->bin_start, c->sorted,
-                       c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);
+    if (p.lds_ok) {
+      const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
+      // tuning knobs for A/B runs (defaults are the shipped configuration)
+      static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
+      static const int nr = getenv("AMHIP_GATHER_NR") ? atoi(getenv("AMHIP_GATHER_NR")) : 2;
+#define AMHIP_LAUNCH_TILED(NT_, NR_)                                                       \
+  do {                                                                                     \
+    AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, NR_>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,              \
+                                  (int)p.lds_bytes));                                      \
+    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, NR_>), dim3(ntiles), dim3(NT_), p.lds_bytes, \
+                       c->stream, p, c->bin_start, c->sorted,                              \
+                       c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);                      \
+  } while (0)
+      if (nt == 256 && nr == 1) AMHIP_LAUNCH_TILED(256, 1);
+      else if (nt == 256) AMHIP_LAUNCH_TILED(256, 2);
+      else if (nt == 1024 && nr == 1) AMHIP_LAUNCH_TILED(1024, 1);
+      else if (nt == 1024) AMHIP_LAUNCH_TILED(1024, 2);
+      else if (nr == 1) AMHIP_LAUNCH_TILED(512, 1);
+      else AMHIP_LAUNCH_TILED(512, 2);
+#undef AMHIP_LAUNCH_TILED
+    } else {
+      dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
+      hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p,
+                         c->bin_start, c->sorted,
+                         c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);
+    }
     AMHIP_TRY(hipGetLastError());
   }
   return AMHIP_OK;
