@@ -185,16 +185,19 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
   *by = g.pos_y + off_y;
 }
 
-static int make_dsm_params(const amhip_grid_desc& g, int radius_sq,
+static int make_dsm_params(const Ctx& c, int radius_sq,
                            double center_easting, double center_northing,
                            DsmParams* out) {
+  const amhip_grid_desc& g = c.grid;
   DsmParams p;
   std::memset(&p, 0, sizeof(p));
   grid_bases(g, &p.base_x, &p.base_y);
   p.res = g.resolution;
   p.inv_res = 1.0 / g.resolution;
-  p.rows = g.rows;
-  p.cols = g.cols;
+  p.rows = c.win_rows;
+  p.cols = c.win_cols;
+  p.i_off = c.win_i0;
+  p.j_off = c.win_j0;
   p.sub_x = center_northing;  // dsm.cc:42
   p.sub_y = center_easting;   // dsm.cc:43
 
@@ -282,15 +285,18 @@ static void normalize3(double* v) {
   v[2] /= n;
 }
 
-static void make_ortho_params(const amhip_grid_desc& g, const amhip_camera& cam,
+static void make_ortho_params(const Ctx& c, const amhip_camera& cam,
                               size_t F, size_t frame_stride, size_t row_step,
                               int channels, int colored, OrthoParams* out) {
+  const amhip_grid_desc& g = c.grid;
   OrthoParams p;
   std::memset(&p, 0, sizeof(p));
   grid_bases(g, &p.base_x, &p.base_y);
   p.res = g.resolution;
-  p.rows = g.rows;
-  p.cols = g.cols;
+  p.rows = c.win_rows;
+  p.cols = c.win_cols;
+  p.i_off = c.win_i0;
+  p.j_off = c.win_j0;
   p.fu = cam.fu;
   p.fv = cam.fv;
   p.cu = cam.cu;
@@ -404,9 +410,18 @@ void amhip_cell_position(const amhip_grid_desc* grid, int i, int j, double* x,
 }
 
 int amhip_ctx_create(const amhip_grid_desc* grid, int device, amhip_ctx** out) {
+  if (!grid) return arg_fail("amhip_ctx_create: null argument");
+  return amhip_ctx_create_window(grid, 0, 0, grid->rows, grid->cols, device, out);
+}
+
+int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int rows, int cols,
+                            int device, amhip_ctx** out) {
   if (!grid || !out) return arg_fail("amhip_ctx_create: null argument");
   if (grid->rows <= 0 || grid->cols <= 0 || !(grid->resolution > 0.0))
     return arg_fail("amhip_ctx_create: empty grid");
+  if (i0 < 0 || j0 < 0 || rows <= 0 || cols <= 0 || i0 + rows > grid->rows ||
+      j0 + cols > grid->cols)
+    return arg_fail("amhip_ctx_create_window: window outside the map");
   *out = nullptr;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -420,7 +435,11 @@ int amhip_ctx_create(const amhip_grid_desc* grid, int device, amhip_ctx** out) {
   Ctx* c = &h->impl;
   c->grid = *grid;
   c->device = device;
-  c->cells = static_cast<size_t>(grid->rows) * static_cast<size_t>(grid->cols);
+  c->win_i0 = i0;
+  c->win_j0 = j0;
+  c->win_rows = rows;
+  c->win_cols = cols;
+  c->cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
   int rc = AMHIP_OK;
   do {
     if ((rc = use_device(c))) break;
@@ -544,7 +563,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   DsmParams p;
-  if ((rc = make_dsm_params(c->grid, radius_sq, center_easting, center_northing, &p)))
+  if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p)))
     return rc;
   return dsm_run(c, dev_xyz, n, p);
 }
@@ -569,6 +588,41 @@ int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
   AMHIP_TRY(hipMemcpyAsync(elevation, c->layers[AMHIP_LAYER_ELEVATION],
                            c->cells * sizeof(float), hipMemcpyDeviceToHost, c->stream));
   return fetch_status(c);
+}
+
+// ---- multi-GPU halo ----------------------------------------------------------
+
+int amhip_halo_select_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
+                          double center_easting, double center_northing,
+                          const int32_t* dest_windows, int nd, double margin_m,
+                          double* dev_out, size_t cap_per_dest, int64_t* dev_counts) {
+  if (!h) return arg_fail("null context");
+  if (nd < 0 || nd > kMaxHaloDests) return arg_fail("amhip_halo_select_dev: 0..8 destinations");
+  if (nd == 0) return AMHIP_OK;
+  if ((n && !dev_xyz) || !dest_windows || !dev_out || !dev_counts || !(margin_m >= 0.0))
+    return arg_fail("amhip_halo_select_dev: bad argument");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  HaloParams hp;
+  std::memset(&hp, 0, sizeof(hp));
+  grid_bases(c->grid, &hp.base_x, &hp.base_y);
+  hp.inv_res = 1.0 / c->grid.resolution;
+  hp.sub_x = center_northing;  // dsm.cc:42
+  hp.sub_y = center_easting;   // dsm.cc:43
+  hp.nd = nd;
+  hp.cap = cap_per_dest;
+  const double mc = margin_m / c->grid.resolution;  // margin in cells
+  for (int d = 0; d < nd; ++d) {
+    const int32_t* w = dest_windows + 4 * d;
+    if (w[2] <= 0 || w[3] <= 0) return arg_fail("amhip_halo_select_dev: empty window");
+    hp.lo_i[d] = (double)w[0] - 0.5 - mc;
+    hp.hi_i[d] = (double)(w[0] + w[2]) - 0.5 + mc;
+    hp.lo_j[d] = (double)w[1] - 0.5 - mc;
+    hp.hi_j[d] = (double)(w[1] + w[3]) - 0.5 + mc;
+  }
+  return halo_select_run(c, dev_xyz, n, hp, dev_out,
+                         reinterpret_cast<unsigned long long*>(dev_counts));
 }
 
 // ---- ortho ----------------------------------------------------------------
@@ -628,7 +682,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
                            hipMemcpyHostToDevice, c->stream));
 
   OrthoParams p;
-  make_ortho_params(c->grid, *cam, F, frame_stride, row_step, channels, colored, &p);
+  make_ortho_params(*c, *cam, F, frame_stride, row_step, channels, colored, &p);
   return ortho_run(c, p, c->frame_poses, dev_frames);
 }
 
@@ -724,6 +778,8 @@ const char* amhip_kernel_name(int kernel) {
       return "k_ortho_backward";
     case AMHIP_K_MISC:
       return "memset/fill";
+    case AMHIP_K_HALO_SELECT:
+      return "k_halo_select";
     default:
       return "?";
   }

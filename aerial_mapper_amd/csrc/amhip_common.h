@@ -36,7 +36,8 @@ constexpr int kMaxW0 = 16;      // largest first-level window (cells) the LDS ga
 struct DsmParams {
   // grid_map_core getPosition: x_i = base_x + res * (-(double)i)
   double base_x, base_y, res;
-  int rows, cols;
+  int rows, cols;    // size of the window this context owns
+  int i_off, j_off;  // its position inside the (global) map
   // dsm.cc:42-43: px = p.x - center_northing, py = p.y - center_easting
   double sub_x, sub_y;
   // binning: bins of B x B cells, grid extended by M cells on every side
@@ -68,6 +69,7 @@ struct FramePose {
 struct OrthoParams {
   double base_x, base_y, res;
   int rows, cols;
+  int i_off, j_off;
   // camera
   double fu, fv, cu, cv;
   double dist[4];
@@ -94,7 +96,9 @@ struct TimedRegion {
 };
 
 struct Ctx {
-  amhip_grid_desc grid;
+  amhip_grid_desc grid;       // the (global) map
+  int win_i0 = 0, win_j0 = 0; // window of it this context owns
+  int win_rows = 0, win_cols = 0;
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -132,8 +136,8 @@ struct Ctx {
   bool timing = false;
   std::vector<TimedRegion> regions;
   std::vector<TimedRegion> free_regions;
-  double slot_ms[AMHIP_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
-  int64_t slot_launches[AMHIP_NUM_KERNELS] = {0, 0, 0, 0, 0, 0};
+  double slot_ms[AMHIP_NUM_KERNELS] = {};
+  int64_t slot_launches[AMHIP_NUM_KERNELS] = {};
 };
 
 // RAII-less helper: bracket a launch sequence with events when timing is on.
@@ -154,6 +158,17 @@ int ensure_bytes(void** ptr, size_t* cap_bytes, size_t need_bytes);
 // launchers (defined in amhip_dsm.hip / amhip_ortho.hip)
 // ---------------------------------------------------------------------------
 int launch_fill(Ctx* c, float* dst, size_t n, float value);
+
+// multi-GPU halo selection
+constexpr int kMaxHaloDests = 8;
+struct HaloParams {
+  double base_x, base_y, inv_res, sub_x, sub_y;
+  int nd;
+  double lo_i[kMaxHaloDests], hi_i[kMaxHaloDests], lo_j[kMaxHaloDests], hi_j[kMaxHaloDests];
+  unsigned long long cap;
+};
+int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
+                    double* dev_out, unsigned long long* dev_counts);
 int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p);
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
               const uint8_t* dev_frames);

@@ -97,8 +97,8 @@ constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 // radius).  Cell i has its centre at continuous coordinate ci == i.
 __device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
                                           double py, uint32_t* bin) {
-  const double cx = (p.base_x - px) * p.inv_res;
-  const double cy = (p.base_y - py) * p.inv_res;
+  const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+  const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
   const double lo = -(double)p.M - 0.5;
   const double hx = (double)(p.rows + p.M) - 0.5;
   const double hy = (double)(p.cols + p.M) - 0.5;
@@ -151,6 +151,49 @@ k_dsm_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
     sorted[3 * slot + 1] = py;
     sorted[3 * slot + 2] = z;
   }
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU: compact the points other windows need (their halo)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_halo_select(const double* __restrict__ xyz, size_t n, HaloParams hp,
+              double* __restrict__ out, unsigned long long* __restrict__ counts) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += stride) {
+    const double x = xyz[3 * idx + 0];
+    const double y = xyz[3 * idx + 1];
+    // continuous cell coordinates in the full map (same frame as point_bin)
+    const double cx = (hp.base_x - (x - hp.sub_x)) * hp.inv_res;
+    const double cy = (hp.base_y - (y - hp.sub_y)) * hp.inv_res;
+#pragma unroll
+    for (int d = 0; d < kMaxHaloDests; ++d) {
+      if (d < hp.nd && cx >= hp.lo_i[d] && cx <= hp.hi_i[d] && cy >= hp.lo_j[d] &&
+          cy <= hp.hi_j[d]) {
+        const unsigned long long slot = atomicAdd(&counts[d], 1ull);
+        if (slot < hp.cap) {
+          double* o = out + ((size_t)d * hp.cap + slot) * 3;
+          o[0] = x;
+          o[1] = y;
+          o[2] = xyz[3 * idx + 2];
+        }
+      }
+    }
+  }
+}
+
+int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
+                    double* dev_out, unsigned long long* dev_counts) {
+  ScopedTimer t(c, AMHIP_K_HALO_SELECT);
+  AMHIP_TRY(hipMemsetAsync(dev_counts, 0, sizeof(unsigned long long) * hp.nd, c->stream));
+  if (n == 0) return AMHIP_OK;
+  size_t grid = (n + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(k_halo_select, dim3((unsigned)grid), dim3(256), 0, c->stream,
+                     dev_xyz, n, hp, dev_out, dev_counts);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -348,8 +391,8 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             int j, float* __restrict__ elevation,
                                             unsigned* __restrict__ dev_err) {
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
-  const double qx = p.base_x + p.res * (-(double)i);
-  const double qy = p.base_y + p.res * (-(double)j);
+  const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
+  const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
   Accum acc = {0.0, 0.0, 0u, false};
   double dmin = 0.0;
   scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
@@ -516,8 +559,8 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       const double px = sorted[3 * (size_t)g + 0];
       const double py = sorted[3 * (size_t)g + 1];
       // same arithmetic as point_bin(): the point's cell in shifted coordinates
-      const double cx = (p.base_x - px) * p.inv_res;
-      const double cy = (p.base_y - py) * p.inv_res;
+      const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+      const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
       int ix = (int)floor(cx + 0.5) + p.M;
       int iy = (int)floor(cy + 0.5) + p.M;
       ix = min(max(ix, 0), p.rows + 2 * p.M - 1) - ox;
@@ -570,14 +613,14 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const double T0 = p.T[0];
   const int nwin2 = 2 * w0 + 2;
   if (i <= i_hi) {
-    const double qx = p.base_x + p.res * (-(double)i);
+    const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
     const int ci = i + p.M - ox;  // this cell's column in the region
     for (int c = 0; c < kCellsPerLane; c += 2) {
       const int jA = j0 + wid * kCellsPerLane + c;
       if (jA > j_hi) break;
       const bool haveB = (jA + 1 <= j_hi) && (c + 1 < kCellsPerLane);
-      const double qyA = p.base_y + p.res * (-(double)jA);
-      const double qyB = p.base_y + p.res * (-(double)(jA + 1));
+      const double qyA = p.base_y + p.res * (-(double)(jA + p.j_off));
+      const double qyB = p.base_y + p.res * (-(double)(jA + 1 + p.j_off));
       const double TB = haveB ? T0 : -1.0;  // d2 < -1 never holds
       const int cj = jA + p.M - oy;
       // Division-free IDW: h = (sum z_i/d_i) / (sum 1/d_i) is kept as N/D with
@@ -672,8 +715,8 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
     const int code = s_flag[f];
     const int fi = i0 + (code % kTileI);
     const int fj = j0 + (code / kTileI);
-    const double fqx = p.base_x + p.res * (-(double)fi);
-    const double fqy = p.base_y + p.res * (-(double)fj);
+    const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
+    const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
     cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, elevation, dev_err);
   }
 }

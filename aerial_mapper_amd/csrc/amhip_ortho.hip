@@ -172,10 +172,10 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   // bounding sphere of the tile's landmarks (cell centres x elevation range)
   const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
   const int j_hi = min(j0 + kTileJ, p.cols) - 1;
-  const double xa = p.base_x + p.res * (-(double)(blockIdx.x * kTileI));
-  const double xb = p.base_x + p.res * (-(double)i_hi);
-  const double ya = p.base_y + p.res * (-(double)j0);
-  const double yb = p.base_y + p.res * (-(double)j_hi);
+  const double xa = p.base_x + p.res * (-(double)((int)(blockIdx.x * kTileI) + p.i_off));
+  const double xb = p.base_x + p.res * (-(double)(i_hi + p.i_off));
+  const double ya = p.base_y + p.res * (-(double)(j0 + p.j_off));
+  const double yb = p.base_y + p.res * (-(double)(j_hi + p.j_off));
   const V3 centre = {0.5 * (xa + xb), 0.5 * (ya + yb),
                      0.5 * ((double)zmin + (double)zmax)};
   const double hx = 0.5 * fabs(xa - xb), hy = 0.5 * fabs(ya - yb),
@@ -184,7 +184,7 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6;
 
   // ---- per-lane fold state ---------------------------------------------------
-  const double lx = p.base_x + p.res * (-(double)i);
+  const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
   float best[kCellsPerLane];
   int best_f[kCellsPerLane];
   int best_u[kCellsPerLane];
@@ -249,7 +249,7 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
 #pragma unroll
         for (int c = 0; c < kCellsPerLane; ++c) {
           const int j = j0 + wid + c * (kOrthoThreads / 64);
-          const double ly = p.base_y + p.res * (-(double)j);
+          const double ly = p.base_y + p.res * (-(double)(j + p.j_off));
           const V3 landmark = {lx, ly, (double)elev[c]};
           const V3 cp = transform_point(T, landmark);
           double u, v;

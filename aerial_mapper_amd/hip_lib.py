@@ -26,18 +26,19 @@ LAYER_NAMES = ["ortho", "elevation", "elevation_angle", "num_observations",
                "observation_index", "colored_ortho"]
 
 # amhip_kernel
-(K_DSM_BIN_COUNT, K_DSM_SCAN, K_DSM_SCATTER, K_DSM_GATHER, K_ORTHO, K_MISC) = range(6)
-NUM_KERNELS = 6
+(K_DSM_BIN_COUNT, K_DSM_SCAN, K_DSM_SCATTER, K_DSM_GATHER, K_ORTHO, K_MISC,
+ K_HALO_SELECT) = range(7)
+NUM_KERNELS = 7
 
 DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = 0, 1, 2
 
 # every symbol include/aerial_mapper_hip.h declares
 EXPORTS = [
     "amhip_abi_version", "amhip_last_error", "amhip_make_grid", "amhip_cell_position",
-    "amhip_ctx_create", "amhip_ctx_destroy", "amhip_ctx_set_stream", "amhip_ctx_synchronize",
+    "amhip_ctx_create", "amhip_ctx_create_window", "amhip_ctx_destroy", "amhip_ctx_set_stream", "amhip_ctx_synchronize",
     "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
     "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
-    "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
+    "amhip_halo_select_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
     "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
 ]
@@ -97,6 +98,8 @@ def load():
     lib.amhip_cell_position.restype = None
     lib.amhip_cell_position.argtypes = [gp, C.c_int, C.c_int, f64p, f64p]
     lib.amhip_ctx_create.argtypes = [gp, C.c_int, C.POINTER(vp)]
+    lib.amhip_ctx_create_window.argtypes = [gp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.POINTER(vp)]
     lib.amhip_ctx_destroy.restype = None
     lib.amhip_ctx_destroy.argtypes = [vp]
     lib.amhip_ctx_set_stream.argtypes = [vp, vp]
@@ -108,6 +111,9 @@ def load():
     lib.amhip_layer_device_ptr.argtypes = [vp, C.c_int]
     lib.amhip_dsm_process_dev.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double]
     lib.amhip_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
+    lib.amhip_halo_select_dev.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double,
+                                          C.POINTER(C.c_int32), C.c_int, C.c_double, vp,
+                                          C.c_size_t, vp]
     lib.amhip_compose_T_G_C.restype = None
     lib.amhip_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amhip_ortho_backward_process_dev.argtypes = [

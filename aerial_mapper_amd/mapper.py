@@ -37,14 +37,22 @@ class GridMapSettings(object):
 class AerialGridMap(object):
     """grid_map::AerialGridMap: geometry + the layers, device resident."""
 
-    def __init__(self, settings, device=0):
+    def __init__(self, settings, device=0, window=None):
+        """window = (i0, j0, rows, cols): own only that part of the map (one tile
+        of a survey spread over several GPUs); positions and results are those of
+        the full map, the layers hold just the window."""
         self.settings = settings
         lib = L.load()
         self.grid = L.make_grid(settings.delta_easting, settings.delta_northing,
                                 settings.resolution, settings.center_easting,
                                 settings.center_northing)
+        if window is None:
+            window = (0, 0, self.grid.rows, self.grid.cols)
+        self.window = tuple(int(v) for v in window)
         h = C.c_void_p()
-        L.check(lib.amhip_ctx_create(C.byref(self.grid), int(device), C.byref(h)))
+        L.check(lib.amhip_ctx_create_window(C.byref(self.grid), self.window[0], self.window[1],
+                                            self.window[2], self.window[3], int(device),
+                                            C.byref(h)))
         self._h = h
         self._lib = lib
         self.device = int(device)
@@ -70,15 +78,15 @@ class AerialGridMap(object):
     # -- geometry ---------------------------------------------------------
     @property
     def rows(self):
-        return self.grid.rows
+        return self.window[2]
 
     @property
     def cols(self):
-        return self.grid.cols
+        return self.window[3]
 
     @property
     def num_cells(self):
-        return self.grid.rows * self.grid.cols
+        return self.window[2] * self.window[3]
 
     @property
     def handle(self):
@@ -92,14 +100,14 @@ class AerialGridMap(object):
     def get(self, layer):
         """Download a layer: float32 array of shape (cols, rows) -- numpy C order
         of an Eigen column-major (rows, cols) matrix, so a[j, i] == layer(i, j)."""
-        out = np.empty((self.grid.cols, self.grid.rows), np.float32)
+        out = np.empty((self.cols, self.rows), np.float32)
         L.check(self._lib.amhip_layer_download(self._h, self._layer_id(layer),
                                                out.ctypes.data))
         return out
 
     def set(self, layer, values):
         a = np.ascontiguousarray(values, np.float32)
-        assert a.shape == (self.grid.cols, self.grid.rows), a.shape
+        assert a.shape == (self.cols, self.rows), a.shape
         L.check(self._lib.amhip_layer_upload(self._h, self._layer_id(layer), a.ctypes.data))
 
     def device_ptr(self, layer):
@@ -116,7 +124,7 @@ class AerialGridMap(object):
 
         holder = _Holder()
         holder.__cuda_array_interface__ = {
-            "shape": (self.grid.cols, self.grid.rows), "typestr": "<f4",
+            "shape": (self.cols, self.rows), "typestr": "<f4",
             "data": (int(ptr), False), "version": 2}
         holder._keepalive = self
         assert n > 0

@@ -1,0 +1,216 @@
+"""One survey map tiled over several GPUs (one process per GPU).
+
+The reference is a single process; this is new design.
+Cells are independent once a rank holds every point within the LAST fallback
+radius (< sqrt(7) m, dsm.cc:133-144) of its window, plus the frames.  So:
+
+  * the map is cut into windows (`TileLayout`), every rank creates
+    `AerialGridMap(settings, device, window=...)` -- cell positions, hence
+    results, are those of the full map;
+  * points are handed to the rank that owns their cell; the only data-path
+    collective is the HALO exchange: every rank selects the points other
+    windows need within `halo_margin()` metres (HIP kernel
+    `amhip_halo_select_dev` on the GPU) and ships them with ONE all_to_all
+    (`torch.distributed`, backend "nccl" = RCCL over xGMI; "gloo" in the CPU
+    tests).  Volume: perimeter x margin x density, a few MB per rank -- latency
+    bound, not bandwidth bound;
+  * frames / poses are replicated; the mosaic needs no exchange.
+
+`route_points()` is the general entry: it also works for clouds that arrive
+partitioned by source instead of by tile (then it moves everything once).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+MAX_DESTS = 8
+
+
+class TileLayout(object):
+    """tiles_i x tiles_j windows of a (rows x cols) map; rank r owns window
+    (r % tiles_i, r // tiles_i).  Window edges are multiples of `align` cells
+    (the DSM gather tile is 64 x 32) except at the map border."""
+
+    def __init__(self, rows, cols, tiles_i, tiles_j, align_i=64, align_j=32):
+        self.rows, self.cols = int(rows), int(cols)
+        self.tiles_i, self.tiles_j = int(tiles_i), int(tiles_j)
+        self.edges_i = self._edges(self.rows, self.tiles_i, align_i)
+        self.edges_j = self._edges(self.cols, self.tiles_j, align_j)
+
+    @staticmethod
+    def _edges(n, parts, align):
+        edges = [0]
+        for k in range(1, parts):
+            e = int(round(n * k / float(parts) / align)) * align
+            e = min(max(e, edges[-1] + 1), n - (parts - k))
+            edges.append(e)
+        edges.append(n)
+        return edges
+
+    @property
+    def world(self):
+        return self.tiles_i * self.tiles_j
+
+    def window(self, rank):
+        ti, tj = rank % self.tiles_i, rank // self.tiles_i
+        i0, i1 = self.edges_i[ti], self.edges_i[ti + 1]
+        j0, j1 = self.edges_j[tj], self.edges_j[tj + 1]
+        return (i0, j0, i1 - i0, j1 - j0)
+
+    def windows(self):
+        return [self.window(r) for r in range(self.world)]
+
+    @staticmethod
+    def for_world(rows, cols, world):
+        """Near-square factorisation, more tiles along the longer axis."""
+        best = (1, world)
+        for a in range(1, world + 1):
+            if world % a == 0:
+                b = world // a
+                if abs(rows / float(a) - cols / float(b)) < \
+                        abs(rows / float(best[0]) - cols / float(best[1])):
+                    best = (a, b)
+        return TileLayout(rows, cols, best[0], best[1])
+
+
+def halo_margin(radius_sq, resolution):
+    """Metres a window has to be grown by so that it contains every point any of
+    its cells can reach: sqrt of the largest squared radius the ladder of
+    dsm.cc:127-144 tries, plus one cell of slack."""
+    tmax = float(radius_sq)
+    lam = 1.0
+    while True:
+        tmax = max(tmax, lam * radius_sq)
+        lam *= 1.1
+        if lam * radius_sq > 7.0:
+            break
+    return math.sqrt(tmax) + resolution
+
+
+def cell_coords(points_xy, grid, center_easting=0.0, center_northing=0.0):
+    """Continuous cell coordinates (cell i has its centre at ci == i) of points
+    in the frame the DSM bins them in (dsm.cc:42-43 offsets applied).  Works on
+    numpy arrays and torch tensors."""
+    base_x = grid.pos_x + (0.5 * grid.length_x - 0.5 * grid.resolution)
+    base_y = grid.pos_y + (0.5 * grid.length_y - 0.5 * grid.resolution)
+    inv = 1.0 / grid.resolution
+    cx = (base_x - (points_xy[:, 0] - center_northing)) * inv
+    cy = (base_y - (points_xy[:, 1] - center_easting)) * inv
+    return cx, cy
+
+
+def in_window(cx, cy, window, margin_cells=0.0):
+    i0, j0, r, c = window
+    return (cx >= i0 - 0.5 - margin_cells) & (cx <= i0 + r - 0.5 + margin_cells) & \
+           (cy >= j0 - 0.5 - margin_cells) & (cy <= j0 + c - 0.5 + margin_cells)
+
+
+def owner_mask(cx, cy, window):
+    """Points whose CELL lies in the window (half-open: each point has exactly
+    one owner)."""
+    i0, j0, r, c = window
+    return (cx >= i0 - 0.5) & (cx < i0 + r - 0.5) & (cy >= j0 - 0.5) & (cy < j0 + c - 0.5)
+
+
+def select_for_windows(points, grid, windows, margin_m, center_easting=0.0,
+                       center_northing=0.0, map_=None, cap=None):
+    """For every window in `windows`: the points of `points` inside it grown by
+    margin_m.  Returns (list of tensors).  CUDA tensors go through the HIP
+    kernel of the context `map_` (<= 8 windows per call); CPU tensors / numpy
+    arrays through plain masking (gloo tests)."""
+    import torch
+    if isinstance(points, np.ndarray):
+        points = torch.from_numpy(points)
+    if not points.is_cuda:
+        cx, cy = cell_coords(points, grid, center_easting, center_northing)
+        mc = margin_m / grid.resolution
+        return [points[in_window(cx, cy, w, mc)] for w in windows]
+    assert map_ is not None, "a device context is needed for CUDA clouds"
+    from . import hip_lib as L
+    lib = L.load()
+    n = points.shape[0]
+    out = []
+    for lo in range(0, len(windows), MAX_DESTS):
+        ws = windows[lo:lo + MAX_DESTS]
+        nd = len(ws)
+        if cap is None:
+            # perimeter strip estimate with generous slack, never more than n
+            cap_d = n
+        else:
+            cap_d = int(cap)
+        cap_d = max(cap_d, 1)
+        buf = torch.empty((nd, cap_d, 3), dtype=torch.float64, device=points.device)
+        counts = torch.zeros(nd, dtype=torch.int64, device=points.device)
+        wins = (C.c_int32 * (4 * nd))(*[int(v) for w in ws for v in w])
+        L.check(lib.amhip_halo_select_dev(
+            map_.handle, C.c_void_p(points.data_ptr()), n, center_easting, center_northing,
+            wins, nd, float(margin_m), C.c_void_p(buf.data_ptr()), cap_d,
+            C.c_void_p(counts.data_ptr())))
+        map_.synchronize()  # the kernel ran on the context's stream
+        cnt = counts.cpu().tolist()
+        for d in range(nd):
+            if cnt[d] > cap_d:
+                raise RuntimeError("halo buffer too small: %d > %d" % (cnt[d], cap_d))
+            out.append(buf[d, :cnt[d]])
+    return out
+
+
+def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_easting=0.0,
+                 center_northing=0.0, map_=None, assume_owned=False, cap=None,
+                 workspace=None):
+    """Exchange points so that this rank ends up with every point inside its
+    window grown by the halo margin.
+
+    points        (N,3) float64 tensor this rank currently holds (any subset of
+                  the cloud; CUDA for nccl/RCCL, CPU for gloo)
+    assume_owned  True: all of `points` already belong to this rank's window
+                  (pre-partitioned cloud) -> they are kept in place and only the
+                  halo strips travel.
+    workspace     optional (M,3) tensor whose first N rows ARE `points` (same
+                  storage) and M - N >= the halo volume: the received points are
+                  written behind the owned ones and no copy of the cloud is made
+                  (only with assume_owned).
+    Returns (N',3): kept points followed by the received ones.
+    """
+    import torch
+    import torch.distributed as dist
+    world = layout.world
+    margin = halo_margin(radius_sq, grid.resolution)
+    if isinstance(points, np.ndarray):
+        points = torch.from_numpy(points)
+    if world == 1:
+        return points
+    wins = layout.windows()
+    others = [r for r in range(world) if r != rank]
+    if assume_owned:
+        keep = points
+        sends = select_for_windows(points, grid, [wins[r] for r in others], margin,
+                                   center_easting, center_northing, map_, cap)
+    else:
+        sel = select_for_windows(points, grid, wins, margin, center_easting, center_northing,
+                                 map_, cap)
+        keep = sel[rank]
+        sends = [sel[r] for r in others]
+    send_counts = [0] * world
+    for r, t in zip(others, sends):
+        send_counts[r] = int(t.shape[0])
+    # 1) counts, 2) payload: ONE all_to_all each
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=points.device)
+    rc = torch.empty_like(sc)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(v) for v in rc.cpu().tolist()]
+    send_buf = torch.cat([t.reshape(-1, 3) for t in sends], 0) if sends else points[:0]
+    total_recv = sum(recv_counts)
+    nk = keep.shape[0]
+    if workspace is not None and assume_owned and workspace.data_ptr() == points.data_ptr() \
+            and workspace.shape[0] >= nk + total_recv:
+        out = workspace[:nk + total_recv]
+    else:
+        out = torch.empty((nk + total_recv, 3), dtype=points.dtype, device=points.device)
+        out[:nk] = keep
+    recv_view = out[nk:]
+    dist.all_to_all_single(recv_view, send_buf.contiguous(),
+                           output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                           group=group)
+    return out

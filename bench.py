@@ -149,17 +149,41 @@ def main():
     import aerial_mapper_amd as A
     from aerial_mapper_amd import synth
 
+    from aerial_mapper_amd import tiling
     wl = WORKLOADS[args.workload]
     side, res = wl["side"], wl["res"]
     L = side * res
-    # rank r owns tile r of a 1 x N strip of tiles (weak scaling)
-    tile_center = (rank * L, 0.0)
-    st = A.GridMapSettings(tile_center[0], tile_center[1], L, L, res)
-    m = A.AerialGridMap(st, device=local_rank)
+    # ONE survey map of world x 1 tiles (weak scaling: every rank owns a
+    # side x side window of it, cell positions are those of the full map)
+    st = A.GridMapSettings(0.0, 0.0, world * L, L, res)
+    layout = tiling.TileLayout(world * side, side, world, 1)
+    win = layout.window(rank)
+    m = A.AerialGridMap(st, device=local_rank, window=win)
     m.set_stream(torch.cuda.current_stream().cuda_stream)
+    # centre of this rank's window in map coordinates (x decreases with i)
+    tile_center = (world * L / 2.0 - (win[0] + win[2] / 2.0) * res, 0.0)
 
-    # inputs, generated in HBM (synthetic, seeded): the tile's points + 4 m halo
-    pts = synth.make_points_torch(wl["points"], L / 2.0 + 4.0, 43 + rank, dev, center=tile_center)
+    # inputs, generated in HBM (synthetic, seeded).  N = 1: the tile's points
+    # plus a 4 m apron.  N > 1: each rank holds exactly the points of ITS
+    # window; the halo strips are exchanged over RCCL inside every step.
+    apron = 4.0 if world == 1 else 0.0
+    n_pts = wl["points"]
+    halo_cap = 0
+    if world > 1:
+        halo_cap = int(4.0 * (2 * (L + L)) * tiling.halo_margin(1, res) * n_pts / (L * L)) + 4096
+    pts_buf = torch.empty((n_pts + halo_cap, 3), dtype=torch.float64, device=dev)
+    pts_buf[:n_pts] = synth.make_points_torch(n_pts, L / 2.0 + apron, 43 + rank, dev,
+                                              center=tile_center)
+    if world > 1:
+        # keep only points whose cell is inside the window (a point exactly on
+        # the upper edge belongs to the neighbour)
+        cxx, cyy = tiling.cell_coords(pts_buf[:n_pts], m.grid)
+        own = tiling.owner_mask(cxx, cyy, win)
+        kept = pts_buf[:n_pts][own]
+        n_pts = int(kept.shape[0])
+        pts_buf[:n_pts] = kept
+        del cxx, cyy, own, kept
+    pts = pts_buf[:n_pts]
     F = wl["frames"]
     ch = 3 if args.colored else 1
     frames = poses = ncam = mosaic = None
@@ -174,7 +198,12 @@ def main():
 
     def step():
         m.reset()
-        dsm.process(pts, m, sync=False)
+        cloud = pts
+        if world > 1:
+            cloud = tiling.route_points(pts, m.grid, layout, rank, radius_sq=1, map_=m,
+                                        assume_owned=True, cap=halo_cap // 2,
+                                        workspace=pts_buf)
+        dsm.process(cloud, m, sync=False)
         if F:
             mosaic.process(poses, frames, m, sync=False)
 
@@ -231,9 +260,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload + ": " + wl["desc"],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
-                       "step": "layers reset + Dsm::process + OrthoBackwardGrid::process, "
-                               "inputs resident in HBM",
-                       "parallelism": "tile-per-gpu x%d" % world},
+                       "step": "layers reset + %sDsm::process + OrthoBackwardGrid::process, "
+                               "inputs resident in HBM" %
+                               ("halo exchange (RCCL all_to_all) + " if world > 1 else ""),
+                       "parallelism": "one map, %d x 1 windows, one per GPU" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,

@@ -1,0 +1,118 @@
+"""world_size-2 (and 4) CPU tests of the multi-GPU path: tile layout, halo
+routing over torch.distributed (gloo here, RCCL on the GPUs), and the property
+that makes tiling exact: a tile's DSM computed from the routed subset equals
+the full-cloud DSM on that tile's cells."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tiles, assume_owned, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from aerial_mapper_amd import synth, tiling
+    import oracle_ffi as OO
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = OO.make_grid(160.0, 128.0, 0.5)
+        layout = tiling.TileLayout(g.rows, g.cols, tiles[0], tiles[1])
+        assert layout.world == world
+        cloud = synth.make_points(60000, 90.0, 77)  # spills over the map border
+        cx, cy = tiling.cell_coords(cloud, g)
+        if assume_owned:
+            mine = cloud[tiling.owner_mask(cx, cy, layout.window(rank))]
+        else:
+            mine = cloud[rank::world]  # partitioned by source, not by tile
+        got = tiling.route_points(torch.from_numpy(np.ascontiguousarray(mine)), g, layout, rank,
+                                  radius_sq=1, assume_owned=assume_owned).numpy()
+        margin = tiling.halo_margin(1, g.resolution)
+        want_mask = tiling.in_window(cx, cy, layout.window(rank), margin / g.resolution)
+        if assume_owned:
+            # points outside every window (beyond the map) have no owner and are
+            # only needed if they fall inside a grown window: they are dropped
+            # by the owned partition, exactly like a pre-partitioned cloud
+            inside_any = np.zeros(len(cloud), bool)
+            for r in range(world):
+                inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
+            want_mask &= inside_any
+        want = cloud[want_mask]
+        key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        same_set = got.shape == want.shape and np.array_equal(key(got), key(want))
+        # exactness of tiling: DSM of the routed subset == DSM of the whole cloud
+        # on this window's cells (oracle, full-map geometry)
+        full = OO.dsm_process(cloud if not assume_owned else cloud[inside_any], g)[1]
+        part = OO.dsm_process(got, g)[1]
+        i0, j0, r, c = layout.window(rank)
+        a, b = full[j0:j0 + c, i0:i0 + r], part[j0:j0 + c, i0:i0 + r]
+        # same neighbour sets; the kd-tree visiting order (hence the last bits
+        # of the double sums) may differ between the two trees
+        nan_ok = np.array_equal(np.isnan(a), np.isnan(b))
+        err = float(np.nanmax(np.abs(a.astype(np.float64) - b))) if (~np.isnan(a)).any() else 0.0
+        ret[rank] = (same_set, nan_ok, err, int(got.shape[0]), int((~np.isnan(a)).sum()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tiles,assume_owned", [(2, (2, 1), True), (2, (1, 2), False),
+                                                       (4, (2, 2), True)])
+def test_route_points_gloo(world, tiles, assume_owned):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tiles, assume_owned, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(world):
+        same_set, nan_ok, err, n, filled = ret[r]
+        assert same_set, "rank %d holds the wrong point set" % r
+        assert nan_ok and err <= 1e-6 and n > 0 and filled > 0, (r, nan_ok, err, n, filled)
+
+
+def test_tile_layout_covers_map_once():
+    from aerial_mapper_amd import tiling
+    for rows, cols, ti, tj in [(10000, 10000, 2, 4), (1000, 777, 3, 2), (64, 32, 1, 1),
+                               (40000, 10000, 8, 1)]:
+        lay = tiling.TileLayout(rows, cols, ti, tj)
+        cover = np.zeros((rows, cols), np.int32) if rows * cols < 5e7 else None
+        area = 0
+        for r in range(lay.world):
+            i0, j0, nr, nc = lay.window(r)
+            assert nr > 0 and nc > 0 and i0 + nr <= rows and j0 + nc <= cols
+            area += nr * nc
+            if cover is not None:
+                cover[i0:i0 + nr, j0:j0 + nc] += 1
+        assert area == rows * cols
+        if cover is not None:
+            assert (cover == 1).all()
+    lay = tiling.TileLayout.for_world(40000, 10000, 8)
+    assert (lay.tiles_i, lay.tiles_j) == (8, 1) or lay.tiles_i * lay.tiles_j == 8
+
+
+def test_halo_margin_is_last_ladder_radius():
+    from aerial_mapper_amd import tiling
+    assert abs(tiling.halo_margin(1, 0.25) - (np.sqrt(1.1 ** 20) + 0.25)) < 1e-9
+    assert abs(tiling.halo_margin(9, 1.0) - (3.0 + 1.0)) < 1e-12
