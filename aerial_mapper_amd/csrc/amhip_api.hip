@@ -241,6 +241,23 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       (unsigned long long)p.nbx * (unsigned long long)p.nby;
   if (nbins + 1 >= 0xFFFFFFFFull) return arg_fail("grid too large for 32-bit bin ids");
 
+  // ---- two-level stripe sort plan (amhip_dsm.hip) -----------------------------
+  p.stripe_rows = 0;
+  p.nstripes = 0;
+  if (p.nbx <= 8192) {
+    int rps = 8192 / p.nbx;          // bins of a stripe must fit the LDS histogram
+    const int want = p.nby / 1024;   // ~1000 stripes keep every CU busy
+    if (want >= 1 && rps > want) rps = want;
+    if (std::getenv("AMHIP_STRIPE_ROWS")) rps = std::atoi(std::getenv("AMHIP_STRIPE_ROWS"));
+    if (rps < 1) rps = 1;
+    if (rps > 8192 / p.nbx && 8192 / p.nbx >= 1) rps = 8192 / p.nbx;
+    const int ns = (p.nby + rps - 1) / rps;
+    if (ns <= 8192) {
+      p.stripe_rows = rps;
+      p.nstripes = ns;
+    }
+  }
+
   // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
   const int kTileI = 64, kTileJ = 32;
   p.tiles_i = (p.rows + kTileI - 1) / kTileI;
@@ -483,7 +500,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->dev_err, c->sorted,       c->rank,        c->bin_start,
+  void* bufs[] = {c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -767,11 +784,11 @@ int amhip_ctx_kernel_time(amhip_ctx* h, int kernel, double* total_ms,
 const char* amhip_kernel_name(int kernel) {
   switch (kernel) {
     case AMHIP_K_DSM_BIN_COUNT:
-      return "k_dsm_bin_count";
-    case AMHIP_K_DSM_SCAN:
-      return "k_scan_partials+k_scan_top+k_scan_final";
+      return "k_dsm_stripe_count";   // + k_dsm_stripe_scan (one-level path: k_dsm_bin_count)
     case AMHIP_K_DSM_SCATTER:
-      return "k_dsm_scatter";
+      return "k_dsm_stripe_scatter"; // (one-level path: k_dsm_scatter)
+    case AMHIP_K_DSM_SCAN:
+      return "k_dsm_stripe_sort";    // (one-level path: k_scan_*)
     case AMHIP_K_DSM_GATHER:
       return "k_dsm_gather";
     case AMHIP_K_ORTHO:

@@ -43,6 +43,8 @@ struct DsmParams {
   // binning: bins of B x B cells, grid extended by M cells on every side
   double inv_res;
   int B, M, nbx, nby;
+  // two-level stripe sort: a stripe = stripe_rows consecutive bin rows (0 = off)
+  int stripe_rows, nstripes;
   // radius ladder (squared radii, exactly the doubles dsm.cc:127-144 uses)
   int nlevels;
   double T[kMaxLevels];
@@ -118,6 +120,10 @@ struct Ctx {
   size_t bin_cap = 0;
   uint32_t* scan_partials = nullptr;
   size_t partial_cap = 0;
+  double* tmp_points = nullptr;    // stripe-ordered points (level 1 of the sort)
+  size_t tmp_points_cap = 0;
+  uint32_t* stripe_ws = nullptr;   // stripe counts / starts / cursors
+  size_t stripe_ws_cap = 0;
   double* stage_points = nullptr;  // H2D staging of host clouds
   size_t stage_points_cap = 0;
 

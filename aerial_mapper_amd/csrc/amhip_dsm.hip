@@ -154,6 +154,176 @@ k_dsm_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
 }
 
 // ---------------------------------------------------------------------------
+// two-level stripe sort (the default binning path)
+// ---------------------------------------------------------------------------
+// The one-level counting sort above pays one device-scope atomic and two
+// random 24..64-byte HBM transactions per point.  The stripe sort replaces it:
+//   level 1  points -> STRIPES (a few consecutive bin rows, ~1000 stripes).
+//            Per-workgroup LDS histograms aggregate the global atomics (one
+//            per stripe per 16 K points) and every workgroup appends runs of
+//            consecutive points to each stripe -> near-streaming writes.
+//   level 2  one workgroup per stripe: LDS histogram over the stripe's bins,
+//            LDS scan -> bin_start[] for those bins, then the points are
+//            placed; a stripe is ~1 MB, so the second read and the random
+//            placement stay inside the XCD's L2.
+// Stripes are whole bin rows, so the final order is still row-major by bin.
+constexpr int kMaxStripes = 8192;
+constexpr int kMaxStripeBins = 8192;
+constexpr int kL1Threads = 256;
+constexpr int kL1Chunk = 16384;  // points per workgroup in the level-1 scatter
+constexpr int kL2Threads = 512;
+
+__device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, double py,
+                                             int* bx, int* by) {
+  const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+  const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+  const double lo = -(double)p.M - 0.5;
+  const double hx = (double)(p.rows + p.M) - 0.5;
+  const double hy = (double)(p.cols + p.M) - 0.5;
+  if (!(cx >= lo && cx < hx && cy >= lo && cy < hy)) return false;  // NaN too
+  int ix = (int)floor(cx + 0.5) + p.M;
+  int iy = (int)floor(cy + 0.5) + p.M;
+  ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
+  iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
+  *bx = ix / p.B;
+  *by = iy / p.B;
+  return true;
+}
+
+__global__ void __launch_bounds__(kL1Threads)
+k_dsm_stripe_count(const double* __restrict__ xyz, size_t n, DsmParams p,
+                   uint32_t* __restrict__ stripe_cnt) {
+  extern __shared__ uint32_t s_hist[];
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_hist[k] = 0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * kL1Threads;
+  for (size_t idx = (size_t)blockIdx.x * kL1Threads + threadIdx.x; idx < n; idx += stride) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_hist[by / p.stripe_rows], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
+    const uint32_t c = s_hist[k];
+    if (c) atomicAdd(&stripe_cnt[k], c);
+  }
+}
+
+// One block: stripe_start = exclusive scan of stripe_cnt (+ total), and a copy
+// that the level-1 scatter uses as its append cursors.
+__global__ void __launch_bounds__(1024)
+k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
+                  uint32_t* __restrict__ stripe_start, uint32_t* __restrict__ cursor) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  unsigned carry = 0;
+  for (int base = 0; base < nstripes; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned v = (i < nstripes) ? stripe_cnt[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
+    if (i < nstripes) {
+      stripe_start[i] = carry + ex;
+      cursor[i] = carry + ex;
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) stripe_start[nstripes] = carry;
+}
+
+__global__ void __launch_bounds__(kL1Threads)
+k_dsm_stripe_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
+                     uint32_t* __restrict__ cursor, double* __restrict__ tmp) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
+  uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
+  const size_t c0 = (size_t)blockIdx.x * kL1Chunk;
+  const size_t c1 = min(c0 + (size_t)kL1Chunk, n);
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_cnt[k] = 0;
+  __syncthreads();
+  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;
+    const double py = xyz[3 * idx + 1] - p.sub_y;
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_cnt[by / p.stripe_rows], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
+    const uint32_t c = s_cnt[k];
+    s_base[k] = c ? atomicAdd(&cursor[k], c) : 0u;
+    s_cnt[k] = 0;
+  }
+  __syncthreads();
+  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {  // (L2 hits)
+    const double px = xyz[3 * idx + 0] - p.sub_x;
+    const double py = xyz[3 * idx + 1] - p.sub_y;
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) {
+      const int st = by / p.stripe_rows;
+      const size_t slot = (size_t)s_base[st] + atomicAdd(&s_cnt[st], 1u);
+      tmp[3 * slot + 0] = px;
+      tmp[3 * slot + 1] = py;
+      tmp[3 * slot + 2] = xyz[3 * idx + 2];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kL2Threads)
+k_dsm_stripe_sort(const double* __restrict__ tmp, DsmParams p,
+                  const uint32_t* __restrict__ stripe_start,
+                  uint32_t* __restrict__ bin_start, double* __restrict__ sorted) {
+  extern __shared__ uint32_t s_bins[];  // bins of this stripe (+ scan scratch behind)
+  const int st = blockIdx.x;
+  const int row0 = st * p.stripe_rows;
+  const int nrow = min(p.stripe_rows, p.nby - row0);
+  const int nb = nrow * p.nbx;
+  uint32_t* s_scan = s_bins + nb;
+  const uint32_t g0 = stripe_start[st];
+  const uint32_t g1 = stripe_start[st + 1];
+  for (int k = threadIdx.x; k < nb; k += kL2Threads) s_bins[k] = 0;
+  __syncthreads();
+  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {
+    const double px = tmp[3 * (size_t)idx + 0];
+    const double py = tmp[3 * (size_t)idx + 1];
+    int bx, by;
+    point_bin_xy(p, px, py, &bx, &by);  // same arithmetic as level 1: always inside
+    atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
+  }
+  __syncthreads();
+  {
+    const int per = (nb + kL2Threads - 1) / kL2Threads;
+    const int lo = threadIdx.x * per;
+    const int hi = min(lo + per, nb);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<kL2Threads>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t* out_start = bin_start + (size_t)row0 * p.nbx;
+  for (int k = threadIdx.x; k < nb; k += kL2Threads) out_start[k] = g0 + s_bins[k];
+  if (st == p.nstripes - 1 && threadIdx.x == 0)
+    bin_start[(size_t)p.nbx * p.nby] = stripe_start[p.nstripes];
+  __syncthreads();
+  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {  // (L2 hits)
+    const double px = tmp[3 * (size_t)idx + 0];
+    const double py = tmp[3 * (size_t)idx + 1];
+    const double pz = tmp[3 * (size_t)idx + 2];
+    int bx, by;
+    point_bin_xy(p, px, py, &bx, &by);
+    const size_t slot = (size_t)g0 + atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
+    sorted[3 * slot + 0] = px;
+    sorted[3 * slot + 1] = py;
+    sorted[3 * slot + 2] = pz;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // multi-GPU: compact the points other windows need (their halo)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -739,37 +909,75 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
   c->last_num_bins = (int64_t)nbins;
   c->last_bin_cells = p.B;
 
+  static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
+  if (p.nstripes > 0 && !force_one_level) {
+    // ---- two-level stripe sort ------------------------------------------------
+    int rc;
+    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
+    if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, 3 * (size_t)p.nstripes + 8)))
+      return rc;
+    uint32_t* stripe_cnt = c->stripe_ws;
+    uint32_t* stripe_start = c->stripe_ws + p.nstripes;          // nstripes + 1
+    uint32_t* stripe_cursor = c->stripe_ws + 2 * p.nstripes + 1;  // nstripes
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      AMHIP_TRY(hipMemsetAsync(stripe_cnt, 0, p.nstripes * sizeof(uint32_t), c->stream));
+      size_t grid = (n + kL1Threads - 1) / kL1Threads;
+      if (grid > 256 * 8) grid = 256 * 8;
+      hipLaunchKernelGGL(k_dsm_stripe_count, dim3((unsigned)grid), dim3(kL1Threads),
+                         p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, n, p, stripe_cnt);
+      hipLaunchKernelGGL(k_dsm_stripe_scan, dim3(1), dim3(1024), 0, c->stream, stripe_cnt,
+                         p.nstripes, stripe_start, stripe_cursor);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      const size_t grid = (n + kL1Chunk - 1) / kL1Chunk;
+      hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
+                         2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, n, p,
+                         stripe_cursor, c->tmp_points);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      const size_t lds = ((size_t)p.stripe_rows * p.nbx + 32) * sizeof(uint32_t);
+      hipLaunchKernelGGL(k_dsm_stripe_sort, dim3((unsigned)p.nstripes), dim3(kL2Threads), lds,
+                         c->stream, c->tmp_points, p, stripe_start, c->bin_start, c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
+  } else {
   {
-    ScopedTimer t(c, AMHIP_K_MISC);
-    AMHIP_TRY(hipMemsetAsync(c->bin_start, 0, (nbins + 1) * sizeof(uint32_t),
-                             c->stream));
-  }
+      ScopedTimer t(c, AMHIP_K_MISC);
+      AMHIP_TRY(hipMemsetAsync(c->bin_start, 0, (nbins + 1) * sizeof(uint32_t),
+                               c->stream));
+    }
   const int block = 256;
   size_t grid_pts = (n + block - 1) / block;
   if (grid_pts > 256 * 16) grid_pts = 256 * 16;
-  {
-    ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
-    hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block),
-                       0, c->stream, dev_xyz, n, p, c->bin_start, c->rank);
-    AMHIP_TRY(hipGetLastError());
-  }
-  {
-    ScopedTimer t(c, AMHIP_K_DSM_SCAN);
-    hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan),
-                       dim3(kScanT), 0, c->stream, c->bin_start, nbins,
-                       c->scan_partials);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream,
-                       c->scan_partials, nblocks_scan, c->bin_start + nbins);
-    hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT),
-                       0, c->stream, c->bin_start, nbins, c->scan_partials);
-    AMHIP_TRY(hipGetLastError());
-  }
-  {
-    ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
-    hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0,
-                       c->stream, dev_xyz, n, p, c->bin_start, c->rank,
-                       c->sorted);
-    AMHIP_TRY(hipGetLastError());
+      {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block),
+                         0, c->stream, dev_xyz, n, p, c->bin_start, c->rank);
+      AMHIP_TRY(hipGetLastError());
+    }
+      {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan),
+                         dim3(kScanT), 0, c->stream, c->bin_start, nbins,
+                         c->scan_partials);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream,
+                         c->scan_partials, nblocks_scan, c->bin_start + nbins);
+      hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT),
+                         0, c->stream, c->bin_start, nbins, c->scan_partials);
+      AMHIP_TRY(hipGetLastError());
+    }
+      {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0,
+                         c->stream, dev_xyz, n, p, c->bin_start, c->rank,
+                         c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
   }
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);

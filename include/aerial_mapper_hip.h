@@ -232,9 +232,9 @@ int amhip_ortho_backward_process(
 
 /* Kernel slots for amhip_ctx_kernel_time(). */
 typedef enum amhip_kernel {
-  AMHIP_K_DSM_BIN_COUNT = 0, /* points -> bin histogram + rank            */
-  AMHIP_K_DSM_SCAN = 1,      /* exclusive scan of the histogram (3 launches) */
-  AMHIP_K_DSM_SCATTER = 2,   /* points -> bin-sorted order                 */
+  AMHIP_K_DSM_BIN_COUNT = 0, /* sort level 1: stripe histogram (+ scan)     */
+  AMHIP_K_DSM_SCAN = 1,      /* sort level 2: per-stripe LDS counting sort  */
+  AMHIP_K_DSM_SCATTER = 2,   /* sort level 1: append points to their stripe */
   AMHIP_K_DSM_GATHER = 3,    /* per-cell radius search + IDW               */
   AMHIP_K_ORTHO = 4,         /* per-tile frame cull + per-cell fold/sample */
   AMHIP_K_MISC = 5,          /* memsets / small helpers                    */
