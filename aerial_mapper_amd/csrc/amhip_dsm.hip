@@ -831,12 +831,16 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
           const double dyB = qyB - xy.y;
           const double d2A = dx2 + dyA * dyA;
           const double d2B = dx2 + dyB * dyB;
+          // (the empty asm keeps these as EXEC-masked blocks: if-converted to
+          // v_cndmask selects they cost 6 extra 64-bit selects per test)
           if (d2A < T0) {  // strict (nanoflann.hpp:157)
+            asm volatile("" ::: "memory");
             NA = fma(NA, d2A, z * PA);
             DA = fma(DA, d2A, PA);
             PA = PA * d2A;
           }
           if (d2B < TB) {
+            asm volatile("" ::: "memory");
             NB = fma(NB, d2B, z * PB);
             DB = fma(DB, d2B, PB);
             PB = PB * d2B;

@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-side", type=int, default=1000,
+    ap.add_argument("--cpu-sample-side", type=int, default=4000,
                     help="cells per side of the sub-tile the CPU oracle is timed on")
     ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
     return ap.parse_args()
