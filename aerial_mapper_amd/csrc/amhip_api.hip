@@ -290,7 +290,6 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     p.lds_bytes = static_cast<unsigned>((bytes + 15) & ~size_t(15));
     if (p.lds_bytes > 150 * 1024) p.lds_ok = 0;
   }
-  p.dbg = std::getenv("AMHIP_DBG") ? std::atoi(std::getenv("AMHIP_DBG")) : 0;
   *out = p;
   return AMHIP_OK;
 }

@@ -58,7 +58,6 @@ struct DsmParams {
   int lds_cells;              // cell-offset table entries reserved (+1 sentinel)
   int tiles_i, tiles_j;
   unsigned lds_bytes;
-  int dbg;                    // timing experiments only (AMHIP_DBG), 0 = off
 };
 
 // Per-frame inverse pose T_C_G = T_G_C^-1 (minkindr inverse()).

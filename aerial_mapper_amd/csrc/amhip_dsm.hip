@@ -603,7 +603,7 @@ constexpr int kTileI = 64;
 constexpr int kTileJ = 32;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
-template <int NT, int NR>
+template <int NT>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
                    const double* __restrict__ sorted,
@@ -696,7 +696,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   if (s_ctl[2] == 0) return;  // empty neighbourhood: every cell stays untouched
 
   const bool use_lds = geom_ok && np <= p.lds_cap;
-  if (p.dbg == 2) return;
   if (!use_lds) {
     // over-full tile (very dense / clustered cloud): global path for all cells
     for (int c = 0; c < kCellsPerLane; ++c) {
@@ -774,7 +773,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   }
   __syncthreads();
 
-  if (p.dbg == 3) return;
   // ---- gather: lane = row index i; the lane's cells are taken two at a time
   // (columns j, j+1): every candidate read from LDS is tested against both,
   // which halves the LDS traffic per test (the LDS pipe is shared by the CU's
@@ -804,7 +802,7 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       // in the region whenever B does).  Two rows are walked per trip of the
       // outer loop as ONE span (lanes wait for each other per trip, and the
       // spread of a two-row candidate count is relatively smaller).
-      const int nrows = p.dbg == 1 ? 0 : (haveB ? nwin2 : nwin2 - 1);
+      const int nrows = haveB ? nwin2 : nwin2 - 1;
       const int* wtab = haveB ? p.wr2 : p.wr;
       const uint32_t* orow = s_off + (cj - w0) * RW + ci;
       for (int r = 0; r < nrows; r += 2) {
@@ -903,12 +901,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   {
     int rc;
-    if ((rc = ensure_capacity(&c->rank, &c->rank_cap, n))) return rc;
     if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * n))) return rc;
     if ((rc = ensure_capacity(&c->bin_start, &c->bin_cap, nbins + 4))) return rc;
-    if ((rc = ensure_capacity(&c->scan_partials, &c->partial_cap,
-                              nblocks_scan + 4)))
-      return rc;
   }
   c->last_num_bins = (int64_t)nbins;
   c->last_bin_cells = p.B;
@@ -950,36 +944,39 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
       AMHIP_TRY(hipGetLastError());
     }
   } else {
-  {
+    // ---- one-level counting sort (fallback: very wide grids, or forced) --------
+    {
+      int rc;
+      if ((rc = ensure_capacity(&c->rank, &c->rank_cap, n))) return rc;
+      if ((rc = ensure_capacity(&c->scan_partials, &c->partial_cap, nblocks_scan + 4))) return rc;
+    }
+    {
       ScopedTimer t(c, AMHIP_K_MISC);
-      AMHIP_TRY(hipMemsetAsync(c->bin_start, 0, (nbins + 1) * sizeof(uint32_t),
-                               c->stream));
+      AMHIP_TRY(hipMemsetAsync(c->bin_start, 0, (nbins + 1) * sizeof(uint32_t), c->stream));
     }
-  const int block = 256;
-  size_t grid_pts = (n + block - 1) / block;
-  if (grid_pts > 256 * 16) grid_pts = 256 * 16;
-      {
+    const int block = 256;
+    size_t grid_pts = (n + block - 1) / block;
+    if (grid_pts > 256 * 16) grid_pts = 256 * 16;
+    {
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
-      hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block),
-                         0, c->stream, dev_xyz, n, p, c->bin_start, c->rank);
+      hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
+                         dev_xyz, n, p, c->bin_start, c->rank);
       AMHIP_TRY(hipGetLastError());
     }
-      {
+    {
       ScopedTimer t(c, AMHIP_K_DSM_SCAN);
-      hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan),
-                         dim3(kScanT), 0, c->stream, c->bin_start, nbins,
-                         c->scan_partials);
-      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream,
-                         c->scan_partials, nblocks_scan, c->bin_start + nbins);
-      hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT),
-                         0, c->stream, c->bin_start, nbins, c->scan_partials);
+      hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan), dim3(kScanT), 0,
+                         c->stream, c->bin_start, nbins, c->scan_partials);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->scan_partials,
+                         nblocks_scan, c->bin_start + nbins);
+      hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT), 0, c->stream,
+                         c->bin_start, nbins, c->scan_partials);
       AMHIP_TRY(hipGetLastError());
     }
-      {
+    {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
-      hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0,
-                         c->stream, dev_xyz, n, p, c->bin_start, c->rank,
-                         c->sorted);
+      hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
+                         dev_xyz, n, p, c->bin_start, c->rank, c->sorted);
       AMHIP_TRY(hipGetLastError());
     }
   }
@@ -987,24 +984,20 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
     if (p.lds_ok) {
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
-      // tuning knobs for A/B runs (defaults are the shipped configuration)
+      // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
-      static const int nr = getenv("AMHIP_GATHER_NR") ? atoi(getenv("AMHIP_GATHER_NR")) : 2;
-#define AMHIP_LAUNCH_TILED(NT_, NR_)                                                       \
+#define AMHIP_LAUNCH_TILED(NT_)                                                            \
   do {                                                                                     \
-    AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, NR_>), \
+    AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_>),  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize,              \
                                   (int)p.lds_bytes));                                      \
-    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, NR_>), dim3(ntiles), dim3(NT_), p.lds_bytes, \
+    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_>), dim3(ntiles), dim3(NT_), p.lds_bytes,    \
                        c->stream, p, c->bin_start, c->sorted,                              \
                        c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);                      \
   } while (0)
-      if (nt == 256 && nr == 1) AMHIP_LAUNCH_TILED(256, 1);
-      else if (nt == 256) AMHIP_LAUNCH_TILED(256, 2);
-      else if (nt == 1024 && nr == 1) AMHIP_LAUNCH_TILED(1024, 1);
-      else if (nt == 1024) AMHIP_LAUNCH_TILED(1024, 2);
-      else if (nr == 1) AMHIP_LAUNCH_TILED(512, 1);
-      else AMHIP_LAUNCH_TILED(512, 2);
+      if (nt == 256) AMHIP_LAUNCH_TILED(256);
+      else if (nt == 1024) AMHIP_LAUNCH_TILED(1024);
+      else AMHIP_LAUNCH_TILED(512);
 #undef AMHIP_LAUNCH_TILED
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));

@@ -239,8 +239,14 @@ def main():
         N = wl["points"]
         b_dsm = 24.0 * N + 4.0 * cells
         b_ortho = (20.0 * cells + F * wl["W"] * wl["H"] * ch + 56.0 * F) if F else 0.0
-        alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho,
-                     "k_dsm_bin_count": 24.0 * N, "k_dsm_scatter": 48.0 * N}
+        alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho}
+        traffic = {}
+        try:  # PMC-measured HBM bytes per launch (committed; same workload only)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tj.get("workload") == args.workload and not args.colored:
+                traffic = {k: v["bytes"] for k, v in tj["kernels"].items()}
+        except Exception:
+            pass
         kern = {}
         for name, (ms, n) in ktimes.items():
             if n:
@@ -266,7 +272,8 @@ def main():
                        "parallelism": "one map, %d x 1 windows, one per GPU" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic.get(dom),
                          "algorithmic_bytes_per_launch": alg_bytes[dom],
                          "kernel_ms": round(dom_ms, 4)},
             "whole_step_hbm": {"algorithmic_bytes": total_alg,

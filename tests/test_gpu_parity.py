@@ -301,3 +301,47 @@ def test_pipeline_dsm_then_ortho_on_device():
         a, b = got[n][same], layers[n][same]
         eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
         assert eq.mean() > 0.9999, (n, float(eq.mean()))
+
+
+def test_dsm_fine_grid_takes_global_gather():
+    # 0.05 m cells: the first search radius spans 20 cells > kMaxW0, so every
+    # cell goes through the global-memory gather kernel
+    sc = S.Scene(12.0, 9.0, 0.05, 9000, seed=80, point_extent=8.0)
+    got, want = _dsm_both(sc)
+    S.assert_dsm_close(got, want)
+
+
+def test_dsm_clustered_cloud_overflows_lds_tiles():
+    # 400 pts/m^2 in one corner: those tiles exceed the LDS point capacity and
+    # fall back to the global path, the rest of the map stays on the LDS path
+    sc = S.Scene(60.0, 40.0, 0.25, 20000, seed=81)
+    rng = np.random.default_rng(5)
+    dense = np.empty((40000, 3))
+    dense[:, 0] = rng.uniform(10.0, 20.0, 40000)
+    dense[:, 1] = rng.uniform(5.0, 15.0, 40000)
+    dense[:, 2] = 400.0 + rng.uniform(-0.5, 0.5, 40000)
+    sc.points = np.ascontiguousarray(np.concatenate([sc.points, dense]))
+    got, want = _dsm_both(sc)
+    S.assert_dsm_close(got, want)
+
+
+def test_dsm_one_level_sort_fallback_matches():
+    # the one-level counting sort (used when a bin row does not fit the LDS
+    # histogram) is forced through its environment knob in a child process
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, oracle_ffi as O, scenarios as S, aerial_mapper_amd as A\n"
+        "sc = S.Scene(150.0, 110.0, 0.5, 70000, seed=82)\n"
+        "rc, want, _ = O.dsm_process(sc.points, sc.grid)\n"
+        "g = sc.grid\n"
+        "m = A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution))\n"
+        "A.Dsm(A.DsmSettings(), m).process(sc.points, m)\n"
+        "S.assert_dsm_close(m.get('elevation'), want)\n"
+        "print('ONE_LEVEL_OK')\n" % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
+    import os
+    env = dict(os.environ, AMHIP_SORT_ONE_LEVEL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and b"ONE_LEVEL_OK" in r.stdout, r.stdout.decode()[-2000:]

@@ -17,13 +17,13 @@ import sys
 
 def short(name):
     name = name.split("(")[0]
-    return name.replace("amhip::", "")
+    return name.replace("void ", "").replace("amhip::", "")
 
 
 def kernel_rows(db_path):
     db = sqlite3.connect(db_path)
     q = ("select name, count(*), avg(end-start), min(end-start), max(end-start), sum(end-start) "
-         "from kernels where name like 'amhip::%' group by name order by 6 desc")
+         "from kernels where name like '%amhip::%' group by name order by 6 desc")
     rows = list(db.execute(q))
     tot = list(db.execute("select sum(end-start) from kernels"))[0][0]
     return rows, tot
@@ -38,7 +38,7 @@ def pmc_rows(db_path, counter):
     val_col = "value" if "value" in cols else "counter_value"
     kcol = "name" if "name" in cols else "kernel_name"
     q = ("select {k}, count(*), avg(v), min(v), max(v) from (select {k}, dispatch_id, sum({v}) as v "
-         "from pmc_events where {n} = ? and {k} like 'amhip::%' group by {k}, dispatch_id) "
+         "from pmc_events where {n} = ? and {k} like '%amhip::%' group by {k}, dispatch_id) "
          "group by {k}").format(k=kcol, v=val_col, n=name_col)
     return {short(r[0]): r[1:] for r in db.execute(q, (counter,))}
 
