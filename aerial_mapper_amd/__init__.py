@@ -8,9 +8,10 @@ class API.  See DESIGN.md / INTEGRATION.md.
 from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,  # noqa: F401
                       DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
 from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, NCamera,  # noqa: F401
-                     OrthoBackwardGrid, OrthoSettings, compose_T_G_C)
+                     OrthoBackwardGrid, OrthoFromPcl, OrthoFromPclSettings, OrthoSettings,
+                     compose_T_G_C)
 
 __all__ = ["AerialGridMap", "GridMapSettings", "Dsm", "DsmSettings", "OrthoBackwardGrid",
-           "OrthoSettings", "NCamera", "compose_T_G_C", "AmhipError", "Camera", "GridDesc",
+           "OrthoSettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "AmhipError", "Camera", "GridDesc",
            "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
            "DIST_EQUIDISTANT"]

@@ -66,6 +66,7 @@ int ensure_capacity(T** ptr, size_t* cap, size_t need) {
 template int ensure_capacity<double>(double**, size_t*, size_t);
 template int ensure_capacity<uint32_t>(uint32_t**, size_t*, size_t);
 template int ensure_capacity<uint8_t>(uint8_t**, size_t*, size_t);
+template int ensure_capacity<int32_t>(int32_t**, size_t*, size_t);
 template int ensure_capacity<FramePose>(FramePose**, size_t*, size_t);
 
 // ---------------------------------------------------------------------------
@@ -185,9 +186,12 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
   *by = g.pos_y + off_y;
 }
 
+// mode 0: dsm::Dsm ladder.  mode 1: ortho::OrthoFromPcl, one search with the
+// squared radius `radius_sq * pcl_lambda` (pcl_lambda = 1 for the first search,
+// 10, 100, ... for the adaptive retries, ortho-from-pcl.cc:63-71).
 static int make_dsm_params(const Ctx& c, int radius_sq,
                            double center_easting, double center_northing,
-                           DsmParams* out) {
+                           DsmParams* out, int mode = 0, int pcl_lambda = 1) {
   const amhip_grid_desc& g = c.grid;
   DsmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -205,13 +209,18 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   // search with T = R, then lambda*R for lambda = 1, 1.1, 1.1^2, ... where
   // lambda is updated by `lambda *= 1.1` and the loop stops once lambda*R > 7.
   int n = 0;
-  p.T[n++] = static_cast<double>(radius_sq);
-  double lambda = 1.0;
-  for (;;) {
-    if (n >= kMaxLevels) return arg_fail("radius ladder too long");
-    p.T[n++] = lambda * radius_sq;
-    lambda *= 1.1;
-    if (lambda * radius_sq > 7.0) break;
+  p.pcl_mode = mode;
+  if (mode == 0) {
+    p.T[n++] = static_cast<double>(radius_sq);
+    double lambda = 1.0;
+    for (;;) {
+      if (n >= kMaxLevels) return arg_fail("radius ladder too long");
+      p.T[n++] = lambda * radius_sq;
+      lambda *= 1.1;
+      if (lambda * radius_sq > 7.0) break;
+    }
+  } else {
+    p.T[n++] = static_cast<double>(pcl_lambda * radius_sq);  // int product, like the reference
   }
   p.nlevels = n;
   double tmax = 0.0;
@@ -231,6 +240,11 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   int B = p.w[0];
   if (B < 1) B = 1;
   if (B > 8) B = 8;
+  if (mode == 1 && pcl_lambda > 1) {
+    // adaptive retries: huge radii -> coarse bins, global gather only
+    B = p.w[0] / 4;
+    if (B < 1) B = 1;
+  }
   p.B = B;
   p.M = ((wmax + B - 1) / B) * B;
   const long long ex = (long long)p.rows + 2LL * p.M;
@@ -263,7 +277,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.tiles_i = (p.rows + kTileI - 1) / kTileI;
   p.tiles_j = (p.cols + kTileJ - 1) / kTileJ;
   const int w0 = p.w[0];
-  p.lds_ok = (w0 >= 1 && w0 <= kMaxW0) ? 1 : 0;
+  p.lds_ok = (w0 >= 1 && w0 <= kMaxW0 && !(mode == 1 && pcl_lambda > 1)) ? 1 : 0;
   if (p.lds_ok) {
     // disc-shaped window: a point whose cell row differs by dj from the query's
     // is at least (|dj| - 0.5) * res away in y; what is left of the radius
@@ -467,7 +481,7 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
     hipError_t e = hipSuccess;
     for (int l = 0; l < AMHIP_NUM_LAYERS && e == hipSuccess; ++l)
       e = hipMalloc(reinterpret_cast<void**>(&c->layers[l]), c->cells * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_err), sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_err), 4 * sizeof(unsigned));
     if (e == hipSuccess)
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_err), sizeof(unsigned), 0);
     if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
@@ -499,7 +513,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -581,7 +595,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   DsmParams p;
   if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p)))
     return rc;
-  return dsm_run(c, dev_xyz, n, p);
+  return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr);
 }
 
 int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
@@ -603,6 +617,73 @@ int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
     return rc;
   AMHIP_TRY(hipMemcpyAsync(elevation, c->layers[AMHIP_LAYER_ELEVATION],
                            c->cells * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+  return fetch_status(c);
+}
+
+// ---- OrthoFromPcl -------------------------------------------------------------
+
+int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
+                                     const int32_t* dev_intensities, size_t n, int radius_sq,
+                                     int adaptive) {
+  if (!h) return arg_fail("null context");                    // CHECK(map)
+  if (n == 0 || !dev_xyz || !dev_intensities)
+    return arg_fail("empty point cloud (CHECK(!pointcloud.empty()))");
+  if (radius_sq <= 0) return arg_fail("interpolation_radius must be >= 1");
+  if (n >= 0x7FFFFFFFull) return arg_fail("more than 2^31-1 points");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  float* out = c->layers[AMHIP_LAYER_ORTHO];
+  DsmParams p;
+  if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1))) return rc;
+  if (!adaptive) return dsm_run(c, dev_xyz, dev_intensities, n, p, out, nullptr, nullptr);
+
+  // use_adaptive_interpolation: cells whose search is empty retry with the
+  // squared radius x10, x100, ... (int lambda, ortho-from-pcl.cc:63-71).  Every
+  // retry is a full pass restricted to the cells no earlier pass has filled.
+  if ((rc = ensure_capacity(&c->fill_mask, &c->fill_mask_cap, c->cells))) return rc;
+  unsigned* unfilled = c->dev_err + 1;  // second word of the device status block
+  AMHIP_TRY(hipMemsetAsync(c->fill_mask, 0, c->cells, c->stream));
+  AMHIP_TRY(hipMemsetAsync(unfilled, 0, sizeof(unsigned), c->stream));
+  if ((rc = dsm_run(c, dev_xyz, dev_intensities, n, p, out, c->fill_mask, unfilled))) return rc;
+  long long lambda = 10;
+  for (;;) {
+    unsigned left = 0;
+    AMHIP_TRY(hipMemcpyAsync(&left, unfilled, sizeof(unsigned), hipMemcpyDeviceToHost, c->stream));
+    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    if (left == 0) break;
+    if (lambda * radius_sq > 0x7FFFFFFFll) break;  // the reference's int product overflows here
+    if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, static_cast<int>(lambda)))) return rc;
+    p.only_unfilled = 1;
+    AMHIP_TRY(hipMemsetAsync(unfilled, 0, sizeof(unsigned), c->stream));
+    if ((rc = dsm_run(c, dev_xyz, dev_intensities, n, p, out, c->fill_mask, unfilled))) return rc;
+    lambda *= 10;
+  }
+  return AMHIP_OK;
+}
+
+int amhip_ortho_from_pcl_process(amhip_ctx* h, const double* host_xyz,
+                                 const int32_t* host_intensities, size_t n, int radius_sq,
+                                 int adaptive, float* ortho) {
+  if (!h) return arg_fail("null context");
+  if (n == 0 || !host_xyz || !host_intensities || !ortho)
+    return arg_fail("empty point cloud / null buffer (CHECK(!pointcloud.empty()))");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
+  if ((rc = ensure_capacity(&c->stage_values, &c->stage_values_cap, n))) return rc;
+  AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ORTHO], ortho, c->cells * sizeof(float),
+                           hipMemcpyHostToDevice, c->stream));
+  AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  AMHIP_TRY(hipMemcpyAsync(c->stage_values, host_intensities, n * sizeof(int32_t),
+                           hipMemcpyHostToDevice, c->stream));
+  if ((rc = amhip_ortho_from_pcl_process_dev(h, c->stage_points, c->stage_values, n, radius_sq,
+                                             adaptive)))
+    return rc;
+  AMHIP_TRY(hipMemcpyAsync(ortho, c->layers[AMHIP_LAYER_ORTHO], c->cells * sizeof(float),
+                           hipMemcpyDeviceToHost, c->stream));
   return fetch_status(c);
 }
 

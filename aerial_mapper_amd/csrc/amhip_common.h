@@ -40,6 +40,11 @@ struct DsmParams {
   int i_off, j_off;  // its position inside the (global) map
   // dsm.cc:42-43: px = p.x - center_northing, py = p.y - center_easting
   double sub_x, sub_y;
+  // 0: dsm::Dsm (exact hit = CHECK failure); 1: ortho::OrthoFromPcl (exact hit
+  // = that point's value, ortho-from-pcl.cc:91-96)
+  int pcl_mode;
+  // adaptive OrthoFromPcl passes: touch only cells no earlier pass has filled
+  int only_unfilled;
   // binning: bins of B x B cells, grid extended by M cells on every side
   double inv_res;
   int B, M, nbx, nby;
@@ -123,6 +128,10 @@ struct Ctx {
   size_t tmp_points_cap = 0;
   uint32_t* stripe_ws = nullptr;   // stripe counts / starts / cursors
   size_t stripe_ws_cap = 0;
+  unsigned char* fill_mask = nullptr;  // OrthoFromPcl adaptive passes
+  size_t fill_mask_cap = 0;
+  int32_t* stage_values = nullptr;     // H2D staging of host intensities
+  size_t stage_values_cap = 0;
   double* stage_points = nullptr;  // H2D staging of host clouds
   size_t stage_points_cap = 0;
 
@@ -174,7 +183,12 @@ struct HaloParams {
 };
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
                     double* dev_out, unsigned long long* dev_counts);
-int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p);
+// values: nullptr -> interpolate the points' z; else one int per point
+// (OrthoFromPcl intensities).  out: the layer to write.  mask (may be null): one
+// byte per cell, set where this call wrote a value; unfilled (may be null):
+// device counter of cells left without a value.
+int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled);
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
               const uint8_t* dev_frames);
 

@@ -131,8 +131,8 @@ k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
 }
 
 __global__ void __launch_bounds__(256)
-k_dsm_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
-              const uint32_t* __restrict__ start,
+k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values, size_t n,
+              DsmParams p, const uint32_t* __restrict__ start,
               const uint32_t* __restrict__ rank, double* __restrict__ sorted) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -141,7 +141,7 @@ k_dsm_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
     if (r == kNoRank) continue;
     const double x = xyz[3 * idx + 0];
     const double y = xyz[3 * idx + 1];
-    const double z = xyz[3 * idx + 2];
+    const double z = values ? (double)values[idx] : xyz[3 * idx + 2];
     const double px = x - p.sub_x;
     const double py = y - p.sub_y;
     uint32_t bin;
@@ -232,8 +232,9 @@ k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
 }
 
 __global__ void __launch_bounds__(kL1Threads)
-k_dsm_stripe_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
-                     uint32_t* __restrict__ cursor, double* __restrict__ tmp) {
+k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values,
+                     size_t n, DsmParams p, uint32_t* __restrict__ cursor,
+                     double* __restrict__ tmp) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
   uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
@@ -263,7 +264,7 @@ k_dsm_stripe_scatter(const double* __restrict__ xyz, size_t n, DsmParams p,
       const size_t slot = (size_t)s_base[st] + atomicAdd(&s_cnt[st], 1u);
       tmp[3 * slot + 0] = px;
       tmp[3 * slot + 1] = py;
-      tmp[3 * slot + 2] = xyz[3 * idx + 2];
+      tmp[3 * slot + 2] = values ? (double)values[idx] : xyz[3 * idx + 2];
     }
   }
 }
@@ -463,6 +464,7 @@ struct Accum {
   double num, den;
   unsigned cnt;
   bool exact;
+  double exact_z;  // value of (one of) the point(s) with d2 == 0
 };
 
 // One IDW term.  1/d2 through v_rcp_f64 + two Newton steps (relative error
@@ -510,7 +512,8 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
           if (d2 > 0.0) {
             idw_add(d2, sorted[3 * (size_t)k + 2], &acc->num, &acc->den);
           } else {
-            acc->exact = true;  // dsm.cc:165 CHECK(distances[i] > 0.0)
+            acc->exact = true;  // dsm.cc:165 CHECK / ortho-from-pcl.cc:91-96
+            acc->exact_z = sorted[3 * (size_t)k + 2];
           }
           acc->cnt++;
         }
@@ -521,19 +524,50 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
   }
 }
 
+// Where a cell's result goes.
+struct CellOut {
+  float* __restrict__ layer;          // elevation (DSM) or ortho (OrthoFromPcl)
+  unsigned char* __restrict__ mask;   // optional: set where a value was written
+  unsigned* __restrict__ unfilled;    // optional: counts cells left without one
+  unsigned* __restrict__ dev_err;
+};
+
+__device__ __forceinline__ void emit_value(const DsmParams& p, const CellOut& o, int i, int j,
+                                           double v) {
+  const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+  o.layer[at] = (float)v;
+  if (o.mask) o.mask[at] = 1;
+}
+
+// Turns an accumulated search into the cell's value.  true = the cell is done.
+__device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& o, int i, int j,
+                                             const Accum& acc) {
+  if (acc.exact) {
+    if (p.pcl_mode)
+      emit_value(p, o, i, j, acc.exact_z);  // ortho-from-pcl.cc:91-96 perfect match
+    else
+      atomicOr(o.dev_err, kDevErrExactHit);  // dsm.cc:165 CHECK(distances[i] > 0.0)
+    return true;
+  }
+  if (acc.cnt > 0) {
+    emit_value(p, o, i, j, acc.num / acc.den);
+    return true;
+  }
+  return false;
+}
+
 // Expanding-radius fallback for a cell whose first search (T[0]) was empty
 // (dsm.cc:133-144): the reference retries with T[1], T[2], ... until a search
 // returns something.  Equivalent: find the nearest point within the LAST
 // radius, pick the first level whose threshold exceeds its d2, gather with
 // that threshold.  Works on the global bin structure.
-__device__ __forceinline__ void cell_fallback_global(const DsmParams& p,
-                                                  const uint32_t* __restrict__ start,
-                                                  const double* __restrict__ sorted,
-                                                  int i, int j, double qx, double qy,
-                                                  float* __restrict__ elevation,
-                                                  unsigned* __restrict__ dev_err) {
-  if (p.nlevels <= 1) return;
-  Accum acc = {0.0, 0.0, 0u, false};
+__device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
+                                                     const uint32_t* __restrict__ start,
+                                                     const double* __restrict__ sorted, int i,
+                                                     int j, double qx, double qy,
+                                                     const CellOut& o) {
+  if (p.nlevels <= 1) return false;
+  Accum acc = {0.0, 0.0, 0u, false, 0.0};
   const int last = p.nlevels - 1;
   double dmin = __builtin_huge_val();
   scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
@@ -544,49 +578,37 @@ __device__ __forceinline__ void cell_fallback_global(const DsmParams& p,
       break;
     }
   }
-  if (level < 0) return;  // nothing within the last radius: cell untouched
+  if (level < 0) return false;  // nothing within the last radius: cell untouched
   scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
-  if (acc.exact) {
-    atomicOr(dev_err, kDevErrExactHit);
-    return;
-  }
-  if (acc.cnt > 0)
-    elevation[(size_t)i + (size_t)j * (size_t)p.rows] = (float)(acc.num / acc.den);
+  return finish_accum(p, o, i, j, acc);
 }
 
 // Whole cell through the global bins (first level + fallback).
 __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
-                                            const double* __restrict__ sorted, int i,
-                                            int j, float* __restrict__ elevation,
-                                            unsigned* __restrict__ dev_err) {
+                                            const double* __restrict__ sorted, int i, int j,
+                                            const CellOut& o) {
+  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
-  Accum acc = {0.0, 0.0, 0u, false};
+  Accum acc = {0.0, 0.0, 0u, false, 0.0};
   double dmin = 0.0;
   scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
-  if (acc.exact) {
-    atomicOr(dev_err, kDevErrExactHit);
-    return;
-  }
-  if (acc.cnt > 0) {
-    elevation[(size_t)i + (size_t)j * (size_t)p.rows] = (float)(acc.num / acc.den);
-    return;
-  }
-  cell_fallback_global(p, start, sorted, i, j, qx, qy, elevation, dev_err);
+  bool done = finish_accum(p, o, i, j, acc);
+  if (!done) done = cell_fallback_global(p, start, sorted, i, j, qx, qy, o);
+  if (!done && o.unfilled) atomicAdd(o.unfilled, 1u);
 }
 
 // Pure global-memory gather: used when the first-level window is too wide for
-// the LDS image (very fine grids).
+// the LDS image (very fine grids) and by the adaptive OrthoFromPcl passes.
 __global__ void __launch_bounds__(256)
 k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
-             const double* __restrict__ sorted, float* __restrict__ elevation,
-             unsigned* __restrict__ dev_err) {
+             const double* __restrict__ sorted, CellOut o) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
-  cell_global(p, start, sorted, i, j, elevation, dev_err);
+  cell_global(p, start, sorted, i, j, o);
 }
 
 // ---------------------------------------------------------------------------
@@ -606,9 +628,7 @@ constexpr int kMaxRegionRows = 96;  // bin rows of a region
 template <int NT>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
-                   const double* __restrict__ sorted,
-                   float* __restrict__ elevation,
-                   unsigned* __restrict__ dev_err) {
+                   const double* __restrict__ sorted, CellOut o) {
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -693,14 +713,18 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   }
   __syncthreads();
   const int np = (int)s_ctl[0];
-  if (s_ctl[2] == 0) return;  // empty neighbourhood: every cell stays untouched
+  if (s_ctl[2] == 0) {  // empty neighbourhood: every cell stays untouched
+    if (o.unfilled && tid == 0)
+      atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
+    return;
+  }
 
   const bool use_lds = geom_ok && np <= p.lds_cap;
   if (!use_lds) {
     // over-full tile (very dense / clustered cloud): global path for all cells
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, elevation, dev_err);
+      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
     }
     return;
   }
@@ -859,44 +883,61 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
           PB *= sc;
         }
       }
-      if (PA == 0.0 || (haveB && PB == 0.0)) {
-        atomicOr(dev_err, kDevErrExactHit);
-      } else {
-        if (DA > 0.0) {
-          elevation[(size_t)i + (size_t)jA * (size_t)p.rows] = (float)(NA / DA);
+      // P == 0 <=> a hit with d2 == 0.  DSM: CHECK failure.  OrthoFromPcl: the
+      // cell takes that point's value -- which is exactly what N/D holds when
+      // there is ONE such point (N = z*Q, D = Q); several coincident ones make
+      // D vanish too and the cell is re-done by the global routine.
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !haveB) break;
+        const double Nn = h ? NB : NA, Dd = h ? DB : DA, Pp = h ? PB : PA;
+        const int jj = jA + h;
+        bool queue = false;
+        if (Pp == 0.0) {
+          if (!p.pcl_mode)
+            atomicOr(o.dev_err, kDevErrExactHit);
+          else if (Dd > 0.0)
+            emit_value(p, o, i, jj, Nn / Dd);
+          else
+            queue = true;
+        } else if (Dd > 0.0) {
+          emit_value(p, o, i, jj, Nn / Dd);
         } else {
-          const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
-          s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c) * kTileI + lane);
+          queue = true;
         }
-        if (haveB) {
-          if (DB > 0.0) {
-            elevation[(size_t)i + (size_t)(jA + 1) * (size_t)p.rows] = (float)(NB / DB);
-          } else {
-            const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
-            s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c + 1) * kTileI + lane);
-          }
+        if (queue) {
+          const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
+          s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c + h) * kTileI + lane);
         }
       }
     }
   }
   __syncthreads();
 
-  // ---- fallback ladder for the queued cells (dense over the workgroup) --------
+  // ---- queued cells (dense over the workgroup): the fallback ladder, or for
+  // OrthoFromPcl the full global routine (several coincident exact hits) ------
   const int nflag = (int)s_ctl[1];
   for (int f = tid; f < nflag; f += NT) {
     const int code = s_flag[f];
     const int fi = i0 + (code % kTileI);
     const int fj = j0 + (code / kTileI);
-    const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
-    const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
-    cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, elevation, dev_err);
+    if (p.pcl_mode) {
+      cell_global(p, start, sorted, fi, fj, o);
+    } else {
+      const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
+      const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
+      const bool done = cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, o);
+      if (!done && o.unfilled) atomicAdd(o.unfilled, 1u);
+    }
   }
 }
 
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
-int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
+int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled) {
+  const CellOut cell_out = {out, mask, unfilled, c->dev_err};
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   {
@@ -932,8 +973,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
       const size_t grid = (n + kL1Chunk - 1) / kL1Chunk;
       hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
-                         2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, n, p,
-                         stripe_cursor, c->tmp_points);
+                         2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, dev_values, n,
+                         p, stripe_cursor, c->tmp_points);
       AMHIP_TRY(hipGetLastError());
     }
     {
@@ -976,7 +1017,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
       hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
-                         dev_xyz, n, p, c->bin_start, c->rank, c->sorted);
+                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted);
       AMHIP_TRY(hipGetLastError());
     }
   }
@@ -992,8 +1033,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize,              \
                                   (int)p.lds_bytes));                                      \
     hipLaunchKernelGGL((k_dsm_gather_tiled<NT_>), dim3(ntiles), dim3(NT_), p.lds_bytes,    \
-                       c->stream, p, c->bin_start, c->sorted,                              \
-                       c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);                      \
+                       c->stream, p, c->bin_start, c->sorted, cell_out);                   \
   } while (0)
       if (nt == 256) AMHIP_LAUNCH_TILED(256);
       else if (nt == 1024) AMHIP_LAUNCH_TILED(1024);
@@ -1001,9 +1041,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p) {
 #undef AMHIP_LAUNCH_TILED
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
-      hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p,
-                         c->bin_start, c->sorted,
-                         c->layers[AMHIP_LAYER_ELEVATION], c->dev_err);
+      hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,
+                         c->sorted, cell_out);
     }
     AMHIP_TRY(hipGetLastError());
   }

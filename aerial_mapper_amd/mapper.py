@@ -319,3 +319,53 @@ class OrthoBackwardGrid(object):
         L.check(lib.amhip_ortho_backward_process(
             map.handle, C.byref(cam), T_G_C.ctypes.data_as(f64p), F, ptrs, steps, ch,
             int(colored), None, None, None, None, None, None))
+
+
+class OrthoFromPclSettings(object):
+    """ortho::Settings of ortho-from-pcl.h:28-35."""
+
+    def __init__(self, show_orthomosaic_opencv=False, interpolation_radius=2,
+                 use_adaptive_interpolation=False, save_orthomosaic_jpg=False,
+                 orthomosaic_jpg_filename=""):
+        self.show_orthomosaic_opencv = show_orthomosaic_opencv
+        self.interpolation_radius = int(interpolation_radius)
+        self.use_adaptive_interpolation = use_adaptive_interpolation
+        self.save_orthomosaic_jpg = save_orthomosaic_jpg
+        self.orthomosaic_jpg_filename = orthomosaic_jpg_filename
+
+
+class OrthoFromPcl(object):
+    """ortho::OrthoFromPcl (ortho-from-pcl.h:37-52): intensity of the cloud's
+    points interpolated into the 'ortho' layer."""
+
+    def __init__(self, settings):
+        self.settings = settings
+
+    def process(self, pointcloud, intensities, map, sync=True):
+        """pointcloud (N,3) float64 + intensities (N,) int32: numpy (host path) or
+        CUDA torch tensors (device-resident path)."""
+        if map is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(map)")
+        lib = L.load()
+        s = self.settings
+        if _is_torch(pointcloud):
+            assert pointcloud.is_cuda and pointcloud.is_contiguous() and pointcloud.element_size() == 8
+            assert intensities.is_cuda and intensities.is_contiguous() and \
+                intensities.element_size() == 4 and not intensities.dtype.is_floating_point
+            n = pointcloud.numel() // 3
+            if n == 0 or intensities.numel() < n:
+                raise L.AmhipError(L.ERR_ARG, "CHECK(!pointcloud.empty()) / CHECK(i < intensities.size())")
+            L.check(lib.amhip_ortho_from_pcl_process_dev(
+                map.handle, C.c_void_p(pointcloud.data_ptr()), C.c_void_p(intensities.data_ptr()),
+                n, s.interpolation_radius, int(bool(s.use_adaptive_interpolation))))
+            if sync:
+                map.synchronize()
+            return
+        pts = np.ascontiguousarray(pointcloud, np.float64).reshape(-1, 3)
+        inten = np.ascontiguousarray(intensities, np.int32).reshape(-1)
+        if pts.shape[0] == 0 or inten.shape[0] < pts.shape[0]:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(!pointcloud.empty()) / CHECK(i < intensities.size())")
+        ortho = map.get("ortho")
+        L.check(lib.amhip_ortho_from_pcl_process(
+            map.handle, pts.ctypes.data, inten.ctypes.data, pts.shape[0],
+            s.interpolation_radius, int(bool(s.use_adaptive_interpolation)), ortho.ctypes.data))

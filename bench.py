@@ -141,6 +141,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # ONE explicit HIP stream for everything in the timed region: torch's
+    # generators, the library's kernels (amhip_ctx_set_stream), the per-kernel
+    # HIP events and -- for N > 1 -- the RCCL all_to_all are all ordered on it.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -159,7 +164,7 @@ def main():
     layout = tiling.TileLayout(world * side, side, world, 1)
     win = layout.window(rank)
     m = A.AerialGridMap(st, device=local_rank, window=win)
-    m.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.set_stream(stream.cuda_stream)
     # centre of this rank's window in map coordinates (x decreases with i)
     tile_center = (world * L / 2.0 - (win[0] + win[2] / 2.0) * res, 0.0)
 

@@ -178,6 +178,25 @@ int amhip_dsm_process(amhip_ctx* ctx, const double* host_xyz, size_t n,
                       int radius_sq, double center_easting,
                       double center_northing, float* elevation);
 
+/* ---- OrthoFromPcl: ortho::OrthoFromPcl::process
+ *      (aerial_mapper_ortho/src/ortho-from-pcl.cc:20-113) --
+ * The DSM's radius search + inverse-squared-distance weighting applied to the
+ * points' INTENSITIES (one int per point), written to the ORTHO layer.
+ * Differences to the DSM that are reproduced: no centre offsets (:30-31); an
+ * exact hit takes that point's value instead of failing (:91-96); no fallback
+ * unless `adaptive` (ortho::Settings::use_adaptive_interpolation), which then
+ * retries with the squared radius x10, x100, ... (int lambda, :63-71) until
+ * every cell has a value (one extra pass over the cloud per retry; stops where
+ * the reference's int product would overflow).  radius_sq is
+ * ortho::Settings::interpolation_radius (squared, like the DSM's).  The _dev
+ * form is asynchronous unless `adaptive` is set. */
+int amhip_ortho_from_pcl_process_dev(amhip_ctx* ctx, const double* dev_xyz,
+                                     const int32_t* dev_intensities, size_t n,
+                                     int radius_sq, int adaptive);
+int amhip_ortho_from_pcl_process(amhip_ctx* ctx, const double* host_xyz,
+                                 const int32_t* host_intensities, size_t n,
+                                 int radius_sq, int adaptive, float* ortho);
+
 /* ---- multi-GPU: halo points of a tiled survey ------------------------------
  * No reference counterpart (the reference is single-process).  When one map
  * is tiled over several GPUs with amhip_ctx_create_window(), a rank's DSM

@@ -323,3 +323,96 @@ void amo_cell_position(const amo_grid* g, int i, int j, double* x, double* y) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// ortho::OrthoFromPcl::process  
+//   aerial_mapper_ortho/src/ortho-from-pcl.cc:20-113
+// Same kd-tree radius search + inverse-squared-distance weighting as the DSM,
+// but: the interpolated quantity is the point's INTENSITY (an int), there is no
+// centre offset (:30-31), an exact hit (d2 == 0) short-circuits to that
+// point's value (:91-96), the fallback only exists with
+// use_adaptive_interpolation and multiplies the squared radius by an INT
+// lambda = 10, 100, ... without upper bound (:63-71), the loop is always
+// single-threaded and the result goes to the "ortho" layer.
+// ---------------------------------------------------------------------------
+extern "C" int amo_ortho_from_pcl_process(const double* xyz, const int32_t* intensities,
+                                          size_t n, const amo_grid* grid, int radius_sq,
+                                          int adaptive, float* ortho) {
+  if (!grid || !ortho || !xyz || !intensities || n == 0) return AMO_ERR_ARG;  // CHECK(!empty)
+#ifdef AMO_USE_VENDORED_NANOFLANN
+  amo::RefCloud cloud;
+  cloud.pts.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    cloud.pts[i].x = xyz[3 * i + 0];
+    cloud.pts[i].y = xyz[3 * i + 1];
+    cloud.pts[i].z = double(intensities[i]);
+  }
+  amo::RefAdaptor ad(cloud);
+  amo::RefTree tree(2, ad, nanoflann::KDTreeSingleIndexAdaptorParams(10));
+  tree.buildIndex();
+#else
+  std::vector<amo::KdPoint> pts(n);
+  for (size_t i = 0; i < n; ++i) {
+    pts[i].x = xyz[3 * i + 0];
+    pts[i].y = xyz[3 * i + 1];
+    pts[i].z = double(intensities[i]);
+  }
+  amo::KdTree2D tree(pts);
+  tree.build();
+#endif
+  const size_t cells = static_cast<size_t>(grid->rows) * static_cast<size_t>(grid->cols);
+  for (size_t lin = 0; lin < cells; ++lin) {
+    int i, j;
+    amo::linear_to_index(*grid, lin, &i, &j);
+    double qx, qy;
+    amo::cell_position(*grid, i, j, &qx, &qy);
+    std::vector<std::pair<int, double> > hits;
+#ifdef AMO_USE_VENDORED_NANOFLANN
+    nanoflann::RadiusResultSet<double, int> result_set(radius_sq, hits);
+    const double query_pt[3] = {qx, qy, 0.0};
+    tree.findNeighbors(result_set, query_pt, nanoflann::SearchParams());
+    if (adaptive) {
+      int lambda = 10;
+      while (result_set.size() == 0u) {
+        nanoflann::RadiusResultSet<double, int> tmp(lambda * radius_sq, hits);
+        tree.findNeighbors(tmp, query_pt, nanoflann::SearchParams());
+        lambda *= 10;
+      }
+    }
+#else
+    hits.clear();
+    tree.radius_search(qx, qy, static_cast<double>(radius_sq), &hits);
+    if (adaptive) {
+      int lambda = 10;
+      while (hits.size() == 0u) {
+        hits.clear();
+        tree.radius_search(qx, qy, static_cast<double>(lambda * radius_sq), &hits);
+        lambda *= 10;
+      }
+    }
+#endif
+    if (hits.empty()) continue;
+    double num = 0.0, den = 0.0;
+    bool perfect = false;
+    for (size_t k = 0; k < hits.size(); ++k) {
+      const double d2 = hits[k].second;
+#ifdef AMO_USE_VENDORED_NANOFLANN
+      const double h = cloud.pts[hits[k].first].z;
+#else
+      const double h = pts[hits[k].first].z;
+#endif
+      if (d2 == 0.0) {  // perfect match, no interpolation needed
+        num = h;
+        den = 1.0;
+        perfect = true;
+      }
+      if (!perfect) {
+        num += h / d2;
+        den += 1.0 / d2;
+      }
+    }
+    ortho[static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(grid->rows)] =
+        static_cast<float>(num / den);
+  }
+  return AMO_OK;
+}

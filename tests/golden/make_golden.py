@@ -88,6 +88,25 @@ def ortho_case(name, length_x, length_y, res, n, seed, num_frames, altitude, col
     print("%-28s %4dx%-4d F=%d coverage=%.3f" % (name, sc.grid.rows, sc.grid.cols, num_frames, cov))
 
 
+def pcl_case(name, length_x, length_y, res, n, seed, radius, adaptive, extent=None,
+             center=(0.0, 0.0), exact_at=None):
+    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=WHICH)
+    half = (max(length_x, length_y) / 2.0 + 4.0) if extent is None else extent
+    pts = synth.make_points(n, half, seed, center=center)
+    inten = ((np.arange(n) * 37 + seed) % 256).astype(np.int32)
+    if exact_at is not None:
+        x, y = O.cell_position(g, exact_at[0], exact_at[1], which=WHICH)
+        pts[3, :2] = (x, y)
+        inten[3] = 249
+    rc, ortho = O.ortho_from_pcl(pts, inten, g, radius, adaptive, which=WHICH)
+    assert rc == O.OK
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="pcl", grid=grid_tuple(g),
+                        points=pts, intensities=inten, radius_sq=radius, adaptive=adaptive,
+                        ortho=ortho)
+    print("%-28s %4dx%-4d pts=%6d untouched=%d" % (name, g.rows, g.cols, n,
+                                                 int((ortho == 255.0).sum())))
+
+
 def main():
     if not O.have_ref():
         raise SystemExit("oracle/_ref/liboracle_ref.so missing: run `make -C oracle` where "
@@ -112,6 +131,10 @@ def main():
     ortho_case("ortho_radtan", 50.0, 40.0, 1.0, 5000, 205, 5, 470.0,
                cam=S.camera(96, 54, 70.0, O.DIST_RADTAN, (-0.28, 0.07, 2e-4, -1e-4)))
     del cam_small
+    pcl_case("pcl_radius2", 50.0, 36.0, 1.0, 2200, 301, 2, False, exact_at=(9, 4))
+    pcl_case("pcl_dense_half_metre", 30.0, 22.0, 0.5, 5000, 302, 1, False, center=(2.0, 1.0))
+    pcl_case("pcl_adaptive_corner", 40.0, 30.0, 1.0, 250, 303, 2, True, extent=8.0,
+             center=(-10.0, -6.0))
 
 
 if __name__ == "__main__":

@@ -64,6 +64,9 @@ def _bind(lib):
         C.POINTER(Grid), C.POINTER(Camera), f64p, f64p,
         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_int, C.c_size_t,
         C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p, f32p, f32p]
+    lib.amo_ortho_from_pcl_process.restype = C.c_int
+    lib.amo_ortho_from_pcl_process.argtypes = [f64p, C.POINTER(C.c_int32), C.c_size_t,
+                                               C.POINTER(Grid), C.c_int, C.c_int, f32p]
     lib.amo_compose_T_G_C.restype = None
     lib.amo_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amo_project_probe.restype = None
@@ -140,6 +143,19 @@ def dsm_process(xyz, g, radius_sq=1, center_easting=0.0, center_northing=0.0,
         center_easting, center_northing, int(bool(multi_thread)),
         int(num_threads), _f32(elevation), _f64(t))
     return rc, elevation, (t[0], t[1])
+
+
+def ortho_from_pcl(xyz, intensities, g, radius_sq=2, adaptive=False, ortho=None, which="port"):
+    """ortho::OrthoFromPcl::process.  Returns (rc, ortho layer)."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    inten = np.ascontiguousarray(intensities, np.int32).reshape(-1)
+    assert inten.shape[0] == xyz.shape[0]
+    if ortho is None:
+        ortho = np.full((g.cols, g.rows), 255.0, np.float32)
+    rc = lib(which).amo_ortho_from_pcl_process(
+        _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)), xyz.shape[0], C.byref(g),
+        int(radius_sq), int(bool(adaptive)), _f32(ortho))
+    return rc, ortho
 
 
 def radius_probe(xyz, qx, qy, radius_sq, cap=4096, which="port"):

@@ -43,6 +43,15 @@ def test_port_reproduces_golden_ortho_bitwise(name):
         assert G.bits_equal(layers[n], d[n]).all(), n
 
 
+@pytest.mark.parametrize("name", G.names("pcl"))
+def test_port_reproduces_golden_from_pcl_bitwise(name):
+    d = G.load(name)
+    rc, ortho = O.ortho_from_pcl(d["points"], d["intensities"], G.grid_of(d), int(d["radius_sq"]),
+                                 bool(d["adaptive"]))
+    assert rc == O.OK
+    assert G.bits_equal(ortho, d["ortho"]).all()
+
+
 # ---------------------------------------------------------------------------
 # own kd-tree == vendored nanoflann, bit for bit (only where _ref was built)
 # ---------------------------------------------------------------------------
@@ -302,3 +311,22 @@ def test_kat_pose_composition():
     cam = S.camera()
     r = O.project_probe(cam, T_G_C, T_G_C[:3])
     assert np.allclose(r["C"], 0.0, atol=1e-12)
+
+
+def test_kat_from_pcl_semantics():
+    # (ortho-from-pcl.cc:20-113) no centre offset, exact hit -> that value,
+    # untouched cells keep the layer value, no fallback unless adaptive
+    g = O.make_grid(12.0, 9.0, 1.0, 100.0, 50.0)
+    cx, cy = O.cell_position(g, 3, 2)
+    far = [[500.0 + k, 500.0, 0.0] for k in range(20)]
+    pts = np.array([[cx + 0.5, cy, 0.0], [cx, cy + 1.0, 0.0]] + far)
+    inten = np.array([10, 40] + [7] * 20, np.int32)
+    rc, o = O.ortho_from_pcl(pts, inten, g, 2, False)
+    want = (10 / 0.25 + 40 / 1.0) / (1 / 0.25 + 1 / 1.0)
+    assert rc == O.OK and o[2, 3] == F32(want)
+    assert (o == 255.0).sum() > 60                      # cells farther than sqrt(2) stay 255
+    pts[0, :2] = (cx, cy)                               # exact hit
+    rc, o = O.ortho_from_pcl(pts, inten, g, 2, False)
+    assert o[2, 3] == 10.0
+    rc, o = O.ortho_from_pcl(pts, inten, g, 2, True)    # adaptive: everything gets a value
+    assert (o == 255.0).sum() == 0
