@@ -110,6 +110,15 @@ __device__ __forceinline__ bool project_visible(const OrthoParams& p,
   return in_box && (c.z > 1e-10);
 }
 
+// asin(|z| / ||p||) exactly as the reference evaluates it
+// (ortho-backward-grid.cc:173-176).  Deliberately NOT inlined: it is needed
+// once per cell and in rare near ties, and inlining libm's asin three times per
+// unrolled cell costs ~25 VGPRs (one wave per SIMD of occupancy).
+__device__ __noinline__ double view_angle(double abs_z, double n2) {
+  const double norm = sqrt(n2);
+  return asin(abs_z / norm);
+}
+
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
@@ -185,7 +194,18 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
 
   // ---- per-lane fold state ---------------------------------------------------
   const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
-  float best[kCellsPerLane];
+  // Running best view per cell.  The reference keeps (float)asin(|z|/||p||) and
+  // accepts a view iff its asin exceeds that float (widened to double).  asin is
+  // monotonic, so unless the two sines are within 2.5e-6 (relative, squared) of
+  // each other the outcome is decided by comparing |z|^2/||p||^2 -- no sqrt, no
+  // division, no asin.  Only near ties (where the float rounding of the stored
+  // angle matters) take the exact route; the winning angle itself is evaluated
+  // once per cell at the end.  Margin: d(asin)/ds >= 1 and asin(s) <= (pi/2) s,
+  // so a relative gap of 1e-6 in s is > 10x the 6e-8 float rounding of the angle.
+  float best[kCellsPerLane];    // stored angle (valid iff have_f)
+  bool have_f[kCellsPerLane];
+  double zb[kCellsPerLane];     // |z| and ||p||^2 of the current best view
+  double n2b[kCellsPerLane];
   int best_f[kCellsPerLane];
   int best_u[kCellsPerLane];
   int best_v[kCellsPerLane];
@@ -197,6 +217,14 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
     best[c] = 0.0f;
     if (i_ok && j < p.cols)
       best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
+    have_f[c] = true;
+    n2b[c] = 1.0;
+    if (best[c] > 0.0f)
+      zb[c] = sin((double)best[c]);  // incremental mode: angle left by earlier batches
+    else if (best[c] == best[c])
+      zb[c] = 0.0;                   // fresh layer: every visible view wins (alpha > 0)
+    else
+      zb[c] = __builtin_huge_val();  // NaN in the layer: `alpha > NaN` never holds
     best_f[c] = -1;
     best_u[c] = 0;
     best_v[c] = 0;
@@ -254,11 +282,32 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
           const V3 cp = transform_point(T, landmark);
           double u, v;
           if (!project_visible(p, cp, &u, &v)) continue;
-          const double norm = sqrt(cp.x * cp.x + cp.y * cp.y + cp.z * cp.z);
-          const double alpha = asin(fabs(cp.z) / norm);
-          if (!(alpha > 0.0)) bad_alpha = true;  // CHECK(alpha > 0.0)
-          if (alpha > (double)best[c]) {
-            best[c] = (float)alpha;
+          const double zz = cp.z * cp.z;
+          const double n2 = cp.x * cp.x + cp.y * cp.y + zz;
+          const double lhs = zz * n2b[c];
+          const double rhs = (zb[c] * zb[c]) * n2;
+          bool accept = lhs > rhs * (1.0 + 2.5e-6);
+          const bool reject = lhs < rhs * (1.0 - 2.5e-6);
+          bool exact = false;
+          if (!accept && !reject) {
+            // near tie: the reference's own arithmetic decides
+            asm volatile("" ::: "memory");
+            if (!have_f[c]) {
+              best[c] = (float)view_angle(zb[c], n2b[c]);
+              have_f[c] = true;
+            }
+            const double alpha = view_angle(fabs(cp.z), n2);
+            if (!(alpha > 0.0)) bad_alpha = true;  // CHECK(alpha > 0.0)
+            if (alpha > (double)best[c]) {
+              best[c] = (float)alpha;
+              accept = true;
+              exact = true;
+            }
+          }
+          if (accept) {
+            have_f[c] = exact;
+            zb[c] = fabs(cp.z);
+            n2b[c] = n2;
             best_f[c] = f;
             accepted[c]++;
             best_v[c] = min((int)round(v), p.height - 1);
@@ -278,6 +327,12 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
     const int j = j0 + wid + c * (kOrthoThreads / 64);
     if (!(i_ok && j < p.cols) || accepted[c] == 0) continue;
     const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+    if (!have_f[c]) {
+      // the winning view's angle, evaluated exactly like the reference does
+      const double alpha = view_angle(zb[c], n2b[c]);
+      if (!(alpha > 0.0)) atomicOr(dev_err, kDevErrAlphaNonPos);  // CHECK(alpha > 0.0)
+      best[c] = (float)alpha;
+    }
     elevation_angle[at] = best[c];
     observation_index[at] = (float)best_f[c];
     // layer_num_observations(x, y) += layer_num_observations(x, y), once per
