@@ -156,9 +156,29 @@ def select_for_windows(points, grid, windows, margin_m, center_easting=0.0,
     return out
 
 
+class TorchComm(object):
+    """The two collectives route_points() needs, over torch.distributed
+    (backend nccl = RCCL on the GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def exchange_counts(self, send_counts_tensor):
+        import torch
+        import torch.distributed as dist
+        recv = torch.empty_like(send_counts_tensor)
+        dist.all_to_all_single(recv, send_counts_tensor, group=self.group)
+        return recv
+
+    def exchange_rows(self, out_rows, in_rows, recv_counts, send_counts):
+        import torch.distributed as dist
+        dist.all_to_all_single(out_rows, in_rows, output_split_sizes=recv_counts,
+                               input_split_sizes=send_counts, group=self.group)
+
+
 def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_easting=0.0,
                  center_northing=0.0, map_=None, assume_owned=False, cap=None,
-                 workspace=None):
+                 workspace=None, comm=None):
     """Exchange points so that this rank ends up with every point inside its
     window grown by the halo margin.
 
@@ -174,8 +194,8 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
     Returns (N',3): kept points followed by the received ones.
     """
     import torch
-    import torch.distributed as dist
     world = layout.world
+    comm = comm or TorchComm(group)
     margin = halo_margin(radius_sq, grid.resolution)
     if isinstance(points, np.ndarray):
         points = torch.from_numpy(points)
@@ -197,8 +217,7 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
         send_counts[r] = int(t.shape[0])
     # 1) counts, 2) payload: ONE all_to_all each
     sc = torch.tensor(send_counts, dtype=torch.int64, device=points.device)
-    rc = torch.empty_like(sc)
-    dist.all_to_all_single(rc, sc, group=group)
+    rc = comm.exchange_counts(sc)
     recv_counts = [int(v) for v in rc.cpu().tolist()]
     send_buf = torch.cat([t.reshape(-1, 3) for t in sends], 0) if sends else points[:0]
     total_recv = sum(recv_counts)
@@ -210,7 +229,5 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
         out = torch.empty((nk + total_recv, 3), dtype=points.dtype, device=points.device)
         out[:nk] = keep
     recv_view = out[nk:]
-    dist.all_to_all_single(recv_view, send_buf.contiguous(),
-                           output_split_sizes=recv_counts, input_split_sizes=send_counts,
-                           group=group)
+    comm.exchange_rows(recv_view, send_buf.contiguous(), recv_counts, send_counts)
     return out

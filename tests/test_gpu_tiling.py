@@ -70,3 +70,90 @@ def test_halo_select_kernel_matches_masks():
         want = sc.points[tiling.in_window(cx, cy, w, margin / g.resolution)]
         assert t.shape[0] == want.shape[0] and want.shape[0] > 0
         assert np.array_equal(key(t.cpu().numpy()), key(want))
+
+
+class _ThreadComm(object):
+    """Stand-in for torch.distributed inside ONE process: every 'rank' is a
+    thread with its own window context on the same GPU.  Lets the CUDA side of
+    route_points() (HIP halo selection, buffers, workspace reuse) run on a
+    1-GPU box; the RCCL calls themselves are covered by the driver's multi-GPU
+    run and, on CPU tensors, by tests/test_tiling_gloo.py."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.counts = {}
+        self.rows = {}
+
+    def bind(self, rank):
+        parent = self
+
+        class _C(object):
+            def exchange_counts(self, sc):
+                import torch
+                parent.counts[rank] = sc.cpu()
+                parent.barrier.wait()
+                out = torch.stack([parent.counts[r][rank] for r in range(parent.world)]).to(sc.device)
+                parent.barrier.wait()
+                return out
+
+            def exchange_rows(self, out_rows, in_rows, recv_counts, send_counts):
+                import torch
+                torch.cuda.synchronize()
+                parent.rows[rank] = (in_rows, send_counts)
+                parent.barrier.wait()
+                pos = 0
+                for r in range(parent.world):
+                    src, sc = parent.rows[r]
+                    off = sum(sc[:rank])
+                    n = sc[rank]
+                    assert n == recv_counts[r]
+                    out_rows[pos:pos + n] = src[off:off + n]
+                    pos += n
+                torch.cuda.synchronize()
+                parent.barrier.wait()
+        return _C()
+
+
+def test_route_points_cuda_path_two_ranks_one_gpu():
+    import threading
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import tiling
+    sc = S.Scene(256.0, 96.0, 0.5, 80000, seed=72, point_extent=140.0)
+    g = sc.grid
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    layout = tiling.TileLayout(g.rows, g.cols, 2, 1)
+    cx, cy = tiling.cell_coords(sc.points, g)
+    rc, full, _ = O.dsm_process(sc.points[tiling.in_window(cx, cy, (0, 0, g.rows, g.cols), 0)], g)
+    comm = _ThreadComm(2)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            win = layout.window(rank)
+            own = sc.points[tiling.owner_mask(cx, cy, win)]
+            n = own.shape[0]
+            buf = torch.empty((n + 20000, 3), dtype=torch.float64, device="cuda")
+            buf[:n] = torch.from_numpy(np.ascontiguousarray(own)).cuda()
+            with A.AerialGridMap(st, window=win) as m:
+                cloud = tiling.route_points(buf[:n], g, layout, rank, radius_sq=1, map_=m,
+                                            assume_owned=True, cap=8000, workspace=buf,
+                                            comm=comm.bind(rank))
+                assert cloud.data_ptr() == buf.data_ptr() and cloud.shape[0] > n
+                A.Dsm(A.DsmSettings(), m).process(cloud, m)
+                out[rank] = (win, m.get("elevation"))
+        except Exception as e:  # surface in the main thread
+            errs.append(e)
+            comm.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(120)
+    assert not errs, errs
+    for rank in range(2):
+        (i0, j0, r, c), elev = out[rank]
+        S.assert_dsm_close(elev, full[j0:j0 + c, i0:i0 + r], tol=1e-6)
