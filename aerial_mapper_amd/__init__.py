@@ -9,9 +9,9 @@ from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,
                       DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
 from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, NCamera,  # noqa: F401
                      OrthoBackwardGrid, OrthoFromPcl, OrthoFromPclSettings, OrthoSettings,
-                     compose_T_G_C)
+                     compose_T_G_C, densify)
 
 __all__ = ["AerialGridMap", "GridMapSettings", "Dsm", "DsmSettings", "OrthoBackwardGrid",
-           "OrthoSettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "AmhipError", "Camera", "GridDesc",
+           "OrthoSettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "AmhipError", "Camera", "GridDesc",
            "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
            "DIST_EQUIDISTANT"]

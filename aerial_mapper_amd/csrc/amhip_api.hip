@@ -687,6 +687,43 @@ int amhip_ortho_from_pcl_process(amhip_ctx* h, const double* host_xyz,
   return fetch_status(c);
 }
 
+// ---- densifier reprojection -----------------------------------------------------
+
+int amhip_densify_dev(amhip_ctx* h, const float* dev_disparity, size_t disp_step,
+                      const uint8_t* dev_image_left, size_t img_step, int width, int height,
+                      const double* K, double baseline, const double* R_G_C,
+                      const double* t_G_C1, double* dev_xyz_out, int32_t* dev_intensity_out,
+                      size_t capacity, int64_t* dev_count) {
+  if (!h) return arg_fail("null context");
+  if (!dev_disparity || !dev_image_left || !K || !R_G_C || !t_G_C1 || !dev_xyz_out ||
+      !dev_intensity_out || !dev_count)
+    return arg_fail("amhip_densify_dev: null argument");
+  if (width <= 0 || height <= 0 || disp_step < (size_t)width * sizeof(float) ||
+      img_step < (size_t)width)
+    return arg_fail("amhip_densify_dev: bad image geometry");
+  if (baseline == 0.0) return arg_fail("CHECK_NE(baseline, 0.0)");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  DensifyParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.width = width;
+  p.height = height;
+  p.disp_step = disp_step;
+  p.img_step = img_step;
+  // stereo projection matrix Q (densifier.cpp:39-46), K row-major
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  p.Q03 = -cx;
+  p.Q11 = fx / fy;
+  p.Q13 = -cy * (fx / fy);
+  p.Q23 = fx;
+  p.Q32 = 1.0 / baseline;
+  for (int k = 0; k < 9; ++k) p.R[k] = R_G_C[k];
+  for (int k = 0; k < 3; ++k) p.t[k] = t_G_C1[k];
+  return densify_run(c, p, dev_disparity, dev_image_left, dev_xyz_out, dev_intensity_out,
+                     capacity, reinterpret_cast<long long*>(dev_count));
+}
+
 // ---- multi-GPU halo ----------------------------------------------------------
 
 int amhip_halo_select_dev(amhip_ctx* h, const double* dev_xyz, size_t n,

@@ -173,6 +173,17 @@ int ensure_bytes(void** ptr, size_t* cap_bytes, size_t need_bytes);
 // ---------------------------------------------------------------------------
 int launch_fill(Ctx* c, float* dst, size_t n, float value);
 
+// stereo densifier reprojection (amhip_densify.hip)
+struct DensifyParams {
+  int width, height;
+  size_t disp_step, img_step;  // bytes per row
+  double Q03, Q11, Q13, Q23, Q32;
+  double R[9], t[3];
+};
+int densify_run(Ctx* c, const DensifyParams& p, const float* dev_disparity,
+                const uint8_t* dev_image_left, double* dev_xyz_out, int32_t* dev_intensity_out,
+                size_t capacity, long long* dev_count);
+
 // multi-GPU halo selection
 constexpr int kMaxHaloDests = 8;
 struct HaloParams {

@@ -39,7 +39,7 @@ EXPORTS = [
     "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
     "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
     "amhip_ortho_from_pcl_process_dev", "amhip_ortho_from_pcl_process",
-    "amhip_halo_select_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
+    "amhip_densify_dev", "amhip_halo_select_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
     "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
 ]
@@ -114,6 +114,8 @@ def load():
     lib.amhip_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
     lib.amhip_ortho_from_pcl_process_dev.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int]
     lib.amhip_ortho_from_pcl_process.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
+    lib.amhip_densify_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_int, C.c_int, f64p,
+                                      C.c_double, f64p, f64p, vp, vp, C.c_size_t, vp]
     lib.amhip_halo_select_dev.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double,
                                           C.POINTER(C.c_int32), C.c_int, C.c_double, vp,
                                           C.c_size_t, vp]

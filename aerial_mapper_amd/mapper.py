@@ -369,3 +369,31 @@ class OrthoFromPcl(object):
         L.check(lib.amhip_ortho_from_pcl_process(
             map.handle, pts.ctypes.data, inten.ctypes.data, pts.shape[0],
             s.interpolation_radius, int(bool(s.use_adaptive_interpolation)), ortho.ctypes.data))
+
+
+def densify(map, disparity, image_left, K, baseline, R_G_C, t_G_C1):
+    """stereo::Densifier::computePointCloud's reprojection (densifier.cpp:48-107) on
+    the GPU of `map`: CUDA torch tensors disparity (H,W) float32 and image_left
+    (H,W) uint8 -> (points (n,3) float64, intensities (n,) int32), both CUDA
+    tensors in raster order, ready for Dsm.process / OrthoFromPcl.process."""
+    import torch
+    assert disparity.is_cuda and disparity.dtype == torch.float32 and disparity.stride(1) == 1
+    assert image_left.is_cuda and image_left.dtype == torch.uint8 and image_left.stride(1) == 1
+    H, W = disparity.shape
+    assert tuple(image_left.shape) == (H, W)
+    f64p = C.POINTER(C.c_double)
+    Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+    Rc = np.ascontiguousarray(R_G_C, np.float64).reshape(9)
+    tc = np.ascontiguousarray(t_G_C1, np.float64).reshape(3)
+    xyz = torch.empty((H * W, 3), dtype=torch.float64, device=disparity.device)
+    inten = torch.empty(H * W, dtype=torch.int32, device=disparity.device)
+    count = torch.zeros(1, dtype=torch.int64, device=disparity.device)
+    L.check(L.load().amhip_densify_dev(
+        map.handle, C.c_void_p(disparity.data_ptr()), disparity.stride(0) * 4,
+        C.c_void_p(image_left.data_ptr()), image_left.stride(0), W, H, Kc.ctypes.data_as(f64p),
+        float(baseline), Rc.ctypes.data_as(f64p), tc.ctypes.data_as(f64p),
+        C.c_void_p(xyz.data_ptr()), C.c_void_p(inten.data_ptr()), H * W,
+        C.c_void_p(count.data_ptr())))
+    map.synchronize()
+    n = int(count.item())
+    return xyz[:n], inten[:n]

@@ -197,6 +197,25 @@ int amhip_ortho_from_pcl_process(amhip_ctx* ctx, const double* host_xyz,
                                  const int32_t* host_intensities, size_t n,
                                  int radius_sq, int adaptive, float* ortho);
 
+/* ---- stereo::Densifier::computePointCloud, reprojection part
+ *      (aerial_mapper_dense_pcl/src/densifier.cpp:25-108) --
+ * Disparity map (float32 rows, disp_step bytes apart) + left rectified image
+ * (8UC1, img_step) -> world points in RASTER order (pixels with disparity <= 1
+ * or infinite z dropped) + their gray values, written to device buffers in
+ * the layout amhip_dsm_process_dev / amhip_ortho_from_pcl_process_dev take, so
+ * the cloud of the incremental pipeline never leaves HBM.  K and R_G_C are
+ * row-major 3x3 (StereoRigParameters::K, RectifiedStereoPair::R_G_C), t_G_C1
+ * is StereoRigParameters::t_G_C1, baseline RectifiedStereoPair::baseline.
+ * dev_count receives the number of valid points (it may exceed `capacity`, the
+ * excess is not written).  Asynchronous.  The block matcher (OpenCV BM/SGBM)
+ * and the ROS PointCloud2 fill stay the reference's. */
+int amhip_densify_dev(amhip_ctx* ctx, const float* dev_disparity, size_t disp_step,
+                      const uint8_t* dev_image_left, size_t img_step, int width,
+                      int height, const double* K, double baseline,
+                      const double* R_G_C, const double* t_G_C1,
+                      double* dev_xyz_out, int32_t* dev_intensity_out,
+                      size_t capacity, int64_t* dev_count);
+
 /* ---- multi-GPU: halo points of a tiled survey ------------------------------
  * No reference counterpart (the reference is single-process).  When one map
  * is tiled over several GPUs with amhip_ctx_create_window(), a rank's DSM

@@ -223,3 +223,49 @@ float amo_color_value_bgr(uint8_t b, uint8_t g, uint8_t r) {
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// stereo::Densifier::computePointCloud  
+//   aerial_mapper_dense_pcl/src/densifier.cpp:25-108
+// Disparity map -> world points, raster order, invalid pixels dropped.  Only
+// the Eigen cloud + intensities are restated (what Stereo::processStereoFrame
+// hands on, stereo.cpp:176-181); the ROS PointCloud2 fill is out of scope.
+//   K, R_G_C  row-major 3x3;  disparity  float32 rows of disp_step BYTES;
+//   image_left 8UC1 rows of img_step bytes.  Returns the number of points.
+// PARITY UNPINNED: no reference test pins these values; Eigen's fixed-size
+// 3x3 * 3x1 product is taken as ((r0*x + r1*y) + r2*z).
+// ---------------------------------------------------------------------------
+extern "C" long amo_densify(const float* disparity, size_t disp_step, const uint8_t* image_left,
+                            size_t img_step, int width, int height, const double* K,
+                            double baseline, const double* R_G_C, const double* t_G_C1,
+                            double* xyz_out, int32_t* intensity_out) {
+  const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  // Q = [1 0 0 -cx; 0 fx/fy 0 -cy*(fx/fy); 0 0 0 fx; 0 0 1/baseline 0]
+  const double Q03 = -cx, Q11 = fx / fy, Q13 = -cy * (fx / fy), Q23 = fx, Q32 = 1.0 / baseline;
+  long n = 0;
+  for (int v = 0; v < height; ++v) {
+    const float* drow = reinterpret_cast<const float*>(
+        reinterpret_cast<const unsigned char*>(disparity) + static_cast<size_t>(v) * disp_step);
+    const uint8_t* irow = image_left + static_cast<size_t>(v) * img_step;
+    for (int u = 0; u < width; ++u) {
+      if (drow[u] > 1) {  // kMaxInvalidDisparity
+        const double w = Q32 * drow[u];
+        const double px = (u + Q03) / w;
+        const double py = (Q11 * v + Q13) / w;
+        const double pz = Q23 / w;
+        const double gx = ((R_G_C[0] * px + R_G_C[1] * py) + R_G_C[2] * pz) + t_G_C1[0];
+        const double gy = ((R_G_C[3] * px + R_G_C[4] * py) + R_G_C[5] * pz) + t_G_C1[1];
+        const double gz = ((R_G_C[6] * px + R_G_C[7] * py) + R_G_C[8] * pz) + t_G_C1[2];
+        const float z = static_cast<float>(gz);
+        if (!std::isinf(z)) {
+          xyz_out[3 * n + 0] = gx;
+          xyz_out[3 * n + 1] = gy;
+          xyz_out[3 * n + 2] = gz;
+          intensity_out[n] = irow[u];
+          ++n;
+        }
+      }
+    }
+  }
+  return n;
+}

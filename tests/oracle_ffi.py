@@ -67,6 +67,9 @@ def _bind(lib):
     lib.amo_ortho_from_pcl_process.restype = C.c_int
     lib.amo_ortho_from_pcl_process.argtypes = [f64p, C.POINTER(C.c_int32), C.c_size_t,
                                                C.POINTER(Grid), C.c_int, C.c_int, f32p]
+    lib.amo_densify.restype = C.c_long
+    lib.amo_densify.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int,
+                                f64p, C.c_double, f64p, f64p, f64p, C.POINTER(C.c_int32)]
     lib.amo_compose_T_G_C.restype = None
     lib.amo_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amo_project_probe.restype = None
@@ -156,6 +159,23 @@ def ortho_from_pcl(xyz, intensities, g, radius_sq=2, adaptive=False, ortho=None,
         _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)), xyz.shape[0], C.byref(g),
         int(radius_sq), int(bool(adaptive)), _f32(ortho))
     return rc, ortho
+
+
+def densify(disparity, image_left, K, baseline, R_G_C, t_G_C1, which="port"):
+    """stereo::Densifier::computePointCloud -> (points (n,3) f64, intensities (n,) i32)."""
+    disp = np.ascontiguousarray(disparity, np.float32)
+    img = np.ascontiguousarray(image_left, np.uint8)
+    h, w = disp.shape
+    assert img.shape == (h, w)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    R = np.ascontiguousarray(R_G_C, np.float64).reshape(9)
+    t = np.ascontiguousarray(t_G_C1, np.float64).reshape(3)
+    xyz = np.empty((h * w, 3), np.float64)
+    inten = np.empty(h * w, np.int32)
+    n = lib(which).amo_densify(_f32(disp), disp.strides[0], img.ctypes.data_as(C.POINTER(C.c_uint8)),
+                               img.strides[0], w, h, _f64(K), float(baseline), _f64(R), _f64(t),
+                               _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)))
+    return xyz[:n].copy(), inten[:n].copy()
 
 
 def radius_probe(xyz, qx, qy, radius_sq, cap=4096, which="port"):

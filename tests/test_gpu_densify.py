@@ -1,0 +1,65 @@
+"""GPU: the densifier's disparity -> world-point reprojection
+against the oracle, and the device-resident chain densify -> DSM -> OrthoFromPcl."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(h, w, seed):
+    rng = np.random.default_rng(seed)
+    disp = rng.uniform(0.0, 80.0, (h, w)).astype(np.float32)
+    disp[rng.random((h, w)) < 0.2] = rng.choice(np.array([0.0, 1.0, -1.0, 0.5], np.float32))
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    K = np.array([[520.0, 0, (w - 1) / 2.0], [0, 531.0, (h - 1) / 2.0], [0, 0, 1]])
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    qw, qx, qy, qz = q
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    return disp, img, K, 0.83, R, np.array([12.5, -40.0, 430.0])
+
+
+@pytest.mark.parametrize("h,w,seed", [(48, 64, 1), (480, 752, 2), (333, 1021, 3)])
+def test_densify_matches_oracle_bitwise_in_raster_order(h, w, seed):
+    import torch
+    import aerial_mapper_amd as A
+    disp, img, K, b, R, t = _case(h, w, seed)
+    want_p, want_i = O.densify(disp, img, K, b, R, t)
+    with A.AerialGridMap(A.GridMapSettings(0, 0, 8, 8, 1.0)) as m:
+        got_p, got_i = A.densify(m, torch.from_numpy(disp).cuda(), torch.from_numpy(img).cuda(),
+                                 K, b, R, t)
+        got_p, got_i = got_p.cpu().numpy(), got_i.cpu().numpy()
+    assert got_p.shape == want_p.shape and want_p.shape[0] > 0.5 * h * w
+    assert np.array_equal(got_p.view(np.uint64), want_p.view(np.uint64))
+    assert np.array_equal(got_i, want_i)
+
+
+def test_densify_feeds_dsm_and_from_pcl_without_leaving_hbm():
+    import torch
+    import aerial_mapper_amd as A
+    h, w = 240, 320
+    rng = np.random.default_rng(9)
+    disp = rng.uniform(30.0, 34.0, (h, w)).astype(np.float32)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    K = np.array([[300.0, 0, (w - 1) / 2.0], [0, 300.0, (h - 1) / 2.0], [0, 0, 1]])
+    R = np.array([[1.0, 0, 0], [0, -1.0, 0], [0, 0, -1.0]])  # looking down
+    t = np.array([0.0, 0.0, 120.0])
+    pts, inten = O.densify(disp, img, K, 10.0, R, t)  # z_r = 300*10/32 ~ 94 m below the camera
+    g = O.make_grid(60.0, 44.0, 1.0)
+    rc, want_elev, _ = O.dsm_process(pts, g)
+    rc2, want_ortho = O.ortho_from_pcl(pts, inten, g, 2, False)
+    assert rc == O.OK and rc2 == O.OK and (~np.isnan(want_elev)).mean() > 0.5
+    with A.AerialGridMap(A.GridMapSettings(0, 0, 60.0, 44.0, 1.0)) as m:
+        dp, di = A.densify(m, torch.from_numpy(disp).cuda(), torch.from_numpy(img).cuda(),
+                           K, 10.0, R, t)
+        A.Dsm(A.DsmSettings(), m).process(dp.contiguous(), m)
+        A.OrthoFromPcl(A.OrthoFromPclSettings()).process(dp.contiguous(), di.contiguous(), m)
+        elev, ortho = m.get("elevation"), m.get("ortho")
+    ok = ~np.isnan(want_elev)
+    assert np.array_equal(np.isnan(elev), ~ok)
+    assert np.abs(elev[ok].astype(np.float64) - want_elev[ok]).max() <= 1e-4
+    assert np.abs(ortho.astype(np.float64) - want_ortho).max() <= 1e-4

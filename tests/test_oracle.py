@@ -330,3 +330,20 @@ def test_kat_from_pcl_semantics():
     assert o[2, 3] == 10.0
     rc, o = O.ortho_from_pcl(pts, inten, g, 2, True)    # adaptive: everything gets a value
     assert (o == 255.0).sum() == 0
+
+
+def test_kat_densify_reprojection():
+    # densifier.cpp:39-75: x = (u - cx) * b / d, y = (fx/fy * v - cy*fx/fy) * b / d, z = fx * b / d,
+    # then R * p + t; disparity <= 1 is invalid; raster order
+    K = np.array([[400.0, 0, 2.0], [0, 200.0, 1.0], [0, 0, 1.0]])
+    disp = np.array([[0.5, 8.0, 1.0], [4.0, 0.0, 16.0]], np.float32)
+    img = np.array([[1, 2, 3], [4, 5, 6]], np.uint8)
+    pts, inten = O.densify(disp, img, K, 2.0, np.eye(3), [10.0, 20.0, 30.0])
+    assert list(inten) == [2, 4, 6]                      # (v,u) = (0,1), (1,0), (1,2)
+    b, fx, fy, cx, cy = 2.0, 400.0, 200.0, 2.0, 1.0
+    exp = []
+    for (v, u) in [(0, 1), (1, 0), (1, 2)]:
+        d = float(disp[v, u])
+        exp.append([(u - cx) * b / d + 10.0, (fx / fy * v - cy * fx / fy) * b / d + 20.0,
+                    fx * b / d + 30.0])
+    assert np.allclose(pts, np.array(exp), rtol=1e-15, atol=1e-12)
