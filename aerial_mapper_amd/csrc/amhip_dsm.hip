@@ -170,7 +170,7 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
 constexpr int kMaxStripes = 8192;
 constexpr int kMaxStripeBins = 8192;
 constexpr int kL1Threads = 256;
-constexpr int kL1Chunk = 16384;  // points per workgroup in the level-1 scatter
+constexpr int kL1Chunk = 65536;  // points per workgroup in the level-1 scatter (A/B: 16K..128K)
 constexpr int kL2Threads = 512;
 
 __device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, double py,

@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--cpu-sample-side", type=int, default=4000,
                     help="cells per side of the sub-tile the CPU oracle is timed on")
     ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
+    ap.add_argument("--host-path", action="store_true",
+                    help="also time ONE pass through the host-buffer (drop-in) entry points, "
+                         "PCIe transfers included (reported as pcie_inclusive, never as value)")
     return ap.parse_args()
 
 
@@ -287,6 +290,25 @@ def main():
             "kernels": kern,
             "dsm_stats": m.dsm_stats(),
         }
+        if world == 1 and args.host_path:
+            # the reference-shaped call: cloud, frames and layers in host memory
+            h_pts = pts.cpu().numpy()
+            h_frames = [f for f in frames.cpu().numpy()] if F else None
+            m.reset()
+            m.synchronize()
+            t0h = time.perf_counter()
+            dsm.process(h_pts, m)
+            t1h = time.perf_counter()
+            if F:
+                mosaic.process(poses, h_frames, m)
+            for name in (["elevation"] + (["elevation_angle", "observation_index", "ortho"] if F else [])):
+                m.get(name)
+            t2h = time.perf_counter()
+            out["pcie_inclusive"] = {
+                "ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
+                "Mcells_per_s": round(cells / (t2h - t0h) / 1e6, 1),
+                "note": "one pass, pageable host buffers: cloud H2D + elevation up/down, frames "
+                        "H2D, output layers D2H"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)

@@ -75,3 +75,24 @@ def test_product_does_not_touch_the_oracle():
                 src = open(os.path.join(base, f), errors="replace").read()
                 assert "oracle_ffi" not in src and "liboracle" not in src and \
                     "amo_" not in src.replace("amo_compat.h", ""), os.path.join(base, f)
+
+
+def test_argument_errors_are_reported_without_a_gpu(L):
+    """Null / empty arguments fail with AMHIP_ERR_ARG before any device work
+    (the reference's CHECK(map), CHECK(!T_G_Bs.empty()), ...)."""
+    lib = L.load()
+    assert lib.amhip_dsm_process_dev(None, None, 10, 1, 0.0, 0.0) == L.ERR_ARG
+    assert b"null context" in lib.amhip_last_error()
+    assert lib.amhip_dsm_process(None, None, 10, 1, 0.0, 0.0, None) == L.ERR_ARG
+    assert lib.amhip_ortho_backward_process_dev(None, None, None, 0, None, 0, 0, 1, 0) == L.ERR_ARG
+    assert lib.amhip_ortho_from_pcl_process_dev(None, None, None, 0, 2, 0) == L.ERR_ARG
+    assert lib.amhip_layer_upload(None, 0, None) == L.ERR_ARG
+    assert lib.amhip_ctx_synchronize(None) == L.ERR_ARG
+    assert lib.amhip_layer_device_ptr(None, 1) is None
+    g = L.make_grid(10.0, 10.0, 1.0)
+    h = C.c_void_p()
+    assert lib.amhip_ctx_create_window(C.byref(g), 5, 5, 10, 10, 0, C.byref(h)) in \
+        (L.ERR_ARG, L.ERR_NO_DEVICE)
+    bad = L.GridDesc()
+    assert lib.amhip_ctx_create(C.byref(bad), 0, C.byref(h)) == L.ERR_ARG
+    assert lib.amhip_kernel_name(3) == b"k_dsm_gather"
