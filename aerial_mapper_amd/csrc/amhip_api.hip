@@ -191,7 +191,8 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
 // 10, 100, ... for the adaptive retries, ortho-from-pcl.cc:63-71).
 static int make_dsm_params(const Ctx& c, int radius_sq,
                            double center_easting, double center_northing,
-                           DsmParams* out, int mode = 0, int pcl_lambda = 1) {
+                           DsmParams* out, int mode = 0, int pcl_lambda = 1,
+                           size_t num_points = 0) {
   const amhip_grid_desc& g = c.grid;
   DsmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -273,7 +274,40 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   }
 
   // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
-  const int kTileI = 64, kTileJ = 32;
+  const int kTileI = 64;
+  // Tile height and LDS point capacity from the cloud's MEAN density (points
+  // per cell): the tile's region must hold E + 5 sqrt(E) points.  64x16 tiles
+  // with 1024 slots need ~37 KB of LDS -> 4 workgroups per CU; denser clouds
+  // take 64x32 / 2048 (2 per CU), then 64x16 / 2048.  A tile that still
+  // overflows (clustered cloud) takes the global-memory path on its own.
+  int kTileJ = 32;
+  int cap = 2048;
+  {
+    const int w0h = p.w[0];
+    const double rho = (double)num_points / ((double)p.rows * (double)p.cols);
+    auto need = [&](int tj) {
+      // bins an interior tile's region spans (same integer arithmetic as the kernel)
+      const int bi = (kTileI + kTileI - 1 + w0h + p.M) / B - (kTileI - w0h + p.M) / B + 1;
+      const int bj = (tj + tj - 1 + w0h + p.M) / B - (tj - w0h + p.M) / B + 1;
+      const double e = rho * (double)(bi * B) * (double)(bj * B);
+      return e + 5.0 * std::sqrt(e);
+    };
+    if (need(16) <= 1024.0) {
+      kTileJ = 16;
+      cap = 1024;
+    } else if (need(32) <= 2048.0) {
+      kTileJ = 32;
+      cap = 2048;
+    } else {
+      kTileJ = 16;
+      cap = 2048;
+    }
+    if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
+      kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
+      cap = kTileJ == 16 ? 1024 : 2048;
+    }
+  }
+  p.tile_j = kTileJ;
   p.tiles_i = (p.rows + kTileI - 1) / kTileI;
   p.tiles_j = (p.cols + kTileJ - 1) / kTileJ;
   const int w0 = p.w[0];
@@ -298,7 +332,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     const int rw = kTileI + 2 * w0 + 2 * (B - 1);
     const int rh = kTileJ + 2 * w0 + 2 * (B - 1);
     p.lds_cells = rw * rh;
-    p.lds_cap = 2048;  // kMaxPtsPerThread * 256
+    p.lds_cap = cap;  // == kCap of the kernel instance
     const size_t bytes = ((size_t)p.lds_cap + 2) * 24 + ((size_t)p.lds_cells + 1) * 4 +
                          (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;
     p.lds_bytes = static_cast<unsigned>((bytes + 15) & ~size_t(15));
@@ -593,7 +627,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   DsmParams p;
-  if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p)))
+  if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n)))
     return rc;
   return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr);
 }
@@ -635,7 +669,7 @@ int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
   if (rc) return rc;
   float* out = c->layers[AMHIP_LAYER_ORTHO];
   DsmParams p;
-  if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1))) return rc;
+  if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1, n))) return rc;
   if (!adaptive) return dsm_run(c, dev_xyz, dev_intensities, n, p, out, nullptr, nullptr);
 
   // use_adaptive_interpolation: cells whose search is empty retry with the
@@ -653,7 +687,7 @@ int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
     AMHIP_TRY(hipStreamSynchronize(c->stream));
     if (left == 0) break;
     if (lambda * radius_sq > 0x7FFFFFFFll) break;  // the reference's int product overflows here
-    if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, static_cast<int>(lambda)))) return rc;
+    if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, static_cast<int>(lambda), n))) return rc;
     p.only_unfilled = 1;
     AMHIP_TRY(hipMemsetAsync(unfilled, 0, sizeof(unsigned), c->stream));
     if ((rc = dsm_run(c, dev_xyz, dev_intensities, n, p, out, c->fill_mask, unfilled))) return rc;

@@ -61,6 +61,7 @@ struct DsmParams {
   int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
   int lds_cap;                // points the tile's LDS image can hold
   int lds_cells;              // cell-offset table entries reserved (+1 sentinel)
+  int tile_j;                 // tile height in cells: 32, or 16 for dense clouds
   int tiles_i, tiles_j;
   unsigned lds_bytes;
 };

@@ -622,10 +622,9 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 // span of LDS points per row.  Cells whose first search is empty are queued
 // in LDS and finished by the fallback path on the global bins.
 constexpr int kTileI = 64;
-constexpr int kTileJ = 32;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
-template <int NT>
+template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
                    const double* __restrict__ sorted, CellOut o) {
@@ -737,9 +736,9 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
     s_wr2[tid] = p.wr2[tid];
   }
   __syncthreads();
-  constexpr int kMaxK = (2048 + NT - 1) / NT;  // lds_cap <= 2048
+  constexpr int kMaxK = (kCap + NT - 1) / NT;  // p.lds_cap == kCap
   uint32_t pslot[kMaxK];                       // cell << 12 | rank  (rank < 4096)
-  uint32_t pglob[kMaxK];                       // index into `sorted`
+  double ppx[kMaxK], ppy[kMaxK], ppz[kMaxK];   // the thread's points (placed after the scan)
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     const int idx = tid + k * NT;
@@ -747,10 +746,12 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
     if (idx < np) {
       int r = 0;
       while (idx >= (int)s_rowp[r + 1]) ++r;
-      const uint32_t g = s_rowg[r] + (uint32_t)(idx - (int)s_rowp[r]);
-      pglob[k] = g;
-      const double px = sorted[3 * (size_t)g + 0];
-      const double py = sorted[3 * (size_t)g + 1];
+      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
+      const double px = sorted[3 * g + 0];
+      const double py = sorted[3 * g + 1];
+      ppx[k] = px;
+      ppy[k] = py;
+      ppz[k] = sorted[3 * g + 2];
       // same arithmetic as point_bin(): the point's cell in shifted coordinates
       const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
       const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
@@ -782,17 +783,13 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
     if (tid == 0) s_off[ncell] = total;
   }
   __syncthreads();
-  // pass 2: re-read the points (L2 hits) and drop them into their sorted slot
+  // pass 2: drop the points into their sorted slot
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     if (pslot[k] != 0xFFFFFFFFu) {
-      const size_t g = pglob[k];
-      const double px = sorted[3 * g + 0];
-      const double py = sorted[3 * g + 1];
-      const double pz = sorted[3 * g + 2];
       const uint32_t pos = s_off[pslot[k] >> 12] + (pslot[k] & 0xFFFu);
-      s_xy[pos] = make_double2(px, py);
-      s_z[pos] = pz;
+      s_xy[pos] = make_double2(ppx[k], ppy[k]);
+      s_z[pos] = ppz[k];
     }
   }
   __syncthreads();
@@ -1027,17 +1024,26 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
-#define AMHIP_LAUNCH_TILED(NT_)                                                            \
-  do {                                                                                     \
-    AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_>),  \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,              \
-                                  (int)p.lds_bytes));                                      \
-    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_>), dim3(ntiles), dim3(NT_), p.lds_bytes,    \
-                       c->stream, p, c->bin_start, c->sorted, cell_out);                   \
+#define AMHIP_LAUNCH_TILED(NT_, TJ_, CAP_)                                                    \
+  do {                                                                                        \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                    \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
+    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
+                       p.lds_bytes, c->stream, p, c->bin_start, c->sorted, cell_out);         \
   } while (0)
-      if (nt == 256) AMHIP_LAUNCH_TILED(256);
-      else if (nt == 1024) AMHIP_LAUNCH_TILED(1024);
-      else AMHIP_LAUNCH_TILED(512);
+      // (tile height, LDS point capacity) picked by make_dsm_params from the
+      // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
+      if (p.tile_j == 16 && p.lds_cap == 1024) {
+        if (nt == 256) AMHIP_LAUNCH_TILED(256, 16, 1024);
+        else AMHIP_LAUNCH_TILED(512, 16, 1024);
+      } else if (p.tile_j == 16) {
+        AMHIP_LAUNCH_TILED(512, 16, 2048);
+      } else {
+        if (nt == 256) AMHIP_LAUNCH_TILED(256, 32, 2048);
+        else if (nt == 1024) AMHIP_LAUNCH_TILED(1024, 32, 2048);
+        else AMHIP_LAUNCH_TILED(512, 32, 2048);
+      }
 #undef AMHIP_LAUNCH_TILED
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
