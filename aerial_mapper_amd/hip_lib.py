@@ -133,10 +133,9 @@ def load():
     lib.amhip_kernel_name.argtypes = [C.c_int]
     lib.amhip_ctx_dsm_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int32)]
-    for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("amhip_abi_version",):
-            pass
+    missing = [name for name in EXPORTS if not hasattr(lib, name)]
+    if missing:
+        raise ImportError("libaerial_mapper_hip.so lacks %s (stale build?)" % missing)
     if lib.amhip_abi_version() != ABI_VERSION:
         raise ImportError("libaerial_mapper_hip.so ABI %d != expected %d"
                           % (lib.amhip_abi_version(), ABI_VERSION))

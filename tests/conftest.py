@@ -13,18 +13,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
-def _gpu_available():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
-
-
-def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU must fail loudly, not skip silently;
-    # without `-m gpu` the marker expression already deselects them.
-    pass
+# `-m gpu` on a box without a GPU fails loudly (AMHIP_ERR_NO_DEVICE), it is never
+# skipped silently; without `-m gpu` the marker expression deselects those tests.
 
 
 @pytest.fixture(scope="session")

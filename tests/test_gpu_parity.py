@@ -345,3 +345,15 @@ def test_dsm_one_level_sort_fallback_matches():
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b"ONE_LEVEL_OK" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def test_ortho_many_frames_cross_the_cull_chunk():
+    # 1100 frames > the 1024-frame cull pass: the candidate list is rebuilt per
+    # chunk while the per-cell fold state carries over
+    cam = S.camera(48, 36, 40.0)
+    sc = S.Scene(60.0, 40.0, 1.0, 9000, seed=83, num_frames=1100, altitude=470.0, cam=cam,
+                 tilt_deg=8.0)
+    got, want = _ortho_both(sc)
+    assert _coverage(want) > 0.5
+    S.assert_layers_equal(got, want, ORTHO_LAYERS)
+    assert np.nanmax(want["observation_index"]) > 1024
