@@ -136,7 +136,18 @@ class AerialGridMap(object):
 
     # -- stream / sync / timing ------------------------------------------
     def set_stream(self, stream_handle):
+        """Run this context's kernels on an existing HIP stream (e.g.
+        torch.cuda.Stream().cuda_stream); None/0 = the context's own stream."""
         L.check(self._lib.amhip_ctx_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+        self._stream_handle = int(stream_handle or 0)
+
+    def wait_for_torch(self, tensor):
+        """Device inputs made by torch on ANOTHER stream than this context's must be
+        complete before the context's kernels read them."""
+        import torch
+        cur = torch.cuda.current_stream(tensor.device)
+        if int(cur.cuda_stream) == 0 or int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
+            cur.synchronize()
 
     def synchronize(self):
         """Waits for the GPU and raises if a device-side CHECK fired."""
@@ -200,6 +211,7 @@ class Dsm(object):
             assert point_cloud.is_cuda and point_cloud.dtype.is_floating_point
             assert point_cloud.element_size() == 8 and point_cloud.is_contiguous()
             n = point_cloud.numel() // 3
+            map.wait_for_torch(point_cloud)
             L.check(lib.amhip_dsm_process_dev(
                 map.handle, C.c_void_p(point_cloud.data_ptr()), n,
                 s.interpolation_radius, s.center_easting, s.center_northing))
@@ -295,6 +307,7 @@ class OrthoBackwardGrid(object):
             row = cam.width * ch
             frame = row * cam.height
             assert images.shape[1] == cam.height and images.shape[2] == cam.width
+            map.wait_for_torch(images)
             L.check(lib.amhip_ortho_backward_process_dev(
                 map.handle, C.byref(cam), T_G_C.ctypes.data_as(f64p), F,
                 C.c_void_p(images.data_ptr()), frame, row, ch, int(colored)))
@@ -355,6 +368,7 @@ class OrthoFromPcl(object):
             n = pointcloud.numel() // 3
             if n == 0 or intensities.numel() < n:
                 raise L.AmhipError(L.ERR_ARG, "CHECK(!pointcloud.empty()) / CHECK(i < intensities.size())")
+            map.wait_for_torch(pointcloud)
             L.check(lib.amhip_ortho_from_pcl_process_dev(
                 map.handle, C.c_void_p(pointcloud.data_ptr()), C.c_void_p(intensities.data_ptr()),
                 n, s.interpolation_radius, int(bool(s.use_adaptive_interpolation))))
@@ -388,6 +402,7 @@ def densify(map, disparity, image_left, K, baseline, R_G_C, t_G_C1):
     xyz = torch.empty((H * W, 3), dtype=torch.float64, device=disparity.device)
     inten = torch.empty(H * W, dtype=torch.int32, device=disparity.device)
     count = torch.zeros(1, dtype=torch.int64, device=disparity.device)
+    map.wait_for_torch(disparity)
     L.check(L.load().amhip_densify_dev(
         map.handle, C.c_void_p(disparity.data_ptr()), disparity.stride(0) * 4,
         C.c_void_p(image_left.data_ptr()), image_left.stride(0), W, H, Kc.ctypes.data_as(f64p),

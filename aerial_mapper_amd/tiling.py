@@ -143,6 +143,7 @@ def select_for_windows(points, grid, windows, margin_m, center_easting=0.0,
         buf = torch.empty((nd, cap_d, 3), dtype=torch.float64, device=points.device)
         counts = torch.zeros(nd, dtype=torch.int64, device=points.device)
         wins = (C.c_int32 * (4 * nd))(*[int(v) for w in ws for v in w])
+        map_.wait_for_torch(points)
         L.check(lib.amhip_halo_select_dev(
             map_.handle, C.c_void_p(points.data_ptr()), n, center_easting, center_northing,
             wins, nd, float(margin_m), C.c_void_p(buf.data_ptr()), cap_d,
