@@ -357,3 +357,17 @@ def test_ortho_many_frames_cross_the_cull_chunk():
     assert _coverage(want) > 0.5
     S.assert_layers_equal(got, want, ORTHO_LAYERS)
     assert np.nanmax(want["observation_index"]) > 1024
+
+
+def test_utm_scale_coordinates():
+    # real surveys live at UTM magnitudes (easting ~4.6e5, northing ~5.3e6): the
+    # map is centred there, the DSM's centre offsets stay 0 (like every shipped
+    # flag file), the cloud and the camera poses carry the large coordinates
+    c = (464980.25, 5272690.5)
+    sc = S.Scene(120.0, 90.0, 0.5, 60000, seed=84, center=c, num_frames=9, altitude=480.0)
+    got, want = _dsm_both(sc)
+    assert (~np.isnan(want)).mean() > 0.99
+    S.assert_dsm_close(got, want)
+    g2, w2 = _ortho_both(sc, elevation=want)
+    assert _coverage(w2) > 0.5
+    S.assert_layers_equal(g2, w2, ORTHO_LAYERS)
