@@ -850,19 +850,29 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
           const double dyB = qyB - xy.y;
           const double d2A = dx2 + dyA * dyA;
           const double d2B = dx2 + dyB * dyB;
-          // (the empty asm keeps these as EXEC-masked blocks: if-converted to
-          // v_cndmask selects they cost 6 extra 64-bit selects per test)
+          // N = N*d + z*P;  D = D*d + P;  P = P*d  as four in-place FP64
+          // instructions under the EXEC mask of the hit test.  (Left to the
+          // compiler this becomes either 6 v_cndmask selects per test or
+          // compute-into-temporaries + 3 masked 64-bit moves.)
           if (d2A < T0) {  // strict (nanoflann.hpp:157)
-            asm volatile("" ::: "memory");
-            NA = fma(NA, d2A, z * PA);
-            DA = fma(DA, d2A, PA);
-            PA = PA * d2A;
+            double t;
+            asm volatile(
+                "v_mul_f64 %3, %2, %4\n\t"
+                "v_fma_f64 %0, %0, %5, %3\n\t"
+                "v_fma_f64 %1, %1, %5, %2\n\t"
+                "v_mul_f64 %2, %2, %5"
+                : "+v"(NA), "+v"(DA), "+v"(PA), "=&v"(t)
+                : "v"(z), "v"(d2A));
           }
           if (d2B < TB) {
-            asm volatile("" ::: "memory");
-            NB = fma(NB, d2B, z * PB);
-            DB = fma(DB, d2B, PB);
-            PB = PB * d2B;
+            double t;
+            asm volatile(
+                "v_mul_f64 %3, %2, %4\n\t"
+                "v_fma_f64 %0, %0, %5, %3\n\t"
+                "v_fma_f64 %1, %1, %5, %2\n\t"
+                "v_mul_f64 %2, %2, %5"
+                : "+v"(NB), "+v"(DB), "+v"(PB), "=&v"(t)
+                : "v"(z), "v"(d2B));
           }
         }
         // keep the running products inside the double range (exact scaling by
