@@ -331,7 +331,9 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     }
     const int rw = kTileI + 2 * w0 + 2 * (B - 1);
     const int rh = kTileJ + 2 * w0 + 2 * (B - 1);
-    p.lds_cells = rw * rh;
+    for (int k = 0; k <= w0; ++k)
+      p.wrp[k] = p.wr2[2 * k] > p.wr2[2 * k + 1] ? p.wr2[2 * k] : p.wr2[2 * k + 1];
+    p.lds_cells = rw * (rh + 4);  // row pairs, +1 pair for the parity shift, +1 spill
     p.lds_cap = cap;  // == kCap of the kernel instance
     const size_t bytes = ((size_t)p.lds_cap + 2) * 24 + ((size_t)p.lds_cells + 1) * 4 +
                          (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;

@@ -59,6 +59,7 @@ struct DsmParams {
   int lds_ok;                 // 0 -> every tile takes the global-memory path
   int wr[2 * kMaxW0 + 1];
   int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
+  int wrp[kMaxW0 + 1];        // per trip (window rows 2k, 2k+1 of the pair): max of wr2
   int lds_cap;                // points the tile's LDS image can hold
   int lds_cells;              // cell-offset table entries reserved (+1 sentinel)
   int tile_j;                 // tile height in cells: 32, or 16 for dense clouds

@@ -639,9 +639,7 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   uint32_t* s_rowp = s_rowg + kMaxRegionRows;        // prefix of the row lengths (+1)
   uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;    // block-scan scratch
   uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext
-  int* s_wr1 = reinterpret_cast<int*>(s_ctl + 4);     // p.wr  (per-lane row index)
-  int* s_wr2 = s_wr1 + 2 * kMaxW0 + 2;                // p.wr2
-  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_wr2 + 2 * kMaxW0 + 2);  // kTileI*kTileJ entries
+  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_ctl + 4);  // kTileI*kTileJ entries
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -674,7 +672,14 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const int nrb = rby1 - rby0 + 1;
   const int RW = (rbx1 - rbx0 + 1) * p.B;
   const int RH = nrb * p.B;
-  const int ncell = RW * RH;
+  // Cell-offset table layout: window rows are walked two at a time, so the
+  // cells of a ROW PAIR are interleaved (x-major, then the row of the pair):
+  // the candidates of one trip -- both rows, columns ci-w .. ci+w -- are then
+  // ONE contiguous span of the LDS point array.  `sh` aligns the pairs with
+  // the tile's first window row (all cell pairs of a tile start on even rows).
+  const int sh = (j0 - w0 + p.M - (rby0 * p.B)) & 1;
+  const int RW2 = 2 * RW;
+  const int ncell = (RH / 2 + 2) * RW2;
   const int ox = rbx0 * p.B;  // region origin in M-shifted cell coordinates
   const int oy = rby0 * p.B;
 
@@ -731,11 +736,8 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   // ---- stage + cell-bin the region's points in LDS --------------------------
   // pass 1: count per cell (LDS atomics), remember (cell, rank) per point
   for (int k = tid; k <= ncell; k += NT) s_off[k] = 0;
-  if (tid < 2 * kMaxW0 + 2) {
-    s_wr1[tid] = tid < 2 * kMaxW0 + 1 ? p.wr[tid] : 0;
-    s_wr2[tid] = p.wr2[tid];
-  }
   __syncthreads();
+  static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
   constexpr int kMaxK = (kCap + NT - 1) / NT;  // p.lds_cap == kCap
   uint32_t pslot[kMaxK];                       // cell << 12 | rank  (rank < 4096)
   double ppx[kMaxK], ppy[kMaxK], ppz[kMaxK];   // the thread's points (placed after the scan)
@@ -761,7 +763,8 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       iy = min(max(iy, 0), p.cols + 2 * p.M - 1) - oy;
       ix = min(max(ix, 0), RW - 1);  // (always inside: the bins are aligned)
       iy = min(max(iy, 0), RH - 1);
-      const uint32_t cell = (uint32_t)(iy * RW + ix);
+      iy += sh;
+      const uint32_t cell = (uint32_t)((iy >> 1) * RW2 + 2 * ix + (iy & 1));
       pslot[k] = (cell << 12) | atomicAdd(&s_off[cell], 1u);
     }
   }
@@ -800,7 +803,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   // four SIMDs and would otherwise co-limit with the FP64 VALU work).
   const int i = i0 + lane;
   const double T0 = p.T[0];
-  const int nwin2 = 2 * w0 + 2;
   if (i <= i_hi) {
     const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
     const int ci = i + p.M - ox;  // this cell's column in the region
@@ -819,28 +821,16 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       // tools/ubench).  D > 0 <=> at least one hit;  P == 0 <=> some hit had
       // d2 == 0 (dsm.cc:165 CHECK(distances[i] > 0.0)).  One division per cell.
       double NA = 0.0, DA = 0.0, PA = 1.0, NB = 0.0, DB = 0.0, PB = 1.0;
-      // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B; it exists
-      // in the region whenever B does).  Two rows are walked per trip of the
-      // outer loop as ONE span (lanes wait for each other per trip, and the
-      // spread of a two-row candidate count is relatively smaller).
-      const int nrows = haveB ? nwin2 : nwin2 - 1;
-      const int* wtab = haveB ? p.wr2 : p.wr;
-      const uint32_t* orow = s_off + (cj - w0) * RW + ci;
-      for (int r = 0; r < nrows; r += 2) {
-        const int w1 = wtab[r];
-        const uint32_t s1 = orow[-w1];
-        const uint32_t len1 = orow[w1 + 1] - s1;
-        uint32_t s2 = 0, len2 = 0;
-        if (r + 1 < nrows) {
-          const int w2 = wtab[r + 1];
-          s2 = orow[RW - w2];
-          len2 = orow[RW + w2 + 1] - s2;
-        }
-        orow += 2 * RW;
-        const uint32_t tot = len1 + len2;
-        const uint32_t off2 = s2 - len1;
-        for (uint32_t t = 0; t < tot; ++t) {
-          const uint32_t k = t + (t < len1 ? s1 : off2);
+      // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B), one row
+      // pair = one contiguous span per trip (lanes wait for each other per
+      // trip, and the spread of a two-row candidate count is relatively smaller).
+      const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * RW2 + 2 * ci;
+      for (int r = 0; r <= w0; ++r) {
+        const int w = p.wrp[r];
+        const uint32_t kb = orow[-2 * w];
+        const uint32_t ke = orow[2 * w + 2];
+        orow += RW2;
+        for (uint32_t k = kb; k < ke; ++k) {
           const double2 xy = s_xy[k];
           const double z = s_z[k];
           // L2_Adaptor, size == 2 (nanoflann.hpp:319-322): 0 + dx*dx, + dy*dy
