@@ -273,6 +273,37 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     }
   }
 
+  // ---- three-pass partition sort plan (amhip_dsm.hip) ---------------------------
+  // Worth it once the cloud is large enough that the sort is bandwidth bound;
+  // sub-partitions are sized for ~1.5 K points (a pass-3 workgroup sorts up to
+  // p3_cap of them in LDS, more through a direct-placement fallback).
+  p.p3_n1 = 0;
+  {
+    size_t min_pts = 1u << 20;
+    if (std::getenv("AMHIP_P3_MIN_POINTS"))
+      min_pts = (size_t)std::atoll(std::getenv("AMHIP_P3_MIN_POINTS"));
+    const int r1 = (p.nby + 127) / 128;
+    const int n1 = (p.nby + r1 - 1) / r1;
+    int cmax = 256 / r1;
+    if (r1 <= 256 && cmax >= 1 && num_points >= min_pts) {
+      double target = 1536.0;
+      if (std::getenv("AMHIP_P3_TARGET")) target = std::atof(std::getenv("AMHIP_P3_TARGET"));
+      int cc = static_cast<int>((double)num_points / ((double)p.nby * target) + 0.5);
+      if (cc < 1) cc = 1;
+      if (cc > cmax) cc = cmax;
+      if (cc > p.nbx) cc = p.nbx;
+      const int w = (p.nbx + cc - 1) / cc;
+      if (w <= 4096 && (long long)n1 * r1 * cc <= 32768) {
+        p.p3_r1 = r1;
+        p.p3_c = cc;
+        p.p3_w = w;
+        p.p3_n1 = n1;
+        p.p3_n2 = r1 * cc;
+        p.p3_cap = 3072;
+      }
+    }
+  }
+
   // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
   const int kTileI = 64;
   // Tile height and LDS point capacity from the cloud's MEAN density (points

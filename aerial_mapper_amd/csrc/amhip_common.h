@@ -57,6 +57,11 @@ struct DsmParams {
   // LDS-tiled gather (first level only): per window row dj in [-w0, w0] the
   // half-width in cells of the disc of squared radius T[0]
   int lds_ok;                 // 0 -> every tile takes the global-memory path
+  // three-pass partition sort plan (p3_n1 == 0: not used)
+  int p3_r1;                  // bin rows per first-pass partition
+  int p3_c, p3_w;             // column blocks per bin row, bins per column block
+  int p3_n1, p3_n2;           // partitions of pass 1; sub-partitions of each (= p3_r1 * p3_c)
+  int p3_cap;                 // points a pass-3 workgroup can sort in LDS
   int wr[2 * kMaxW0 + 1];
   int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
   int wrp[kMaxW0 + 1];        // per trip (window rows 2k, 2k+1 of the pair): max of wr2

@@ -325,6 +325,282 @@ k_dsm_stripe_sort(const double* __restrict__ tmp, DsmParams p,
 }
 
 // ---------------------------------------------------------------------------
+// three-pass partition sort (the default for clouds that are worth it)
+// ---------------------------------------------------------------------------
+// The stripe sort above appends 24-byte records to ~1000 open runs per
+// workgroup straight from registers; the partially written cache lines do not
+// survive in the L2 until their neighbours arrive, and the PMC counters show
+// 2-3x the algorithmic write traffic.  Here every pass sorts its chunk in LDS
+// first and then writes each run with consecutive lanes on consecutive
+// addresses, so whole lines leave the CU at once; the price is a third pass
+// (partition counts per pass are limited by run length = chunk / partitions):
+//   count    one read of the cloud: private LDS histograms over (k1, k2)
+//            [k1 = group of p3_r1 bin rows, k2 = (row in group, column block)],
+//            one row of counters per workgroup (no global atomics), then a
+//            reduction + scan -> the exact final position of every (k1, k2).
+//   pass 1   cloud -> k1 partitions      (<= 128, LDS-staged runs)
+//   pass 2   k1 partition -> its k2 sub-partitions (<= 256, LDS-staged runs)
+//   pass 3   one workgroup per sub-partition (~1.5 K points, fits LDS):
+//            counting sort by bin in LDS, bin_start[] for its bins, one
+//            contiguous coalesced copy out.
+// Sub-partitions are ordered (bin row, column block), so the result is the
+// same row-major-by-bin order the gather kernels expect.
+constexpr int kP3CountThreads = 1024;
+constexpr int kP3Threads = 512;
+constexpr int kP3Chunk = 2560;  // points staged per scatter workgroup (70 KB of LDS: 2 per CU)
+constexpr int kP3PerThread = kP3Chunk / kP3Threads;
+constexpr int kP3MaxKeys = 256;
+constexpr int kP3PlaceThreads = 256;
+
+__device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
+                                        int* k2) {
+  int bx, by;
+  if (!point_bin_xy(p, px, py, &bx, &by)) return false;
+  const int a = by / p.p3_r1;
+  *k1 = a;
+  *k2 = (by - a * p.p3_r1) * p.p3_c + bx / p.p3_w;
+  return true;
+}
+
+__global__ void __launch_bounds__(kP3CountThreads)
+k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
+               uint32_t* __restrict__ hist_rows) {
+  extern __shared__ uint32_t s_hist[];
+  const int nk = p.p3_n1 * p.p3_n2;
+  for (int k = threadIdx.x; k < nk; k += kP3CountThreads) s_hist[k] = 0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * kP3CountThreads;
+  for (size_t idx = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; idx < n; idx += stride) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+    int k1, k2;
+    if (p3_keys(p, px, py, &k1, &k2)) atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+  }
+  __syncthreads();
+  uint32_t* row = hist_rows + (size_t)blockIdx.x * nk;
+  for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
+}
+
+__global__ void __launch_bounds__(256)
+k_dsm_p3_reduce(const uint32_t* __restrict__ hist_rows, int nrows, int nk,
+                uint32_t* __restrict__ cnt) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nk) return;
+  uint32_t s = 0;
+  for (int r = 0; r < nrows; ++r) s += hist_rows[(size_t)r * nk + k];
+  cnt[k] = s;
+}
+
+// One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
+// copy as the pass-2 append cursors; start1 / cursor1 for pass 1; blk2 = first
+// pass-2 workgroup of every k1 partition (partitions are cut into chunks).
+__global__ void __launch_bounds__(1024)
+k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
+              uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
+              uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
+              uint32_t* __restrict__ blk2) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  __shared__ unsigned s_start1[kP3MaxKeys + 1];
+  const int nk = n1 * n2;
+  unsigned carry = 0;
+  for (int base = 0; base < nk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned v = (i < nk) ? cnt[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
+    if (i < nk) {
+      start2[i] = carry + ex;
+      cursor2[i] = carry + ex;
+      if (i % n2 == 0) s_start1[i / n2] = carry + ex;
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    start2[nk] = carry;
+    s_start1[n1] = carry;
+  }
+  __syncthreads();
+  const int k = threadIdx.x;
+  unsigned nblk = 0;
+  if (k < n1) {
+    start1[k] = s_start1[k];
+    cursor1[k] = s_start1[k];
+    nblk = (s_start1[k + 1] - s_start1[k] + kP3Chunk - 1) / kP3Chunk;
+  }
+  if (k == 0) start1[n1] = carry;
+  unsigned total;
+  const unsigned ex = block_excl_scan<1024>(nblk, &total, lds);
+  if (k < n1) blk2[k] = ex;
+  if (k == 0) blk2[n1] = total;
+}
+
+// Passes 1 and 2.  kFirst: chunk of the input cloud, key k1, values/centre
+// handling of the reference; else: chunk of one k1 partition, key k2.
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ values, size_t n,
+                 DsmParams p, const uint32_t* __restrict__ start1,
+                 const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
+                 double* __restrict__ dst) {
+  extern __shared__ double s_pts[];                                       // 3 * kP3Chunk
+  uint32_t* s_dest = reinterpret_cast<uint32_t*>(s_pts + 3 * kP3Chunk);   // kP3Chunk
+  uint32_t* s_cnt = s_dest + kP3Chunk;                                    // kP3MaxKeys
+  uint32_t* s_off = s_cnt + kP3MaxKeys;
+  uint32_t* s_base = s_off + kP3MaxKeys;
+  uint32_t* s_scan = s_base + kP3MaxKeys;  // 24
+  const int tid = threadIdx.x;
+  int nkeys;
+  size_t c0, c1;
+  if (kFirst) {
+    c0 = (size_t)blockIdx.x * kP3Chunk;
+    c1 = min(c0 + (size_t)kP3Chunk, n);
+    nkeys = p.p3_n1;
+  } else {
+    const int n1 = p.p3_n1;
+    const uint32_t b = blockIdx.x;
+    if (b >= blk2[n1]) return;
+    int lo = 0, hi = n1;  // blk2[lo] <= b < blk2[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (blk2[mid] <= b) lo = mid; else hi = mid;
+    }
+    c0 = (size_t)start1[lo] + (size_t)(b - blk2[lo]) * kP3Chunk;
+    c1 = min(c0 + (size_t)kP3Chunk, (size_t)start1[lo + 1]);
+    nkeys = p.p3_n2;
+    cursor += (size_t)lo * p.p3_n2;
+  }
+  if (tid < kP3MaxKeys) s_cnt[tid] = 0;
+  __syncthreads();
+  double px[kP3PerThread], py[kP3PerThread], pz[kP3PerThread];
+  uint32_t slot[kP3PerThread];  // key << 12 | rank in the chunk's run of that key
+#pragma unroll
+  for (int k = 0; k < kP3PerThread; ++k) {
+    const size_t idx = c0 + tid + (size_t)k * kP3Threads;
+    slot[k] = 0xFFFFFFFFu;
+    if (idx < c1) {
+      double x = src[3 * idx + 0], y = src[3 * idx + 1];
+      double z;
+      if (kFirst) {
+        x -= p.sub_x;
+        y -= p.sub_y;
+        z = values ? (double)values[idx] : src[3 * idx + 2];
+      } else {
+        z = src[3 * idx + 2];
+      }
+      px[k] = x;
+      py[k] = y;
+      pz[k] = z;
+      int k1, k2;
+      if (p3_keys(p, x, y, &k1, &k2)) {
+        const int key = kFirst ? k1 : k2;
+        slot[k] = ((uint32_t)key << 12) | atomicAdd(&s_cnt[key], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
+    if (tid < nkeys) {
+      s_off[tid] = ex;
+      s_base[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+    }
+    if (tid == 0) s_scan[23] = total;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kP3PerThread; ++k) {
+    if (slot[k] != 0xFFFFFFFFu) {
+      const uint32_t key = slot[k] >> 12, rank = slot[k] & 0xFFFu;
+      const uint32_t q = s_off[key] + rank;
+      s_pts[3 * q + 0] = px[k];
+      s_pts[3 * q + 1] = py[k];
+      s_pts[3 * q + 2] = pz[k];
+      s_dest[q] = s_base[key] + rank;
+    }
+  }
+  __syncthreads();
+  const uint32_t ne = 3u * s_scan[23];
+  for (uint32_t e = tid; e < ne; e += kP3Threads) {
+    const uint32_t q = e / 3u;
+    dst[3 * (size_t)s_dest[q] + (e - 3u * q)] = s_pts[e];
+  }
+}
+
+// Pass 3: one workgroup per (k1, k2) sub-partition.
+__global__ void __launch_bounds__(kP3PlaceThreads)
+k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
+               const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+               double* __restrict__ sorted) {
+  extern __shared__ double s_pts[];                                  // 3 * cap
+  uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
+  uint32_t* s_scan = s_bins + p.p3_w;                                // 24
+  const int tid = threadIdx.x;
+  const int sp = blockIdx.x;
+  const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
+  const int rr = k2 / p.p3_c;
+  const int row = k1 * p.p3_r1 + rr;
+  const int bx0 = (k2 - rr * p.p3_c) * p.p3_w;
+  const int nbw = min(p.p3_w, p.nbx - bx0);
+  if (sp == 0 && tid == 0)
+    bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
+  if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
+  const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  for (int k = tid; k < nbw; k += kP3PlaceThreads) s_bins[k] = 0;
+  __syncthreads();
+  for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+    int bx, by;
+    point_bin_xy(p, src[3 * (size_t)idx + 0], src[3 * (size_t)idx + 1], &bx, &by);
+    atomicAdd(&s_bins[bx - bx0], 1u);
+  }
+  __syncthreads();
+  {
+    const int per = (nbw + kP3PlaceThreads - 1) / kP3PlaceThreads;
+    const int lo = tid * per;
+    const int hi = min(lo + per, nbw);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<kP3PlaceThreads>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
+  for (int k = tid; k < nbw; k += kP3PlaceThreads) out_start[k] = g0 + s_bins[k];
+  __syncthreads();
+  const bool in_lds = (int)(g1 - g0) <= cap;
+  for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {  // (L2 hits)
+    const double px = src[3 * (size_t)idx + 0];
+    const double py = src[3 * (size_t)idx + 1];
+    const double pz = src[3 * (size_t)idx + 2];
+    int bx, by;
+    point_bin_xy(p, px, py, &bx, &by);
+    const uint32_t q = atomicAdd(&s_bins[bx - bx0], 1u);
+    if (in_lds) {
+      s_pts[3 * q + 0] = px;
+      s_pts[3 * q + 1] = py;
+      s_pts[3 * q + 2] = pz;
+    } else {  // over-full sub-partition (clustered cloud): place directly
+      const size_t o = (size_t)g0 + q;
+      sorted[3 * o + 0] = px;
+      sorted[3 * o + 1] = py;
+      sorted[3 * o + 2] = pz;
+    }
+  }
+  if (!in_lds) return;
+  __syncthreads();
+  const uint32_t ne = 3u * (g1 - g0);
+  double* out = sorted + 3 * (size_t)g0;
+  for (uint32_t e = tid; e < ne; e += kP3PlaceThreads) out[e] = s_pts[e];
+}
+
+// ---------------------------------------------------------------------------
 // multi-GPU: compact the points other windows need (their halo)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -946,7 +1222,62 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   c->last_bin_cells = p.B;
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
-  if (p.nstripes > 0 && !force_one_level) {
+  static const bool force_two_level = getenv("AMHIP_SORT_TWO_LEVEL") != nullptr;
+  if (p.p3_n1 > 0 && !force_one_level && !force_two_level) {
+    // ---- three-pass partition sort ---------------------------------------------
+    const int n1 = p.p3_n1, n2 = p.p3_n2, nk = n1 * n2;
+    size_t gcount = (n + 8191) / 8192;
+    if (gcount > 256) gcount = 256;
+    if (gcount < 1) gcount = 1;
+    int rc;
+    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
+    const size_t ws_words = gcount * (size_t)nk + 3 * (size_t)nk + 3 * (size_t)n1 + 16;
+    if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, ws_words))) return rc;
+    uint32_t* hist_rows = c->stripe_ws;
+    uint32_t* cnt = hist_rows + gcount * (size_t)nk;
+    uint32_t* start2 = cnt + nk;       // nk + 1
+    uint32_t* cursor2 = start2 + nk + 1;
+    uint32_t* start1 = cursor2 + nk;   // n1 + 1
+    uint32_t* cursor1 = start1 + n1 + 1;
+    uint32_t* blk2 = cursor1 + n1;     // n1 + 1
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      const size_t lds = (size_t)nk * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dsm_p3_count, dim3((unsigned)gcount), dim3(kP3CountThreads), lds,
+                         c->stream, dev_xyz, n, p, hist_rows);
+      hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0,
+                         c->stream, hist_rows, (int)gcount, nk, cnt);
+      hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
+                         cursor2, start1, cursor1, blk2);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      const size_t lds = (size_t)kP3Chunk * 28 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
+      hipLaunchKernelGGL(k_dsm_p3_scatter<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
+                         c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted);
+      hipLaunchKernelGGL(k_dsm_p3_scatter<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
+                         lds, c->stream, c->sorted, (const int32_t*)nullptr, n, p, start1, blk2,
+                         cursor2, c->tmp_points);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
+                         c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
+  } else if (p.nstripes > 0 && !force_one_level) {
     // ---- two-level stripe sort ------------------------------------------------
     int rc;
     if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;

@@ -325,26 +325,48 @@ def test_dsm_clustered_cloud_overflows_lds_tiles():
     S.assert_dsm_close(got, want)
 
 
-def test_dsm_one_level_sort_fallback_matches():
-    # the one-level counting sort (used when a bin row does not fit the LDS
-    # histogram) is forced through its environment knob in a child process
+@pytest.mark.parametrize("knobs", [
+    {"AMHIP_SORT_ONE_LEVEL": "1"},
+    {"AMHIP_SORT_TWO_LEVEL": "1"},
+    {"AMHIP_P3_MIN_POINTS": "0"},
+    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "48"},
+], ids=["one-level", "two-level", "three-pass", "three-pass-many-blocks"])
+def test_dsm_every_sort_path_matches(knobs):
+    # The binning sort has three implementations (one-level counting sort for
+    # very wide grids, two-level stripe sort, three-pass partition sort for
+    # large clouds); each is forced through its environment knob in a child
+    # process, on a uniform cloud, a clustered one (over-full LDS partitions)
+    # and the intensity variant (OrthoFromPcl).
+    import os
     import subprocess
     import sys
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
         "import numpy as np, oracle_ffi as O, scenarios as S, aerial_mapper_amd as A\n"
-        "sc = S.Scene(150.0, 110.0, 0.5, 70000, seed=82)\n"
-        "rc, want, _ = O.dsm_process(sc.points, sc.grid)\n"
-        "g = sc.grid\n"
-        "m = A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution))\n"
-        "A.Dsm(A.DsmSettings(), m).process(sc.points, m)\n"
-        "S.assert_dsm_close(m.get('elevation'), want)\n"
-        "print('ONE_LEVEL_OK')\n" % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
-    import os
-    env = dict(os.environ, AMHIP_SORT_ONE_LEVEL="1")
+        "def run(sc):\n"
+        "    rc, want, _ = O.dsm_process(sc.points, sc.grid)\n"
+        "    g = sc.grid\n"
+        "    m = A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution))\n"
+        "    A.Dsm(A.DsmSettings(), m).process(sc.points, m)\n"
+        "    S.assert_dsm_close(m.get('elevation'), want)\n"
+        "    inten = (np.arange(sc.points.shape[0]) %% 251).astype(np.int32)\n"
+        "    rc, want_o = O.ortho_from_pcl(sc.points, inten, g)\n"
+        "    A.OrthoFromPcl(A.OrthoFromPclSettings()).process(sc.points, inten, m)\n"
+        "    np.testing.assert_allclose(m.get('ortho'), want_o, rtol=0, atol=1e-3)\n"
+        "run(S.Scene(150.0, 110.0, 0.5, 70000, seed=82))\n"
+        "sc = S.Scene(60.0, 40.0, 0.25, 20000, seed=81)\n"
+        "rng = np.random.default_rng(5)\n"
+        "dense = np.empty((40000, 3))\n"
+        "dense[:, 0] = rng.uniform(10.0, 20.0, 40000)\n"
+        "dense[:, 1] = rng.uniform(5.0, 15.0, 40000)\n"
+        "dense[:, 2] = 400.0 + rng.uniform(-0.5, 0.5, 40000)\n"
+        "sc.points = np.ascontiguousarray(np.concatenate([sc.points, dense]))\n"
+        "run(sc)\n"
+        "print('SORT_PATH_OK')\n" % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
+    env = dict(os.environ, **knobs)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0 and b"ONE_LEVEL_OK" in r.stdout, r.stdout.decode()[-2000:]
+    assert r.returncode == 0 and b"SORT_PATH_OK" in r.stdout, r.stdout.decode()[-2000:]
 
 
 def test_ortho_many_frames_cross_the_cull_chunk():
