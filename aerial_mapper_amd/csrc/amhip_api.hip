@@ -299,7 +299,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
         p.p3_w = w;
         p.p3_n1 = n1;
         p.p3_n2 = r1 * cc;
-        p.p3_cap = 3072;
+        p.p3_cap = std::getenv("AMHIP_P3_CAP") ? std::atoi(std::getenv("AMHIP_P3_CAP")) : 2048;
       }
     }
   }
