@@ -8,10 +8,10 @@ class API.  See DESIGN.md / INTEGRATION.md.
 from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,  # noqa: F401
                       DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
 from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, NCamera,  # noqa: F401
-                     OrthoBackwardGrid, OrthoFromPcl, OrthoFromPclSettings, OrthoSettings,
-                     compose_T_G_C, densify)
+                     OrthoBackwardGrid, OrthoForwardHomography, OrthoForwardHomographySettings,
+                     OrthoFromPcl, OrthoFromPclSettings, OrthoSettings, compose_T_G_C, densify)
 
 __all__ = ["AerialGridMap", "GridMapSettings", "Dsm", "DsmSettings", "OrthoBackwardGrid",
-           "OrthoSettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "AmhipError", "Camera", "GridDesc",
+           "OrthoSettings", "OrthoForwardHomography", "OrthoForwardHomographySettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "AmhipError", "Camera", "GridDesc",
            "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
            "DIST_EQUIDISTANT"]

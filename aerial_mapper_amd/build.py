@@ -18,7 +18,8 @@ LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaerial_mapper_hip.so")
 SHIM_PATH = os.path.join(LIB_DIR, "libaerial_mapper_shim.so")
 
-HIP_SOURCES = ["amhip_api.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip"]
+HIP_SOURCES = ["amhip_api.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
+               "amhip_forward.hip"]
 HIP_HEADERS = ["amhip_common.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box
@@ -75,11 +76,16 @@ def build_shim(force=False, verbose=False):
         return SHIM_PATH
     cxx = os.environ.get("CXX", "g++")
     cmd = [cxx, "-O2", "-std=c++11", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
-           "-Wall", "-I" + inc, "-o", SHIM_PATH] + srcs + \
+           "-Wall", "-fvisibility-inlines-hidden", "-I" + inc, "-o", SHIM_PATH] + srcs + \
           ["-L" + LIB_DIR, "-laerial_mapper_hip", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    # Like the reference, three headers define a struct ortho::Settings; that is
+    # only safe while none of its (implicit) members is emitted out of line.
+    nm = subprocess.run(["nm", SHIM_PATH], stdout=subprocess.PIPE, universal_newlines=True).stdout
+    if "_ZN5ortho8Settings" in nm:
+        raise RuntimeError("ortho::Settings member emitted out of line in the shim: ODR clash")
     return SHIM_PATH
 
 

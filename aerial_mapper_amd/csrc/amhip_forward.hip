@@ -1,0 +1,825 @@
+// amhip_forward.hip -- homography-based forward orthomosaic on MI355X.
+//
+// Replaces ortho::OrthoForwardHomography (aerial_mapper_ortho/src/
+// ortho-forward-homography.cc): per frame the four image corners are
+// intersected with the ground plane (:85-112 / :143-170), the image ->
+// mosaic homography is solved (cv::getPerspectiveTransform), the frame is
+// warped into the mosaic with nearest-neighbour sampling (cv::warpPerspective,
+// INTER_NEAREST, BORDER_CONSTANT) and fed to an OpenCV FeatherBlender
+// (L1 distance transform of the frame's mask x 0.02, truncated at 1 = the
+// blend weight); blend() divides the weighted sums by the summed weights.
+//
+// Mapping to the GPU (everything per mosaic pixel is independent except the
+// distance transform, which is separable):
+//   k_fwd_undistort  only for cameras with a distortion model (remap, bilinear)
+//   k_fwd_warp       G frames at once: inverse homography per pixel in double
+//                    with OpenCV's evaluation order, u8 sample + mask
+//   k_fwd_dt_rows    one wave per (row, frame): distance to the nearest zero of
+//                    the row = prefix-max / suffix-min of zero positions
+//   k_fwd_dt_cols    one lane per (column, frame): min-plus sweep down and up;
+//                    rows + columns = the exact L1 transform (what OpenCV's 3x3
+//                    chamfer with a = 1, b = 2 computes); distances saturate at
+//                    255, the weight saturates at 50
+//   k_fwd_feed       per pixel, frames of the batch in ascending order:
+//                    dst += (short)(src * w), weight += w  (float sums in the
+//                    reference's order, 16-bit wrap like cv::Point3_<short>)
+//   k_fwd_blend      normalizeUsingWeightMap + mask + Blender::blend
+// The 8x8 solve and the 3x3 inverse run on the host in double (a few hundred
+// flops per frame).
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "amhip_common.h"
+
+namespace amhip {
+
+struct FwdFrame {
+  double m[9];  // mosaic pixel -> image pixel (inverse of the frame's homography)
+};
+
+struct Mosaic {
+  amhip_mosaic_desc desc;
+  amhip_camera cam;
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  size_t pixels = 0;
+  // blender state (cv::detail::FeatherBlender dst_ / dst_weight_map_)
+  int16_t* dst16 = nullptr;   // H x W x 3
+  float* dst_weight = nullptr;
+  // result_ / result_mask_
+  int16_t* result16 = nullptr;
+  uint8_t* result_mask = nullptr;
+  // per-batch workspaces
+  uint8_t* warped = nullptr;   // G x H x W x ch
+  size_t warped_cap = 0;
+  uint8_t* mask = nullptr;     // G x H x W
+  size_t mask_cap = 0;
+  uint8_t* dist = nullptr;     // G x H x W
+  size_t dist_cap = 0;
+  uint8_t* undist = nullptr;   // G undistorted frames
+  size_t undist_cap = 0;
+  uint8_t* stage = nullptr;    // host frames staged to the device
+  size_t stage_cap = 0;
+  FwdFrame* frames = nullptr;
+  size_t frames_cap = 0;
+};
+
+static int fwd_arg_fail(const char* msg) {
+  set_last_error(msg);
+  return AMHIP_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------
+// host: the homography of one frame
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Q {
+  double w, x, y, z;
+};
+
+void rotation_matrix(const Q& q, double R[9]) {  // Eigen::Quaterniond::toRotationMatrix
+  const double tx = 2.0 * q.x, ty = 2.0 * q.y, tz = 2.0 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+  const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+  const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  R[0] = 1.0 - (tyy + tzz);
+  R[1] = txy - twz;
+  R[2] = txz + twy;
+  R[3] = txy + twz;
+  R[4] = 1.0 - (txx + tzz);
+  R[5] = tyz - twx;
+  R[6] = txz - twy;
+  R[7] = tyz + twx;
+  R[8] = 1.0 - (txx + tyy);
+}
+
+void distort_host(const amhip_camera& c, double* px, double* py) {
+  double x = *px, y = *py;
+  if (c.distortion == AMHIP_DIST_RADTAN) {
+    const double k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
+    const double mx2 = x * x, my2 = y * y, mxy = x * y;
+    const double rho2 = mx2 + my2;
+    const double rad = k1 * rho2 + k2 * rho2 * rho2;
+    const double nx = x + (x * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2));
+    const double ny = y + (y * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2));
+    x = nx;
+    y = ny;
+  } else if (c.distortion == AMHIP_DIST_EQUIDISTANT) {
+    const double r = std::sqrt(x * x + y * y);
+    const double theta = std::atan(r);
+    const double th2 = theta * theta, th4 = th2 * th2, th6 = th4 * th2, th8 = th4 * th4;
+    const double thetad =
+        theta * (1.0 + c.dist[0] * th2 + c.dist[1] * th4 + c.dist[2] * th6 + c.dist[3] * th8);
+    const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+    x = x * scaling;
+    y = y * scaling;
+  }
+  *px = x;
+  *py = y;
+}
+
+// aslam distortion undistort(): Gauss-Newton on distort(y) = y_d, 5 iterations
+void undistort_normalized(const amhip_camera& c, double* px, double* py) {
+  if (c.distortion == AMHIP_DIST_NONE) return;
+  const double yx = *px, yy = *py;
+  double bx = yx, by = yy;
+  for (int it = 0; it < 5; ++it) {
+    double dx = bx, dy = by;
+    distort_host(c, &dx, &dy);
+    const double h = 1e-6;
+    double ax = bx + h, ay = by, cx = bx - h, cy = by;
+    distort_host(c, &ax, &ay);
+    distort_host(c, &cx, &cy);
+    const double j00 = (ax - cx) / (2.0 * h), j10 = (ay - cy) / (2.0 * h);
+    ax = bx; ay = by + h; cx = bx; cy = by - h;
+    distort_host(c, &ax, &ay);
+    distort_host(c, &cx, &cy);
+    const double j01 = (ax - cx) / (2.0 * h), j11 = (ay - cy) / (2.0 * h);
+    const double ex = yx - dx, ey = yy - dy;
+    const double a = j00 * j00 + j10 * j10, b = j00 * j01 + j10 * j11,
+                 d = j01 * j01 + j11 * j11;
+    const double gx = j00 * ex + j10 * ey, gy = j01 * ex + j11 * ey;
+    const double det = a * d - b * b;
+    bx = bx + (d * gx - b * gy) / det;
+    by = by + (a * gy - b * gx) / det;
+    if (ex * ex + ey * ey <= 1e-8) break;
+  }
+  *px = bx;
+  *py = by;
+}
+
+bool solve8(double A[8][9]) {  // Gaussian elimination with partial pivoting
+  for (int col = 0; col < 8; ++col) {
+    int piv = col;
+    for (int r = col + 1; r < 8; ++r)
+      if (std::fabs(A[r][col]) > std::fabs(A[piv][col])) piv = r;
+    if (A[piv][col] == 0.0) return false;
+    if (piv != col)
+      for (int k = 0; k < 9; ++k) std::swap(A[piv][k], A[col][k]);
+    for (int r = col + 1; r < 8; ++r) {
+      const double f = A[r][col] / A[col][col];
+      if (f == 0.0) continue;
+      for (int k = col; k < 9; ++k) A[r][k] = A[r][k] - f * A[col][k];
+    }
+  }
+  for (int r = 7; r >= 0; --r) {
+    double s = A[r][8];
+    for (int k = r + 1; k < 8; ++k) s = s - A[r][k] * A[k][8];
+    A[r][8] = s / A[r][r];
+  }
+  return true;
+}
+
+// ortho-forward-homography.cc:85-112 (updateOrthomosaic) / :143-170 (batch; it
+// offsets BOTH ground coordinates by width/2 -- `batch_quirk`).
+bool frame_homography(const amhip_camera& cam, const amhip_mosaic_desc& ds, const double* T,
+                      bool batch_quirk, double M[9]) {
+  const double W1 = static_cast<double>(cam.width - 1), H1 = static_cast<double>(cam.height - 1);
+  const double kp[4][2] = {{0.0, 0.0}, {W1, 0.0}, {W1, H1}, {0.0, H1}};
+  const Q q = {T[3], T[4], T[5], T[6]};
+  double R[9];
+  rotation_matrix(q, R);
+  float src[4][2], dst[4][2];
+  for (int k = 0; k < 4; ++k) {
+    double rx = (kp[k][0] - cam.cu) / cam.fu;  // PinholeCamera::backProject3
+    double ry = (kp[k][1] - cam.cv) / cam.fv;
+    undistort_normalized(cam, &rx, &ry);
+    const double ray[3] = {rx, ry, 1.0};
+    const double rz = (R[6] * ray[0] + R[7] * ray[1]) + R[8] * ray[2];
+    const double scale = -(T[2] - ds.ground_plane_elevation_m) / rz;
+    double S[9];
+    for (int e = 0; e < 9; ++e) S[e] = scale * R[e];
+    const double vx = (S[0] * ray[0] + S[1] * ray[1]) + S[2] * ray[2];
+    const double vy = (S[3] * ray[0] + S[4] * ray[1]) + S[5] * ray[2];
+    const double gx = (T[0] + vx) - ds.origin[0];
+    const double gy = (T[1] + vy) - ds.origin[1];
+    const double off_x = static_cast<double>(ds.width_mosaic_pixels) / 2.0;
+    const double off_y =
+        static_cast<double>(batch_quirk ? ds.width_mosaic_pixels : ds.height_mosaic_pixels) / 2.0;
+    dst[k][0] = static_cast<float>(gy + off_x);
+    dst[k][1] = static_cast<float>(gx + off_y);
+    src[k][0] = static_cast<float>(kp[k][0]);
+    src[k][1] = static_cast<float>(kp[k][1]);
+  }
+  double A[8][9];
+  for (int i = 0; i < 4; ++i) {
+    const double sx = src[i][0], sy = src[i][1], dx = dst[i][0], dy = dst[i][1];
+    const double r0[9] = {sx, sy, 1.0, 0.0, 0.0, 0.0, -sx * dx, -sy * dx, dx};
+    const double r1[9] = {0.0, 0.0, 0.0, sx, sy, 1.0, -sx * dy, -sy * dy, dy};
+    std::memcpy(A[i], r0, sizeof(r0));
+    std::memcpy(A[i + 4], r1, sizeof(r1));
+  }
+  if (!solve8(A)) return false;
+  for (int k = 0; k < 8; ++k) M[k] = A[k][8];
+  M[8] = 1.0;
+  return true;
+}
+
+bool invert3(const double S[9], double D[9]) {  // cv::invert, 3x3 closed form
+  double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) +
+             S[2] * (S[3] * S[7] - S[4] * S[6]);
+  if (d == 0.0) return false;
+  d = 1.0 / d;
+  double t[9];
+  t[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+  t[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+  t[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+  t[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+  t[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+  t[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+  t[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+  t[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+  t[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+  std::memcpy(D, t, sizeof(t));
+  return true;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+struct FwdGeom {
+  int mw, mh;          // mosaic
+  int iw, ih, ch;      // frames
+  int bw0;             // cv::warpPerspective block width (X0 is evaluated at block starts)
+  size_t frame_stride; // bytes between frames
+  size_t row_step;     // bytes between rows of a frame
+};
+
+__device__ __forceinline__ int round_half_even_sat(double v) {
+  v = fmax((double)INT_MIN, fmin((double)INT_MAX, v));
+  return (int)rint(v);
+}
+
+__device__ __forceinline__ void distort_dev(const amhip_camera& c, double* px, double* py) {
+  double x = *px, y = *py;
+  if (c.distortion == AMHIP_DIST_RADTAN) {
+    const double k1 = c.dist[0], k2 = c.dist[1], p1 = c.dist[2], p2 = c.dist[3];
+    const double mx2 = x * x, my2 = y * y, mxy = x * y;
+    const double rho2 = mx2 + my2;
+    const double rad = k1 * rho2 + k2 * rho2 * rho2;
+    const double nx = x + (x * rad + 2.0 * p1 * mxy + p2 * (rho2 + 2.0 * mx2));
+    const double ny = y + (y * rad + 2.0 * p2 * mxy + p1 * (rho2 + 2.0 * my2));
+    x = nx;
+    y = ny;
+  } else if (c.distortion == AMHIP_DIST_EQUIDISTANT) {
+    const double r = sqrt(x * x + y * y);
+    const double theta = atan(r);
+    const double th2 = theta * theta, th4 = th2 * th2, th6 = th4 * th2, th8 = th4 * th4;
+    const double thetad =
+        theta * (1.0 + c.dist[0] * th2 + c.dist[1] * th4 + c.dist[2] * th6 + c.dist[3] * th8);
+    const double scaling = (r > 1e-8) ? thetad / r : 1.0;
+    x = x * scaling;
+    y = y * scaling;
+  }
+  *px = x;
+  *py = y;
+}
+
+// aslam MappedUndistorter::processImage = cv::remap(INTER_LINEAR, BORDER_CONSTANT)
+// with 1/32-pixel coordinates and 15-bit weights.  out: G x ih x iw x ch, packed.
+__global__ void __launch_bounds__(256)
+k_fwd_undistort(amhip_camera cam, FwdGeom g, const uint8_t* __restrict__ frames, int G,
+                uint8_t* __restrict__ out) {
+  const int u = blockIdx.x * 256 + threadIdx.x;
+  const int v = blockIdx.y;
+  const int f = blockIdx.z;
+  if (u >= g.iw || f >= G) return;
+  double x = ((double)u - cam.cu) / cam.fu;
+  double y = ((double)v - cam.cv) / cam.fv;
+  distort_dev(cam, &x, &y);
+  const float mx = (float)(cam.fu * x + cam.cu);
+  const float my = (float)(cam.fv * y + cam.cv);
+  const int sx = round_half_even_sat((double)mx * 32.0);
+  const int sy = round_half_even_sat((double)my * 32.0);
+  const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32,
+            w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  const uint8_t* src = frames + (size_t)f * g.frame_stride;
+  for (int c = 0; c < g.ch; ++c) {
+    auto px = [&](int xx, int yy) -> int {
+      if (xx < 0 || yy < 0 || xx >= g.iw || yy >= g.ih) return 0;
+      return src[(size_t)yy * g.row_step + (size_t)xx * g.ch + c];
+    };
+    const int acc =
+        w00 * px(ix, iy) + w01 * px(ix + 1, iy) + w10 * px(ix, iy + 1) + w11 * px(ix + 1, iy + 1);
+    out[(((size_t)f * g.ih + v) * g.iw + u) * g.ch + c] = (uint8_t)((acc + (1 << 14)) >> 15);
+  }
+}
+
+// cv::warpPerspective(INTER_NEAREST, BORDER_CONSTANT) of G frames + addImage's mask.
+__global__ void __launch_bounds__(256)
+k_fwd_warp(FwdGeom g, const FwdFrame* __restrict__ fr, const uint8_t* __restrict__ frames, int G,
+           uint8_t* __restrict__ warped, uint8_t* __restrict__ mask) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y;
+  const int f = blockIdx.z;
+  if (x >= g.mw || f >= G) return;
+  const double* M = fr[f].m;
+  const int xs = (x / g.bw0) * g.bw0;  // block start
+  const int x1 = x - xs;
+  const double X0 = M[0] * xs + M[1] * y + M[2];
+  const double Y0 = M[3] * xs + M[4] * y + M[5];
+  const double W0 = M[6] * xs + M[7] * y + M[8];
+  double W = W0 + M[6] * x1;
+  W = W != 0.0 ? 1.0 / W : 0.0;
+  int X = round_half_even_sat((X0 + M[0] * x1) * W);
+  int Y = round_half_even_sat((Y0 + M[3] * x1) * W);
+  X = max(-32768, min(32767, X));  // saturate_cast<short>
+  Y = max(-32768, min(32767, Y));
+  const bool inside = X >= 0 && Y >= 0 && X < g.iw && Y < g.ih;
+  const size_t at = ((size_t)f * g.mh + y) * g.mw + x;
+  const uint8_t* src = frames + (size_t)f * g.frame_stride + (size_t)Y * g.row_step +
+                       (size_t)X * g.ch;
+  bool any = false;
+  for (int c = 0; c < g.ch; ++c) {
+    const uint8_t v = inside ? src[c] : (uint8_t)0;
+    warped[at * g.ch + c] = v;
+    any = any || v > 0;  // (img > 0.1) per channel, RGB2GRAY of 0/255 is non-zero iff any is
+  }
+  mask[at] = any ? 255 : 0;
+}
+
+// rows: distance to the nearest zero of the same row (saturated at 255)
+__global__ void __launch_bounds__(256)
+k_fwd_dt_rows(const uint8_t* __restrict__ mask, uint8_t* __restrict__ dist, int w, size_t nrows) {
+  const int lane = threadIdx.x & 63;
+  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const uint8_t* m = mask + row * (size_t)w;
+  uint8_t* d = dist + row * (size_t)w;
+  const int kFar = 1 << 24;
+  int last = -kFar;
+  for (int x0 = 0; x0 < w; x0 += 64) {
+    const int x = x0 + lane;
+    int v = (x < w && m[x] == 0) ? x : -kFar;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(v, off, 64);
+      if (lane >= off) v = max(v, o);
+    }
+    v = max(v, last);
+    if (x < w) d[x] = (uint8_t)min(x - v, 255);
+    last = __shfl(v, 63, 64);
+  }
+  int next = kFar;
+  for (int x0 = ((w - 1) / 64) * 64; x0 >= 0; x0 -= 64) {
+    const int x = x0 + lane;
+    int v = (x < w && m[x] == 0) ? x : kFar;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_down(v, off, 64);
+      if (lane + off < 64) v = min(v, o);
+    }
+    v = min(v, next);
+    if (x < w) d[x] = (uint8_t)min((int)d[x], min(v - x, 255));
+    next = __shfl(v, 0, 64);
+  }
+}
+
+// columns: d(x, y) = min_y' (|y - y'| + row distance(x, y')), in place
+__global__ void __launch_bounds__(256)
+k_fwd_dt_cols(uint8_t* __restrict__ dist, int w, int h, int G) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int f = blockIdx.y;
+  if (x >= w || f >= G) return;
+  uint8_t* col = dist + (size_t)f * w * h + x;
+  int d = 255;
+  for (int y = 0; y < h; ++y) {
+    d = min((int)col[(size_t)y * w], min(d + 1, 255));
+    col[(size_t)y * w] = (uint8_t)d;
+  }
+  d = 255;
+  for (int y = h - 1; y >= 0; --y) {
+    d = min((int)col[(size_t)y * w], min(d + 1, 255));
+    col[(size_t)y * w] = (uint8_t)d;
+  }
+}
+
+__device__ __forceinline__ float feather_weight(int d) {
+  // createWeightMap: multiply(dist, 0.02f) then threshold(1, THRESH_TRUNC);
+  // a saturated distance (>= 255) is far beyond the truncation point (50)
+  const float v = (float)d * 0.02f;
+  return v > 1.0f ? 1.0f : v;
+}
+
+// FeatherBlender::feed for the G frames of a batch, ascending
+__global__ void __launch_bounds__(256)
+k_fwd_feed(const uint8_t* __restrict__ warped, const uint8_t* __restrict__ dist, int ch, int G,
+           size_t pixels, int16_t* __restrict__ dst16, float* __restrict__ dst_weight) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= pixels) return;
+  int16_t a0 = dst16[3 * k + 0], a1 = dst16[3 * k + 1], a2 = dst16[3 * k + 2];
+  float ws = dst_weight[k];
+  for (int f = 0; f < G; ++f) {
+    const size_t at = (size_t)f * pixels + k;
+    const float w = feather_weight(dist[at]);
+    const uint8_t* s = warped + at * ch;
+    const int v0 = s[0], v1 = s[ch == 1 ? 0 : 1], v2 = s[ch == 1 ? 0 : 2];
+    a0 = (int16_t)(a0 + (int16_t)(int)((float)v0 * w));
+    a1 = (int16_t)(a1 + (int16_t)(int)((float)v1 * w));
+    a2 = (int16_t)(a2 + (int16_t)(int)((float)v2 * w));
+    ws += w;
+  }
+  dst16[3 * k + 0] = a0;
+  dst16[3 * k + 1] = a1;
+  dst16[3 * k + 2] = a2;
+  dst_weight[k] = ws;
+}
+
+// feed(result_, result_mask_) of updateOrthomosaic (:118): 16-bit source
+__global__ void __launch_bounds__(256)
+k_fwd_feed16(const int16_t* __restrict__ src, const uint8_t* __restrict__ dist, size_t pixels,
+             int16_t* __restrict__ dst16, float* __restrict__ dst_weight) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= pixels) return;
+  const float w = feather_weight(dist[k]);
+  for (int c = 0; c < 3; ++c)
+    dst16[3 * k + c] = (int16_t)(dst16[3 * k + c] + (int16_t)(int)((float)src[3 * k + c] * w));
+  dst_weight[k] += w;
+}
+
+// FeatherBlender::blend (+ the "unobserved pixels" pass of batch(), :178-186)
+__global__ void __launch_bounds__(256)
+k_fwd_blend(int16_t* __restrict__ dst16, const float* __restrict__ dst_weight, size_t pixels,
+            int batch_tail, int16_t* __restrict__ result, uint8_t* __restrict__ result_mask) {
+  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= pixels) return;
+  const float eps = 1e-5f;
+  const float wsum = dst_weight[k];
+  const float den = wsum + eps;
+  int16_t r[3];
+  for (int c = 0; c < 3; ++c) {
+    // float division, correctly rounded (double quotient of two floats rounds
+    // to the same float), then static_cast<short>
+    const float q = (float)((double)(float)dst16[3 * k + c] / (double)den);
+    r[c] = (int16_t)(int)q;
+  }
+  const bool on = wsum > eps;
+  if (!on) r[0] = r[1] = r[2] = 0;
+  for (int c = 0; c < 3; ++c) dst16[3 * k + c] = r[c];  // normalizeUsingWeightMap is in place
+  if (batch_tail && !(r[0] > 0 && r[1] > 0 && r[2] > 0)) r[0] = r[1] = r[2] = 0;
+  for (int c = 0; c < 3; ++c) result[3 * k + c] = r[c];
+  result_mask[k] = on ? 255 : 0;
+}
+
+// ---------------------------------------------------------------------------
+// host driver
+// ---------------------------------------------------------------------------
+static int fwd_use(Mosaic* m) {
+  AMHIP_TRY(hipSetDevice(m->device));
+  return AMHIP_OK;
+}
+
+static int fwd_prepare_blender(Mosaic* m) {  // prepareBlenderForNextImage()
+  AMHIP_TRY(hipMemsetAsync(m->dst16, 0, m->pixels * 3 * sizeof(int16_t), m->stream));
+  AMHIP_TRY(hipMemsetAsync(m->dst_weight, 0, m->pixels * sizeof(float), m->stream));
+  return AMHIP_OK;
+}
+
+static FwdGeom fwd_geom(const Mosaic* m, int ch, size_t frame_stride, size_t row_step) {
+  FwdGeom g;
+  g.mw = m->desc.width_mosaic_pixels;
+  g.mh = m->desc.height_mosaic_pixels;
+  g.iw = m->cam.width;
+  g.ih = m->cam.height;
+  g.ch = ch;
+  const int bh0 = std::min(32 / 2, g.mh);
+  g.bw0 = std::min(32 * 32 / bh0, g.mw);
+  g.frame_stride = frame_stride;
+  g.row_step = row_step;
+  return g;
+}
+
+static int fwd_distance(Mosaic* m, const uint8_t* mask, uint8_t* dist, int G) {
+  const int w = m->desc.width_mosaic_pixels, h = m->desc.height_mosaic_pixels;
+  const size_t nrows = (size_t)h * G;
+  hipLaunchKernelGGL(k_fwd_dt_rows, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, m->stream,
+                     mask, dist, w, nrows);
+  hipLaunchKernelGGL(k_fwd_dt_cols, dim3((unsigned)((w + 255) / 256), (unsigned)G), dim3(256), 0,
+                     m->stream, dist, w, h, G);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+// frames of one batch chunk: device-resident, G of them starting at `frames`
+static int fwd_feed_frames(Mosaic* m, const double* T_G_C, int G, const uint8_t* frames,
+                           size_t frame_stride, size_t row_step, int ch, bool quirk) {
+  std::vector<FwdFrame> host(G);
+  for (int f = 0; f < G; ++f) {
+    double M[9];
+    if (!frame_homography(m->cam, m->desc, T_G_C + 7 * (size_t)f, quirk, M) ||
+        !invert3(M, host[f].m))
+      return fwd_arg_fail("forward homography: degenerate frame (camera parallel to the ground?)");
+  }
+  int rc;
+  if ((rc = ensure_capacity(&m->warped, &m->warped_cap, (size_t)G * m->pixels * ch))) return rc;
+  if ((rc = ensure_capacity(&m->mask, &m->mask_cap, (size_t)G * m->pixels))) return rc;
+  if ((rc = ensure_capacity(&m->dist, &m->dist_cap, (size_t)G * m->pixels))) return rc;
+  {
+    void* p = m->frames;
+    size_t cap = m->frames_cap * sizeof(FwdFrame);
+    if ((rc = ensure_bytes(&p, &cap, (size_t)G * sizeof(FwdFrame)))) return rc;
+    m->frames = static_cast<FwdFrame*>(p);
+    m->frames_cap = cap / sizeof(FwdFrame);
+  }
+  // (pageable source: the copy is complete when the call returns)
+  AMHIP_TRY(hipMemcpyAsync(m->frames, host.data(), (size_t)G * sizeof(FwdFrame),
+                           hipMemcpyHostToDevice, m->stream));
+  AMHIP_TRY(hipStreamSynchronize(m->stream));
+  FwdGeom g = fwd_geom(m, ch, frame_stride, row_step);
+  const uint8_t* src = frames;
+  if (m->cam.distortion != AMHIP_DIST_NONE) {
+    const size_t fbytes = (size_t)g.iw * g.ih * ch;
+    if ((rc = ensure_capacity(&m->undist, &m->undist_cap, (size_t)G * fbytes))) return rc;
+    hipLaunchKernelGGL(k_fwd_undistort, dim3((unsigned)((g.iw + 255) / 256), (unsigned)g.ih,
+                                             (unsigned)G),
+                       dim3(256), 0, m->stream, m->cam, g, frames, G, m->undist);
+    src = m->undist;
+    g.frame_stride = fbytes;
+    g.row_step = (size_t)g.iw * ch;
+  }
+  hipLaunchKernelGGL(k_fwd_warp, dim3((unsigned)((g.mw + 255) / 256), (unsigned)g.mh, (unsigned)G),
+                     dim3(256), 0, m->stream, g, m->frames, src, G, m->warped, m->mask);
+  AMHIP_TRY(hipGetLastError());
+  if ((rc = fwd_distance(m, m->mask, m->dist, G))) return rc;
+  hipLaunchKernelGGL(k_fwd_feed, dim3((unsigned)((m->pixels + 255) / 256)), dim3(256), 0,
+                     m->stream, m->warped, m->dist, ch, G, m->pixels, m->dst16, m->dst_weight);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+static int fwd_blend(Mosaic* m, bool batch_tail) {
+  hipLaunchKernelGGL(k_fwd_blend, dim3((unsigned)((m->pixels + 255) / 256)), dim3(256), 0,
+                     m->stream, m->dst16, m->dst_weight, m->pixels, batch_tail ? 1 : 0,
+                     m->result16, m->result_mask);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+static int fwd_batch_chunk_size(const Mosaic* m, int ch) {
+  const size_t per_frame = m->pixels * (size_t)(ch + 2);
+  size_t g = (size_t(512) << 20) / (per_frame ? per_frame : 1);
+  if (g < 1) g = 1;
+  if (g > 64) g = 64;
+  return (int)g;
+}
+
+static int fwd_batch_dev(Mosaic* m, const double* T_G_C, size_t F, const uint8_t* frames,
+                         size_t frame_stride, size_t row_step, int ch) {
+  const int gmax = fwd_batch_chunk_size(m, ch);
+  for (size_t f0 = 0; f0 < F; f0 += (size_t)gmax) {
+    const int G = (int)std::min<size_t>((size_t)gmax, F - f0);
+    const int rc = fwd_feed_frames(m, T_G_C + 7 * f0, G, frames + f0 * frame_stride, frame_stride,
+                                   row_step, ch, /*quirk=*/true);
+    if (rc) return rc;
+  }
+  int rc = fwd_blend(m, /*batch_tail=*/true);
+  return rc;
+}
+
+static int fwd_update_dev(Mosaic* m, const double* T_G_C7, const uint8_t* frame, size_t row_step,
+                          int ch) {
+  int rc;
+  if ((rc = fwd_feed_frames(m, T_G_C7, 1, frame, 0, row_step, ch, /*quirk=*/false))) return rc;
+  if ((rc = fwd_blend(m, false))) return rc;       // blender_->blend(result_, result_mask_)
+  if ((rc = fwd_prepare_blender(m))) return rc;    // prepareBlenderForNextImage()
+  if ((rc = ensure_capacity(&m->dist, &m->dist_cap, m->pixels))) return rc;
+  if ((rc = fwd_distance(m, m->result_mask, m->dist, 1))) return rc;  // addImage(result_, mask_)
+  hipLaunchKernelGGL(k_fwd_feed16, dim3((unsigned)((m->pixels + 255) / 256)), dim3(256), 0,
+                     m->stream, m->result16, m->dist, m->pixels, m->dst16, m->dst_weight);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+static int fwd_download(Mosaic* m, int16_t* result, uint8_t* mask) {
+  if (result)
+    AMHIP_TRY(hipMemcpyAsync(result, m->result16, m->pixels * 3 * sizeof(int16_t),
+                             hipMemcpyDeviceToHost, m->stream));
+  if (mask)
+    AMHIP_TRY(hipMemcpyAsync(mask, m->result_mask, m->pixels, hipMemcpyDeviceToHost, m->stream));
+  AMHIP_TRY(hipStreamSynchronize(m->stream));
+  return AMHIP_OK;
+}
+
+static int fwd_stage(Mosaic* m, const uint8_t* const* images, const size_t* steps, size_t F,
+                     int ch, size_t* frame_bytes) {
+  const size_t row = (size_t)m->cam.width * ch;
+  const size_t fb = row * (size_t)m->cam.height;
+  int rc;
+  if ((rc = ensure_capacity(&m->stage, &m->stage_cap, F * fb))) return rc;
+  for (size_t f = 0; f < F; ++f) {
+    if (!images[f]) return fwd_arg_fail("null image");
+    if (steps[f] < row) return fwd_arg_fail("image step smaller than a row");
+    AMHIP_TRY(hipMemcpy2DAsync(m->stage + f * fb, row, images[f], steps[f], row,
+                               (size_t)m->cam.height, hipMemcpyHostToDevice, m->stream));
+  }
+  *frame_bytes = fb;
+  return AMHIP_OK;
+}
+
+}  // namespace amhip
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace amhip;
+
+struct amhip_mosaic {
+  Mosaic impl;
+};
+
+extern "C" {
+
+int amhip_mosaic_homography(const amhip_mosaic_desc* desc, const amhip_camera* cam,
+                            const double* T_G_C7, int batch_quirk, double* M9) {
+  if (!desc || !cam || !T_G_C7 || !M9) return fwd_arg_fail("amhip_mosaic_homography: null argument");
+  if (!frame_homography(*cam, *desc, T_G_C7, batch_quirk != 0, M9))
+    return fwd_arg_fail("forward homography: degenerate frame");
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_create(const amhip_mosaic_desc* desc, const amhip_camera* cam, int device,
+                        amhip_mosaic** out) {
+  if (!desc || !cam || !out) return fwd_arg_fail("amhip_mosaic_create: null argument");  // CHECK(ncameras_)
+  if (desc->width_mosaic_pixels <= 0 || desc->height_mosaic_pixels <= 0 || cam->width <= 0 ||
+      cam->height <= 0)
+    return fwd_arg_fail("amhip_mosaic_create: empty mosaic or image");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    set_last_error("no HIP device available (libaerial_mapper_hip has no CPU fallback)");
+    return AMHIP_ERR_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) return fwd_arg_fail("amhip_mosaic_create: bad device index");
+  amhip_mosaic* h = new amhip_mosaic();
+  Mosaic* m = &h->impl;
+  m->desc = *desc;
+  m->cam = *cam;
+  m->device = device;
+  m->pixels = (size_t)desc->width_mosaic_pixels * (size_t)desc->height_mosaic_pixels;
+  int rc = AMHIP_OK;
+  do {
+    if ((rc = fwd_use(m))) break;
+    hipError_t e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "hipStreamCreate", __FILE__, __LINE__);
+      break;
+    }
+    m->stream = m->own_stream;
+    void* p = nullptr;
+    size_t cap = 0;
+    if ((rc = ensure_bytes(&p, &cap, m->pixels * 3 * sizeof(int16_t)))) break;
+    m->dst16 = static_cast<int16_t*>(p);
+    p = nullptr; cap = 0;
+    if ((rc = ensure_bytes(&p, &cap, m->pixels * sizeof(float)))) break;
+    m->dst_weight = static_cast<float*>(p);
+    p = nullptr; cap = 0;
+    if ((rc = ensure_bytes(&p, &cap, m->pixels * 3 * sizeof(int16_t)))) break;
+    m->result16 = static_cast<int16_t*>(p);
+    p = nullptr; cap = 0;
+    if ((rc = ensure_bytes(&p, &cap, m->pixels))) break;
+    m->result_mask = static_cast<uint8_t*>(p);
+    if ((rc = fwd_prepare_blender(m))) break;  // constructor (:27)
+    hipError_t e2 = hipMemsetAsync(m->result16, 0, m->pixels * 3 * sizeof(int16_t), m->stream);
+    if (e2 == hipSuccess) e2 = hipMemsetAsync(m->result_mask, 0, m->pixels, m->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(m->stream);
+    if (e2 != hipSuccess) rc = hip_fail(e2, "mosaic init", __FILE__, __LINE__);
+  } while (0);
+  if (rc) {
+    amhip_mosaic_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_destroy(amhip_mosaic* h) {
+  if (!h) return AMHIP_OK;
+  Mosaic* m = &h->impl;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  void* bufs[] = {m->dst16, m->dst_weight, m->result16, m->result_mask, m->warped, m->mask,
+                  m->dist,  m->undist,     m->stage,    m->frames};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
+  delete h;
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_set_stream(amhip_mosaic* h, void* hip_stream) {
+  if (!h) return fwd_arg_fail("null mosaic");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  AMHIP_TRY(hipStreamSynchronize(m->stream));
+  m->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : m->own_stream;
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_synchronize(amhip_mosaic* h) {
+  if (!h) return fwd_arg_fail("null mosaic");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  AMHIP_TRY(hipStreamSynchronize(m->stream));
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_reset(amhip_mosaic* h) {
+  if (!h) return fwd_arg_fail("null mosaic");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  if ((rc = fwd_prepare_blender(m))) return rc;
+  AMHIP_TRY(hipMemsetAsync(m->result16, 0, m->pixels * 3 * sizeof(int16_t), m->stream));
+  AMHIP_TRY(hipMemsetAsync(m->result_mask, 0, m->pixels, m->stream));
+  return AMHIP_OK;
+}
+
+int amhip_mosaic_batch_dev(amhip_mosaic* h, const double* T_G_C, size_t num_frames,
+                           const void* dev_frames, size_t frame_stride, size_t row_step,
+                           int channels) {
+  if (!h || !T_G_C || !dev_frames) return fwd_arg_fail("amhip_mosaic_batch_dev: null argument");
+  if (channels != 1 && channels != 3) return fwd_arg_fail("channels must be 1 (8UC1) or 3 (8UC3)");
+  Mosaic* m = &h->impl;
+  if (row_step < (size_t)m->cam.width * channels) return fwd_arg_fail("row_step smaller than a row");
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  return fwd_batch_dev(m, T_G_C, num_frames, static_cast<const uint8_t*>(dev_frames), frame_stride,
+                       row_step, channels);
+}
+
+int amhip_mosaic_batch(amhip_mosaic* h, const double* T_G_C, size_t num_frames,
+                       const void* const* images, const size_t* steps, int channels,
+                       int16_t* result, uint8_t* result_mask) {
+  if (!h || !T_G_C || !images || !steps) return fwd_arg_fail("amhip_mosaic_batch: null argument");
+  if (channels != 1 && channels != 3) return fwd_arg_fail("channels must be 1 (8UC1) or 3 (8UC3)");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  // frames are staged in chunks so that host-side memory use stays bounded
+  const int gmax = fwd_batch_chunk_size(m, channels);
+  for (size_t f0 = 0; f0 < num_frames; f0 += (size_t)gmax) {
+    const size_t G = std::min<size_t>((size_t)gmax, num_frames - f0);
+    size_t fb = 0;
+    if ((rc = fwd_stage(m, reinterpret_cast<const uint8_t* const*>(images) + f0, steps + f0, G,
+                        channels, &fb)))
+      return rc;
+    if ((rc = fwd_feed_frames(m, T_G_C + 7 * f0, (int)G, m->stage, fb,
+                              (size_t)m->cam.width * channels, channels, /*quirk=*/true)))
+      return rc;
+  }
+  if ((rc = fwd_blend(m, /*batch_tail=*/true))) return rc;
+  return fwd_download(m, result, result_mask);
+}
+
+int amhip_mosaic_update_dev(amhip_mosaic* h, const double* T_G_C7, const void* dev_frame,
+                            size_t row_step, int channels) {
+  if (!h || !T_G_C7 || !dev_frame) return fwd_arg_fail("amhip_mosaic_update_dev: null argument");
+  if (channels != 1 && channels != 3) return fwd_arg_fail("channels must be 1 (8UC1) or 3 (8UC3)");
+  Mosaic* m = &h->impl;
+  if (row_step < (size_t)m->cam.width * channels) return fwd_arg_fail("row_step smaller than a row");
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  return fwd_update_dev(m, T_G_C7, static_cast<const uint8_t*>(dev_frame), row_step, channels);
+}
+
+int amhip_mosaic_update(amhip_mosaic* h, const double* T_G_C7, const void* image, size_t step,
+                        int channels, int16_t* result, uint8_t* result_mask) {
+  if (!h || !T_G_C7 || !image) return fwd_arg_fail("amhip_mosaic_update: null argument");
+  if (channels != 1 && channels != 3) return fwd_arg_fail("channels must be 1 (8UC1) or 3 (8UC3)");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  size_t fb = 0;
+  const uint8_t* img = static_cast<const uint8_t*>(image);
+  if ((rc = fwd_stage(m, &img, &step, 1, channels, &fb))) return rc;
+  if ((rc = fwd_update_dev(m, T_G_C7, m->stage, (size_t)m->cam.width * channels, channels)))
+    return rc;
+  return fwd_download(m, result, result_mask);
+}
+
+int amhip_mosaic_download(amhip_mosaic* h, int16_t* result, uint8_t* result_mask) {
+  if (!h) return fwd_arg_fail("null mosaic");
+  Mosaic* m = &h->impl;
+  int rc = fwd_use(m);
+  if (rc) return rc;
+  return fwd_download(m, result, result_mask);
+}
+
+int amhip_mosaic_device_ptr(amhip_mosaic* h, void** result_16sc3, void** result_mask) {
+  if (!h) return fwd_arg_fail("null mosaic");
+  if (result_16sc3) *result_16sc3 = h->impl.result16;
+  if (result_mask) *result_mask = h->impl.result_mask;
+  return AMHIP_OK;
+}
+
+}  // extern "C"

@@ -42,6 +42,10 @@ EXPORTS = [
     "amhip_densify_dev", "amhip_halo_select_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
     "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
+    "amhip_mosaic_create", "amhip_mosaic_destroy", "amhip_mosaic_set_stream",
+    "amhip_mosaic_synchronize", "amhip_mosaic_reset", "amhip_mosaic_batch",
+    "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
+    "amhip_mosaic_download", "amhip_mosaic_device_ptr", "amhip_mosaic_homography",
 ]
 
 
@@ -60,6 +64,12 @@ class Camera(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32),
                 ("distortion", C.c_int32), ("_pad", C.c_int32),
                 ("dist", C.c_double * 4)]
+
+
+class MosaicDesc(C.Structure):
+    """amhip_mosaic_desc"""
+    _fields_ = [("width_mosaic_pixels", C.c_int32), ("height_mosaic_pixels", C.c_int32),
+                ("ground_plane_elevation_m", C.c_double), ("origin", C.c_double * 3)]
 
 
 class AmhipError(RuntimeError):
@@ -133,6 +143,21 @@ def load():
     lib.amhip_kernel_name.argtypes = [C.c_int]
     lib.amhip_ctx_dsm_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int32)]
+    mp = C.POINTER(MosaicDesc)
+    lib.amhip_mosaic_create.argtypes = [mp, cp, C.c_int, C.POINTER(vp)]
+    lib.amhip_mosaic_destroy.argtypes = [vp]
+    lib.amhip_mosaic_set_stream.argtypes = [vp, vp]
+    lib.amhip_mosaic_synchronize.argtypes = [vp]
+    lib.amhip_mosaic_reset.argtypes = [vp]
+    lib.amhip_mosaic_batch.argtypes = [vp, f64p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t),
+                                       C.c_int, vp, vp]
+    lib.amhip_mosaic_batch_dev.argtypes = [vp, f64p, C.c_size_t, vp, C.c_size_t, C.c_size_t,
+                                           C.c_int]
+    lib.amhip_mosaic_update.argtypes = [vp, f64p, vp, C.c_size_t, C.c_int, vp, vp]
+    lib.amhip_mosaic_update_dev.argtypes = [vp, f64p, vp, C.c_size_t, C.c_int]
+    lib.amhip_mosaic_download.argtypes = [vp, vp, vp]
+    lib.amhip_mosaic_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.amhip_mosaic_homography.argtypes = [mp, cp, f64p, C.c_int, f64p]
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:
         raise ImportError("libaerial_mapper_hip.so lacks %s (stale build?)" % missing)

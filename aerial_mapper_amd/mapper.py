@@ -412,3 +412,153 @@ def densify(map, disparity, image_left, K, baseline, R_G_C, t_G_C1):
     map.synchronize()
     n = int(count.item())
     return xyz[:n], inten[:n]
+
+
+# ---------------------------------------------------------------------------
+# ortho::OrthoForwardHomography
+# ---------------------------------------------------------------------------
+class OrthoForwardHomographySettings(object):
+    """ortho::Settings of ortho-forward-homography.h:33-42."""
+
+    def __init__(self, batch=True, ground_plane_elevation_m=414.0, width_mosaic_pixels=1000,
+                 height_mosaic_pixels=1000, origin=(0.0, 0.0, 0.0), nframe_id="map",
+                 filename_mosaic_output="/tmp/result.jpg"):
+        self.batch = batch
+        self.ground_plane_elevation_m = float(ground_plane_elevation_m)
+        self.width_mosaic_pixels = int(width_mosaic_pixels)
+        self.height_mosaic_pixels = int(height_mosaic_pixels)
+        self.origin = tuple(float(v) for v in origin)
+        self.nframe_id = nframe_id
+        self.filename_mosaic_output = filename_mosaic_output
+
+
+class OrthoForwardHomography(object):
+    """ortho::OrthoForwardHomography (ortho-forward-homography.h:44-52): the
+    mosaic (result_, CV_16SC3) and its mask live on the device; `result()`
+    downloads them.  imshow / imwrite / ROS publishing are the caller's."""
+
+    def __init__(self, ncameras, settings, device=0):
+        if ncameras is None:
+            raise L.AmhipError(L.ERR_ARG, "CHECK(ncameras_) (ortho-forward-homography.cc:26)")
+        lib = L.load()
+        self.ncameras = ncameras
+        self.settings = settings
+        self.desc = L.MosaicDesc()
+        self.desc.width_mosaic_pixels = settings.width_mosaic_pixels
+        self.desc.height_mosaic_pixels = settings.height_mosaic_pixels
+        self.desc.ground_plane_elevation_m = settings.ground_plane_elevation_m
+        for k in range(3):
+            self.desc.origin[k] = settings.origin[k]
+        self.handle = C.c_void_p()
+        L.check(lib.amhip_mosaic_create(C.byref(self.desc), C.byref(ncameras.camera), int(device),
+                                        C.byref(self.handle)))
+        self._torch_stream = None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            L.load().amhip_mosaic_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_stream(self, hip_stream):
+        L.check(L.load().amhip_mosaic_set_stream(self.handle, C.c_void_p(hip_stream or 0)))
+        self._torch_stream = hip_stream
+
+    def synchronize(self):
+        L.check(L.load().amhip_mosaic_synchronize(self.handle))
+
+    def reset(self):
+        L.check(L.load().amhip_mosaic_reset(self.handle))
+
+    def _wait_for_torch(self, tensor):
+        import torch
+        cur = torch.cuda.current_stream(tensor.device).cuda_stream
+        if self._torch_stream != cur:
+            torch.cuda.current_stream(tensor.device).synchronize()
+
+    def homography(self, T_G_B, batch=True):
+        """The image -> mosaic homography of one frame (3x3, float64)."""
+        T_G_C = compose_T_G_C(np.asarray(T_G_B, np.float64).reshape(1, 7), self.ncameras.T_C_B)
+        M = np.zeros(9)
+        f64p = C.POINTER(C.c_double)
+        L.check(L.load().amhip_mosaic_homography(C.byref(self.desc), C.byref(self.ncameras.camera),
+                                                 T_G_C.ctypes.data_as(f64p), int(bool(batch)),
+                                                 M.ctypes.data_as(f64p)))
+        return M.reshape(3, 3)
+
+    @staticmethod
+    def _host_image(im):
+        im = np.asarray(im)
+        if im.dtype != np.uint8 or im.strides[-1] != 1 or \
+                (im.ndim == 3 and (im.shape[2] != 3 or im.strides[1] != 3)):
+            im = np.ascontiguousarray(im, np.uint8)
+        return im
+
+    def batch(self, T_G_Bs, images, sync=True):
+        """OrthoForwardHomography::batch.  images: list of numpy uint8 rasters
+        ((H,W) or (H,W,3)) or one CUDA torch uint8 tensor (F,H,W[,3])."""
+        T_G_C = compose_T_G_C(T_G_Bs, self.ncameras.T_C_B)
+        F = T_G_C.shape[0]
+        lib = L.load()
+        cam = self.ncameras.camera
+        f64p = C.POINTER(C.c_double)
+        if _is_torch(images):
+            assert images.is_cuda and images.is_contiguous() and images.element_size() == 1
+            ch = 3 if images.dim() == 4 else 1
+            assert images.shape[0] >= F and images.shape[1] == cam.height and images.shape[2] == cam.width
+            row = cam.width * ch
+            self._wait_for_torch(images)
+            L.check(lib.amhip_mosaic_batch_dev(self.handle, T_G_C.ctypes.data_as(f64p), F,
+                                               C.c_void_p(images.data_ptr()), row * cam.height, row, ch))
+            if sync:
+                self.synchronize()
+            return
+        if len(images) != F:
+            raise L.AmhipError(L.ERR_ARG, "poses and images differ in number")
+        ims = [self._host_image(im) for im in images]
+        ch = 3 if (F and ims[0].ndim == 3) else 1
+        ptrs = (C.c_void_p * max(F, 1))()
+        steps = (C.c_size_t * max(F, 1))()
+        for k, im in enumerate(ims):
+            if (3 if im.ndim == 3 else 1) != ch:
+                raise L.AmhipError(L.ERR_ARG, "mixed gray / colour frames")
+            ptrs[k] = im.ctypes.data
+            steps[k] = im.strides[0]
+        L.check(lib.amhip_mosaic_batch(self.handle, T_G_C.ctypes.data_as(f64p), F, ptrs, steps, ch,
+                                       None, None))
+
+    def updateOrthomosaic(self, T_G_B, image, sync=True):
+        """OrthoForwardHomography::updateOrthomosaic (one frame, incremental)."""
+        T_G_C = compose_T_G_C(np.asarray(T_G_B, np.float64).reshape(1, 7), self.ncameras.T_C_B)
+        lib = L.load()
+        cam = self.ncameras.camera
+        f64p = C.POINTER(C.c_double)
+        if _is_torch(image):
+            assert image.is_cuda and image.is_contiguous() and image.element_size() == 1
+            ch = 3 if image.dim() == 3 else 1
+            self._wait_for_torch(image)
+            L.check(lib.amhip_mosaic_update_dev(self.handle, T_G_C.ctypes.data_as(f64p),
+                                                C.c_void_p(image.data_ptr()), cam.width * ch, ch))
+            if sync:
+                self.synchronize()
+            return
+        im = self._host_image(image)
+        ch = 3 if im.ndim == 3 else 1
+        L.check(lib.amhip_mosaic_update(self.handle, T_G_C.ctypes.data_as(f64p),
+                                        C.c_void_p(im.ctypes.data), im.strides[0], ch, None, None))
+
+    def result(self):
+        """(result_ as (H,W,3) int16, result_mask_ as (H,W) uint8)."""
+        h, w = self.desc.height_mosaic_pixels, self.desc.width_mosaic_pixels
+        res = np.empty((h, w, 3), np.int16)
+        mask = np.empty((h, w), np.uint8)
+        L.check(L.load().amhip_mosaic_download(self.handle, C.c_void_p(res.ctypes.data),
+                                               C.c_void_p(mask.ctypes.data)))
+        return res, mask

@@ -266,6 +266,62 @@ int amhip_ortho_backward_process(
     float* observation_index, float* num_observations, float* ortho,
     float* colored_ortho);
 
+/* ---- ortho::OrthoForwardHomography
+ *      (aerial_mapper_ortho/src/ortho-forward-homography.cc; SURVEY section 8b/8f,
+ *      named in the API surface to keep) --
+ * A mosaic is the object's state: Settings::{width,height}_mosaic_pixels,
+ * ground_plane_elevation_m, origin (ortho-forward-homography.h:33-42), the
+ * camera, the FeatherBlender accumulators and result_ / result_mask_.
+ * result_ is CV_16SC3 (height x width x 3 int16, row-major; a gray frame is
+ * replicated into the three channels, :45-47), result_mask_ CV_8U (255 where
+ * the summed feather weight exceeds 1e-5).  Poses are T_G_C (amhip_compose_T_G_C).
+ *   amhip_mosaic_batch    = OrthoForwardHomography::batch (:137-189): every
+ *       frame is warped (4 corner rays on the ground plane -> homography ->
+ *       nearest-neighbour warp) and fed to the blender, then blended and the
+ *       "unobserved pixels" set to 0.  batch() offsets both ground axes by
+ *       width/2 (:155-158) -- reproduced.
+ *   amhip_mosaic_update   = ::updateOrthomosaic (:74-135): feed the frame, blend,
+ *       start a new blender holding the previous result.
+ * The _dev forms take device-resident frames (frame f at dev_frames + f *
+ * frame_stride, rows row_step bytes apart), run asynchronously on the mosaic's
+ * stream and leave the result on the device (amhip_mosaic_device_ptr /
+ * amhip_mosaic_download).  imshow / imwrite / ROS publishing stay with the
+ * caller.  OpenCV / aslam semantics are restated, see oracle/amo_forward.cc
+ * for the list ("parity unpinned": the reference has no tests for this path). */
+typedef struct amhip_mosaic amhip_mosaic;
+
+typedef struct amhip_mosaic_desc {
+  int32_t width_mosaic_pixels;
+  int32_t height_mosaic_pixels;
+  double ground_plane_elevation_m;
+  double origin[3];
+} amhip_mosaic_desc;
+
+int amhip_mosaic_create(const amhip_mosaic_desc* desc, const amhip_camera* cam, int device,
+                        amhip_mosaic** out);
+int amhip_mosaic_destroy(amhip_mosaic* mosaic);
+int amhip_mosaic_set_stream(amhip_mosaic* mosaic, void* hip_stream);
+int amhip_mosaic_synchronize(amhip_mosaic* mosaic);
+/* fresh blender + zero result (a newly constructed object) */
+int amhip_mosaic_reset(amhip_mosaic* mosaic);
+int amhip_mosaic_batch(amhip_mosaic* mosaic, const double* T_G_C, size_t num_frames,
+                       const void* const* images, const size_t* steps, int channels,
+                       int16_t* result_16sc3, uint8_t* result_mask);
+int amhip_mosaic_batch_dev(amhip_mosaic* mosaic, const double* T_G_C, size_t num_frames,
+                           const void* dev_frames, size_t frame_stride, size_t row_step,
+                           int channels);
+int amhip_mosaic_update(amhip_mosaic* mosaic, const double* T_G_C7, const void* image,
+                        size_t step, int channels, int16_t* result_16sc3,
+                        uint8_t* result_mask);
+int amhip_mosaic_update_dev(amhip_mosaic* mosaic, const double* T_G_C7, const void* dev_frame,
+                            size_t row_step, int channels);
+int amhip_mosaic_download(amhip_mosaic* mosaic, int16_t* result_16sc3, uint8_t* result_mask);
+int amhip_mosaic_device_ptr(amhip_mosaic* mosaic, void** result_16sc3, void** result_mask);
+/* The image -> mosaic homography of one frame (row-major 3x3, M[8] = 1); host
+ * arithmetic only.  batch_quirk != 0: batch()'s offsets. */
+int amhip_mosaic_homography(const amhip_mosaic_desc* desc, const amhip_camera* cam,
+                            const double* T_G_C7, int batch_quirk, double* M9);
+
 /* ---- measurement ----------------------------------------------------------*/
 
 /* Kernel slots for amhip_ctx_kernel_time(). */

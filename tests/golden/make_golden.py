@@ -107,7 +107,40 @@ def pcl_case(name, length_x, length_y, res, n, seed, radius, adaptive, extent=No
                                                  int((ortho == 255.0).sum())))
 
 
+def fwd_case(name, cam, mosaic_wh, ground, origin, num_frames, half_extent, altitude, seed,
+             colored=False, incremental=False, tilt=4.0):
+    """ortho::OrthoForwardHomography (oracle/amo_forward.cc; OpenCV/aslam
+    semantics restated -- parity unpinned): batch() or a sequence of
+    updateOrthomosaic() calls."""
+    desc = O.mosaic_desc(mosaic_wh[0], mosaic_wh[1], ground, origin)
+    poses = synth.make_lawnmower_poses(num_frames, half_extent, altitude, seed, tilt_deg=tilt,
+                                       center=(origin[0], origin[1]))
+    frames = synth.make_frames(num_frames, cam.height, cam.width, 3 if colored else 1, salt=seed)
+    # smooth the hash frames a little so that zero pixels (mask holes) exist but are rare
+    frames = np.ascontiguousarray(np.where(frames < 6, 0, frames).astype(np.uint8))
+    T_C_B = np.array([0.02, -0.01, 0.03, 1.0, 0.0, 0.0, 0.0])
+    fm = O.ForwardMosaic(cam, desc, T_C_B, which=WHICH)
+    steps = []
+    if incremental:
+        for k in range(num_frames):
+            assert fm.update(poses[k], frames[k]) == O.OK
+            steps.append(fm.result.copy())
+    else:
+        assert fm.batch(poses, [f for f in frames]) == O.OK
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"), kind="fwd", camera=cam_tuple(cam),
+        mosaic=np.array([mosaic_wh[0], mosaic_wh[1], ground] + list(origin), np.float64),
+        T_G_B=poses, T_C_B=T_C_B, frames=frames, colored=colored, incremental=incremental,
+        result=fm.result, mask=fm.mask,
+        step_checksums=np.array([int(s.astype(np.int64).sum()) for s in steps], np.int64))
+    print("%-28s %4dx%-4d F=%d covered=%.3f" % (name, mosaic_wh[0], mosaic_wh[1], num_frames,
+                                                float((fm.mask > 0).mean())))
+
+
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    if only == "fwd":
+        return main_fwd()
     if not O.have_ref():
         raise SystemExit("oracle/_ref/liboracle_ref.so missing: run `make -C oracle` where "
                          "/root/reference exists")
@@ -135,6 +168,18 @@ def main():
     pcl_case("pcl_dense_half_metre", 30.0, 22.0, 0.5, 5000, 302, 1, False, center=(2.0, 1.0))
     pcl_case("pcl_adaptive_corner", 40.0, 30.0, 1.0, 250, 303, 2, True, extent=8.0,
              center=(-10.0, -6.0))
+    main_fwd()
+
+
+def main_fwd():
+    fwd_case("fwd_batch_gray", S.camera(96, 54, 70.0), (160, 120), 400.0, (0.0, 0.0, 0.0), 8,
+             40.0, 470.0, 401)
+    fwd_case("fwd_batch_colored", S.camera(80, 60, 64.0), (128, 144), 400.0, (3.0, -2.0, 0.0), 6,
+             36.0, 465.0, 402, colored=True)
+    fwd_case("fwd_incremental_gray", S.camera(96, 54, 70.0), (150, 110), 400.0, (0.0, 0.0, 0.0),
+             5, 30.0, 470.0, 403, incremental=True)
+    fwd_case("fwd_batch_radtan", S.camera(96, 54, 70.0, O.DIST_RADTAN, (-0.28, 0.07, 2e-4, -1e-4)),
+             (160, 120), 400.0, (0.0, 0.0, 0.0), 6, 36.0, 470.0, 404)
 
 
 if __name__ == "__main__":

@@ -32,6 +32,12 @@ class Camera(C.Structure):
                 ("dist", C.c_double * 4)]
 
 
+class MosaicDesc(C.Structure):
+    """amo_mosaic_desc / amhip_mosaic_desc (identical layout)."""
+    _fields_ = [("width_mosaic_pixels", C.c_int32), ("height_mosaic_pixels", C.c_int32),
+                ("ground_plane_elevation_m", C.c_double), ("origin", C.c_double * 3)]
+
+
 DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = 0, 1, 2
 OK, ERR_ARG, ERR_EXACT_HIT, ERR_ALPHA_NONPOS = 0, 1, 2, 3
 
@@ -70,6 +76,20 @@ def _bind(lib):
     lib.amo_densify.restype = C.c_long
     lib.amo_densify.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_int,
                                 f64p, C.c_double, f64p, f64p, f64p, C.POINTER(C.c_int32)]
+    lib.amo_fwd_homography.restype = C.c_int
+    lib.amo_fwd_homography.argtypes = [C.POINTER(Camera), C.POINTER(MosaicDesc), f64p, C.c_int, f64p]
+    lib.amo_fwd_distance_l1.restype = None
+    lib.amo_fwd_distance_l1.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.amo_fwd_create.restype = C.c_void_p
+    lib.amo_fwd_create.argtypes = [C.POINTER(Camera), C.POINTER(MosaicDesc)]
+    lib.amo_fwd_destroy.restype = None
+    lib.amo_fwd_destroy.argtypes = [C.c_void_p]
+    lib.amo_fwd_batch.restype = C.c_int
+    lib.amo_fwd_batch.argtypes = [C.c_void_p, f64p, f64p, C.POINTER(C.c_void_p),
+                                  C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.amo_fwd_update.restype = C.c_int
+    lib.amo_fwd_update.argtypes = [C.c_void_p, f64p, f64p, C.c_void_p, C.c_size_t, C.c_int,
+                                   C.c_void_p, C.c_void_p]
     lib.amo_compose_T_G_C.restype = None
     lib.amo_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amo_project_probe.restype = None
@@ -233,3 +253,72 @@ def project_probe(cam, T_G_C7, landmark, which="port"):
 
 def color_value_bgr(b, g, r, which="port"):
     return np.float32(lib(which).amo_color_value_bgr(b, g, r))
+
+
+def mosaic_desc(width, height, ground, origin=(0.0, 0.0, 0.0)):
+    d = MosaicDesc()
+    d.width_mosaic_pixels, d.height_mosaic_pixels = int(width), int(height)
+    d.ground_plane_elevation_m = float(ground)
+    for k in range(3):
+        d.origin[k] = float(origin[k])
+    return d
+
+
+def fwd_homography(cam, desc, T_G_C7, batch_quirk=True, which="port"):
+    T = np.ascontiguousarray(T_G_C7, np.float64).reshape(7)
+    M = np.zeros(9)
+    rc = lib(which).amo_fwd_homography(C.byref(cam), C.byref(desc), _f64(T), int(bool(batch_quirk)),
+                                       _f64(M))
+    return rc, M.reshape(3, 3)
+
+
+def fwd_distance_l1(mask, which="port"):
+    mask = np.ascontiguousarray(mask, np.uint8)
+    out = np.empty(mask.shape, np.float32)
+    lib(which).amo_fwd_distance_l1(C.c_void_p(mask.ctypes.data), mask.shape[1], mask.shape[0],
+                                   C.c_void_p(out.ctypes.data))
+    return out
+
+
+class ForwardMosaic(object):
+    """ortho::OrthoForwardHomography on the CPU oracle (stateful, like the class)."""
+
+    def __init__(self, cam, desc, T_C_B=(0, 0, 0, 1, 0, 0, 0), which="port"):
+        self.lib = lib(which)
+        self.cam, self.desc = cam, desc
+        self.T_C_B = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
+        self.h = self.lib.amo_fwd_create(C.byref(cam), C.byref(desc))
+        assert self.h
+        hh, ww = desc.height_mosaic_pixels, desc.width_mosaic_pixels
+        self.result = np.zeros((hh, ww, 3), np.int16)
+        self.mask = np.zeros((hh, ww), np.uint8)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.amo_fwd_destroy(self.h)
+            self.h = None
+
+    def batch(self, T_G_B, images):
+        T_G_B = np.ascontiguousarray(T_G_B, np.float64).reshape(-1, 7)
+        F = T_G_B.shape[0]
+        assert len(images) == F
+        ch = 3 if (F and images[0].ndim == 3) else 1
+        ptrs = (C.c_void_p * max(F, 1))()
+        steps = (C.c_size_t * max(F, 1))()
+        for k, im in enumerate(images):
+            assert im.dtype == np.uint8 and im.strides[-1] == 1
+            ptrs[k] = im.ctypes.data
+            steps[k] = im.strides[0]
+        rc = self.lib.amo_fwd_batch(self.h, _f64(T_G_B), _f64(self.T_C_B), ptrs, steps, ch, F,
+                                    C.c_void_p(self.result.ctypes.data),
+                                    C.c_void_p(self.mask.ctypes.data))
+        return rc
+
+    def update(self, T_G_B7, image):
+        T = np.ascontiguousarray(T_G_B7, np.float64).reshape(7)
+        ch = 3 if image.ndim == 3 else 1
+        assert image.dtype == np.uint8 and image.strides[-1] == 1
+        return self.lib.amo_fwd_update(self.h, _f64(T), _f64(self.T_C_B),
+                                       C.c_void_p(image.ctypes.data), image.strides[0], ch,
+                                       C.c_void_p(self.result.ctypes.data),
+                                       C.c_void_p(self.mask.ctypes.data))

@@ -1,0 +1,130 @@
+"""CPU tests of the forward-homography oracle (oracle/amo_forward.cc): the
+committed golden fixtures and known-answer cases derived from
+ortho-forward-homography.cc and the OpenCV pieces it calls (restated; the
+reference has no tests for this path -> parity unpinned)."""
+import numpy as np
+import pytest
+
+import golden_io as G
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+
+def _mosaic_of(d):
+    m = d["mosaic"]
+    return O.mosaic_desc(int(m[0]), int(m[1]), float(m[2]), [float(v) for v in m[3:6]])
+
+
+@pytest.mark.parametrize("name", G.names("fwd"))
+def test_oracle_reproduces_forward_golden(name):
+    d = G.load(name)
+    fm = O.ForwardMosaic(G.camera_of(d), _mosaic_of(d), d["T_C_B"])
+    frames = d["frames"]
+    if bool(d["incremental"]):
+        sums = []
+        for k in range(frames.shape[0]):
+            assert fm.update(d["T_G_B"][k], frames[k]) == O.OK
+            sums.append(int(fm.result.astype(np.int64).sum()))
+        assert sums == [int(v) for v in d["step_checksums"]]
+    else:
+        assert fm.batch(d["T_G_B"], [f for f in frames]) == O.OK
+    assert np.array_equal(fm.result, d["result"])
+    assert np.array_equal(fm.mask, d["mask"])
+
+
+def _nadir_pose(px, py, h):
+    # R_G_C = Rx(pi): camera x -> +x, y -> -y, optical axis -> -z
+    return np.array([px, py, h, 0.0, 1.0, 0.0, 0.0])
+
+
+def test_nadir_homography_known_answer():
+    # ray of pixel (u, v) = ((u-cu)/f, (v-cv)/f, 1) -> ground point
+    # (px + s rx, py - s ry) with s = h - ground; mosaic (x, y) = (G_y + W/2, G_x + H/2)
+    cam = S.camera(96, 54, 70.0)
+    desc = O.mosaic_desc(200, 120, 400.0, (1.0, -2.0, 0.0))
+    T = _nadir_pose(11.0, 7.0, 470.0)
+    rc, M = O.fwd_homography(cam, desc, T, batch_quirk=False)
+    assert rc == O.OK
+    s = 470.0 - 400.0
+    for (u, v) in [(0.0, 0.0), (95.0, 53.0), (47.5, 26.5), (10.0, 40.0)]:
+        p = M @ np.array([u, v, 1.0])
+        x, y = p[0] / p[2], p[1] / p[2]
+        gx = 11.0 + s * (u - cam.cu) / cam.fu - 1.0
+        gy = 7.0 - s * (v - cam.cv) / cam.fv + 2.0
+        assert abs(x - (gy + 100.0)) < 2e-4 and abs(y - (gx + 60.0)) < 2e-4
+    # batch() offsets BOTH axes by width/2 (ortho-forward-homography.cc:155-158)
+    rc, Mb = O.fwd_homography(cam, desc, T, batch_quirk=True)
+    pb = Mb @ np.array([47.5, 26.5, 1.0])
+    p = M @ np.array([47.5, 26.5, 1.0])
+    assert abs((pb[1] / pb[2] - p[1] / p[2]) - (100.0 - 60.0)) < 2e-4
+    assert abs(pb[0] / pb[2] - p[0] / p[2]) < 2e-4
+
+
+def test_distance_transform_is_exact_l1():
+    rng = np.random.default_rng(3)
+    for shape, density in [((23, 31), 0.9), ((40, 17), 0.98), ((12, 12), 0.5)]:
+        mask = (rng.uniform(size=shape) < density).astype(np.uint8) * 255
+        mask[rng.integers(shape[0]), rng.integers(shape[1])] = 0
+        got = O.fwd_distance_l1(mask)
+        zy, zx = np.nonzero(mask == 0)
+        yy, xx = np.mgrid[0:shape[0], 0:shape[1]]
+        want = np.min(np.abs(yy[..., None] - zy) + np.abs(xx[..., None] - zx), axis=-1)
+        assert np.array_equal(got, want.astype(np.float32))
+    # no zero pixel at all: "infinite" everywhere (weight saturates at 1)
+    assert O.fwd_distance_l1(np.full((5, 7), 255, np.uint8)).min() > 1e6
+
+
+def test_single_frame_feather_weights_and_normalisation():
+    # one constant frame seen from a level camera: inside the footprint the
+    # weight is min(0.02 * L1 distance to the footprint's outside, 1) and
+    # result = (short)((short)(v * w) / (w + 1e-5))
+    cam = S.camera(64, 48, 50.0)
+    desc = O.mosaic_desc(140, 120, 400.0)
+    frame = np.full((48, 64), 200, np.uint8)
+    fm = O.ForwardMosaic(cam, desc)
+    assert fm.batch(_nadir_pose(0.0, 0.0, 460.0)[None], [frame]) == O.OK
+    on = fm.mask > 0
+    assert 0.2 < on.mean() < 0.6
+    dist = O.fwd_distance_l1((on * 255).astype(np.uint8))
+    # the mask of the fed image is exactly where the result is covered
+    w = np.minimum(dist * np.float32(0.02), np.float32(1.0)).astype(np.float32)
+    fed = (np.float32(200.0) * w).astype(np.int16)
+    want = (fed.astype(np.float32) / (w + np.float32(1e-5))).astype(np.int16)
+    want[~on] = 0
+    want[want <= 0] = 0
+    assert np.array_equal(fm.result[..., 0], want)
+    assert np.array_equal(fm.result[..., 0], fm.result[..., 1])
+    assert np.array_equal(fm.result[..., 0], fm.result[..., 2])
+
+
+def test_incremental_keeps_previous_result_where_new_frame_is_absent():
+    cam = S.camera(64, 48, 50.0)
+    desc = O.mosaic_desc(160, 120, 400.0)
+    a = np.full((48, 64), 180, np.uint8)
+    b = np.full((48, 64), 90, np.uint8)
+    fm = O.ForwardMosaic(cam, desc)
+    assert fm.update(_nadir_pose(-20.0, 0.0, 460.0), a) == O.OK
+    first = fm.result.copy()
+    first_mask = fm.mask.copy()
+    assert fm.update(_nadir_pose(25.0, 0.0, 460.0), b) == O.OK
+    only_first = (first_mask > 0) & (fm.result[..., 0] > 100)
+    assert only_first.any()
+    # union of both footprints is covered
+    assert (fm.mask > 0).sum() > (first_mask > 0).sum()
+    # far from the second footprint the first result survives up to the
+    # re-normalisation (short)((short)(r * w) / (w + eps)) <= r
+    assert (fm.result[..., 0][only_first] <= first[..., 0][only_first]).all()
+
+
+def test_zero_pixels_inside_a_frame_are_holes():
+    # addImage: mask = image > 0.1 -- black pixels of the frame do not count
+    cam = S.camera(64, 48, 50.0)
+    desc = O.mosaic_desc(140, 120, 400.0)
+    frame = np.full((48, 64), 150, np.uint8)
+    frame[20:28, 30:40] = 0
+    fm = O.ForwardMosaic(cam, desc)
+    assert fm.batch(_nadir_pose(0.0, 0.0, 460.0)[None], [frame]) == O.OK
+    full = O.ForwardMosaic(cam, desc)
+    assert full.batch(_nadir_pose(0.0, 0.0, 460.0)[None], [np.full((48, 64), 150, np.uint8)]) == O.OK
+    assert ((full.mask > 0) & (fm.mask == 0)).sum() > 50
