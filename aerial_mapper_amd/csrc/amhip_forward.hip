@@ -12,8 +12,9 @@
 // Mapping to the GPU (everything per mosaic pixel is independent except the
 // distance transform, which is separable):
 //   k_fwd_undistort  only for cameras with a distortion model (remap, bilinear)
-//   k_fwd_warp       G frames at once: inverse homography per pixel in double
-//                    with OpenCV's evaluation order, u8 sample + mask
+//   k_fwd_warp       up to 64 frames at once, each on the bounding region of its
+//                    footprint only: inverse homography per pixel in double with
+//                    OpenCV's evaluation order, u8 sample + mask
 //   k_fwd_dt_rows    one wave per (row, frame): distance to the nearest zero of
 //                    the row = prefix-max / suffix-min of zero positions
 //   k_fwd_dt_cols    one lane per (column, frame): min-plus sweep down and up;
@@ -38,6 +39,14 @@ namespace amhip {
 
 struct FwdFrame {
   double m[9];  // mosaic pixel -> image pixel (inverse of the frame's homography)
+  // Region of the mosaic the frame can touch: the bounding box of its four
+  // ground points (+ margin), clipped.  Outside of it the warped image is the
+  // border value 0, i.e. mask 0, distance 0, feather weight 0 -- the frame
+  // contributes nothing there, so every kernel works on the region only.  One
+  // ring of the region is guaranteed to be outside the footprint (or the
+  // mosaic ends there, which is how cv::distanceTransform treats its border).
+  int x0, y0, w, h;
+  unsigned long long off;  // first pixel of the region in the per-batch buffers
 };
 
 struct Mosaic {
@@ -313,16 +322,19 @@ k_fwd_undistort(amhip_camera cam, FwdGeom g, const uint8_t* __restrict__ frames,
   }
 }
 
-// cv::warpPerspective(INTER_NEAREST, BORDER_CONSTANT) of G frames + addImage's mask.
+// cv::warpPerspective(INTER_NEAREST, BORDER_CONSTANT) of G frames + addImage's mask,
+// evaluated on every frame's region only.
 __global__ void __launch_bounds__(256)
 k_fwd_warp(FwdGeom g, const FwdFrame* __restrict__ fr, const uint8_t* __restrict__ frames, int G,
            uint8_t* __restrict__ warped, uint8_t* __restrict__ mask) {
-  const int x = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y;
   const int f = blockIdx.z;
-  if (x >= g.mw || f >= G) return;
-  const double* M = fr[f].m;
-  const int xs = (x / g.bw0) * g.bw0;  // block start
+  const FwdFrame& F = fr[f];
+  const int rx = blockIdx.x * 256 + threadIdx.x;
+  const int ry = blockIdx.y;
+  if (rx >= F.w || ry >= F.h) return;
+  const int x = F.x0 + rx, y = F.y0 + ry;
+  const double* M = F.m;
+  const int xs = (x / g.bw0) * g.bw0;  // start of OpenCV's block
   const int x1 = x - xs;
   const double X0 = M[0] * xs + M[1] * y + M[2];
   const double Y0 = M[3] * xs + M[4] * y + M[5];
@@ -334,7 +346,7 @@ k_fwd_warp(FwdGeom g, const FwdFrame* __restrict__ fr, const uint8_t* __restrict
   X = max(-32768, min(32767, X));  // saturate_cast<short>
   Y = max(-32768, min(32767, Y));
   const bool inside = X >= 0 && Y >= 0 && X < g.iw && Y < g.ih;
-  const size_t at = ((size_t)f * g.mh + y) * g.mw + x;
+  const size_t at = (size_t)F.off + (size_t)ry * F.w + rx;
   const uint8_t* src = frames + (size_t)f * g.frame_stride + (size_t)Y * g.row_step +
                        (size_t)X * g.ch;
   bool any = false;
@@ -346,14 +358,38 @@ k_fwd_warp(FwdGeom g, const FwdFrame* __restrict__ fr, const uint8_t* __restrict
   mask[at] = any ? 255 : 0;
 }
 
-// rows: distance to the nearest zero of the same row (saturated at 255)
+// A "plane" is one W x H raster of the distance transform: a frame's region, or
+// the whole mosaic (feed(result_, result_mask_) of updateOrthomosaic).
+struct DtPlane {
+  int w, h;
+  unsigned long long off;
+};
+__device__ __forceinline__ DtPlane dt_plane(const FwdFrame* fr, int f, int mw, int mh) {
+  DtPlane p;
+  if (fr) {
+    p.w = fr[f].w;
+    p.h = fr[f].h;
+    p.off = fr[f].off;
+  } else {
+    p.w = mw;
+    p.h = mh;
+    p.off = 0;
+  }
+  return p;
+}
+
+// rows: distance to the nearest zero of the same row (saturated at 255).
+// One wave per row; grid = (ceil(max rows / 4), planes).
 __global__ void __launch_bounds__(256)
-k_fwd_dt_rows(const uint8_t* __restrict__ mask, uint8_t* __restrict__ dist, int w, size_t nrows) {
+k_fwd_dt_rows(const FwdFrame* __restrict__ fr, int mw, int mh, const uint8_t* __restrict__ mask,
+              uint8_t* __restrict__ dist) {
+  const DtPlane P = dt_plane(fr, blockIdx.y, mw, mh);
   const int lane = threadIdx.x & 63;
-  const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= nrows) return;
-  const uint8_t* m = mask + row * (size_t)w;
-  uint8_t* d = dist + row * (size_t)w;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= P.h) return;
+  const int w = P.w;
+  const uint8_t* m = mask + P.off + (size_t)row * w;
+  uint8_t* d = dist + P.off + (size_t)row * w;
   const int kFar = 1 << 24;
   int last = -kFar;
   for (int x0 = 0; x0 < w; x0 += 64) {
@@ -383,20 +419,22 @@ k_fwd_dt_rows(const uint8_t* __restrict__ mask, uint8_t* __restrict__ dist, int 
   }
 }
 
-// columns: d(x, y) = min_y' (|y - y'| + row distance(x, y')), in place
+// columns: d(x, y) = min_y' (|y - y'| + row distance(x, y')), in place.
+// One lane per column; grid = (ceil(max width / 256), planes).
 __global__ void __launch_bounds__(256)
-k_fwd_dt_cols(uint8_t* __restrict__ dist, int w, int h, int G) {
+k_fwd_dt_cols(const FwdFrame* __restrict__ fr, int mw, int mh, uint8_t* __restrict__ dist) {
+  const DtPlane P = dt_plane(fr, blockIdx.y, mw, mh);
   const int x = blockIdx.x * 256 + threadIdx.x;
-  const int f = blockIdx.y;
-  if (x >= w || f >= G) return;
-  uint8_t* col = dist + (size_t)f * w * h + x;
+  if (x >= P.w) return;
+  uint8_t* col = dist + P.off + x;
+  const size_t w = (size_t)P.w;
   int d = 255;
-  for (int y = 0; y < h; ++y) {
+  for (int y = 0; y < P.h; ++y) {
     d = min((int)col[(size_t)y * w], min(d + 1, 255));
     col[(size_t)y * w] = (uint8_t)d;
   }
   d = 255;
-  for (int y = h - 1; y >= 0; --y) {
+  for (int y = P.h - 1; y >= 0; --y) {
     d = min((int)col[(size_t)y * w], min(d + 1, 255));
     col[(size_t)y * w] = (uint8_t)d;
   }
@@ -409,16 +447,41 @@ __device__ __forceinline__ float feather_weight(int d) {
   return v > 1.0f ? 1.0f : v;
 }
 
-// FeatherBlender::feed for the G frames of a batch, ascending
+// FeatherBlender::feed for the G frames of a batch, ascending.  The launch
+// covers the union (ux0, uy0, uw, uh) of the frames' regions; a frame whose
+// region does not contain the pixel would add (short)(0 * 0) and weight 0.
 __global__ void __launch_bounds__(256)
-k_fwd_feed(const uint8_t* __restrict__ warped, const uint8_t* __restrict__ dist, int ch, int G,
-           size_t pixels, int16_t* __restrict__ dst16, float* __restrict__ dst_weight) {
-  const size_t k = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (k >= pixels) return;
-  int16_t a0 = dst16[3 * k + 0], a1 = dst16[3 * k + 1], a2 = dst16[3 * k + 2];
-  float ws = dst_weight[k];
+k_fwd_feed(const FwdFrame* __restrict__ fr, const uint8_t* __restrict__ warped,
+           const uint8_t* __restrict__ dist, int ch, int G, int mw, int ux0, int uy0, int uw,
+           int16_t* __restrict__ dst16, float* __restrict__ dst_weight) {
+  __shared__ int s_roi[64][4];
+  __shared__ unsigned long long s_off[64];
+  if (threadIdx.x < G) {
+    s_roi[threadIdx.x][0] = fr[threadIdx.x].x0;
+    s_roi[threadIdx.x][1] = fr[threadIdx.x].y0;
+    s_roi[threadIdx.x][2] = fr[threadIdx.x].w;
+    s_roi[threadIdx.x][3] = fr[threadIdx.x].h;
+    s_off[threadIdx.x] = fr[threadIdx.x].off;
+  }
+  __syncthreads();
+  const int rx = blockIdx.x * 256 + threadIdx.x;
+  if (rx >= uw) return;
+  const int x = ux0 + rx, y = uy0 + blockIdx.y;
+  const size_t k = (size_t)y * mw + x;
+  int16_t a0 = 0, a1 = 0, a2 = 0;
+  float ws = 0.0f;
+  bool loaded = false;
   for (int f = 0; f < G; ++f) {
-    const size_t at = (size_t)f * pixels + k;
+    const int px = x - s_roi[f][0], py = y - s_roi[f][1];
+    if (px < 0 || py < 0 || px >= s_roi[f][2] || py >= s_roi[f][3]) continue;
+    if (!loaded) {
+      a0 = dst16[3 * k + 0];
+      a1 = dst16[3 * k + 1];
+      a2 = dst16[3 * k + 2];
+      ws = dst_weight[k];
+      loaded = true;
+    }
+    const size_t at = (size_t)s_off[f] + (size_t)py * s_roi[f][2] + px;
     const float w = feather_weight(dist[at]);
     const uint8_t* s = warped + at * ch;
     const int v0 = s[0], v1 = s[ch == 1 ? 0 : 1], v2 = s[ch == 1 ? 0 : 2];
@@ -427,6 +490,7 @@ k_fwd_feed(const uint8_t* __restrict__ warped, const uint8_t* __restrict__ dist,
     a2 = (int16_t)(a2 + (int16_t)(int)((float)v2 * w));
     ws += w;
   }
+  if (!loaded) return;
   dst16[3 * k + 0] = a0;
   dst16[3 * k + 1] = a1;
   dst16[3 * k + 2] = a2;
@@ -497,61 +561,138 @@ static FwdGeom fwd_geom(const Mosaic* m, int ch, size_t frame_stride, size_t row
   return g;
 }
 
-static int fwd_distance(Mosaic* m, const uint8_t* mask, uint8_t* dist, int G) {
-  const int w = m->desc.width_mosaic_pixels, h = m->desc.height_mosaic_pixels;
-  const size_t nrows = (size_t)h * G;
-  hipLaunchKernelGGL(k_fwd_dt_rows, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, m->stream,
-                     mask, dist, w, nrows);
-  hipLaunchKernelGGL(k_fwd_dt_cols, dim3((unsigned)((w + 255) / 256), (unsigned)G), dim3(256), 0,
-                     m->stream, dist, w, h, G);
+// distance transform of the regions of G frames (fr != null) or of one
+// mosaic-sized plane (fr == null)
+static int fwd_distance(Mosaic* m, const FwdFrame* fr, int G, int max_w, int max_h,
+                        const uint8_t* mask, uint8_t* dist) {
+  const int mw = m->desc.width_mosaic_pixels, mh = m->desc.height_mosaic_pixels;
+  hipLaunchKernelGGL(k_fwd_dt_rows, dim3((unsigned)((max_h + 3) / 4), (unsigned)G), dim3(256), 0,
+                     m->stream, fr, mw, mh, mask, dist);
+  hipLaunchKernelGGL(k_fwd_dt_cols, dim3((unsigned)((max_w + 255) / 256), (unsigned)G), dim3(256),
+                     0, m->stream, fr, mw, mh, dist);
   AMHIP_TRY(hipGetLastError());
   return AMHIP_OK;
 }
 
-// frames of one batch chunk: device-resident, G of them starting at `frames`
-static int fwd_feed_frames(Mosaic* m, const double* T_G_C, int G, const uint8_t* frames,
+// The region of the mosaic a frame can touch (see FwdFrame).  Mfwd maps image
+// to mosaic pixels; the source rectangle grown by one pixel is mapped forward
+// and its bounding box grown by two mosaic pixels.  If the rectangle reaches
+// the homography's vanishing line the footprint is unbounded: whole mosaic.
+static void fwd_region(const Mosaic* m, const double Mfwd[9], FwdFrame* out) {
+  const int mw = m->desc.width_mosaic_pixels, mh = m->desc.height_mosaic_pixels;
+  const double xs[2] = {-1.0, (double)m->cam.width}, ys[2] = {-1.0, (double)m->cam.height};
+  double lo_x = 1e300, hi_x = -1e300, lo_y = 1e300, hi_y = -1e300;
+  bool bounded = true;
+  double w_ref = 0.0;
+  for (int a = 0; a < 2 && bounded; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const double w = Mfwd[6] * xs[a] + Mfwd[7] * ys[b] + Mfwd[8];
+      if (a == 0 && b == 0) w_ref = w;
+      if (!(w * w_ref > 0.0) || !(std::fabs(w) > 1e-9 * std::fabs(Mfwd[8]))) {
+        bounded = false;
+        break;
+      }
+      const double X = (Mfwd[0] * xs[a] + Mfwd[1] * ys[b] + Mfwd[2]) / w;
+      const double Y = (Mfwd[3] * xs[a] + Mfwd[4] * ys[b] + Mfwd[5]) / w;
+      if (!(std::fabs(X) < 1e9 && std::fabs(Y) < 1e9)) {
+        bounded = false;
+        break;
+      }
+      lo_x = std::min(lo_x, X);
+      hi_x = std::max(hi_x, X);
+      lo_y = std::min(lo_y, Y);
+      hi_y = std::max(hi_y, Y);
+    }
+  int x0 = 0, y0 = 0, x1 = mw - 1, y1 = mh - 1;
+  if (bounded) {
+    x0 = std::max(0, (int)std::floor(lo_x) - 2);
+    y0 = std::max(0, (int)std::floor(lo_y) - 2);
+    x1 = std::min(mw - 1, (int)std::ceil(hi_x) + 2);
+    y1 = std::min(mh - 1, (int)std::ceil(hi_y) + 2);
+  }
+  out->x0 = x0;
+  out->y0 = y0;
+  out->w = std::max(0, x1 - x0 + 1);
+  out->h = std::max(0, y1 - y0 + 1);
+}
+
+constexpr int kFwdMaxFrames = 64;                       // frames per launch (k_fwd_feed's table)
+constexpr size_t kFwdChunkBytes = size_t(512) << 20;    // warped + mask + dist per launch
+
+// feed `F` device-resident frames, ascending, in chunks
+static int fwd_feed_frames(Mosaic* m, const double* T_G_C, size_t F, const uint8_t* frames,
                            size_t frame_stride, size_t row_step, int ch, bool quirk) {
-  std::vector<FwdFrame> host(G);
-  for (int f = 0; f < G; ++f) {
-    double M[9];
-    if (!frame_homography(m->cam, m->desc, T_G_C + 7 * (size_t)f, quirk, M) ||
-        !invert3(M, host[f].m))
-      return fwd_arg_fail("forward homography: degenerate frame (camera parallel to the ground?)");
+  std::vector<FwdFrame> host;
+  size_t f0 = 0;
+  while (f0 < F) {
+    // ---- plan one chunk ----------------------------------------------------------
+    host.clear();
+    size_t px = 0;
+    int max_w = 0, max_h = 0, ux0 = INT_MAX, uy0 = INT_MAX, ux1 = -1, uy1 = -1;
+    while (f0 + host.size() < F && (int)host.size() < kFwdMaxFrames) {
+      FwdFrame fr;
+      double M[9];
+      if (!frame_homography(m->cam, m->desc, T_G_C + 7 * (f0 + host.size()), quirk, M) ||
+          !invert3(M, fr.m))
+        return fwd_arg_fail("forward homography: degenerate frame (camera parallel to the ground?)");
+      fwd_region(m, M, &fr);
+      const size_t rpx = (size_t)fr.w * fr.h;
+      if (!host.empty() && (px + rpx) * (size_t)(ch + 2) > kFwdChunkBytes) break;
+      fr.off = px;
+      px += rpx;
+      if (rpx) {
+        max_w = std::max(max_w, fr.w);
+        max_h = std::max(max_h, fr.h);
+        ux0 = std::min(ux0, fr.x0);
+        uy0 = std::min(uy0, fr.y0);
+        ux1 = std::max(ux1, fr.x0 + fr.w - 1);
+        uy1 = std::max(uy1, fr.y0 + fr.h - 1);
+      }
+      host.push_back(fr);
+    }
+    const int G = (int)host.size();
+    const uint8_t* chunk_frames = frames + f0 * frame_stride;
+    f0 += (size_t)G;
+    if (px == 0) continue;  // none of the chunk's frames reaches the mosaic
+    // ---- run it -------------------------------------------------------------------
+    int rc;
+    if ((rc = ensure_capacity(&m->warped, &m->warped_cap, px * ch))) return rc;
+    if ((rc = ensure_capacity(&m->mask, &m->mask_cap, px))) return rc;
+    if ((rc = ensure_capacity(&m->dist, &m->dist_cap, px))) return rc;
+    {
+      void* p = m->frames;
+      size_t cap = m->frames_cap * sizeof(FwdFrame);
+      if ((rc = ensure_bytes(&p, &cap, (size_t)kFwdMaxFrames * sizeof(FwdFrame)))) return rc;
+      m->frames = static_cast<FwdFrame*>(p);
+      m->frames_cap = cap / sizeof(FwdFrame);
+    }
+    // (pageable source: wait so that `host` may be reused for the next chunk)
+    AMHIP_TRY(hipMemcpyAsync(m->frames, host.data(), (size_t)G * sizeof(FwdFrame),
+                             hipMemcpyHostToDevice, m->stream));
+    AMHIP_TRY(hipStreamSynchronize(m->stream));
+    FwdGeom g = fwd_geom(m, ch, frame_stride, row_step);
+    const uint8_t* src = chunk_frames;
+    if (m->cam.distortion != AMHIP_DIST_NONE) {
+      const size_t fbytes = (size_t)g.iw * g.ih * ch;
+      if ((rc = ensure_capacity(&m->undist, &m->undist_cap, (size_t)G * fbytes))) return rc;
+      hipLaunchKernelGGL(k_fwd_undistort,
+                         dim3((unsigned)((g.iw + 255) / 256), (unsigned)g.ih, (unsigned)G),
+                         dim3(256), 0, m->stream, m->cam, g, chunk_frames, G, m->undist);
+      src = m->undist;
+      g.frame_stride = fbytes;
+      g.row_step = (size_t)g.iw * ch;
+    }
+    hipLaunchKernelGGL(k_fwd_warp,
+                       dim3((unsigned)((max_w + 255) / 256), (unsigned)max_h, (unsigned)G),
+                       dim3(256), 0, m->stream, g, m->frames, src, G, m->warped, m->mask);
+    AMHIP_TRY(hipGetLastError());
+    if ((rc = fwd_distance(m, m->frames, G, max_w, max_h, m->mask, m->dist))) return rc;
+    const int uw = ux1 - ux0 + 1, uh = uy1 - uy0 + 1;
+    hipLaunchKernelGGL(k_fwd_feed, dim3((unsigned)((uw + 255) / 256), (unsigned)uh), dim3(256), 0,
+                       m->stream, m->frames, m->warped, m->dist, ch, G, g.mw, ux0, uy0, uw,
+                       m->dst16, m->dst_weight);
+    AMHIP_TRY(hipGetLastError());
   }
-  int rc;
-  if ((rc = ensure_capacity(&m->warped, &m->warped_cap, (size_t)G * m->pixels * ch))) return rc;
-  if ((rc = ensure_capacity(&m->mask, &m->mask_cap, (size_t)G * m->pixels))) return rc;
-  if ((rc = ensure_capacity(&m->dist, &m->dist_cap, (size_t)G * m->pixels))) return rc;
-  {
-    void* p = m->frames;
-    size_t cap = m->frames_cap * sizeof(FwdFrame);
-    if ((rc = ensure_bytes(&p, &cap, (size_t)G * sizeof(FwdFrame)))) return rc;
-    m->frames = static_cast<FwdFrame*>(p);
-    m->frames_cap = cap / sizeof(FwdFrame);
-  }
-  // (pageable source: the copy is complete when the call returns)
-  AMHIP_TRY(hipMemcpyAsync(m->frames, host.data(), (size_t)G * sizeof(FwdFrame),
-                           hipMemcpyHostToDevice, m->stream));
-  AMHIP_TRY(hipStreamSynchronize(m->stream));
-  FwdGeom g = fwd_geom(m, ch, frame_stride, row_step);
-  const uint8_t* src = frames;
-  if (m->cam.distortion != AMHIP_DIST_NONE) {
-    const size_t fbytes = (size_t)g.iw * g.ih * ch;
-    if ((rc = ensure_capacity(&m->undist, &m->undist_cap, (size_t)G * fbytes))) return rc;
-    hipLaunchKernelGGL(k_fwd_undistort, dim3((unsigned)((g.iw + 255) / 256), (unsigned)g.ih,
-                                             (unsigned)G),
-                       dim3(256), 0, m->stream, m->cam, g, frames, G, m->undist);
-    src = m->undist;
-    g.frame_stride = fbytes;
-    g.row_step = (size_t)g.iw * ch;
-  }
-  hipLaunchKernelGGL(k_fwd_warp, dim3((unsigned)((g.mw + 255) / 256), (unsigned)g.mh, (unsigned)G),
-                     dim3(256), 0, m->stream, g, m->frames, src, G, m->warped, m->mask);
-  AMHIP_TRY(hipGetLastError());
-  if ((rc = fwd_distance(m, m->mask, m->dist, G))) return rc;
-  hipLaunchKernelGGL(k_fwd_feed, dim3((unsigned)((m->pixels + 255) / 256)), dim3(256), 0,
-                     m->stream, m->warped, m->dist, ch, G, m->pixels, m->dst16, m->dst_weight);
-  AMHIP_TRY(hipGetLastError());
   return AMHIP_OK;
 }
 
@@ -563,25 +704,11 @@ static int fwd_blend(Mosaic* m, bool batch_tail) {
   return AMHIP_OK;
 }
 
-static int fwd_batch_chunk_size(const Mosaic* m, int ch) {
-  const size_t per_frame = m->pixels * (size_t)(ch + 2);
-  size_t g = (size_t(512) << 20) / (per_frame ? per_frame : 1);
-  if (g < 1) g = 1;
-  if (g > 64) g = 64;
-  return (int)g;
-}
-
 static int fwd_batch_dev(Mosaic* m, const double* T_G_C, size_t F, const uint8_t* frames,
                          size_t frame_stride, size_t row_step, int ch) {
-  const int gmax = fwd_batch_chunk_size(m, ch);
-  for (size_t f0 = 0; f0 < F; f0 += (size_t)gmax) {
-    const int G = (int)std::min<size_t>((size_t)gmax, F - f0);
-    const int rc = fwd_feed_frames(m, T_G_C + 7 * f0, G, frames + f0 * frame_stride, frame_stride,
-                                   row_step, ch, /*quirk=*/true);
-    if (rc) return rc;
-  }
-  int rc = fwd_blend(m, /*batch_tail=*/true);
-  return rc;
+  int rc = fwd_feed_frames(m, T_G_C, F, frames, frame_stride, row_step, ch, /*quirk=*/true);
+  if (rc) return rc;
+  return fwd_blend(m, /*batch_tail=*/true);
 }
 
 static int fwd_update_dev(Mosaic* m, const double* T_G_C7, const uint8_t* frame, size_t row_step,
@@ -591,7 +718,9 @@ static int fwd_update_dev(Mosaic* m, const double* T_G_C7, const uint8_t* frame,
   if ((rc = fwd_blend(m, false))) return rc;       // blender_->blend(result_, result_mask_)
   if ((rc = fwd_prepare_blender(m))) return rc;    // prepareBlenderForNextImage()
   if ((rc = ensure_capacity(&m->dist, &m->dist_cap, m->pixels))) return rc;
-  if ((rc = fwd_distance(m, m->result_mask, m->dist, 1))) return rc;  // addImage(result_, mask_)
+  if ((rc = fwd_distance(m, nullptr, 1, m->desc.width_mosaic_pixels, m->desc.height_mosaic_pixels,
+                         m->result_mask, m->dist)))
+    return rc;  // addImage(result_, result_mask_)
   hipLaunchKernelGGL(k_fwd_feed16, dim3((unsigned)((m->pixels + 255) / 256)), dim3(256), 0,
                      m->stream, m->result16, m->dist, m->pixels, m->dst16, m->dst_weight);
   AMHIP_TRY(hipGetLastError());
@@ -765,17 +894,20 @@ int amhip_mosaic_batch(amhip_mosaic* h, const double* T_G_C, size_t num_frames,
   Mosaic* m = &h->impl;
   int rc = fwd_use(m);
   if (rc) return rc;
-  // frames are staged in chunks so that host-side memory use stays bounded
-  const int gmax = fwd_batch_chunk_size(m, channels);
-  for (size_t f0 = 0; f0 < num_frames; f0 += (size_t)gmax) {
-    const size_t G = std::min<size_t>((size_t)gmax, num_frames - f0);
+  // frames are staged to the device in chunks of bounded size
+  const size_t fbytes = (size_t)m->cam.width * m->cam.height * channels;
+  size_t gmax = (size_t(1) << 30) / (fbytes ? fbytes : 1);
+  if (gmax < 1) gmax = 1;
+  for (size_t f0 = 0; f0 < num_frames; f0 += gmax) {
+    const size_t G = std::min<size_t>(gmax, num_frames - f0);
     size_t fb = 0;
     if ((rc = fwd_stage(m, reinterpret_cast<const uint8_t* const*>(images) + f0, steps + f0, G,
                         channels, &fb)))
       return rc;
-    if ((rc = fwd_feed_frames(m, T_G_C + 7 * f0, (int)G, m->stage, fb,
+    if ((rc = fwd_feed_frames(m, T_G_C + 7 * f0, G, m->stage, fb,
                               (size_t)m->cam.width * channels, channels, /*quirk=*/true)))
       return rc;
+    AMHIP_TRY(hipStreamSynchronize(m->stream));  // the staging buffer is reused
   }
   if ((rc = fwd_blend(m, /*batch_tail=*/true))) return rc;
   return fwd_download(m, result, result_mask);

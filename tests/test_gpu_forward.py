@@ -199,3 +199,33 @@ def test_argument_errors():
     with A.OrthoForwardHomography(_ncam(cam), _settings(desc)) as mosaic:
         with pytest.raises(A.AmhipError):
             mosaic.batch(np.zeros((2, 7)), [np.zeros((48, 64), np.uint8)])
+
+
+def test_frames_outside_partially_inside_and_strongly_tilted():
+    # frame 0 misses the mosaic completely, frame 1 is cut by its edge, the
+    # others are tilted up to ~55 deg (long, thin footprints; a horizon-crossing
+    # one makes the kernels fall back to the whole mosaic as their region)
+    A = _A()
+    cam = S.camera(128, 96, 100.0)
+    desc = O.mosaic_desc(320, 320, 400.0)
+    poses = synth.make_lawnmower_poses(8, 60.0, 500.0, 41, tilt_deg=55.0)
+    poses[0, 0:2] = (900.0, 900.0)
+    poses[1, 0:2] = (150.0, -155.0)
+    frames = synth.make_frames(8, 96, 128, 1, salt=23)
+    fm = O.ForwardMosaic(cam, desc)
+    assert fm.batch(poses, [f for f in frames]) == O.OK
+    with A.OrthoForwardHomography(_ncam(cam), _settings(desc)) as mosaic:
+        mosaic.batch(poses, [f for f in frames])
+        res, mask = mosaic.result()
+        _assert_same(res, fm.result, "result")
+        _assert_same(mask, fm.mask, "mask")
+        # the same frames one at a time
+        mosaic.reset()
+        fi = O.ForwardMosaic(cam, desc)
+        for k in range(8):
+            assert fi.update(poses[k], frames[k]) == O.OK
+            mosaic.updateOrthomosaic(poses[k], frames[k])
+        res, mask = mosaic.result()
+    assert (fm.mask > 0).mean() > 0.2
+    _assert_same(res, fi.result, "incremental result")
+    _assert_same(mask, fi.mask, "incremental mask")
