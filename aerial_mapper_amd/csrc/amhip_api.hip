@@ -300,6 +300,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
         p.p3_n1 = n1;
         p.p3_n2 = r1 * cc;
         p.p3_cap = std::getenv("AMHIP_P3_CAP") ? std::atoi(std::getenv("AMHIP_P3_CAP")) : 2048;
+        if (p.p3_cap > 2048) p.p3_cap = 2048;  // kP3PlaceMaxCap
+        if (p.p3_cap < 64) p.p3_cap = 64;
       }
     }
   }
@@ -336,6 +338,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
       kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
       cap = kTileJ == 16 ? 1024 : 2048;
+        if (p.p3_cap > 2048) p.p3_cap = 2048;  // kP3PlaceMaxCap
+        if (p.p3_cap < 64) p.p3_cap = 64;
     }
   }
   p.tile_j = kTileJ;
@@ -967,12 +971,15 @@ int amhip_ctx_kernel_time(amhip_ctx* h, int kernel, double* total_ms,
 
 const char* amhip_kernel_name(int kernel) {
   switch (kernel) {
+    // sort slots: named after the kernels of the default path for large clouds
+    // (three-pass partition sort); the stripe sort / one-level sort fallbacks
+    // report their count / scatter / placement launches in the same slots
     case AMHIP_K_DSM_BIN_COUNT:
-      return "k_dsm_stripe_count";   // + k_dsm_stripe_scan (one-level path: k_dsm_bin_count)
+      return "k_dsm_p3_count";    // + k_dsm_p3_reduce, k_dsm_p3_scan
     case AMHIP_K_DSM_SCATTER:
-      return "k_dsm_stripe_scatter"; // (one-level path: k_dsm_scatter)
+      return "k_dsm_p3_scatter";  // both scatter passes
     case AMHIP_K_DSM_SCAN:
-      return "k_dsm_stripe_sort";    // (one-level path: k_scan_*)
+      return "k_dsm_p3_place";
     case AMHIP_K_DSM_GATHER:
       return "k_dsm_gather";
     case AMHIP_K_ORTHO:

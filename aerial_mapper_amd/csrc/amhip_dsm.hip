@@ -351,6 +351,8 @@ constexpr int kP3Chunk = 2560;  // points staged per scatter workgroup (70 KB of
 constexpr int kP3PerThread = kP3Chunk / kP3Threads;
 constexpr int kP3MaxKeys = 256;
 constexpr int kP3PlaceThreads = 256;
+constexpr int kP3PlaceMaxCap = 2048;  // LDS capacity (points) the register-resident path handles
+constexpr int kP3PlacePer = kP3PlaceMaxCap / kP3PlaceThreads;
 
 __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
                                         int* k2) {
@@ -550,10 +552,32 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
   for (int k = tid; k < nbw; k += kP3PlaceThreads) s_bins[k] = 0;
   __syncthreads();
-  for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
-    int bx, by;
-    point_bin_xy(p, src[3 * (size_t)idx + 0], src[3 * (size_t)idx + 1], &bx, &by);
-    atomicAdd(&s_bins[bx - bx0], 1u);
+  const bool in_lds = (int)(g1 - g0) <= cap && cap <= kP3PlaceMaxCap;
+  // the sub-partition is read ONCE: a thread keeps its points (<= 8) in
+  // registers between the count and the placement
+  double px[kP3PlacePer], py[kP3PlacePer], pz[kP3PlacePer];
+  int pb[kP3PlacePer];
+  if (in_lds) {
+#pragma unroll
+    for (int k = 0; k < kP3PlacePer; ++k) {
+      const uint32_t idx = g0 + tid + (uint32_t)k * kP3PlaceThreads;
+      pb[k] = -1;
+      if (idx < g1) {
+        px[k] = src[3 * (size_t)idx + 0];
+        py[k] = src[3 * (size_t)idx + 1];
+        pz[k] = src[3 * (size_t)idx + 2];
+        int bx, by;
+        point_bin_xy(p, px[k], py[k], &bx, &by);
+        pb[k] = bx - bx0;
+        atomicAdd(&s_bins[pb[k]], 1u);
+      }
+    }
+  } else {
+    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+      int bx, by;
+      point_bin_xy(p, src[3 * (size_t)idx + 0], src[3 * (size_t)idx + 1], &bx, &by);
+      atomicAdd(&s_bins[bx - bx0], 1u);
+    }
   }
   __syncthreads();
   {
@@ -574,26 +598,30 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
   uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
   for (int k = tid; k < nbw; k += kP3PlaceThreads) out_start[k] = g0 + s_bins[k];
   __syncthreads();
-  const bool in_lds = (int)(g1 - g0) <= cap;
-  for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {  // (L2 hits)
-    const double px = src[3 * (size_t)idx + 0];
-    const double py = src[3 * (size_t)idx + 1];
-    const double pz = src[3 * (size_t)idx + 2];
-    int bx, by;
-    point_bin_xy(p, px, py, &bx, &by);
-    const uint32_t q = atomicAdd(&s_bins[bx - bx0], 1u);
-    if (in_lds) {
-      s_pts[3 * q + 0] = px;
-      s_pts[3 * q + 1] = py;
-      s_pts[3 * q + 2] = pz;
-    } else {  // over-full sub-partition (clustered cloud): place directly
-      const size_t o = (size_t)g0 + q;
-      sorted[3 * o + 0] = px;
-      sorted[3 * o + 1] = py;
-      sorted[3 * o + 2] = pz;
+  if (!in_lds) {
+    // over-full sub-partition (clustered cloud): second read, direct placement
+    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+      const double x = src[3 * (size_t)idx + 0];
+      const double y = src[3 * (size_t)idx + 1];
+      const double z = src[3 * (size_t)idx + 2];
+      int bx, by;
+      point_bin_xy(p, x, y, &bx, &by);
+      const size_t o = (size_t)g0 + atomicAdd(&s_bins[bx - bx0], 1u);
+      sorted[3 * o + 0] = x;
+      sorted[3 * o + 1] = y;
+      sorted[3 * o + 2] = z;
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < kP3PlacePer; ++k) {
+    if (pb[k] >= 0) {
+      const uint32_t q = atomicAdd(&s_bins[pb[k]], 1u);
+      s_pts[3 * q + 0] = px[k];
+      s_pts[3 * q + 1] = py[k];
+      s_pts[3 * q + 2] = pz[k];
     }
   }
-  if (!in_lds) return;
   __syncthreads();
   const uint32_t ne = 3u * (g1 - g0);
   double* out = sorted + 3 * (size_t)g0;

@@ -326,9 +326,9 @@ int amhip_mosaic_homography(const amhip_mosaic_desc* desc, const amhip_camera* c
 
 /* Kernel slots for amhip_ctx_kernel_time(). */
 typedef enum amhip_kernel {
-  AMHIP_K_DSM_BIN_COUNT = 0, /* sort level 1: stripe histogram (+ scan)     */
-  AMHIP_K_DSM_SCAN = 1,      /* sort level 2: per-stripe LDS counting sort  */
-  AMHIP_K_DSM_SCATTER = 2,   /* sort level 1: append points to their stripe */
+  AMHIP_K_DSM_BIN_COUNT = 0, /* sort: partition histogram (+ reduce, scan)  */
+  AMHIP_K_DSM_SCAN = 1,      /* sort: in-LDS placement of the sub-partitions */
+  AMHIP_K_DSM_SCATTER = 2,   /* sort: the two LDS-staged scatter passes      */
   AMHIP_K_DSM_GATHER = 3,    /* per-cell radius search + IDW               */
   AMHIP_K_ORTHO = 4,         /* per-tile frame cull + per-cell fold/sample */
   AMHIP_K_MISC = 5,          /* memsets / small helpers                    */

@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("-o", "--out")
     ap.add_argument("--title", default="rocprofv3 summary")
+    ap.add_argument("--traffic-json", help="write the per-step HBM traffic of bench.py's kernel slots")
+    ap.add_argument("--workload", default="cfg3")
+    ap.add_argument("--note", default="")
     a = ap.parse_args()
     lines = ["# " + a.title, ""]
     if a.trace:
@@ -71,6 +74,30 @@ def main():
             lines.append("| %s | %d | %.0f | %.0f | %.0f | %.1f | %s |" %
                          (k, c, avg, mn, mx, mb, ("%.1f" % (2 * mb)) if ctr == "FETCH_SIZE" else "-"))
         lines.append("")
+    if a.traffic_json and a.fetch and a.write:
+        import json
+        slot = lambda k: ("k_dsm_gather" if k.startswith("k_dsm_gather") else
+                          "k_dsm_p3_scatter" if k.startswith("k_dsm_p3_scatter") else
+                          "k_dsm_p3_count" if k.startswith(("k_dsm_p3_count", "k_dsm_p3_reduce", "k_dsm_p3_scan")) else k)
+        fetch, write = pmc_rows(a.fetch, "FETCH_SIZE"), pmc_rows(a.write, "WRITE_SIZE")
+        steps = max(c for k, (c, *_r) in fetch.items() if k.startswith("k_dsm_gather"))
+        out = {}
+        for k in sorted(set(fetch) | set(write)):
+            fr = fetch.get(k, (0, 0.0))
+            wr = write.get(k, (0, 0.0))
+            e = out.setdefault(slot(k), {"fetch_raw_bytes": 0, "write_bytes": 0})
+            e["fetch_raw_bytes"] += int(fr[0] * fr[1] * 1024 / steps)
+            e["write_bytes"] += int(wr[0] * wr[1] * 1024 / steps)
+        for e in out.values():
+            e["bytes"] = 2 * e["fetch_raw_bytes"] + e["write_bytes"]
+        json.dump({"_comment": "HBM traffic per bench step and kernel slot from rocprofv3 PMC passes (separate "
+                               "--pmc FETCH_SIZE and --pmc WRITE_SIZE runs with --kernel-trace only). FETCH_SIZE / "
+                               "WRITE_SIZE are KiB; gfx950 counts 128-B read requests at 64 B, so reads are doubled "
+                               "(MI355X_MICROARCH.md section HBM; checked on known byte counts: k_fill_f32 400.0 MB "
+                               "written -> WRITE 400.0 MB, k_scan_partials 100.4 MB read -> FETCH 50.2 MB). bench.py "
+                               "copies `bytes` of the dominant kernel into roofline.traffic when the workload matches. "
+                               + a.note,
+                   "workload": a.workload, "kernels": out}, open(a.traffic_json, "w"), indent=1)
     text = "\n".join(lines)
     if a.out:
         open(a.out, "w").write(text + "\n")
