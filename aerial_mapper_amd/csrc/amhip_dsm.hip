@@ -386,11 +386,16 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
 __global__ void __launch_bounds__(256)
 k_dsm_p3_reduce(const uint32_t* __restrict__ hist_rows, int nrows, int nk,
                 uint32_t* __restrict__ cnt) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nk) return;
+  // 64 counters per workgroup, the rows dealt to its four waves
+  __shared__ uint32_t s_part[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
   uint32_t s = 0;
-  for (int r = 0; r < nrows; ++r) s += hist_rows[(size_t)r * nk + k];
-  cnt[k] = s;
+  if (k < nk)
+    for (int r = wid; r < nrows; r += 4) s += hist_rows[(size_t)r * nk + k];
+  s_part[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
 }
 
 // One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
@@ -1275,7 +1280,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_count, dim3((unsigned)gcount), dim3(kP3CountThreads), lds,
                          c->stream, dev_xyz, n, p, hist_rows);
-      hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0,
+      hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2);
