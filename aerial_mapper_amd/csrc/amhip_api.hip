@@ -616,9 +616,18 @@ int amhip_layers_reset(amhip_ctx* h) {
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
-  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+  // layers nothing has written since the previous reset still hold their
+  // initial values (e.g. colored_ortho in a gray pipeline)
+  for (int l = 0; l < AMHIP_NUM_LAYERS; ++l) {
+    if (c->layer_state[l] == 0) continue;
     if ((rc = launch_fill(c, c->layers[l], c->cells, layer_init_value(l)))) return rc;
+    if (c->layer_state[l] == 1) c->layer_state[l] = 0;
+  }
   return AMHIP_OK;
+}
+
+static inline void touch(Ctx* c, int layer) {
+  if (c->layer_state[layer] == 0) c->layer_state[layer] = 1;
 }
 
 int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
@@ -626,6 +635,7 @@ int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
+  touch(c, layer);
   AMHIP_TRY(hipMemcpyAsync(c->layers[layer], host, c->cells * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipStreamSynchronize(c->stream));
@@ -645,6 +655,7 @@ int amhip_layer_download(amhip_ctx* h, int layer, float* host) {
 
 void* amhip_layer_device_ptr(amhip_ctx* h, int layer) {
   if (!h || !valid_layer(layer)) return nullptr;
+  h->impl.layer_state[layer] = 2;  // the caller may write through the pointer at any time
   return h->impl.layers[layer];
 }
 
@@ -666,6 +677,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   DsmParams p;
   if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n)))
     return rc;
+  touch(c, AMHIP_LAYER_ELEVATION);
   return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr);
 }
 
@@ -679,6 +691,7 @@ int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
+  touch(c, AMHIP_LAYER_ELEVATION);
   AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ELEVATION], elevation,
                            c->cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
@@ -705,6 +718,7 @@ int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
   int rc = use_device(c);
   if (rc) return rc;
   float* out = c->layers[AMHIP_LAYER_ORTHO];
+  touch(c, AMHIP_LAYER_ORTHO);
   DsmParams p;
   if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1, n))) return rc;
   if (!adaptive) return dsm_run(c, dev_xyz, dev_intensities, n, p, out, nullptr, nullptr);
@@ -744,6 +758,7 @@ int amhip_ortho_from_pcl_process(amhip_ctx* h, const double* host_xyz,
   if (rc) return rc;
   if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
   if ((rc = ensure_capacity(&c->stage_values, &c->stage_values_cap, n))) return rc;
+  touch(c, AMHIP_LAYER_ORTHO);
   AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ORTHO], ortho, c->cells * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
@@ -888,6 +903,10 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
 
   OrthoParams p;
   make_ortho_params(*c, *cam, F, frame_stride, row_step, channels, colored, &p);
+  touch(c, AMHIP_LAYER_ELEVATION_ANGLE);
+  touch(c, AMHIP_LAYER_OBSERVATION_INDEX);
+  touch(c, AMHIP_LAYER_NUM_OBSERVATIONS);
+  touch(c, colored ? AMHIP_LAYER_COLORED_ORTHO : AMHIP_LAYER_ORTHO);
   return ortho_run(c, p, c->frame_poses, dev_frames);
 }
 
@@ -909,9 +928,11 @@ int amhip_ortho_backward_process(
                                         elevation_angle, num_observations,
                                         observation_index, colored_ortho};
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
-    if (ups[l])
+    if (ups[l]) {
+      touch(c, l);
       AMHIP_TRY(hipMemcpyAsync(c->layers[l], ups[l], bytes, hipMemcpyHostToDevice,
                                c->stream));
+    }
   // stage the frames densely: [F][H][W*channels]
   const size_t row = (size_t)cam->width * (size_t)channels;
   const size_t frame = row * (size_t)cam->height;

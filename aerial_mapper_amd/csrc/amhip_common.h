@@ -119,6 +119,10 @@ struct Ctx {
 
   float* layers[AMHIP_NUM_LAYERS] = {nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr};
+  // 0: holds its initial value since the last reset (a reset need not touch
+  // it); 1: possibly written; 2: its device pointer was handed out (the caller
+  // may write at any time: always refilled)
+  unsigned char layer_state[AMHIP_NUM_LAYERS] = {1, 1, 1, 1, 1, 1};
   unsigned* dev_err = nullptr;   // device error word
   unsigned* host_err = nullptr;  // pinned mirror
 

@@ -393,3 +393,42 @@ def test_utm_scale_coordinates():
     g2, w2 = _ortho_both(sc, elevation=want)
     assert _coverage(w2) > 0.5
     S.assert_layers_equal(g2, w2, ORTHO_LAYERS)
+
+
+def test_reset_restores_every_layer_whatever_wrote_it():
+    # amhip_layers_reset only refills layers that may have been written since the
+    # previous reset; whoever writes (kernels, uploads, a torch view) must be seen
+    import torch
+    A = _A()
+    sc = S.Scene(60.0, 44.0, 1.0, 5000, seed=90, num_frames=4, altitude=470.0, colored=True)
+    init = {"ortho": 255.0, "elevation": np.nan, "elevation_angle": 0.0, "num_observations": 0.0,
+            "observation_index": np.nan, "colored_ortho": np.nan}
+
+    def pristine(m):
+        for name, v in init.items():
+            a = m.get(name)
+            ok = np.isnan(a).all() if np.isnan(v) else (a == v).all()
+            assert ok, name
+
+    with _map_for(sc, A) as m:
+        m.reset()
+        pristine(m)
+        A.Dsm(A.DsmSettings(), m).process(sc.points, m)
+        ncam = A.NCamera(sc.cam.fu, sc.cam.fv, sc.cam.cu, sc.cam.cv, sc.cam.width, sc.cam.height)
+        A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=True), m).process(
+            sc.poses, sc.frames, m)
+        assert not np.isnan(m.get("colored_ortho")).all()
+        m.reset()
+        pristine(m)
+        m.reset()          # nothing written in between: no fill needed, still pristine
+        pristine(m)
+        m.set("num_observations", np.full((m.cols, m.rows), 3.0, np.float32))
+        m.reset()
+        pristine(m)
+        t = m.as_torch("elevation_angle")
+        m.reset()
+        t.fill_(7.0)       # a write the library cannot see
+        torch.cuda.synchronize()
+        m.reset()
+        m.synchronize()
+        pristine(m)
