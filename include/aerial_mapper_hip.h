@@ -322,6 +322,28 @@ int amhip_mosaic_device_ptr(amhip_mosaic* mosaic, void** result_16sc3, void** re
 int amhip_mosaic_homography(const amhip_mosaic_desc* desc, const amhip_camera* cam,
                             const double* T_G_C7, int batch_quirk, double* M9);
 
+/* ---- io::AerialMapperIO::loadPointCloudFromFile
+ *      (aerial_mapper_io/src/aerial-mapper-io.cc:309-347) --
+ * The text point-cloud format in front of the DSM: whitespace separated
+ * records `x y z intensity`, read like `infile >> x >> y >> z >> intensity`
+ * (tokens four at a time; reading stops at the first token that is not a
+ * number; an incomplete last record is dropped), points with z <= -100 dropped.
+ * host_text is the file's content (e.g. mmap'ed).  The text is tokenised and
+ * parsed on the GPU -- decimal -> double correctly rounded (Eisel-Lemire; the
+ * rare inputs it cannot decide are re-done with strtod on the host and counted
+ * in *num_strtod_tokens) -- and the result stays on the device in the layout
+ * amhip_dsm_process_dev / amhip_ortho_from_pcl_process_dev take: dev_xyz = 3 *
+ * num_points doubles (AoS), dev_intensities = num_points int32, file order.
+ * Both buffers are allocated here; release them with amhip_io_free().
+ * Synchronous.  Pose files (`x y z qw qx qy qz`, :103-121) are a few KB and are
+ * read on the host by the C++ shim. */
+int amhip_io_parse_point_cloud_text(int device, const char* host_text, size_t len,
+                                    double** dev_xyz, int32_t** dev_intensities,
+                                    size_t* num_points, size_t* num_strtod_tokens);
+int amhip_io_download_point_cloud(const double* dev_xyz, const int32_t* dev_intensities,
+                                  size_t n, double* host_xyz, int32_t* host_intensities);
+int amhip_io_free(void* dev_ptr);
+
 /* ---- measurement ----------------------------------------------------------*/
 
 /* Kernel slots for amhip_ctx_kernel_time(). */

@@ -90,6 +90,10 @@ def _bind(lib):
     lib.amo_fwd_update.restype = C.c_int
     lib.amo_fwd_update.argtypes = [C.c_void_p, f64p, f64p, C.c_void_p, C.c_size_t, C.c_int,
                                    C.c_void_p, C.c_void_p]
+    lib.amo_io_load_point_cloud.restype = C.c_size_t
+    lib.amo_io_load_point_cloud.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.amo_io_load_poses.restype = C.c_size_t
+    lib.amo_io_load_poses.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
     lib.amo_compose_T_G_C.restype = None
     lib.amo_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amo_project_probe.restype = None
@@ -322,3 +326,22 @@ class ForwardMosaic(object):
                                        C.c_void_p(image.ctypes.data), image.strides[0], ch,
                                        C.c_void_p(self.result.ctypes.data),
                                        C.c_void_p(self.mask.ctypes.data))
+
+
+def io_load_point_cloud(text, with_intensities=True, which="port"):
+    """io::AerialMapperIO::loadPointCloudFromFile on an in-memory file (bytes)."""
+    cap = text.count(b"\n") + text.count(b" ") // 3 + 8
+    xyz = np.empty((cap, 3), np.float64)
+    inten = np.empty(cap, np.int32)
+    n = lib(which).amo_io_load_point_cloud(text, len(text), C.c_void_p(xyz.ctypes.data),
+                                           C.c_void_p(inten.ctypes.data) if with_intensities else None,
+                                           cap)
+    assert n <= cap
+    return xyz[:n].copy(), inten[:n].copy()
+
+
+def io_load_poses(text, which="port"):
+    cap = len(text.split()) // 7 + 4
+    out = np.empty((cap, 7), np.float64)
+    n = lib(which).amo_io_load_poses(text, len(text), C.c_void_p(out.ctypes.data), cap)
+    return out[:n].copy()

@@ -52,3 +52,11 @@ def test_cpp_forward_homography_class_matches_oracle(exe_forward, mode):
                        stderr=subprocess.STDOUT, timeout=300)
     print(r.stdout.decode())
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+def test_cpp_io_loaders_match_the_reference_loops(tmp_path_factory, tmp_path):
+    exe_io = _compile(tmp_path_factory, "shim_io_parity.cc")
+    r = subprocess.run([exe_io, str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=300)
+    print(r.stdout.decode())
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
