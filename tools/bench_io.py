@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Supplementary benchmark of the point-cloud text loader (amhip_io.hip) on one
+MI355X (NOT the headline metric -- that is bench.py).
+
+    python tools/bench_io.py [--points N] [--reps K]
+
+Builds an `x y z intensity` text file of N points in memory ("%.15g", the
+precision the reference writes with), parses it with
+amhip_io_parse_point_cloud_text (host text -> cloud resident in HBM) and with
+the reference's iostream loop (oracle/amo_io.cc) on a bounded sample; prints one
+JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--points", type=int, default=50_000_000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--block", type=int, default=500_000)
+    args = ap.parse_args()
+    from aerial_mapper_amd import io as AIO
+    import oracle_ffi as O
+
+    rng = np.random.default_rng(5)
+    nb = args.block
+    xyz = np.c_[rng.uniform(-1250, 1250, nb), rng.uniform(-1250, 1250, nb), rng.uniform(390, 410, nb)]
+    inten = rng.integers(0, 256, nb)
+    block = "".join("%.15g %.15g %.15g %d\n" % (a, b, c, i)
+                    for (a, b, c), i in zip(xyz.tolist(), inten.tolist())).encode()
+    reps = max(1, args.points // nb)
+    text = block * reps
+    n = nb * reps
+
+    cloud = AIO.parse_point_cloud_text(block)   # warm-up (module load, allocator)
+    assert cloud.n == nb
+    cloud.close()
+    best = 1e9
+    for _ in range(args.reps):
+        t0 = time.perf_counter()
+        cloud = AIO.parse_point_cloud_text(text)
+        dt = time.perf_counter() - t0
+        assert cloud.n == n
+        best = min(best, dt)
+        if _ + 1 < args.reps:
+            cloud.close()
+    # parity on the sample block (bit-exact) + CPU timing
+    t0 = time.perf_counter()
+    want_xyz, want_int = O.io_load_point_cloud(block)
+    tc = time.perf_counter() - t0
+    got_xyz = cloud.xyz[:nb].cpu().numpy()
+    got_int = cloud.intensities[:nb].cpu().numpy()
+    out = {
+        "metric": "Mpoints/s (loadPointCloudFromFile: text in host memory -> cloud in HBM)",
+        "value": round(n / best / 1e6, 1), "unit": "Mpoints/s", "n_gpus": 1,
+        "seconds": round(best, 4), "text_GB": round(len(text) / 1e9, 3),
+        "text_GBps": round(len(text) / best / 1e9, 2), "points": n,
+        "note": "includes the pageable host->device copy of the text; tokens that needed the "
+                "host strtod path: %d" % cloud.strtod_tokens,
+        "cpu_baseline": {"value": round(nb / tc / 1e6, 3), "unit": "Mpoints/s", "cores": 1,
+                         "kind": "reference",
+                         "sample": "the reference's `infile >> x >> y >> z >> intensity` loop "
+                                   "(oracle/amo_io.cc) on the first %d points: %.2f s" % (nb, tc)},
+        "parity_sample": {"points": nb,
+                          "xyz_mismatch": int((got_xyz.view(np.uint64) != want_xyz.view(np.uint64)).sum()),
+                          "intensity_mismatch": int((got_int != want_int).sum())},
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

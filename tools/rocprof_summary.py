@@ -16,7 +16,7 @@ import sys
 
 
 def short(name):
-    name = name.split("(")[0]
+    name = name.replace("(anonymous namespace)::", "").split("(")[0]
     return name.replace("void ", "").replace("amhip::", "")
 
 
