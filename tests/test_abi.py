@@ -65,6 +65,16 @@ def test_fails_loudly_without_gpu(L):
     with pytest.raises(A.AmhipError) as ei:
         A.AerialGridMap(A.GridMapSettings(0, 0, 10, 10, 1.0))
     assert ei.value.status == L.ERR_NO_DEVICE
+    # the widened entry points have no CPU path either
+    with pytest.raises(A.AmhipError) as ei:
+        A.OrthoForwardHomography(A.NCamera(100.0, 100.0, 31.5, 23.5, 64, 48),
+                                 A.OrthoForwardHomographySettings(width_mosaic_pixels=32,
+                                                                  height_mosaic_pixels=32))
+    assert ei.value.status == L.ERR_NO_DEVICE
+    from aerial_mapper_amd import io as AIO
+    with pytest.raises(A.AmhipError) as ei:
+        AIO.parse_point_cloud_text(b"1 2 3 4\n")
+    assert ei.value.status == L.ERR_NO_DEVICE
 
 
 def test_product_does_not_touch_the_oracle():
@@ -96,3 +106,23 @@ def test_argument_errors_are_reported_without_a_gpu(L):
     bad = L.GridDesc()
     assert lib.amhip_ctx_create(C.byref(bad), 0, C.byref(h)) == L.ERR_ARG
     assert lib.amhip_kernel_name(3) == b"k_dsm_gather"
+    assert lib.amhip_mosaic_batch_dev(None, None, 0, None, 0, 0, 1) == L.ERR_ARG
+    assert lib.amhip_mosaic_update(None, None, None, 0, 1, None, None) == L.ERR_ARG
+    assert lib.amhip_mosaic_create(None, None, 0, C.byref(h)) == L.ERR_ARG
+    n = C.c_size_t()
+    assert lib.amhip_io_parse_point_cloud_text(0, b"1 2 3 4", 7, None, None, C.byref(n), None) == L.ERR_ARG
+    # the homography helper is host arithmetic: usable (and checked) without a GPU
+    desc = L.MosaicDesc()
+    desc.width_mosaic_pixels, desc.height_mosaic_pixels, desc.ground_plane_elevation_m = 200, 120, 400.0
+    cam = O.Camera()
+    cam.fu = cam.fv = 70.0
+    cam.cu, cam.cv, cam.width, cam.height = 47.5, 26.5, 96, 54
+    T = np.array([11.0, 7.0, 470.0, 0.0, 1.0, 0.0, 0.0])
+    M = np.zeros(9)
+    f64p = C.POINTER(C.c_double)
+    lcam = L.Camera.from_buffer_copy(bytes(cam))
+    assert lib.amhip_mosaic_homography(C.byref(desc), C.byref(lcam), T.ctypes.data_as(f64p), 1,
+                                       M.ctypes.data_as(f64p)) == L.OK
+    odesc = O.mosaic_desc(200, 120, 400.0)
+    rc, want = O.fwd_homography(cam, odesc, T, True)
+    assert rc == O.OK and np.array_equal(M.reshape(3, 3).view(np.uint64), want.view(np.uint64))
