@@ -933,6 +933,18 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
+// |v| outside [2^-960, 2^960] (within ~1e19 of the ends of the double range)
+__device__ __forceinline__ bool exponent_extreme(double v) {
+  const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7FFu;
+  return (e - 63u) > 1920u;
+}
+
+// |v| outside [2^-332, 2^332] (about 1e-100 .. 1e100), zero, denormal, inf or NaN
+__device__ __forceinline__ bool exponent_far_from_one(double v) {
+  const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7FFu;
+  return (e - 691u) > 664u;
+}
+
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
@@ -1130,6 +1142,7 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       // tools/ubench).  D > 0 <=> at least one hit;  P == 0 <=> some hit had
       // d2 == 0 (dsm.cc:165 CHECK(distances[i] > 0.0)).  One division per cell.
       double NA = 0.0, DA = 0.0, PA = 1.0, NB = 0.0, DB = 0.0, PB = 1.0;
+      bool suspectA = false, suspectB = false;
       // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B), one row
       // pair = one contiguous span per trip (lanes wait for each other per
       // trip, and the spread of a two-row candidate count is relatively smaller).
@@ -1175,45 +1188,51 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
           }
         }
         // keep the running products inside the double range (exact scaling by
-        // powers of two; N, D, P share the factor so N/D is unaffected)
-        if (!(PA > 1e-100 && PA < 1e100) && PA != 0.0) {
+        // powers of two; N, D, P share the factor so N/D is unaffected).  The
+        // test looks at the exponent field only: outside 2^-332 .. 2^332
+        // (three integer instructions per trip instead of a chain of FP64
+        // compares; zero falls out of the range too and is left alone inside).
+        if (exponent_far_from_one(PA) && PA != 0.0) {
+          // within ONE trip the product may even have left the double range
+          // (dozens of points within millimetres of the centre): remember it
+          if (exponent_extreme(PA)) suspectA = true;
           const double sc = PA < 1.0 ? 0x1p+400 : 0x1p-400;
           NA *= sc;
           DA *= sc;
           PA *= sc;
         }
-        if (!(PB > 1e-100 && PB < 1e100) && PB != 0.0) {
+        if (exponent_far_from_one(PB) && PB != 0.0) {
+          if (exponent_extreme(PB)) suspectB = true;
           const double sc = PB < 1.0 ? 0x1p+400 : 0x1p-400;
           NB *= sc;
           DB *= sc;
           PB *= sc;
         }
       }
-      // P == 0 <=> a hit with d2 == 0.  DSM: CHECK failure.  OrthoFromPcl: the
-      // cell takes that point's value -- which is exactly what N/D holds when
-      // there is ONE such point (N = z*Q, D = Q); several coincident ones make
-      // D vanish too and the cell is re-done by the global routine.
+      // P == 0 <=> a hit with d2 == 0 -- or a product that underflowed inside
+      // one trip.  Either way (and whenever the running values came close to
+      // the ends of the double range) the cell is re-done by the global
+      // routine, which weights with reciprocals and tracks exact hits
+      // explicitly: DSM -> CHECK failure (dsm.cc:165), OrthoFromPcl -> that
+      // point's value (ortho-from-pcl.cc:91-96).
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (h == 1 && !haveB) break;
         const double Nn = h ? NB : NA, Dd = h ? DB : DA, Pp = h ? PB : PA;
+        const bool suspect = h ? suspectB : suspectA;
         const int jj = jA + h;
-        bool queue = false;
-        if (Pp == 0.0) {
-          if (!p.pcl_mode)
-            atomicOr(o.dev_err, kDevErrExactHit);
-          else if (Dd > 0.0)
-            emit_value(p, o, i, jj, Nn / Dd);
-          else
-            queue = true;
+        int queue = 0;  // 1: no first-level neighbour (ladder), 2: redo the whole cell
+        if (Pp == 0.0 || suspect || !(Dd < 0x1p+1000) || !(fabs(Nn) < 0x1p+1000)) {
+          queue = 2;
         } else if (Dd > 0.0) {
           emit_value(p, o, i, jj, Nn / Dd);
         } else {
-          queue = true;
+          queue = 1;
         }
         if (queue) {
           const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
-          s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c + h) * kTileI + lane);
+          s_flag[slot] = (uint16_t)(((wid * kCellsPerLane + c + h) * kTileI + lane) |
+                                    (queue == 2 ? 0x8000 : 0));
         }
       }
     }
@@ -1224,10 +1243,11 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   // OrthoFromPcl the full global routine (several coincident exact hits) ------
   const int nflag = (int)s_ctl[1];
   for (int f = tid; f < nflag; f += NT) {
-    const int code = s_flag[f];
+    const int code = s_flag[f] & 0x7FFF;
+    const bool redo = (s_flag[f] & 0x8000) != 0;
     const int fi = i0 + (code % kTileI);
     const int fj = j0 + (code / kTileI);
-    if (p.pcl_mode) {
+    if (p.pcl_mode || redo) {
       cell_global(p, start, sorted, fi, fj, o);
     } else {
       const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));

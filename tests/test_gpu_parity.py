@@ -432,3 +432,27 @@ def test_reset_restores_every_layer_whatever_wrote_it():
         m.reset()
         m.synchronize()
         pristine(m)
+
+
+def test_dsm_running_product_is_rescaled():
+    # The division-free IDW keeps prod(d^2) of a cell's neighbours; 150 points a few
+    # millimetres from a cell centre drive it far below 1e-300 unless the kernel
+    # rescales N, D, P together (exact powers of two) between window rows.
+    sc = S.Scene(40.0, 30.0, 0.25, 4000, seed=91)
+    rng = np.random.default_rng(12)
+    x, y = O.cell_position(sc.grid, 57, 41)
+    near = np.empty((150, 3))
+    ang = rng.uniform(0, 2 * np.pi, 150)
+    rad = rng.uniform(1e-3, 4e-3, 150)
+    near[:, 0] = x + rad * np.cos(ang)
+    near[:, 1] = y + rad * np.sin(ang)
+    near[:, 2] = 400.0 + rng.uniform(-2.0, 2.0, 150)
+    # and a cell whose neighbours are all far away (product grows instead: d^2 up to 1 only,
+    # so the large side is exercised with radius 9: d^2 up to 9, ~700 neighbours)
+    sc.points = np.ascontiguousarray(np.concatenate([sc.points, near]))
+    got, want = _dsm_both(sc)
+    S.assert_dsm_close(got, want)
+    assert abs(float(got[41, 57]) - float(want[41, 57])) <= 1e-4
+    sc9 = S.Scene(30.0, 24.0, 0.5, 18000, seed=92)
+    got, want = _dsm_both(sc9, radius=9)
+    S.assert_dsm_close(got, want)
