@@ -456,3 +456,29 @@ def test_dsm_running_product_is_rescaled():
     sc9 = S.Scene(30.0, 24.0, 0.5, 18000, seed=92)
     got, want = _dsm_both(sc9, radius=9)
     S.assert_dsm_close(got, want)
+
+
+@pytest.mark.parametrize("lx,ly,res,n", [(1.0, 1.0, 1.0, 1), (1.0, 1.0, 1.0, 40), (7.0, 1.0, 1.0, 30),
+                                         (1.0, 9.0, 0.5, 25), (3.0, 2.0, 0.25, 3), (65.0, 17.0, 1.0, 900),
+                                         (16.25, 64.25, 0.25, 5000)])
+def test_dsm_degenerate_and_odd_grid_shapes(lx, ly, res, n):
+    # 1x1, single row / column, sizes just past a tile edge (64 x 16 cells), one point
+    sc = S.Scene(lx, ly, res, n, seed=93 + n, point_extent=max(lx, ly) / 2.0 + 1.5)
+    got, want = _dsm_both(sc)
+    assert got.shape == want.shape == (sc.grid.cols, sc.grid.rows)
+    S.assert_dsm_close(got, want)
+
+
+def test_dsm_ignores_non_finite_points():
+    # NaN / inf coordinates never satisfy d2 < T in the reference's search; a NaN
+    # height does reach the interpolation (and poisons that cell) in both
+    sc = S.Scene(30.0, 20.0, 0.5, 3000, seed=94)
+    pts = sc.points.copy()
+    pts[5, 0] = np.nan
+    pts[17, 1] = np.inf
+    pts[29, 0] = -np.inf
+    pts[41, 2] = np.nan
+    sc.points = np.ascontiguousarray(pts)
+    got, want = _dsm_both(sc)
+    S.assert_dsm_close(got, want)
+    assert np.isnan(want).sum() > 0
