@@ -616,18 +616,48 @@ int amhip_layers_reset(amhip_ctx* h) {
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
-  // layers nothing has written since the previous reset still hold their
-  // initial values (e.g. colored_ortho in a gray pipeline)
+  // Lazy: nothing is written here.  A layer that is already in its initial
+  // state (physically, 0, or logically, 3) stays as it is; a written one becomes
+  // "logically initial": the next kernel that produces it writes the initial
+  // value into the cells it leaves alone (fused fill), anything else that
+  // needs the memory (download, device pointer, a partial writer) fills it
+  // first (materialize()).  Layers whose device pointer was handed out are
+  // refilled eagerly.  AMHIP_EAGER_RESET=1 restores the plain fills.
+  static const bool eager = std::getenv("AMHIP_EAGER_RESET") != nullptr;
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l) {
-    if (c->layer_state[l] == 0) continue;
+    unsigned char& st = c->layer_state[l];
+    if (st == 0 || st == 3) continue;
+    if (st == 1 && !eager) {
+      st = 3;
+      continue;
+    }
     if ((rc = launch_fill(c, c->layers[l], c->cells, layer_init_value(l)))) return rc;
-    if (c->layer_state[l] == 1) c->layer_state[l] = 0;
+    if (st == 1) st = 0;
   }
   return AMHIP_OK;
 }
 
-static inline void touch(Ctx* c, int layer) {
+// the layer's memory is about to be read or partially written by someone who
+// does not know about the lazy state
+static int materialize(Ctx* c, int layer) {
+  if (c->layer_state[layer] != 3) return AMHIP_OK;
+  const int rc = launch_fill(c, c->layers[layer], c->cells, layer_init_value(layer));
+  if (rc) return rc;
+  c->layer_state[layer] = 0;
+  return AMHIP_OK;
+}
+
+// partial writer: materialize, then dirty
+static int touch(Ctx* c, int layer) {
+  const int rc = materialize(c, layer);
+  if (rc) return rc;
   if (c->layer_state[layer] == 0) c->layer_state[layer] = 1;
+  return AMHIP_OK;
+}
+
+// full overwrite (upload): no need to fill first
+static void overwrite(Ctx* c, int layer) {
+  if (c->layer_state[layer] != 2) c->layer_state[layer] = 1;
 }
 
 int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
@@ -635,7 +665,7 @@ int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
-  touch(c, layer);
+  overwrite(c, layer);
   AMHIP_TRY(hipMemcpyAsync(c->layers[layer], host, c->cells * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipStreamSynchronize(c->stream));
@@ -647,6 +677,7 @@ int amhip_layer_download(amhip_ctx* h, int layer, float* host) {
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
+  if ((rc = materialize(c, layer))) return rc;
   AMHIP_TRY(hipMemcpyAsync(host, c->layers[layer], c->cells * sizeof(float),
                            hipMemcpyDeviceToHost, c->stream));
   AMHIP_TRY(hipStreamSynchronize(c->stream));
@@ -655,8 +686,10 @@ int amhip_layer_download(amhip_ctx* h, int layer, float* host) {
 
 void* amhip_layer_device_ptr(amhip_ctx* h, int layer) {
   if (!h || !valid_layer(layer)) return nullptr;
-  h->impl.layer_state[layer] = 2;  // the caller may write through the pointer at any time
-  return h->impl.layers[layer];
+  Ctx* c = &h->impl;
+  if (use_device(c) != AMHIP_OK || materialize(c, layer) != AMHIP_OK) return nullptr;
+  c->layer_state[layer] = 2;  // the caller may write through the pointer at any time
+  return c->layers[layer];
 }
 
 // ---- DSM ------------------------------------------------------------------
@@ -677,8 +710,14 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   DsmParams p;
   if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n)))
     return rc;
-  touch(c, AMHIP_LAYER_ELEVATION);
-  return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr);
+  // a logically-initial elevation layer is filled by the gather itself
+  const bool fused_fill = c->layer_state[AMHIP_LAYER_ELEVATION] == 3;
+  if (fused_fill)
+    c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
+  else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
+    return rc;
+  return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr,
+                 fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION));
 }
 
 int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
@@ -691,7 +730,7 @@ int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
-  touch(c, AMHIP_LAYER_ELEVATION);
+  overwrite(c, AMHIP_LAYER_ELEVATION);
   AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ELEVATION], elevation,
                            c->cells * sizeof(float), hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
@@ -718,10 +757,18 @@ int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
   int rc = use_device(c);
   if (rc) return rc;
   float* out = c->layers[AMHIP_LAYER_ORTHO];
-  touch(c, AMHIP_LAYER_ORTHO);
   DsmParams p;
   if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1, n))) return rc;
-  if (!adaptive) return dsm_run(c, dev_xyz, dev_intensities, n, p, out, nullptr, nullptr);
+  if (!adaptive) {
+    const bool fused_fill = c->layer_state[AMHIP_LAYER_ORTHO] == 3;
+    if (fused_fill)
+      c->layer_state[AMHIP_LAYER_ORTHO] = 1;
+    else if ((rc = touch(c, AMHIP_LAYER_ORTHO)))
+      return rc;
+    return dsm_run(c, dev_xyz, dev_intensities, n, p, out, nullptr, nullptr, fused_fill,
+                   layer_init_value(AMHIP_LAYER_ORTHO));
+  }
+  if ((rc = touch(c, AMHIP_LAYER_ORTHO))) return rc;
 
   // use_adaptive_interpolation: cells whose search is empty retry with the
   // squared radius x10, x100, ... (int lambda, ortho-from-pcl.cc:63-71).  Every
@@ -758,7 +805,7 @@ int amhip_ortho_from_pcl_process(amhip_ctx* h, const double* host_xyz,
   if (rc) return rc;
   if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
   if ((rc = ensure_capacity(&c->stage_values, &c->stage_values_cap, n))) return rc;
-  touch(c, AMHIP_LAYER_ORTHO);
+  overwrite(c, AMHIP_LAYER_ORTHO);
   AMHIP_TRY(hipMemcpyAsync(c->layers[AMHIP_LAYER_ORTHO], ortho, c->cells * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
   AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
@@ -903,10 +950,23 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
 
   OrthoParams p;
   make_ortho_params(*c, *cam, F, frame_stride, row_step, channels, colored, &p);
-  touch(c, AMHIP_LAYER_ELEVATION_ANGLE);
-  touch(c, AMHIP_LAYER_OBSERVATION_INDEX);
-  touch(c, AMHIP_LAYER_NUM_OBSERVATIONS);
-  touch(c, colored ? AMHIP_LAYER_COLORED_ORTHO : AMHIP_LAYER_ORTHO);
+  // layer states (lazy reset): the kernel reads elevation; elevation_angle,
+  // observation_index and the output layer are either all produced with a
+  // fused fill or all materialized; num_observations stays logically 0
+  const int out_layer = colored ? AMHIP_LAYER_COLORED_ORTHO : AMHIP_LAYER_ORTHO;
+  if ((rc = materialize(c, AMHIP_LAYER_ELEVATION))) return rc;
+  const int outs[3] = {AMHIP_LAYER_ELEVATION_ANGLE, AMHIP_LAYER_OBSERVATION_INDEX, out_layer};
+  p.virt_out = 1;
+  for (int k = 0; k < 3; ++k)
+    if (c->layer_state[outs[k]] != 3) p.virt_out = 0;
+  for (int k = 0; k < 3; ++k) {
+    if (p.virt_out)
+      c->layer_state[outs[k]] = 1;
+    else if ((rc = touch(c, outs[k])))
+      return rc;
+  }
+  p.virt_nobs = c->layer_state[AMHIP_LAYER_NUM_OBSERVATIONS] == 3 ? 1 : 0;
+  if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
   return ortho_run(c, p, c->frame_poses, dev_frames);
 }
 
@@ -929,7 +989,7 @@ int amhip_ortho_backward_process(
                                         observation_index, colored_ortho};
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (ups[l]) {
-      touch(c, l);
+      overwrite(c, l);
       AMHIP_TRY(hipMemcpyAsync(c->layers[l], ups[l], bytes, hipMemcpyHostToDevice,
                                c->stream));
     }
@@ -951,9 +1011,11 @@ int amhip_ortho_backward_process(
                                     elevation_angle, num_observations,
                                     observation_index, colored_ortho};
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
-    if (downs[l])
+    if (downs[l]) {
+      if ((rc = materialize(c, l))) return rc;
       AMHIP_TRY(hipMemcpyAsync(downs[l], c->layers[l], bytes, hipMemcpyDeviceToHost,
                                c->stream));
+    }
   return fetch_status(c);
 }
 

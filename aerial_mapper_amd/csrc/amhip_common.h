@@ -95,6 +95,11 @@ struct OrthoParams {
   // only valid when distortion == NONE
   double pl[4][3];
   int cull;
+  // lazy reset: elevation_angle / observation_index / the output layer are
+  // logically in their initial state but their memory is not filled -- do not
+  // read them, and write the initial values into every cell no view is
+  // accepted for; same for num_observations (initial 0: `+= itself` keeps it)
+  int virt_out, virt_nobs;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
@@ -121,7 +126,8 @@ struct Ctx {
                                      nullptr, nullptr, nullptr};
   // 0: holds its initial value since the last reset (a reset need not touch
   // it); 1: possibly written; 2: its device pointer was handed out (the caller
-  // may write at any time: always refilled)
+  // may write at any time: always refilled); 3: logically initial, memory not
+  // filled (lazy reset: the next producer kernel fuses the fill)
   unsigned char layer_state[AMHIP_NUM_LAYERS] = {1, 1, 1, 1, 1, 1};
   unsigned* dev_err = nullptr;   // device error word
   unsigned* host_err = nullptr;  // pinned mirror
@@ -210,7 +216,8 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
 // byte per cell, set where this call wrote a value; unfilled (may be null):
 // device counter of cells left without a value.
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled);
+            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
+            bool fill_untouched = false, float init_value = 0.0f);
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
               const uint8_t* dev_frames);
 

@@ -839,7 +839,17 @@ struct CellOut {
   unsigned char* __restrict__ mask;   // optional: set where a value was written
   unsigned* __restrict__ unfilled;    // optional: counts cells left without one
   unsigned* __restrict__ dev_err;
+  // The layer is logically in its initial state but its memory has not been
+  // filled (amhip_layers_reset is lazy): every cell this call leaves without a
+  // value gets the initial value written instead of being left untouched.
+  int fill_untouched;
+  float init_value;
 };
+
+__device__ __forceinline__ void leave_untouched(const DsmParams& p, const CellOut& o, int i,
+                                                int j) {
+  if (o.fill_untouched) o.layer[(size_t)i + (size_t)j * (size_t)p.rows] = o.init_value;
+}
 
 __device__ __forceinline__ void emit_value(const DsmParams& p, const CellOut& o, int i, int j,
                                            double v) {
@@ -906,7 +916,10 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
   scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
   bool done = finish_accum(p, o, i, j, acc);
   if (!done) done = cell_fallback_global(p, start, sorted, i, j, qx, qy, o);
-  if (!done && o.unfilled) atomicAdd(o.unfilled, 1u);
+  if (!done) {
+    leave_untouched(p, o, i, j);
+    if (o.unfilled) atomicAdd(o.unfilled, 1u);
+  }
 }
 
 // Pure global-memory gather: used when the first-level window is too wide for
@@ -1041,6 +1054,12 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   if (s_ctl[2] == 0) {  // empty neighbourhood: every cell stays untouched
     if (o.unfilled && tid == 0)
       atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
+    if (o.fill_untouched) {
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
+        if (i <= i_hi && j <= j_hi) leave_untouched(p, o, i, j);
+      }
+    }
     return;
   }
 
@@ -1253,7 +1272,10 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
       const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
       const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
       const bool done = cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, o);
-      if (!done && o.unfilled) atomicAdd(o.unfilled, 1u);
+      if (!done) {
+        leave_untouched(p, o, fi, fj);
+        if (o.unfilled) atomicAdd(o.unfilled, 1u);
+      }
     }
   }
 }
@@ -1262,8 +1284,9 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
 // host driver
 // ---------------------------------------------------------------------------
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled) {
-  const CellOut cell_out = {out, mask, unfilled, c->dev_err};
+            const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
+            bool fill_untouched, float init_value) {
+  const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value};
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   {

@@ -130,6 +130,17 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
+// aerial-mapper-grid-map.cc:40-48: elevation_angle 0, observation_index NaN,
+// ortho 255 / colored_ortho NaN
+__device__ __forceinline__ void write_initial(const OrthoParams& p, float* __restrict__ angle,
+                                              float* __restrict__ index, float* __restrict__ out,
+                                              int i, int j) {
+  const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+  angle[at] = 0.0f;
+  index[at] = __builtin_nanf("");
+  out[at] = p.colored ? __builtin_nanf("") : 255.0f;
+}
+
 __global__ void __launch_bounds__(kOrthoThreads)
 k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
                  const uint8_t* __restrict__ frames,
@@ -176,7 +187,16 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
     zmin = fminf(zmin, s_red[w]);
     zmax = fmaxf(zmax, s_red[kOrthoThreads / 64 + w]);
   }
-  if (!(zmin <= zmax)) return;  // no finite elevation in this tile
+  if (!(zmin <= zmax)) {  // no finite elevation in this tile: every cell keeps its values
+    if (p.virt_out && i_ok) {
+#pragma unroll
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int j = j0 + wid + c * (kOrthoThreads / 64);
+        if (j < p.cols) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+      }
+    }
+    return;
+  }
 
   // bounding sphere of the tile's landmarks (cell centres x elevation range)
   const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
@@ -215,7 +235,7 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   for (int c = 0; c < kCellsPerLane; ++c) {
     const int j = j0 + wid + c * (kOrthoThreads / 64);
     best[c] = 0.0f;
-    if (i_ok && j < p.cols)
+    if (i_ok && j < p.cols && !p.virt_out)
       best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
     have_f[c] = true;
     n2b[c] = 1.0;
@@ -325,7 +345,11 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
 #pragma unroll
   for (int c = 0; c < kCellsPerLane; ++c) {
     const int j = j0 + wid + c * (kOrthoThreads / 64);
-    if (!(i_ok && j < p.cols) || accepted[c] == 0) continue;
+    if (!(i_ok && j < p.cols)) continue;
+    if (accepted[c] == 0) {
+      if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+      continue;
+    }
     const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
     if (!have_f[c]) {
       // the winning view's angle, evaluated exactly like the reference does
@@ -337,10 +361,12 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
     observation_index[at] = (float)best_f[c];
     // layer_num_observations(x, y) += layer_num_observations(x, y), once per
     // accepted update (ortho-backward-grid.cc:183): doubles the stored value.
-    float nobs = num_observations[at];
-    if (nobs != 0.0f) {
-      for (int n = 0; n < accepted[c]; ++n) nobs += nobs;
-      num_observations[at] = nobs;
+    if (!p.virt_nobs) {
+      float nobs = num_observations[at];
+      if (nobs != 0.0f) {
+        for (int n = 0; n < accepted[c]; ++n) nobs += nobs;
+        num_observations[at] = nobs;
+      }
     }
     const uint8_t* px = frames + (size_t)best_f[c] * p.frame_stride +
                         (size_t)best_v[c] * p.row_step;

@@ -274,8 +274,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload + ": " + wl["desc"],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
-                       "step": "layers reset + %sDsm::process + OrthoBackwardGrid::process, "
-                               "inputs resident in HBM" %
+                       "step": "layers reset (lazy: the fills are fused into the kernels that "
+                               "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
+                               "%sDsm::process + OrthoBackwardGrid::process, inputs resident in HBM" %
                                ("halo exchange (RCCL all_to_all) + " if world > 1 else ""),
                        "parallelism": "one map, %d x 1 windows, one per GPU" % world},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),

@@ -151,10 +151,20 @@ int amhip_ctx_synchronize(amhip_ctx* ctx);
  *      GridMap's matrices do in incremental mode,
  *      main-ortho-backward-grid-incremental.cc:153-162) --------------------*/
 
-int amhip_layers_reset(amhip_ctx* ctx); /* AerialGridMap::initialize() values */
+/* AerialGridMap::initialize() values (aerial-mapper-grid-map.cc:40-48).  The
+ * reset is lazy: it writes nothing; the next call that produces a layer
+ * (DSM -> elevation, OrthoFromPcl -> ortho, OrthoBackwardGrid ->
+ * elevation_angle / observation_index / ortho|colored_ortho) also writes the
+ * initial value into the cells it leaves alone, and anything else that needs
+ * the memory (download, device pointer, a batch on top of uploaded layers)
+ * fills the layer first.  Observable contents are always those of an eager
+ * fill; AMHIP_EAGER_RESET=1 in the environment restores the plain fills. */
+int amhip_layers_reset(amhip_ctx* ctx);
 int amhip_layer_upload(amhip_ctx* ctx, int layer, const float* host);
 int amhip_layer_download(amhip_ctx* ctx, int layer, float* host);
-/* Device address of a layer (rows*cols floats) or NULL. */
+/* Device address of a layer (rows*cols floats) or NULL.  The layer is
+ * filled if its reset was still pending and is refilled eagerly from then on
+ * (the library cannot see writes through the pointer). */
 void* amhip_layer_device_ptr(amhip_ctx* ctx, int layer);
 
 /* ---- DSM: dsm::Dsm::process (dsm.cc:186-201) ----------------------------*/

@@ -482,3 +482,67 @@ def test_dsm_ignores_non_finite_points():
     got, want = _dsm_both(sc)
     S.assert_dsm_close(got, want)
     assert np.isnan(want).sum() > 0
+
+
+def _lazy_reset_scenario():
+    """DSM with large holes (whole tiles without points), a clustered corner
+    (over-full LDS tiles), the mosaic on top (tiles without elevation), then a
+    second round after reset().  Returns every layer after each stage."""
+    A = _A()
+    sc = S.Scene(90.0, 70.0, 0.25, 30000, seed=95, num_frames=5, altitude=470.0)
+    pts = sc.points[(sc.points[:, 0] < 5.0) | (sc.points[:, 1] > 20.0)]
+    rng = np.random.default_rng(3)
+    dense = np.c_[rng.uniform(-40, -32, 30000), rng.uniform(-30, -22, 30000),
+                  400.0 + rng.uniform(-0.5, 0.5, 30000)]
+    pts = np.ascontiguousarray(np.concatenate([pts, dense]))
+    inten = (np.arange(pts.shape[0]) % 251).astype(np.int32)
+    ncam = A.NCamera(sc.cam.fu, sc.cam.fv, sc.cam.cu, sc.cam.cv, sc.cam.width, sc.cam.height)
+    names = ["ortho", "elevation", "elevation_angle", "num_observations", "observation_index",
+             "colored_ortho"]
+    out = []
+    with _map_for(sc, A) as m:
+        for rnd in range(2):
+            A.Dsm(A.DsmSettings(), m).process(pts if rnd == 0 else pts[::3], m)
+            A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m).process(sc.poses, sc.frames, m)
+            out.append({n: m.get(n) for n in names})
+            m.reset()
+            A.Dsm(A.DsmSettings(), m).process(np.zeros((0, 3)), m)      # empty cloud: no-op
+            A.OrthoFromPcl(A.OrthoFromPclSettings()).process(pts[::2], inten[::2], m)
+            out.append({n: m.get(n) for n in names})
+            m.reset()
+    return out
+
+
+def test_lazy_reset_is_indistinguishable_from_eager_fills():
+    # amhip_layers_reset writes nothing; the producers fuse the fill.  Every layer
+    # must hold exactly what plain fills would have left (AMHIP_EAGER_RESET=1).
+    import os
+    import pickle
+    import subprocess
+    import sys
+    lazy = _lazy_reset_scenario()
+    code = ("import sys, pickle; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parity as T\n"
+            "sys.stdout.buffer.write(pickle.dumps(T._lazy_reset_scenario()))\n"
+            % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMHIP_EAGER_RESET="1"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    eager = pickle.loads(r.stdout)
+    assert len(eager) == len(lazy) == 4
+    for a, b in zip(lazy, eager):
+        for n in a:
+            # (the DSM's double sums may differ in order between runs: compare the
+            # pattern exactly and the values to the parity tolerance)
+            assert np.array_equal(np.isnan(a[n]), np.isnan(b[n])), n
+            np.testing.assert_allclose(np.nan_to_num(a[n]), np.nan_to_num(b[n]), rtol=0,
+                                       atol=1e-4 if n in ("elevation", "ortho") else 0, err_msg=n)
+    # untouched regions really hold the initial values
+    first = lazy[0]
+    assert np.isnan(first["elevation"]).sum() > 1000
+    assert (first["ortho"][np.isnan(first["elevation"])] == 255.0).all()
+    assert (first["elevation_angle"][np.isnan(first["elevation"])] == 0.0).all()
+    assert np.isnan(first["colored_ortho"]).all() and (first["num_observations"] == 0).all()
+    second = lazy[1]
+    assert np.isnan(second["elevation"]).all()          # reset + empty cloud
+    assert (second["ortho"] == 255.0).sum() > 1000 and (second["ortho"] != 255.0).sum() > 1000
