@@ -11,17 +11,26 @@
 // the inverse-squared-distance weights differs (bin order instead of kd-tree
 // visiting order), which moves the double sums by ~1e-16 relative.
 //
-// Kernels (all memory-bound integer/FP64 streaming work, no MFMA):
-//   k_dsm_bin_count   read xyz (24 B/pt), histogram the bins with global
-//                     atomics, remember each point's rank inside its bin
-//   k_scan_*          exclusive scan of the histogram -> bin start offsets
-//   k_dsm_scatter     read xyz + rank, write the (centre-shifted) point to its
-//                     slot: points of one bin become contiguous, bins of one
-//                     bin-row are contiguous, so a cell's window is one
-//                     contiguous span per bin-row
-//   k_dsm_gather      one lane per cell (64 consecutive rows of one column per
-//                     wave -> coalesced layer writes); radius search + IDW;
-//                     cells with an empty first search walk the ladder
+// Kernels (integer / FP64 streaming work, no MFMA), see DESIGN.md section 4:
+//   sort     k_dsm_p3_*      three-pass partition sort (default for >= 1 M
+//                            points): count -> two LDS-staged scatter passes ->
+//                            in-LDS placement per sub-partition
+//            k_dsm_stripe_*  two-level stripe sort (smaller clouds)
+//            k_dsm_bin_count / k_scan_* / k_dsm_scatter
+//                            one-level counting sort with global atomics
+//                            (very wide grids; fallback)
+//            All three leave the points of one bin contiguous, bins row-major,
+//            and bin_start[] = exclusive offsets.
+//   gather   k_dsm_gather_tiled   one workgroup per 64 x 16 (or 64 x 32) cells:
+//                            stage the tile's points in LDS once, re-bin them
+//                            at cell granularity, per-lane radius search +
+//                            division-free IDW; fallback ladder / overflow /
+//                            numerically extreme cells go to
+//            cell_global / cell_fallback_global / k_dsm_gather
+//                            the same search on the global bins (also used for
+//                            grids finer than 16 cells per radius and the
+//                            adaptive OrthoFromPcl passes)
+//   k_halo_select           multi-GPU: compact the points other windows need
 #include <cstdlib>
 
 #include "amhip_common.h"
@@ -154,7 +163,7 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
 }
 
 // ---------------------------------------------------------------------------
-// two-level stripe sort (the default binning path)
+// two-level stripe sort (clouds below the partition sort's threshold; AMHIP_SORT_TWO_LEVEL=1)
 // ---------------------------------------------------------------------------
 // The one-level counting sort above pays one device-scope atomic and two
 // random 24..64-byte HBM transactions per point.  The stripe sort replaces it:
