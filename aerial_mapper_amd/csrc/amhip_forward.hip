@@ -73,8 +73,12 @@ struct Mosaic {
   size_t undist_cap = 0;
   uint8_t* stage = nullptr;    // host frames staged to the device
   size_t stage_cap = 0;
-  FwdFrame* frames = nullptr;
+  FwdFrame* frames = nullptr;      // per-frame table of one call, device
   size_t frames_cap = 0;
+  FwdFrame* host_frames = nullptr; // its pinned staging copy
+  size_t host_frames_cap = 0;
+  hipEvent_t frames_event = nullptr;
+  bool frames_pending = false;
 };
 
 static int fwd_arg_fail(const char* msg) {
@@ -622,74 +626,105 @@ constexpr size_t kFwdChunkBytes = size_t(512) << 20;    // warped + mask + dist 
 // feed `F` device-resident frames, ascending, in chunks
 static int fwd_feed_frames(Mosaic* m, const double* T_G_C, size_t F, const uint8_t* frames,
                            size_t frame_stride, size_t row_step, int ch, bool quirk) {
-  std::vector<FwdFrame> host;
-  size_t f0 = 0;
-  while (f0 < F) {
-    // ---- plan one chunk ----------------------------------------------------------
-    host.clear();
-    size_t px = 0;
-    int max_w = 0, max_h = 0, ux0 = INT_MAX, uy0 = INT_MAX, ux1 = -1, uy1 = -1;
-    while (f0 + host.size() < F && (int)host.size() < kFwdMaxFrames) {
-      FwdFrame fr;
-      double M[9];
-      if (!frame_homography(m->cam, m->desc, T_G_C + 7 * (f0 + host.size()), quirk, M) ||
-          !invert3(M, fr.m))
-        return fwd_arg_fail("forward homography: degenerate frame (camera parallel to the ground?)");
-      fwd_region(m, M, &fr);
-      const size_t rpx = (size_t)fr.w * fr.h;
-      if (!host.empty() && (px + rpx) * (size_t)(ch + 2) > kFwdChunkBytes) break;
-      fr.off = px;
-      px += rpx;
-      if (rpx) {
-        max_w = std::max(max_w, fr.w);
-        max_h = std::max(max_h, fr.h);
-        ux0 = std::min(ux0, fr.x0);
-        uy0 = std::min(uy0, fr.y0);
-        ux1 = std::max(ux1, fr.x0 + fr.w - 1);
-        uy1 = std::max(uy1, fr.y0 + fr.h - 1);
-      }
-      host.push_back(fr);
+  if (F == 0) return AMHIP_OK;
+  // ---- plan: homography + region of every frame, cut into chunks ------------------
+  struct Chunk {
+    size_t first;
+    int count, max_w, max_h, ux0, uy0, ux1, uy1;
+    size_t px;
+  };
+  int rc;
+  // the pinned staging table of the previous call may still be in flight
+  if (m->frames_pending) {
+    AMHIP_TRY(hipEventSynchronize(m->frames_event));
+    m->frames_pending = false;
+  }
+  if (m->host_frames_cap < F) {
+    if (m->host_frames) AMHIP_TRY(hipHostFree(m->host_frames));
+    m->host_frames = nullptr;
+    m->host_frames_cap = 0;
+    const size_t want = F + F / 4 + 64;
+    AMHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&m->host_frames), want * sizeof(FwdFrame), 0));
+    m->host_frames_cap = want;
+  }
+  std::vector<Chunk> chunks;
+  Chunk cur = {0, 0, 0, 0, INT_MAX, INT_MAX, -1, -1, 0};
+  for (size_t f = 0; f < F; ++f) {
+    FwdFrame fr;
+    double M[9];
+    if (!frame_homography(m->cam, m->desc, T_G_C + 7 * f, quirk, M) || !invert3(M, fr.m))
+      return fwd_arg_fail("forward homography: degenerate frame (camera parallel to the ground?)");
+    fwd_region(m, M, &fr);
+    const size_t rpx = (size_t)fr.w * fr.h;
+    if (cur.count > 0 &&
+        (cur.count >= kFwdMaxFrames || (cur.px + rpx) * (size_t)(ch + 2) > kFwdChunkBytes)) {
+      chunks.push_back(cur);
+      cur = Chunk{f, 0, 0, 0, INT_MAX, INT_MAX, -1, -1, 0};
     }
-    const int G = (int)host.size();
-    const uint8_t* chunk_frames = frames + f0 * frame_stride;
-    f0 += (size_t)G;
-    if (px == 0) continue;  // none of the chunk's frames reaches the mosaic
-    // ---- run it -------------------------------------------------------------------
-    int rc;
-    if ((rc = ensure_capacity(&m->warped, &m->warped_cap, px * ch))) return rc;
-    if ((rc = ensure_capacity(&m->mask, &m->mask_cap, px))) return rc;
-    if ((rc = ensure_capacity(&m->dist, &m->dist_cap, px))) return rc;
-    {
-      void* p = m->frames;
-      size_t cap = m->frames_cap * sizeof(FwdFrame);
-      if ((rc = ensure_bytes(&p, &cap, (size_t)kFwdMaxFrames * sizeof(FwdFrame)))) return rc;
-      m->frames = static_cast<FwdFrame*>(p);
-      m->frames_cap = cap / sizeof(FwdFrame);
+    fr.off = cur.px;
+    cur.px += rpx;
+    ++cur.count;
+    if (rpx) {
+      cur.max_w = std::max(cur.max_w, fr.w);
+      cur.max_h = std::max(cur.max_h, fr.h);
+      cur.ux0 = std::min(cur.ux0, fr.x0);
+      cur.uy0 = std::min(cur.uy0, fr.y0);
+      cur.ux1 = std::max(cur.ux1, fr.x0 + fr.w - 1);
+      cur.uy1 = std::max(cur.uy1, fr.y0 + fr.h - 1);
     }
-    // (pageable source: wait so that `host` may be reused for the next chunk)
-    AMHIP_TRY(hipMemcpyAsync(m->frames, host.data(), (size_t)G * sizeof(FwdFrame),
-                             hipMemcpyHostToDevice, m->stream));
-    AMHIP_TRY(hipStreamSynchronize(m->stream));
-    FwdGeom g = fwd_geom(m, ch, frame_stride, row_step);
-    const uint8_t* src = chunk_frames;
+    m->host_frames[f] = fr;
+  }
+  chunks.push_back(cur);
+  size_t max_px = 0;
+  int max_count = 0;
+  for (const Chunk& c : chunks) {
+    max_px = std::max(max_px, c.px);
+    max_count = std::max(max_count, c.count);
+  }
+  if (max_px == 0) return AMHIP_OK;  // no frame reaches the mosaic
+  if ((rc = ensure_capacity(&m->warped, &m->warped_cap, max_px * ch))) return rc;
+  if ((rc = ensure_capacity(&m->mask, &m->mask_cap, max_px))) return rc;
+  if ((rc = ensure_capacity(&m->dist, &m->dist_cap, max_px))) return rc;
+  {
+    void* p = m->frames;
+    size_t cap = m->frames_cap * sizeof(FwdFrame);
+    if ((rc = ensure_bytes(&p, &cap, F * sizeof(FwdFrame)))) return rc;
+    m->frames = static_cast<FwdFrame*>(p);
+    m->frames_cap = cap / sizeof(FwdFrame);
+  }
+  FwdGeom g0 = fwd_geom(m, ch, frame_stride, row_step);
+  const size_t fbytes = (size_t)g0.iw * g0.ih * ch;
+  if (m->cam.distortion != AMHIP_DIST_NONE &&
+      (rc = ensure_capacity(&m->undist, &m->undist_cap, (size_t)max_count * fbytes)))
+    return rc;
+  // ONE pinned -> device copy of the whole table: nothing below waits on the host
+  AMHIP_TRY(hipMemcpyAsync(m->frames, m->host_frames, F * sizeof(FwdFrame), hipMemcpyHostToDevice,
+                           m->stream));
+  AMHIP_TRY(hipEventRecord(m->frames_event, m->stream));
+  m->frames_pending = true;
+  // ---- run the chunks ----------------------------------------------------------------
+  for (const Chunk& c : chunks) {
+    if (c.px == 0) continue;  // none of the chunk's frames reaches the mosaic
+    const int G = c.count;
+    const FwdFrame* table = m->frames + c.first;
+    FwdGeom g = g0;
+    const uint8_t* src = frames + c.first * frame_stride;
     if (m->cam.distortion != AMHIP_DIST_NONE) {
-      const size_t fbytes = (size_t)g.iw * g.ih * ch;
-      if ((rc = ensure_capacity(&m->undist, &m->undist_cap, (size_t)G * fbytes))) return rc;
       hipLaunchKernelGGL(k_fwd_undistort,
                          dim3((unsigned)((g.iw + 255) / 256), (unsigned)g.ih, (unsigned)G),
-                         dim3(256), 0, m->stream, m->cam, g, chunk_frames, G, m->undist);
+                         dim3(256), 0, m->stream, m->cam, g, src, G, m->undist);
       src = m->undist;
       g.frame_stride = fbytes;
       g.row_step = (size_t)g.iw * ch;
     }
     hipLaunchKernelGGL(k_fwd_warp,
-                       dim3((unsigned)((max_w + 255) / 256), (unsigned)max_h, (unsigned)G),
-                       dim3(256), 0, m->stream, g, m->frames, src, G, m->warped, m->mask);
+                       dim3((unsigned)((c.max_w + 255) / 256), (unsigned)c.max_h, (unsigned)G),
+                       dim3(256), 0, m->stream, g, table, src, G, m->warped, m->mask);
     AMHIP_TRY(hipGetLastError());
-    if ((rc = fwd_distance(m, m->frames, G, max_w, max_h, m->mask, m->dist))) return rc;
-    const int uw = ux1 - ux0 + 1, uh = uy1 - uy0 + 1;
+    if ((rc = fwd_distance(m, table, G, c.max_w, c.max_h, m->mask, m->dist))) return rc;
+    const int uw = c.ux1 - c.ux0 + 1, uh = c.uy1 - c.uy0 + 1;
     hipLaunchKernelGGL(k_fwd_feed, dim3((unsigned)((uw + 255) / 256), (unsigned)uh), dim3(256), 0,
-                       m->stream, m->frames, m->warped, m->dist, ch, G, g.mw, ux0, uy0, uw,
+                       m->stream, table, m->warped, m->dist, ch, G, g.mw, c.ux0, c.uy0, uw,
                        m->dst16, m->dst_weight);
     AMHIP_TRY(hipGetLastError());
   }
@@ -802,6 +837,11 @@ int amhip_mosaic_create(const amhip_mosaic_desc* desc, const amhip_camera* cam, 
       break;
     }
     m->stream = m->own_stream;
+    e = hipEventCreateWithFlags(&m->frames_event, hipEventDisableTiming);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "hipEventCreate", __FILE__, __LINE__);
+      break;
+    }
     void* p = nullptr;
     size_t cap = 0;
     if ((rc = ensure_bytes(&p, &cap, m->pixels * 3 * sizeof(int16_t)))) break;
@@ -838,6 +878,8 @@ int amhip_mosaic_destroy(amhip_mosaic* h) {
                   m->dist,  m->undist,     m->stage,    m->frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
+  if (m->host_frames) (void)hipHostFree(m->host_frames);
+  if (m->frames_event) (void)hipEventDestroy(m->frames_event);
   if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   delete h;
   return AMHIP_OK;
