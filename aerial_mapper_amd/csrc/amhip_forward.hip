@@ -432,13 +432,38 @@ k_fwd_dt_cols(const FwdFrame* __restrict__ fr, int mw, int mh, uint8_t* __restri
   if (x >= P.w) return;
   uint8_t* col = dist + P.off + x;
   const size_t w = (size_t)P.w;
+  // the chain d = min(v[y], d + 1) is cheap; what costs is the latency of the
+  // loads, so eight rows are fetched at a time before the chain runs over them
+  constexpr int U = 8;
   int d = 255;
-  for (int y = 0; y < P.h; ++y) {
+  int y = 0;
+  for (; y + U <= P.h; y += U) {
+    int v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = col[(size_t)(y + k) * w];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      d = min(v[k], min(d + 1, 255));
+      col[(size_t)(y + k) * w] = (uint8_t)d;
+    }
+  }
+  for (; y < P.h; ++y) {
     d = min((int)col[(size_t)y * w], min(d + 1, 255));
     col[(size_t)y * w] = (uint8_t)d;
   }
   d = 255;
-  for (int y = P.h - 1; y >= 0; --y) {
+  y = P.h - 1;
+  for (; y - U + 1 >= 0; y -= U) {
+    int v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = col[(size_t)(y - k) * w];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      d = min(v[k], min(d + 1, 255));
+      col[(size_t)(y - k) * w] = (uint8_t)d;
+    }
+  }
+  for (; y >= 0; --y) {
     d = min((int)col[(size_t)y * w], min(d + 1, 255));
     col[(size_t)y * w] = (uint8_t)d;
   }
@@ -452,32 +477,53 @@ __device__ __forceinline__ float feather_weight(int d) {
 }
 
 // FeatherBlender::feed for the G frames of a batch, ascending.  The launch
-// covers the union (ux0, uy0, uw, uh) of the frames' regions; a frame whose
-// region does not contain the pixel would add (short)(0 * 0) and weight 0.
+// covers the union (ux0, uy0, uw, uh) of the frames' regions; a workgroup owns a
+// strip of 256 pixels of one mosaic row, first lists (in ascending order) the
+// frames whose region meets the strip, then every pixel walks that short list.
+// A frame whose region does not contain the pixel would add (short)(0 * 0) and
+// weight 0.
 __global__ void __launch_bounds__(256)
 k_fwd_feed(const FwdFrame* __restrict__ fr, const uint8_t* __restrict__ warped,
            const uint8_t* __restrict__ dist, int ch, int G, int mw, int ux0, int uy0, int uw,
            int16_t* __restrict__ dst16, float* __restrict__ dst_weight) {
   __shared__ int s_roi[64][4];
   __shared__ unsigned long long s_off[64];
-  if (threadIdx.x < G) {
-    s_roi[threadIdx.x][0] = fr[threadIdx.x].x0;
-    s_roi[threadIdx.x][1] = fr[threadIdx.x].y0;
-    s_roi[threadIdx.x][2] = fr[threadIdx.x].w;
-    s_roi[threadIdx.x][3] = fr[threadIdx.x].h;
-    s_off[threadIdx.x] = fr[threadIdx.x].off;
+  __shared__ int s_n;
+  const int xs = ux0 + blockIdx.x * 256;  // the strip: [xs, xs + 256) x {y}
+  const int y = uy0 + blockIdx.y;
+  if (threadIdx.x < 64) {  // G <= 64: one wave builds the list with a ballot
+    bool meets = false;
+    int x0 = 0, y0 = 0, w = 0, h = 0;
+    if ((int)threadIdx.x < G) {
+      x0 = fr[threadIdx.x].x0;
+      y0 = fr[threadIdx.x].y0;
+      w = fr[threadIdx.x].w;
+      h = fr[threadIdx.x].h;
+      meets = w > 0 && y >= y0 && y < y0 + h && x0 < xs + 256 && x0 + w > xs;
+    }
+    const unsigned long long m = __ballot(meets);
+    if (meets) {
+      const int k = __popcll(m & ((1ull << threadIdx.x) - 1ull));
+      s_roi[k][0] = x0;
+      s_roi[k][1] = y0;
+      s_roi[k][2] = w;
+      s_roi[k][3] = h;
+      s_off[k] = fr[threadIdx.x].off;
+    }
+    if (threadIdx.x == 0) s_n = __popcll(m);
   }
   __syncthreads();
+  const int n = s_n;
   const int rx = blockIdx.x * 256 + threadIdx.x;
-  if (rx >= uw) return;
-  const int x = ux0 + rx, y = uy0 + blockIdx.y;
+  if (n == 0 || rx >= uw) return;
+  const int x = ux0 + rx;
   const size_t k = (size_t)y * mw + x;
   int16_t a0 = 0, a1 = 0, a2 = 0;
   float ws = 0.0f;
   bool loaded = false;
-  for (int f = 0; f < G; ++f) {
+  for (int f = 0; f < n; ++f) {
     const int px = x - s_roi[f][0], py = y - s_roi[f][1];
-    if (px < 0 || py < 0 || px >= s_roi[f][2] || py >= s_roi[f][3]) continue;
+    if (px < 0 || px >= s_roi[f][2]) continue;
     if (!loaded) {
       a0 = dst16[3 * k + 0];
       a1 = dst16[3 * k + 1];
