@@ -1000,9 +1000,13 @@ int amhip_ortho_backward_process(
   for (size_t f = 0; f < F; ++f) {
     if (!images[f]) return arg_fail("null image");
     if (steps[f] < row) return arg_fail("image step smaller than a row");
-    AMHIP_TRY(hipMemcpy2DAsync(c->stage_frames + f * frame, row, images[f], steps[f],
-                               row, (size_t)cam->height, hipMemcpyHostToDevice,
-                               c->stream));
+    if (steps[f] == row)  // dense rows (the usual cv::Mat): one linear copy
+      AMHIP_TRY(hipMemcpyAsync(c->stage_frames + f * frame, images[f], frame,
+                               hipMemcpyHostToDevice, c->stream));
+    else
+      AMHIP_TRY(hipMemcpy2DAsync(c->stage_frames + f * frame, row, images[f], steps[f],
+                                 row, (size_t)cam->height, hipMemcpyHostToDevice,
+                                 c->stream));
   }
   if ((rc = amhip_ortho_backward_process_dev(h, cam, host_T_G_C, F, c->stage_frames,
                                              frame, row, channels, colored)))

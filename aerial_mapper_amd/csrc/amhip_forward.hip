@@ -827,8 +827,11 @@ static int fwd_stage(Mosaic* m, const uint8_t* const* images, const size_t* step
   for (size_t f = 0; f < F; ++f) {
     if (!images[f]) return fwd_arg_fail("null image");
     if (steps[f] < row) return fwd_arg_fail("image step smaller than a row");
-    AMHIP_TRY(hipMemcpy2DAsync(m->stage + f * fb, row, images[f], steps[f], row,
-                               (size_t)m->cam.height, hipMemcpyHostToDevice, m->stream));
+    if (steps[f] == row)  // dense rows: one linear copy
+      AMHIP_TRY(hipMemcpyAsync(m->stage + f * fb, images[f], fb, hipMemcpyHostToDevice, m->stream));
+    else
+      AMHIP_TRY(hipMemcpy2DAsync(m->stage + f * fb, row, images[f], steps[f], row,
+                                 (size_t)m->cam.height, hipMemcpyHostToDevice, m->stream));
   }
   *frame_bytes = fb;
   return AMHIP_OK;

@@ -97,10 +97,14 @@ class AerialGridMap(object):
     def _layer_id(layer):
         return L.LAYER_NAMES.index(layer) if isinstance(layer, str) else int(layer)
 
-    def get(self, layer):
+    def get(self, layer, out=None):
         """Download a layer: float32 array of shape (cols, rows) -- numpy C order
-        of an Eigen column-major (rows, cols) matrix, so a[j, i] == layer(i, j)."""
-        out = np.empty((self.cols, self.rows), np.float32)
+        of an Eigen column-major (rows, cols) matrix, so a[j, i] == layer(i, j).
+        `out`: an existing array of that shape to fill (like the GridMap's own
+        matrices in the C++ shim) instead of a fresh allocation."""
+        if out is None:
+            out = np.empty((self.cols, self.rows), np.float32)
+        assert out.dtype == np.float32 and out.shape == (self.cols, self.rows) and out.flags.c_contiguous
         L.check(self._lib.amhip_layer_download(self._h, self._layer_id(layer),
                                                out.ctypes.data))
         return out

@@ -295,6 +295,10 @@ def main():
             # the reference-shaped call: cloud, frames and layers in host memory
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None
+            out_names = ["elevation"] + (["elevation_angle", "observation_index", "ortho"] if F else [])
+            # the caller's layer matrices exist (and are touched) before the call,
+            # like the GridMap's in the C++ shim
+            h_layers = {n: np.zeros((m.cols, m.rows), np.float32) for n in out_names}
             m.reset()
             m.synchronize()
             t0h = time.perf_counter()
@@ -302,8 +306,8 @@ def main():
             t1h = time.perf_counter()
             if F:
                 mosaic.process(poses, h_frames, m)
-            for name in (["elevation"] + (["elevation_angle", "observation_index", "ortho"] if F else [])):
-                m.get(name)
+            for name in out_names:
+                m.get(name, out=h_layers[name])
             t2h = time.perf_counter()
             out["pcie_inclusive"] = {
                 "ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
