@@ -59,9 +59,11 @@ def parse():
     ap.add_argument("--cpu-sample-side", type=int, default=4000,
                     help="cells per side of the sub-tile the CPU oracle is timed on")
     ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
-    ap.add_argument("--host-path", action="store_true",
-                    help="also time ONE pass through the host-buffer (drop-in) entry points, "
-                         "PCIe transfers included (reported as pcie_inclusive, never as value)")
+    ap.add_argument("--host-path", action="store_true", default=True,
+                    help="(default at N = 1) also time ONE pass through the host-buffer (drop-in) "
+                         "entry points, PCIe transfers included (reported as pcie_inclusive, never "
+                         "as value)")
+    ap.add_argument("--no-host-path", dest="host_path", action="store_false")
     return ap.parse_args()
 
 
