@@ -386,7 +386,83 @@ static void normalize3(double* v) {
   v[2] /= n;
 }
 
-static void make_ortho_params(const Ctx& c, const amhip_camera& cam,
+// Conservative view cone of a camera WITH distortion: the largest normalised
+// radius rho = sqrt(x^2 + y^2) / z a landmark can have and still project into
+// the image (plus margins).  The reference tests nothing but the image box
+// (ortho-backward-grid.cc:164-171), so where the distortion polynomial folds
+// back, far off-axis landmarks DO count as visible -- the bound covers that.
+// A landmark is visible only if |distort(p)| <= B, B = farthest image corner
+// (+1 pixel) in distorted normalised coordinates; |distort(p)| is bounded from
+// below by g(|p|), and the supremum of {r : g(r) <= B} is found on a grid with
+// a Lipschitz margin per step (so no dip between samples is missed) plus an
+// analytic tail.  false = no usable bound (the kernel then tests every frame).
+static bool distorted_view_cone(const amhip_camera& cam, double* cone) {
+  double B = 0.0;
+  const double us[2] = {-1.0, (double)cam.width}, vs[2] = {-1.0, (double)cam.height};
+  for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < 2; ++b) {
+      const double x = (us[a] - cam.cu) / cam.fu, y = (vs[b] - cam.cv) / cam.fv;
+      B = std::max(B, std::sqrt(x * x + y * y));
+    }
+  B = B * (1.0 + 1e-9) + 1e-9;
+  if (cam.distortion == AMHIP_DIST_RADTAN) {
+    const double k1 = cam.dist[0], k2 = cam.dist[1];
+    const double c = 4.5 * (std::fabs(cam.dist[2]) + std::fabs(cam.dist[3]));  // tangential <= c r^2
+    auto g = [&](double r) {
+      const double r2 = r * r;
+      return r * std::fabs(1.0 + k1 * r2 + k2 * r2 * r2) - c * r2;
+    };
+    auto lip = [&](double r) {
+      const double r2 = r * r;
+      return 1.0 + 3.0 * std::fabs(k1) * r2 + 5.0 * std::fabs(k2) * r2 * r2 + 2.0 * c * r;
+    };
+    const double Rmax = 1e4;
+    // tail r >= Rmax: the leading term must dominate for good
+    if (k2 != 0.0) {
+      const double lead = std::fabs(k2) * Rmax * Rmax * Rmax * Rmax;
+      if (!(lead > 2.0 * (std::fabs(k1) * Rmax * Rmax + 1.0 + c * Rmax)) ||
+          !(0.5 * lead * Rmax > 2.0 * B))
+        return false;
+    } else if (k1 != 0.0) {
+      const double lead = std::fabs(k1) * Rmax * Rmax;
+      if (!(lead > 2.0 * (1.0 + c * Rmax)) || !(0.5 * lead * Rmax > 2.0 * B)) return false;
+    } else if (c != 0.0) {
+      return false;  // r - c r^2: no bound
+    }
+    double rstar = 0.0;
+    double r = 0.0;
+    while (r < Rmax) {
+      const double h = r < 20.0 ? 5e-4 : r * 2.5e-5;
+      const double rn = r + h;
+      if (g(r) <= B + h * lip(rn)) rstar = rn;
+      r = rn;
+    }
+    if (!(rstar < 0.5 * Rmax)) return false;
+    *cone = rstar * (1.0 + 1e-6) + 1e-6;
+    return true;
+  }
+  if (cam.distortion == AMHIP_DIST_EQUIDISTANT) {
+    const double* k = cam.dist;
+    auto td = [&](double th) {
+      const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+      return std::fabs(th * (1.0 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8));
+    };
+    const double half_pi = 1.5707963267948966;
+    const double t2 = half_pi * half_pi, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double L = 1.0 + 3.0 * std::fabs(k[0]) * t2 + 5.0 * std::fabs(k[1]) * t4 +
+                     7.0 * std::fabs(k[2]) * t6 + 9.0 * std::fabs(k[3]) * t8;
+    const double h = 2e-5;
+    double tstar = 0.0;
+    for (double th = 0.0; th < half_pi; th += h)
+      if (td(th) <= B + h * L) tstar = th + h;
+    if (!(tstar < half_pi - 2e-3)) return false;  // sees (numerically) the whole half space
+    *cone = std::tan(tstar) * (1.0 + 1e-6) + 1e-6;
+    return true;
+  }
+  return false;
+}
+
+static void make_ortho_params(Ctx& c, const amhip_camera& cam,
                               size_t F, size_t frame_stride, size_t row_step,
                               int channels, int colored, OrthoParams* out) {
   const amhip_grid_desc& g = c.grid;
@@ -415,7 +491,34 @@ static void make_ortho_params(const Ctx& c, const amhip_camera& cam,
   // optical centre; a landmark with z > 0 projects into [0,W) x [0,H) only if
   // it is on the inner side of all four.
   p.cull = (cam.distortion == AMHIP_DIST_NONE && cam.fu > 0.0 && cam.fv > 0.0) ? 1 : 0;
-  if (p.cull) {
+  double cone = 0.0;
+  bool have_cone = false;
+  if (cam.distortion != AMHIP_DIST_NONE && cam.fu > 0.0 && cam.fv > 0.0 &&
+      !std::getenv("AMHIP_NO_DISTORTED_CULL")) {
+    // (a few hundred thousand evaluations: cached per camera)
+    if (c.cone_state == 0 || std::memcmp(&c.cone_cam, &cam, sizeof(cam)) != 0) {
+      c.cone_cam = cam;
+      c.cone_state = distorted_view_cone(cam, &c.cone) ? 1 : 2;
+    }
+    have_cone = c.cone_state == 1;
+    cone = c.cone;
+  }
+  if (have_cone) {
+    // every visible landmark has |x| <= cone * z and |y| <= cone * z
+    p.cull = 1;
+    double l[3] = {1.0, 0.0, cone}, r[3] = {-1.0, 0.0, cone};
+    double t[3] = {0.0, 1.0, cone}, b[3] = {0.0, -1.0, cone};
+    normalize3(l);
+    normalize3(r);
+    normalize3(t);
+    normalize3(b);
+    for (int k = 0; k < 3; ++k) {
+      p.pl[0][k] = l[k];
+      p.pl[1][k] = r[k];
+      p.pl[2][k] = t[k];
+      p.pl[3][k] = b[k];
+    }
+  } else if (p.cull) {
     const double W = cam.width, H = cam.height;
     double l[3] = {cam.fu, 0.0, cam.cu};          // u >= 0
     double r[3] = {-cam.fu, 0.0, W - cam.cu};     // u <  W

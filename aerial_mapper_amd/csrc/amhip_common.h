@@ -153,6 +153,9 @@ struct Ctx {
   size_t stage_points_cap = 0;
 
   // ortho workspaces
+  amhip_camera cone_cam = {};    // camera the cached view cone belongs to
+  double cone = 0.0;             // distorted_view_cone() result
+  int cone_state = 0;            // 0: none cached, 1: usable bound, 2: no bound
   FramePose* frame_poses = nullptr;
   size_t frame_pose_cap = 0;
   uint8_t* stage_frames = nullptr;

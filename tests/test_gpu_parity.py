@@ -546,3 +546,41 @@ def test_lazy_reset_is_indistinguishable_from_eager_fills():
     second = lazy[1]
     assert np.isnan(second["elevation"]).all()          # reset + empty cloud
     assert (second["ortho"] == 255.0).sum() > 1000 and (second["ortho"] != 255.0).sum() > 1000
+
+
+@pytest.mark.parametrize("kind,dist", [
+    ("radtan", (-0.28, 0.07, 2e-4, -1e-4)),      # monotone radial polynomial
+    ("radtan", (-0.30, 0.0, 1e-3, -5e-4)),       # folds back at rho ~ 1.8: far cells "visible"
+    ("equidistant", (-0.02, 0.004, -0.001, 0.0002)),
+    ("equidistant", (-0.8, 0.0, 0.0, 0.0)),      # theta_d returns to 0 at 64 deg off axis
+])
+def test_ortho_distorted_cameras_are_culled_conservatively(kind, dist):
+    # 30 m above ground over a 200 m map: most frames see a cell only far off
+    # axis or not at all.  With a distortion model the kernel culls frames
+    # against a cone derived from the distortion polynomial (incl. the regions
+    # where it folds back into the image, which the reference counts as
+    # visible); the result must equal the brute-force oracle bit for bit.
+    A = _A()
+    model = O.DIST_RADTAN if kind == "radtan" else O.DIST_EQUIDISTANT
+    sc = S.Scene(200.0, 160.0, 1.0, 60000, seed=96, num_frames=30, altitude=430.0,
+                 cam=S.camera(96, 54, 70.0, model, dist), tilt_deg=6.0)
+    rc, elevation, _ = O.dsm_process(sc.points, sc.grid)
+    assert rc == O.OK
+    layers = O.new_layers(sc.grid)
+    layers["elevation"] = elevation.copy()
+    assert O.ortho_process(sc.grid, sc.cam, sc.poses, sc.T_C_B, sc.frames, layers) == O.OK
+    seen = ~np.isnan(layers["observation_index"])
+    assert 0.05 < seen.mean()
+    with _map_for(sc, A) as m:
+        m.set("elevation", elevation)
+        ncam = A.NCamera(sc.cam.fu, sc.cam.fv, sc.cam.cu, sc.cam.cv, sc.cam.width, sc.cam.height,
+                         model, dist)
+        A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m).process(sc.poses, sc.frames, m)
+        got = {n: m.get(n) for n in ORTHO_LAYERS}
+    if kind == "equidistant":
+        # atan comes from two libms: allow the documented handful of cells
+        same = got["observation_index"].view(np.uint32) == layers["observation_index"].view(np.uint32)
+        same |= np.isnan(got["observation_index"]) & np.isnan(layers["observation_index"])
+        assert (~same).sum() <= 4
+    else:
+        S.assert_layers_equal(got, layers, ORTHO_LAYERS)
