@@ -218,6 +218,9 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
 // (OrthoFromPcl intensities).  out: the layer to write.  mask (may be null): one
 // byte per cell, set where this call wrote a value; unfilled (may be null):
 // device counter of cells left without a value.
+// amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
+int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+             const DsmParams& p);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
             bool fill_untouched = false, float init_value = 0.0f);

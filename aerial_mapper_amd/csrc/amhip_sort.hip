@@ -1,0 +1,848 @@
+// amhip_sort.hip -- binning of the point cloud on MI355X (gfx950).
+//
+// Replaces Dsm::initializeAndFillKdTree (aerial_mapper_dsm/src/dsm.cc:36-52):
+// instead of a kd-tree the points are sorted into a uniform grid of bins of
+// B x B cells (B = first search radius in cells), bins row-major, with
+// bin_start[] = exclusive offsets; dsm.cc:42-43's centre offsets are applied on
+// the way.  Three implementations produce the same order:
+//   k_dsm_p3_*      three-pass partition sort (default for >= 1 M points):
+//                   count -> two LDS-staged scatter passes -> in-LDS placement
+//   k_dsm_stripe_*  two-level stripe sort (smaller clouds)
+//   k_dsm_bin_count / k_scan_* / k_dsm_scatter
+//                   one-level counting sort with global atomics (very wide
+//                   grids; fallback)
+// plus k_halo_select, the multi-GPU halo compaction (same streaming shape).
+#include <cstdlib>
+
+#include "amhip_common.h"
+#include "amhip_device.h"
+
+namespace amhip {
+
+// ---------------------------------------------------------------------------
+// binning
+// ---------------------------------------------------------------------------
+constexpr uint32_t kNoRank = 0xFFFFFFFFu;
+
+// Bin of a (centre-shifted) point, or false if it lies more than M cells
+// outside the grid (it can then never be inside any cell's last fallback
+// radius).  Cell i has its centre at continuous coordinate ci == i.
+__device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
+                                          double py, uint32_t* bin) {
+  const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+  const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+  const double lo = -(double)p.M - 0.5;
+  const double hx = (double)(p.rows + p.M) - 0.5;
+  const double hy = (double)(p.cols + p.M) - 0.5;
+  if (!(cx >= lo && cx < hx && cy >= lo && cy < hy)) return false;  // NaN too
+  int ix = (int)floor(cx + 0.5) + p.M;
+  int iy = (int)floor(cy + 0.5) + p.M;
+  ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
+  iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
+  const int bx = ix / p.B;
+  const int by = iy / p.B;
+  *bin = (uint32_t)by * (uint32_t)p.nbx + (uint32_t)bx;
+  return true;
+}
+
+__global__ void __launch_bounds__(256)
+k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
+                uint32_t* __restrict__ cnt, uint32_t* __restrict__ rank) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += stride) {
+    const double x = xyz[3 * idx + 0];
+    const double y = xyz[3 * idx + 1];
+    const double px = x - p.sub_x;  // dsm.cc:42
+    const double py = y - p.sub_y;  // dsm.cc:43
+    uint32_t bin;
+    uint32_t r = kNoRank;
+    if (point_bin(p, px, py, &bin)) r = atomicAdd(&cnt[bin], 1u);
+    rank[idx] = r;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values, size_t n,
+              DsmParams p, const uint32_t* __restrict__ start,
+              const uint32_t* __restrict__ rank, double* __restrict__ sorted) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += stride) {
+    const uint32_t r = rank[idx];
+    if (r == kNoRank) continue;
+    const double x = xyz[3 * idx + 0];
+    const double y = xyz[3 * idx + 1];
+    const double z = values ? (double)values[idx] : xyz[3 * idx + 2];
+    const double px = x - p.sub_x;
+    const double py = y - p.sub_y;
+    uint32_t bin;
+    point_bin(p, px, py, &bin);  // same arithmetic as the count pass
+    const size_t slot = (size_t)start[bin] + r;
+    sorted[3 * slot + 0] = px;
+    sorted[3 * slot + 1] = py;
+    sorted[3 * slot + 2] = z;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// two-level stripe sort (clouds below the partition sort's threshold; AMHIP_SORT_TWO_LEVEL=1)
+// ---------------------------------------------------------------------------
+// The one-level counting sort above pays one device-scope atomic and two
+// random 24..64-byte HBM transactions per point.  The stripe sort replaces it:
+//   level 1  points -> STRIPES (a few consecutive bin rows, ~1000 stripes).
+//            Per-workgroup LDS histograms aggregate the global atomics (one
+//            per stripe per 16 K points) and every workgroup appends runs of
+//            consecutive points to each stripe -> near-streaming writes.
+//   level 2  one workgroup per stripe: LDS histogram over the stripe's bins,
+//            LDS scan -> bin_start[] for those bins, then the points are
+//            placed; a stripe is ~1 MB, so the second read and the random
+//            placement stay inside the XCD's L2.
+// Stripes are whole bin rows, so the final order is still row-major by bin.
+constexpr int kMaxStripes = 8192;
+constexpr int kMaxStripeBins = 8192;
+constexpr int kL1Threads = 256;
+constexpr int kL1Chunk = 65536;  // points per workgroup in the level-1 scatter (A/B: 16K..128K)
+constexpr int kL2Threads = 512;
+
+__device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, double py,
+                                             int* bx, int* by) {
+  const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+  const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+  const double lo = -(double)p.M - 0.5;
+  const double hx = (double)(p.rows + p.M) - 0.5;
+  const double hy = (double)(p.cols + p.M) - 0.5;
+  if (!(cx >= lo && cx < hx && cy >= lo && cy < hy)) return false;  // NaN too
+  int ix = (int)floor(cx + 0.5) + p.M;
+  int iy = (int)floor(cy + 0.5) + p.M;
+  ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
+  iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
+  *bx = ix / p.B;
+  *by = iy / p.B;
+  return true;
+}
+
+__global__ void __launch_bounds__(kL1Threads)
+k_dsm_stripe_count(const double* __restrict__ xyz, size_t n, DsmParams p,
+                   uint32_t* __restrict__ stripe_cnt) {
+  extern __shared__ uint32_t s_hist[];
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_hist[k] = 0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * kL1Threads;
+  for (size_t idx = (size_t)blockIdx.x * kL1Threads + threadIdx.x; idx < n; idx += stride) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_hist[by / p.stripe_rows], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
+    const uint32_t c = s_hist[k];
+    if (c) atomicAdd(&stripe_cnt[k], c);
+  }
+}
+
+// One block: stripe_start = exclusive scan of stripe_cnt (+ total), and a copy
+// that the level-1 scatter uses as its append cursors.
+__global__ void __launch_bounds__(1024)
+k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
+                  uint32_t* __restrict__ stripe_start, uint32_t* __restrict__ cursor) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  unsigned carry = 0;
+  for (int base = 0; base < nstripes; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned v = (i < nstripes) ? stripe_cnt[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
+    if (i < nstripes) {
+      stripe_start[i] = carry + ex;
+      cursor[i] = carry + ex;
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) stripe_start[nstripes] = carry;
+}
+
+__global__ void __launch_bounds__(kL1Threads)
+k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values,
+                     size_t n, DsmParams p, uint32_t* __restrict__ cursor,
+                     double* __restrict__ tmp) {
+  extern __shared__ uint32_t s_mem[];
+  uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
+  uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
+  const size_t c0 = (size_t)blockIdx.x * kL1Chunk;
+  const size_t c1 = min(c0 + (size_t)kL1Chunk, n);
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_cnt[k] = 0;
+  __syncthreads();
+  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;
+    const double py = xyz[3 * idx + 1] - p.sub_y;
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_cnt[by / p.stripe_rows], 1u);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
+    const uint32_t c = s_cnt[k];
+    s_base[k] = c ? atomicAdd(&cursor[k], c) : 0u;
+    s_cnt[k] = 0;
+  }
+  __syncthreads();
+  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {  // (L2 hits)
+    const double px = xyz[3 * idx + 0] - p.sub_x;
+    const double py = xyz[3 * idx + 1] - p.sub_y;
+    int bx, by;
+    if (point_bin_xy(p, px, py, &bx, &by)) {
+      const int st = by / p.stripe_rows;
+      const size_t slot = (size_t)s_base[st] + atomicAdd(&s_cnt[st], 1u);
+      tmp[3 * slot + 0] = px;
+      tmp[3 * slot + 1] = py;
+      tmp[3 * slot + 2] = values ? (double)values[idx] : xyz[3 * idx + 2];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kL2Threads)
+k_dsm_stripe_sort(const double* __restrict__ tmp, DsmParams p,
+                  const uint32_t* __restrict__ stripe_start,
+                  uint32_t* __restrict__ bin_start, double* __restrict__ sorted) {
+  extern __shared__ uint32_t s_bins[];  // bins of this stripe (+ scan scratch behind)
+  const int st = blockIdx.x;
+  const int row0 = st * p.stripe_rows;
+  const int nrow = min(p.stripe_rows, p.nby - row0);
+  const int nb = nrow * p.nbx;
+  uint32_t* s_scan = s_bins + nb;
+  const uint32_t g0 = stripe_start[st];
+  const uint32_t g1 = stripe_start[st + 1];
+  for (int k = threadIdx.x; k < nb; k += kL2Threads) s_bins[k] = 0;
+  __syncthreads();
+  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {
+    const double px = tmp[3 * (size_t)idx + 0];
+    const double py = tmp[3 * (size_t)idx + 1];
+    int bx, by;
+    point_bin_xy(p, px, py, &bx, &by);  // same arithmetic as level 1: always inside
+    atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
+  }
+  __syncthreads();
+  {
+    const int per = (nb + kL2Threads - 1) / kL2Threads;
+    const int lo = threadIdx.x * per;
+    const int hi = min(lo + per, nb);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<kL2Threads>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t* out_start = bin_start + (size_t)row0 * p.nbx;
+  for (int k = threadIdx.x; k < nb; k += kL2Threads) out_start[k] = g0 + s_bins[k];
+  if (st == p.nstripes - 1 && threadIdx.x == 0)
+    bin_start[(size_t)p.nbx * p.nby] = stripe_start[p.nstripes];
+  __syncthreads();
+  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {  // (L2 hits)
+    const double px = tmp[3 * (size_t)idx + 0];
+    const double py = tmp[3 * (size_t)idx + 1];
+    const double pz = tmp[3 * (size_t)idx + 2];
+    int bx, by;
+    point_bin_xy(p, px, py, &bx, &by);
+    const size_t slot = (size_t)g0 + atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
+    sorted[3 * slot + 0] = px;
+    sorted[3 * slot + 1] = py;
+    sorted[3 * slot + 2] = pz;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// three-pass partition sort (the default for clouds that are worth it)
+// ---------------------------------------------------------------------------
+// The stripe sort above appends 24-byte records to ~1000 open runs per
+// workgroup straight from registers; the partially written cache lines do not
+// survive in the L2 until their neighbours arrive, and the PMC counters show
+// 2-3x the algorithmic write traffic.  Here every pass sorts its chunk in LDS
+// first and then writes each run with consecutive lanes on consecutive
+// addresses, so whole lines leave the CU at once; the price is a third pass
+// (partition counts per pass are limited by run length = chunk / partitions):
+//   count    one read of the cloud: private LDS histograms over (k1, k2)
+//            [k1 = group of p3_r1 bin rows, k2 = (row in group, column block)],
+//            one row of counters per workgroup (no global atomics), then a
+//            reduction + scan -> the exact final position of every (k1, k2).
+//   pass 1   cloud -> k1 partitions      (<= 128, LDS-staged runs)
+//   pass 2   k1 partition -> its k2 sub-partitions (<= 256, LDS-staged runs)
+//   pass 3   one workgroup per sub-partition (~1.5 K points, fits LDS):
+//            counting sort by bin in LDS, bin_start[] for its bins, one
+//            contiguous coalesced copy out.
+// Sub-partitions are ordered (bin row, column block), so the result is the
+// same row-major-by-bin order the gather kernels expect.
+constexpr int kP3CountThreads = 1024;
+constexpr int kP3Threads = 512;
+constexpr int kP3Chunk = 2560;  // points staged per scatter workgroup (70 KB of LDS: 2 per CU)
+constexpr int kP3PerThread = kP3Chunk / kP3Threads;
+constexpr int kP3MaxKeys = 256;
+constexpr int kP3PlaceThreads = 256;
+constexpr int kP3PlaceMaxCap = 2048;  // LDS capacity (points) the register-resident path handles
+constexpr int kP3PlacePer = kP3PlaceMaxCap / kP3PlaceThreads;
+
+__device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
+                                        int* k2) {
+  int bx, by;
+  if (!point_bin_xy(p, px, py, &bx, &by)) return false;
+  const int a = by / p.p3_r1;
+  *k1 = a;
+  *k2 = (by - a * p.p3_r1) * p.p3_c + bx / p.p3_w;
+  return true;
+}
+
+__global__ void __launch_bounds__(kP3CountThreads)
+k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
+               uint32_t* __restrict__ hist_rows) {
+  extern __shared__ uint32_t s_hist[];
+  const int nk = p.p3_n1 * p.p3_n2;
+  for (int k = threadIdx.x; k < nk; k += kP3CountThreads) s_hist[k] = 0;
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * kP3CountThreads;
+  for (size_t idx = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; idx < n; idx += stride) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+    int k1, k2;
+    if (p3_keys(p, px, py, &k1, &k2)) atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+  }
+  __syncthreads();
+  uint32_t* row = hist_rows + (size_t)blockIdx.x * nk;
+  for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
+}
+
+__global__ void __launch_bounds__(256)
+k_dsm_p3_reduce(const uint32_t* __restrict__ hist_rows, int nrows, int nk,
+                uint32_t* __restrict__ cnt) {
+  // 64 counters per workgroup, the rows dealt to its four waves
+  __shared__ uint32_t s_part[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  uint32_t s = 0;
+  if (k < nk)
+    for (int r = wid; r < nrows; r += 4) s += hist_rows[(size_t)r * nk + k];
+  s_part[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
+}
+
+// One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
+// copy as the pass-2 append cursors; start1 / cursor1 for pass 1; blk2 = first
+// pass-2 workgroup of every k1 partition (partitions are cut into chunks).
+__global__ void __launch_bounds__(1024)
+k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
+              uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
+              uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
+              uint32_t* __restrict__ blk2) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  __shared__ unsigned s_start1[kP3MaxKeys + 1];
+  const int nk = n1 * n2;
+  unsigned carry = 0;
+  for (int base = 0; base < nk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned v = (i < nk) ? cnt[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
+    if (i < nk) {
+      start2[i] = carry + ex;
+      cursor2[i] = carry + ex;
+      if (i % n2 == 0) s_start1[i / n2] = carry + ex;
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    start2[nk] = carry;
+    s_start1[n1] = carry;
+  }
+  __syncthreads();
+  const int k = threadIdx.x;
+  unsigned nblk = 0;
+  if (k < n1) {
+    start1[k] = s_start1[k];
+    cursor1[k] = s_start1[k];
+    nblk = (s_start1[k + 1] - s_start1[k] + kP3Chunk - 1) / kP3Chunk;
+  }
+  if (k == 0) start1[n1] = carry;
+  unsigned total;
+  const unsigned ex = block_excl_scan<1024>(nblk, &total, lds);
+  if (k < n1) blk2[k] = ex;
+  if (k == 0) blk2[n1] = total;
+}
+
+// Passes 1 and 2.  kFirst: chunk of the input cloud, key k1, values/centre
+// handling of the reference; else: chunk of one k1 partition, key k2.
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ values, size_t n,
+                 DsmParams p, const uint32_t* __restrict__ start1,
+                 const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
+                 double* __restrict__ dst) {
+  extern __shared__ double s_pts[];                                       // 3 * kP3Chunk
+  uint32_t* s_dest = reinterpret_cast<uint32_t*>(s_pts + 3 * kP3Chunk);   // kP3Chunk
+  uint32_t* s_cnt = s_dest + kP3Chunk;                                    // kP3MaxKeys
+  uint32_t* s_off = s_cnt + kP3MaxKeys;
+  uint32_t* s_base = s_off + kP3MaxKeys;
+  uint32_t* s_scan = s_base + kP3MaxKeys;  // 24
+  const int tid = threadIdx.x;
+  int nkeys;
+  size_t c0, c1;
+  if (kFirst) {
+    c0 = (size_t)blockIdx.x * kP3Chunk;
+    c1 = min(c0 + (size_t)kP3Chunk, n);
+    nkeys = p.p3_n1;
+  } else {
+    const int n1 = p.p3_n1;
+    const uint32_t b = blockIdx.x;
+    if (b >= blk2[n1]) return;
+    int lo = 0, hi = n1;  // blk2[lo] <= b < blk2[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (blk2[mid] <= b) lo = mid; else hi = mid;
+    }
+    c0 = (size_t)start1[lo] + (size_t)(b - blk2[lo]) * kP3Chunk;
+    c1 = min(c0 + (size_t)kP3Chunk, (size_t)start1[lo + 1]);
+    nkeys = p.p3_n2;
+    cursor += (size_t)lo * p.p3_n2;
+  }
+  if (tid < kP3MaxKeys) s_cnt[tid] = 0;
+  __syncthreads();
+  double px[kP3PerThread], py[kP3PerThread], pz[kP3PerThread];
+  uint32_t slot[kP3PerThread];  // key << 12 | rank in the chunk's run of that key
+#pragma unroll
+  for (int k = 0; k < kP3PerThread; ++k) {
+    const size_t idx = c0 + tid + (size_t)k * kP3Threads;
+    slot[k] = 0xFFFFFFFFu;
+    if (idx < c1) {
+      double x = src[3 * idx + 0], y = src[3 * idx + 1];
+      double z;
+      if (kFirst) {
+        x -= p.sub_x;
+        y -= p.sub_y;
+        z = values ? (double)values[idx] : src[3 * idx + 2];
+      } else {
+        z = src[3 * idx + 2];
+      }
+      px[k] = x;
+      py[k] = y;
+      pz[k] = z;
+      int k1, k2;
+      if (p3_keys(p, x, y, &k1, &k2)) {
+        const int key = kFirst ? k1 : k2;
+        slot[k] = ((uint32_t)key << 12) | atomicAdd(&s_cnt[key], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
+    if (tid < nkeys) {
+      s_off[tid] = ex;
+      s_base[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+    }
+    if (tid == 0) s_scan[23] = total;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kP3PerThread; ++k) {
+    if (slot[k] != 0xFFFFFFFFu) {
+      const uint32_t key = slot[k] >> 12, rank = slot[k] & 0xFFFu;
+      const uint32_t q = s_off[key] + rank;
+      s_pts[3 * q + 0] = px[k];
+      s_pts[3 * q + 1] = py[k];
+      s_pts[3 * q + 2] = pz[k];
+      s_dest[q] = s_base[key] + rank;
+    }
+  }
+  __syncthreads();
+  const uint32_t ne = 3u * s_scan[23];
+  for (uint32_t e = tid; e < ne; e += kP3Threads) {
+    const uint32_t q = e / 3u;
+    dst[3 * (size_t)s_dest[q] + (e - 3u * q)] = s_pts[e];
+  }
+}
+
+// Pass 3: one workgroup per (k1, k2) sub-partition.
+__global__ void __launch_bounds__(kP3PlaceThreads)
+k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
+               const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+               double* __restrict__ sorted) {
+  extern __shared__ double s_pts[];                                  // 3 * cap
+  uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
+  uint32_t* s_scan = s_bins + p.p3_w;                                // 24
+  const int tid = threadIdx.x;
+  const int sp = blockIdx.x;
+  const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
+  const int rr = k2 / p.p3_c;
+  const int row = k1 * p.p3_r1 + rr;
+  const int bx0 = (k2 - rr * p.p3_c) * p.p3_w;
+  const int nbw = min(p.p3_w, p.nbx - bx0);
+  if (sp == 0 && tid == 0)
+    bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
+  if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
+  const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  for (int k = tid; k < nbw; k += kP3PlaceThreads) s_bins[k] = 0;
+  __syncthreads();
+  const bool in_lds = (int)(g1 - g0) <= cap && cap <= kP3PlaceMaxCap;
+  // the sub-partition is read ONCE: a thread keeps its points (<= 8) in
+  // registers between the count and the placement
+  double px[kP3PlacePer], py[kP3PlacePer], pz[kP3PlacePer];
+  int pb[kP3PlacePer];
+  if (in_lds) {
+#pragma unroll
+    for (int k = 0; k < kP3PlacePer; ++k) {
+      const uint32_t idx = g0 + tid + (uint32_t)k * kP3PlaceThreads;
+      pb[k] = -1;
+      if (idx < g1) {
+        px[k] = src[3 * (size_t)idx + 0];
+        py[k] = src[3 * (size_t)idx + 1];
+        pz[k] = src[3 * (size_t)idx + 2];
+        int bx, by;
+        point_bin_xy(p, px[k], py[k], &bx, &by);
+        pb[k] = bx - bx0;
+        atomicAdd(&s_bins[pb[k]], 1u);
+      }
+    }
+  } else {
+    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+      int bx, by;
+      point_bin_xy(p, src[3 * (size_t)idx + 0], src[3 * (size_t)idx + 1], &bx, &by);
+      atomicAdd(&s_bins[bx - bx0], 1u);
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (nbw + kP3PlaceThreads - 1) / kP3PlaceThreads;
+    const int lo = tid * per;
+    const int hi = min(lo + per, nbw);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<kP3PlaceThreads>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
+  for (int k = tid; k < nbw; k += kP3PlaceThreads) out_start[k] = g0 + s_bins[k];
+  __syncthreads();
+  if (!in_lds) {
+    // over-full sub-partition (clustered cloud): second read, direct placement
+    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+      const double x = src[3 * (size_t)idx + 0];
+      const double y = src[3 * (size_t)idx + 1];
+      const double z = src[3 * (size_t)idx + 2];
+      int bx, by;
+      point_bin_xy(p, x, y, &bx, &by);
+      const size_t o = (size_t)g0 + atomicAdd(&s_bins[bx - bx0], 1u);
+      sorted[3 * o + 0] = x;
+      sorted[3 * o + 1] = y;
+      sorted[3 * o + 2] = z;
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < kP3PlacePer; ++k) {
+    if (pb[k] >= 0) {
+      const uint32_t q = atomicAdd(&s_bins[pb[k]], 1u);
+      s_pts[3 * q + 0] = px[k];
+      s_pts[3 * q + 1] = py[k];
+      s_pts[3 * q + 2] = pz[k];
+    }
+  }
+  __syncthreads();
+  const uint32_t ne = 3u * (g1 - g0);
+  double* out = sorted + 3 * (size_t)g0;
+  for (uint32_t e = tid; e < ne; e += kP3PlaceThreads) out[e] = s_pts[e];
+}
+
+// ---------------------------------------------------------------------------
+// multi-GPU: compact the points other windows need (their halo)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_halo_select(const double* __restrict__ xyz, size_t n, HaloParams hp,
+              double* __restrict__ out, unsigned long long* __restrict__ counts) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
+       idx += stride) {
+    const double x = xyz[3 * idx + 0];
+    const double y = xyz[3 * idx + 1];
+    // continuous cell coordinates in the full map (same frame as point_bin)
+    const double cx = (hp.base_x - (x - hp.sub_x)) * hp.inv_res;
+    const double cy = (hp.base_y - (y - hp.sub_y)) * hp.inv_res;
+#pragma unroll
+    for (int d = 0; d < kMaxHaloDests; ++d) {
+      if (d < hp.nd && cx >= hp.lo_i[d] && cx <= hp.hi_i[d] && cy >= hp.lo_j[d] &&
+          cy <= hp.hi_j[d]) {
+        const unsigned long long slot = atomicAdd(&counts[d], 1ull);
+        if (slot < hp.cap) {
+          double* o = out + ((size_t)d * hp.cap + slot) * 3;
+          o[0] = x;
+          o[1] = y;
+          o[2] = xyz[3 * idx + 2];
+        }
+      }
+    }
+  }
+}
+
+int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
+                    double* dev_out, unsigned long long* dev_counts) {
+  ScopedTimer t(c, AMHIP_K_HALO_SELECT);
+  AMHIP_TRY(hipMemsetAsync(dev_counts, 0, sizeof(unsigned long long) * hp.nd, c->stream));
+  if (n == 0) return AMHIP_OK;
+  size_t grid = (n + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(k_halo_select, dim3((unsigned)grid), dim3(256), 0, c->stream,
+                     dev_xyz, n, hp, dev_out, dev_counts);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan of a u32 array, in place (3 launches)
+// ---------------------------------------------------------------------------
+constexpr int kScanT = 256;
+constexpr int kScanI = 16;
+constexpr int kScanE = kScanT * kScanI;
+
+__global__ void __launch_bounds__(kScanT)
+k_scan_partials(const uint32_t* __restrict__ in, size_t n,
+                uint32_t* __restrict__ partials) {
+  __shared__ unsigned lds[kScanT / 64 + 1];
+  const size_t base = (size_t)blockIdx.x * kScanE + (size_t)threadIdx.x * kScanI;
+  unsigned s = 0;
+  if (base + kScanI <= n) {
+    const uint4* v = reinterpret_cast<const uint4*>(in + base);
+#pragma unroll
+    for (int k = 0; k < kScanI / 4; ++k) {
+      const uint4 q = v[k];
+      s += q.x + q.y + q.z + q.w;
+    }
+  } else {
+    for (int k = 0; k < kScanI; ++k)
+      if (base + k < n) s += in[base + k];
+  }
+  unsigned total;
+  (void)block_excl_scan<kScanT>(s, &total, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// One block; exclusive scan of partials[0..nb) in place, grand total to *total.
+__global__ void __launch_bounds__(1024)
+k_scan_top(uint32_t* __restrict__ partials, size_t nb,
+           uint32_t* __restrict__ total_out) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  unsigned carry = 0;
+  for (size_t base = 0; base < nb; base += 1024) {
+    const size_t i = base + threadIdx.x;
+    const unsigned v = (i < nb) ? partials[i] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
+    if (i < nb) partials[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(kScanT)
+k_scan_final(uint32_t* __restrict__ data, size_t n,
+             const uint32_t* __restrict__ partials) {
+  __shared__ unsigned lds[kScanT / 64 + 1];
+  const size_t base = (size_t)blockIdx.x * kScanE + (size_t)threadIdx.x * kScanI;
+  unsigned v[kScanI];
+  const bool full = base + kScanI <= n;
+  if (full) {
+    const uint4* src = reinterpret_cast<const uint4*>(data + base);
+#pragma unroll
+    for (int k = 0; k < kScanI / 4; ++k) {
+      const uint4 q = src[k];
+      v[4 * k + 0] = q.x;
+      v[4 * k + 1] = q.y;
+      v[4 * k + 2] = q.z;
+      v[4 * k + 3] = q.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanI; ++k) v[k] = (base + k < n) ? data[base + k] : 0u;
+  }
+  unsigned s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanI; ++k) s += v[k];
+  unsigned total;
+  unsigned run = block_excl_scan<kScanT>(s, &total, lds) + partials[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanI; ++k) {
+    const unsigned t = v[k];
+    v[k] = run;
+    run += t;
+  }
+  if (full) {
+    uint4* dst = reinterpret_cast<uint4*>(data + base);
+#pragma unroll
+    for (int k = 0; k < kScanI / 4; ++k)
+      dst[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < kScanI; ++k)
+      if (base + k < n) data[base + k] = v[k];
+  }
+}
+
+
+// ---------------------------------------------------------------------------
+// host driver: sort `n` points into c->sorted / c->bin_start
+// ---------------------------------------------------------------------------
+int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+             const DsmParams& p) {
+  const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
+  const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
+  {
+    int rc;
+    if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * n))) return rc;
+    if ((rc = ensure_capacity(&c->bin_start, &c->bin_cap, nbins + 4))) return rc;
+  }
+  c->last_num_bins = (int64_t)nbins;
+  c->last_bin_cells = p.B;
+
+  static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
+  static const bool force_two_level = getenv("AMHIP_SORT_TWO_LEVEL") != nullptr;
+  if (p.p3_n1 > 0 && !force_one_level && !force_two_level) {
+    // ---- three-pass partition sort ---------------------------------------------
+    const int n1 = p.p3_n1, n2 = p.p3_n2, nk = n1 * n2;
+    size_t gcount = (n + 8191) / 8192;
+    if (gcount > 256) gcount = 256;
+    if (gcount < 1) gcount = 1;
+    int rc;
+    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
+    const size_t ws_words = gcount * (size_t)nk + 3 * (size_t)nk + 3 * (size_t)n1 + 16;
+    if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, ws_words))) return rc;
+    uint32_t* hist_rows = c->stripe_ws;
+    uint32_t* cnt = hist_rows + gcount * (size_t)nk;
+    uint32_t* start2 = cnt + nk;       // nk + 1
+    uint32_t* cursor2 = start2 + nk + 1;
+    uint32_t* start1 = cursor2 + nk;   // n1 + 1
+    uint32_t* cursor1 = start1 + n1 + 1;
+    uint32_t* blk2 = cursor1 + n1;     // n1 + 1
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      const size_t lds = (size_t)nk * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dsm_p3_count, dim3((unsigned)gcount), dim3(kP3CountThreads), lds,
+                         c->stream, dev_xyz, n, p, hist_rows);
+      hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
+                         c->stream, hist_rows, (int)gcount, nk, cnt);
+      hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
+                         cursor2, start1, cursor1, blk2);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      const size_t lds = (size_t)kP3Chunk * 28 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
+      hipLaunchKernelGGL(k_dsm_p3_scatter<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
+                         c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted);
+      hipLaunchKernelGGL(k_dsm_p3_scatter<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
+                         lds, c->stream, c->sorted, (const int32_t*)nullptr, n, p, start1, blk2,
+                         cursor2, c->tmp_points);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
+                         c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
+  } else if (p.nstripes > 0 && !force_one_level) {
+    // ---- two-level stripe sort ------------------------------------------------
+    int rc;
+    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
+    if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, 3 * (size_t)p.nstripes + 8)))
+      return rc;
+    uint32_t* stripe_cnt = c->stripe_ws;
+    uint32_t* stripe_start = c->stripe_ws + p.nstripes;          // nstripes + 1
+    uint32_t* stripe_cursor = c->stripe_ws + 2 * p.nstripes + 1;  // nstripes
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      AMHIP_TRY(hipMemsetAsync(stripe_cnt, 0, p.nstripes * sizeof(uint32_t), c->stream));
+      size_t grid = (n + kL1Threads - 1) / kL1Threads;
+      if (grid > 256 * 8) grid = 256 * 8;
+      hipLaunchKernelGGL(k_dsm_stripe_count, dim3((unsigned)grid), dim3(kL1Threads),
+                         p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, n, p, stripe_cnt);
+      hipLaunchKernelGGL(k_dsm_stripe_scan, dim3(1), dim3(1024), 0, c->stream, stripe_cnt,
+                         p.nstripes, stripe_start, stripe_cursor);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      const size_t grid = (n + kL1Chunk - 1) / kL1Chunk;
+      hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
+                         2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, dev_values, n,
+                         p, stripe_cursor, c->tmp_points);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      const size_t lds = ((size_t)p.stripe_rows * p.nbx + 32) * sizeof(uint32_t);
+      hipLaunchKernelGGL(k_dsm_stripe_sort, dim3((unsigned)p.nstripes), dim3(kL2Threads), lds,
+                         c->stream, c->tmp_points, p, stripe_start, c->bin_start, c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
+  } else {
+    // ---- one-level counting sort (fallback: very wide grids, or forced) --------
+    {
+      int rc;
+      if ((rc = ensure_capacity(&c->rank, &c->rank_cap, n))) return rc;
+      if ((rc = ensure_capacity(&c->scan_partials, &c->partial_cap, nblocks_scan + 4))) return rc;
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_MISC);
+      AMHIP_TRY(hipMemsetAsync(c->bin_start, 0, (nbins + 1) * sizeof(uint32_t), c->stream));
+    }
+    const int block = 256;
+    size_t grid_pts = (n + block - 1) / block;
+    if (grid_pts > 256 * 16) grid_pts = 256 * 16;
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
+                         dev_xyz, n, p, c->bin_start, c->rank);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+      hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan), dim3(kScanT), 0,
+                         c->stream, c->bin_start, nbins, c->scan_partials);
+      hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->scan_partials,
+                         nblocks_scan, c->bin_start + nbins);
+      hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT), 0, c->stream,
+                         c->bin_start, nbins, c->scan_partials);
+      AMHIP_TRY(hipGetLastError());
+    }
+    {
+      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+      hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
+                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted);
+      AMHIP_TRY(hipGetLastError());
+    }
+  }
+  return AMHIP_OK;
+}
+
+}  // namespace amhip
