@@ -412,7 +412,7 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
   if (tid < kP3MaxKeys) s_cnt[tid] = 0;
   __syncthreads();
   double px[kP3PerThread], py[kP3PerThread], pz[kP3PerThread];
-  uint32_t slot[kP3PerThread];  // key << 12 | rank in the chunk's run of that key
+  uint32_t slot[kP3PerThread];  // key << 13 | rank in the chunk's run of that key
 #pragma unroll
   for (int k = 0; k < kP3PerThread; ++k) {
     const size_t idx = c0 + tid + (size_t)k * kP3Threads;
@@ -433,7 +433,7 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
       int k1, k2;
       if (p3_keys(p, x, y, &k1, &k2)) {
         const int key = kFirst ? k1 : k2;
-        slot[k] = ((uint32_t)key << 12) | atomicAdd(&s_cnt[key], 1u);
+        slot[k] = ((uint32_t)key << 13) | atomicAdd(&s_cnt[key], 1u);
       }
     }
   }
@@ -452,7 +452,7 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
 #pragma unroll
   for (int k = 0; k < kP3PerThread; ++k) {
     if (slot[k] != 0xFFFFFFFFu) {
-      const uint32_t key = slot[k] >> 12, rank = slot[k] & 0xFFFu;
+      const uint32_t key = slot[k] >> 13, rank = slot[k] & 0x1FFFu;
       const uint32_t q = s_off[key] + rank;
       s_pts[3 * q + 0] = px[k];
       s_pts[3 * q + 1] = py[k];
