@@ -584,3 +584,83 @@ def test_ortho_distorted_cameras_are_culled_conservatively(kind, dist):
         assert (~same).sum() <= 4
     else:
         S.assert_layers_equal(got, layers, ORTHO_LAYERS)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_dsm_random_configurations(seed):
+    # randomized sweep over grid shape, resolution, squared radius, density,
+    # map centre / dsm centre offsets and an optional dense cluster: exercises the
+    # window tables (odd and even radii in cells), both tile heights, the LDS
+    # capacity heuristics, the fallback ladder and the sort paths by size
+    rng = np.random.default_rng(1000 + seed)
+    res = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 2.0]))
+    cells_x = int(rng.integers(3, 500))
+    cells_y = int(rng.integers(3, 400))
+    while cells_x * cells_y > 160000:
+        cells_x = max(3, cells_x // 2)
+    lx, ly = cells_x * res, cells_y * res
+    radius = int(rng.choice([1, 1, 2, 3, 5]))
+    density = float(rng.choice([0.05, 0.3, 1.0, 4.0, 12.0, 40.0]))          # points per m^2
+    n = int(min(250000, max(1, density * (lx + 6) * (ly + 6))))
+    center = (float(rng.uniform(-500, 500)), float(rng.uniform(-500, 500)))
+    ce, cn = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3))) if seed % 3 == 0 else (0.0, 0.0)
+    sc = S.Scene(lx, ly, res, n, seed=2000 + seed, center=center,
+                 point_extent=max(lx, ly) / 2.0 + 3.0)
+    pts = sc.points
+    if seed % 4 == 1:      # a dense cluster somewhere inside
+        k = min(20000, n)
+        c0 = np.array([center[0] + rng.uniform(-lx / 4, lx / 4), center[1] + rng.uniform(-ly / 4, ly / 4)])
+        cl = np.c_[c0[0] + rng.normal(0, 2 * res, k), c0[1] + rng.normal(0, 2 * res, k),
+                   400.0 + rng.uniform(-1, 1, k)]
+        pts = np.concatenate([pts, cl])
+    # dsm.cc:42-43 subtracts center_NORTHING from x and center_EASTING from y
+    pts = pts + np.array([cn, ce, 0.0])
+    sc.points = np.ascontiguousarray(pts)
+    # an exact hit would abort both implementations: nudge coincident points
+    got, want = _dsm_both(sc, radius=radius, ce=ce, cn=cn)
+    S.assert_dsm_close(got, want)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ortho_random_configurations(seed):
+    # randomized sweep over image size / focal length / principal point, flight
+    # altitude and tilt (up to horizon-grazing), T_C_B, batch splitting, colour,
+    # distortion model and elevation holes; every layer must match the oracle
+    rng = np.random.default_rng(3000 + seed)
+    A = _A()
+    W, H = int(rng.integers(40, 200)), int(rng.integers(30, 150))
+    f = float(rng.uniform(0.5, 1.6) * W)
+    model = [O.DIST_NONE, O.DIST_NONE, O.DIST_RADTAN][seed % 3]
+    dist = (float(rng.uniform(-0.3, 0.05)), float(rng.uniform(-0.02, 0.08)),
+            float(rng.uniform(-1e-3, 1e-3)), float(rng.uniform(-1e-3, 1e-3))) if model else (0, 0, 0, 0)
+    cam = S.camera(W, H, f, model, dist)
+    cam.cu += float(rng.uniform(-3, 3))
+    cam.cv += float(rng.uniform(-3, 3))
+    res = float(rng.choice([0.25, 0.5, 1.0]))
+    lx, ly = float(rng.integers(20, 120)), float(rng.integers(20, 100))
+    F = int(rng.integers(1, 40))
+    colored = bool(seed % 2)
+    tilt = float(rng.choice([2.0, 8.0, 25.0, 70.0]))
+    alt = 400.0 + float(rng.uniform(15.0, 200.0))
+    sc = S.Scene(lx, ly, res, int(2.0 * lx * ly), seed=4000 + seed, num_frames=F, cam=cam,
+                 altitude=alt, colored=colored, tilt_deg=tilt,
+                 center=(float(rng.uniform(-200, 200)), float(rng.uniform(-200, 200))))
+    if seed % 4 == 2:       # a strip without points -> NaN elevation
+        sc.points = np.ascontiguousarray(sc.points[sc.points[:, 0] < sc.center[0] + lx / 6])
+    T_C_B = np.r_[rng.uniform(-0.2, 0.2, 3), rng.normal(size=4) * 0.02 + np.array([1.0, 0, 0, 0])]
+    T_C_B[3:] /= np.linalg.norm(T_C_B[3:])
+    rc, elevation, _ = O.dsm_process(sc.points, sc.grid)
+    assert rc == O.OK
+    layers = O.new_layers(sc.grid)
+    layers["elevation"] = elevation.copy()
+    cuts = sorted(set([0, F] + [int(v) for v in rng.integers(0, F + 1, 2)]))
+    with _map_for(sc, A) as m:
+        m.set("elevation", elevation)
+        ncam = A.NCamera(cam.fu, cam.fv, cam.cu, cam.cv, W, H, model, dist, T_C_B)
+        mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=colored), m)
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            assert O.ortho_process(sc.grid, cam, sc.poses[lo:hi], T_C_B, sc.frames[lo:hi], layers,
+                                   colored=colored) == O.OK
+            mosaic.process(sc.poses[lo:hi], sc.frames[lo:hi], m)
+        got = {n: m.get(n) for n in ORTHO_LAYERS}
+    S.assert_layers_equal(got, layers, ORTHO_LAYERS)
