@@ -229,3 +229,41 @@ def test_frames_outside_partially_inside_and_strongly_tilted():
     assert (fm.mask > 0).mean() > 0.2
     _assert_same(res, fi.result, "incremental result")
     _assert_same(mask, fi.mask, "incremental mask")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_forward_random_configurations(seed):
+    # randomized sweep: image / mosaic sizes (incl. non-square, smaller than a
+    # warp block), focal length, altitude, tilt, origin, T_C_B, colour, sparse
+    # frames (many zero pixels = mask holes), batch vs incremental
+    rng = np.random.default_rng(5000 + seed)
+    A = _A()
+    W, H = int(rng.integers(24, 160)), int(rng.integers(20, 120))
+    cam = S.camera(W, H, float(rng.uniform(0.6, 1.5) * W))
+    mw, mh = int(rng.integers(9, 420)), int(rng.integers(9, 360))
+    origin = (float(rng.uniform(-50, 50)), float(rng.uniform(-50, 50)), float(rng.uniform(-5, 5)))
+    desc = O.mosaic_desc(mw, mh, 400.0 + float(rng.uniform(-10, 10)), origin)
+    F = int(rng.integers(1, 24))
+    colored = bool(seed % 2)
+    incremental = seed % 3 == 0
+    poses = synth.make_lawnmower_poses(F, 0.4 * min(mw, mh), 400.0 + float(rng.uniform(20, 300)),
+                                       6000 + seed, tilt_deg=float(rng.choice([3.0, 15.0, 45.0])),
+                                       center=(origin[0], origin[1]))
+    if not incremental:   # batch() offsets both axes by width/2: keep the strip in view
+        poses[:, 0] += (mw - mh) / 2.0
+    frames = synth.make_frames(F, H, W, 3 if colored else 1, salt=seed)
+    frames = np.where(frames < int(rng.choice([1, 40, 160])), 0, frames).astype(np.uint8)
+    T_C_B = np.r_[rng.uniform(-0.3, 0.3, 3), rng.normal(size=4) * 0.03 + np.array([1.0, 0, 0, 0])]
+    T_C_B[3:] /= np.linalg.norm(T_C_B[3:])
+    fm = O.ForwardMosaic(cam, desc, T_C_B)
+    with A.OrthoForwardHomography(_ncam(cam, T_C_B), _settings(desc)) as mosaic:
+        if incremental:
+            for k in range(F):
+                assert fm.update(poses[k], frames[k]) == O.OK
+                mosaic.updateOrthomosaic(poses[k], frames[k])
+        else:
+            assert fm.batch(poses, [f for f in frames]) == O.OK
+            mosaic.batch(poses, [f for f in frames])
+        res, mask = mosaic.result()
+    _assert_same(res, fm.result, "result")
+    _assert_same(mask, fm.mask, "mask")
