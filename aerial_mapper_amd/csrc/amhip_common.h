@@ -145,6 +145,10 @@ struct Ctx {
   size_t tmp_points_cap = 0;
   uint32_t* stripe_ws = nullptr;   // stripe counts / starts / cursors
   size_t stripe_ws_cap = 0;
+  uint8_t* tile_occ = nullptr;         // per gather tile: any point within the last radius
+  size_t tile_occ_cap = 0;
+  int* tile_list = nullptr;            // sparse gather: [count (4 ints)] [occupied tile ids]
+  size_t tile_list_cap = 0;
   unsigned char* fill_mask = nullptr;  // OrthoFromPcl adaptive passes
   size_t fill_mask_cap = 0;
   int32_t* stage_values = nullptr;     // H2D staging of host intensities

@@ -228,6 +228,30 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
+// One lane per gather tile: does any binned point lie within the LAST fallback
+// radius of the tile?  (Tile numbering: ti + tj * tiles_i, as in the gather.)
+__global__ void __launch_bounds__(256)
+k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
+                     uint8_t* __restrict__ occ, int* __restrict__ list,
+                     unsigned* __restrict__ count) {
+  const int tile = blockIdx.x * 256 + threadIdx.x;
+  if (tile >= p.tiles_i * p.tiles_j) return;
+  const int ti = tile % p.tiles_i, tj = tile / p.tiles_i;
+  const int i0 = ti * kTileI, j0 = tj * tile_j;
+  const int i_hi = min(i0 + kTileI, p.rows) - 1;
+  const int j_hi = min(j0 + tile_j, p.cols) - 1;
+  const int wl = p.w[p.nlevels - 1];
+  const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
+  const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
+  uint32_t tot = 0;
+  for (int by = ey0; by <= ey1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    tot += row[ex1 + 1] - row[ex0];
+  }
+  occ[tile] = tot ? 1 : 0;
+  if (list && tot) list[atomicAdd(count, 1u)] = tile;  // (order is irrelevant)
+}
+
 // |v| outside [2^-960, 2^960] (within ~1e19 of the ends of the double range)
 __device__ __forceinline__ bool exponent_extreme(double v) {
   const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7FFu;
@@ -241,12 +265,12 @@ __device__ __forceinline__ bool exponent_far_from_one(double v) {
 }
 
 template <int NT, int kTileJ, int kCap>
-__global__ void __launch_bounds__(NT)
-k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
-                   const double* __restrict__ sorted, CellOut o) {
+__device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* __restrict__ start,
+                                            const double* __restrict__ sorted,
+                                            const uint8_t* __restrict__ tile_occ, const CellOut& o,
+                                            const int tile, unsigned char* smem) {
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // [xy: cap+1 double2][z: cap+1 double (+pad)][cell offsets][rows][ctl][flags]
   double2* s_xy = reinterpret_cast<double2*>(smem);
   double* s_z = reinterpret_cast<double*>(smem + (size_t)(p.lds_cap + 1) * 16);
@@ -261,17 +285,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const int lane = tid & 63;
   const int wid = tid >> 6;
 
-  // XCD-aware tile order: consecutive tiles (which share halo points) go to
-  // the same XCD's L2.  Blocks are dealt round-robin to the 8 XCDs, so give
-  // XCD x the x-th contiguous chunk of the tile list (bijective for any count).
-  const int ntiles = p.tiles_i * p.tiles_j;
-  int tile;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, k = b >> 3;
-    const int q = ntiles >> 3, r = ntiles & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
   const int ti = tile % p.tiles_i;
   const int tj = tile / p.tiles_i;
   const int i0 = ti * kTileI;
@@ -279,6 +292,21 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const int i_hi = min(i0 + kTileI, p.rows) - 1;
   const int j_hi = min(j0 + kTileJ, p.cols) - 1;
   const int w0 = p.w[0];
+
+  // No point within the LAST fallback radius of the tile (k_dsm_tile_occupancy):
+  // every cell stays untouched.  In incremental mapping this is most of the map,
+  // so the test is one byte, read before anything else.
+  if (tile_occ[tile] == 0) {
+    if (o.unfilled && tid == 0)
+      atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
+    if (o.fill_untouched) {
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
+        if (i <= i_hi && j <= j_hi) leave_untouched(p, o, i, j);
+      }
+    }
+    return;
+  }
 
   // region of bins holding every first-level candidate of the tile
   const int rbx0 = (i0 - w0 + p.M) / p.B;
@@ -306,18 +334,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
     s_rowg[tid] = gs;
     s_rowp[tid + 1] = row[rbx1 + 1] - gs;
   }
-  if (tid == NT - 1) {
-    // anything at all within the LAST fallback radius of the tile?
-    const int wl = p.w[p.nlevels - 1];
-    const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
-    const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
-    uint32_t tot = 0;
-    for (int by = ey0; by <= ey1; ++by) {
-      const uint32_t* row = start + (size_t)by * p.nbx;
-      tot += row[ex1 + 1] - row[ex0];
-    }
-    s_ctl[2] = tot;
-  }
   __syncthreads();
   if (tid == 0) {
     uint32_t run = 0;
@@ -333,18 +349,6 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   }
   __syncthreads();
   const int np = (int)s_ctl[0];
-  if (s_ctl[2] == 0) {  // empty neighbourhood: every cell stays untouched
-    if (o.unfilled && tid == 0)
-      atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
-    if (o.fill_untouched) {
-      for (int c = 0; c < kCellsPerLane; ++c) {
-        const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-        if (i <= i_hi && j <= j_hi) leave_untouched(p, o, i, j);
-      }
-    }
-    return;
-  }
-
   const bool use_lds = geom_ok && np <= p.lds_cap;
   if (!use_lds) {
     // over-full tile (very dense / clustered cloud): global path for all cells
@@ -562,6 +566,40 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   }
 }
 
+// Dense launch: one workgroup per tile.  XCD-aware tile order: consecutive tiles
+// (which share halo points) go to the same XCD's L2.  Blocks are dealt
+// round-robin to the 8 XCDs, so XCD x gets the x-th contiguous chunk of the tile
+// list (bijective for any count).
+template <int NT, int kTileJ, int kCap>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
+                   const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                   CellOut o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntiles = p.tiles_i * p.tiles_j;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, k = b >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem);
+}
+
+// Sparse launch (a small cloud on a large map, e.g. one stereo pair of an
+// incremental mapping run): a fixed grid walks the list of occupied tiles.
+template <int NT, int kTileJ, int kCap>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
+                          const double* __restrict__ sorted,
+                          const uint8_t* __restrict__ tile_occ, const int* __restrict__ tile_list,
+                          const unsigned* __restrict__ tile_count, CellOut o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned count = *tile_count;
+  for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+    gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem);
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
@@ -577,15 +615,44 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
     if (p.lds_ok) {
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
+      {
+        int rc;
+        if ((rc = ensure_capacity(&c->tile_occ, &c->tile_occ_cap, (size_t)ntiles + 16))) return rc;
+      }
+      // Sparse call (few points per map cell, the layer already materialized):
+      // only the occupied tiles are visited, by a fixed grid walking their list.
+      const bool sparse = !fill_untouched && ntiles > 8192 &&
+                          (double)n * 16.0 < (double)p.rows * (double)p.cols;
+      int* tile_list = nullptr;
+      unsigned* tile_count = nullptr;
+      if (sparse) {
+        int rc;
+        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, (size_t)ntiles + 4))) return rc;
+        tile_count = reinterpret_cast<unsigned*>(c->tile_list);
+        tile_list = c->tile_list + 4;
+        AMHIP_TRY(hipMemsetAsync(tile_count, 0, sizeof(unsigned), c->stream));
+      }
+      hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
+                         p, p.tile_j, c->bin_start, c->tile_occ, tile_list, tile_count);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
 #define AMHIP_LAUNCH_TILED(NT_, TJ_, CAP_)                                                    \
   do {                                                                                        \
-    AMHIP_TRY(hipFuncSetAttribute(                                                            \
-        reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                    \
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
-    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
-                       p.lds_bytes, c->stream, p, c->bin_start, c->sorted, cell_out);         \
+    if (sparse) {                                                                             \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),           \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                     \
+      hipLaunchKernelGGL((k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>), dim3(8192), dim3(NT_),  \
+                         p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,     \
+                         tile_list, tile_count, cell_out);                                    \
+    } else {                                                                                  \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                     \
+      hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),       \
+                         p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,     \
+                         cell_out);                                                           \
+    }                                                                                         \
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU

@@ -165,13 +165,13 @@ k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
 
 __global__ void __launch_bounds__(kL1Threads)
 k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values,
-                     size_t n, DsmParams p, uint32_t* __restrict__ cursor,
+                     size_t n, size_t chunk, DsmParams p, uint32_t* __restrict__ cursor,
                      double* __restrict__ tmp) {
   extern __shared__ uint32_t s_mem[];
   uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
   uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
-  const size_t c0 = (size_t)blockIdx.x * kL1Chunk;
-  const size_t c1 = min(c0 + (size_t)kL1Chunk, n);
+  const size_t c0 = (size_t)blockIdx.x * chunk;
+  const size_t c1 = min(c0 + chunk, n);
   for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_cnt[k] = 0;
   __syncthreads();
   for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {
@@ -792,10 +792,15 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     }
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
-      const size_t grid = (n + kL1Chunk - 1) / kL1Chunk;
+      // 64 K points per workgroup for big clouds (long runs per stripe); small
+      // clouds (incremental mapping) are cut finer so that the chip is still filled
+      size_t chunk = (n / 1024 + 255) & ~size_t(255);
+      if (chunk < 2048) chunk = 2048;
+      if (chunk > (size_t)kL1Chunk) chunk = kL1Chunk;
+      const size_t grid = (n + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
                          2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, dev_values, n,
-                         p, stripe_cursor, c->tmp_points);
+                         chunk, p, stripe_cursor, c->tmp_points);
       AMHIP_TRY(hipGetLastError());
     }
     {

@@ -11,6 +11,7 @@ import pytest
 
 import oracle_ffi as O
 import scenarios as S
+from aerial_mapper_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -664,3 +665,27 @@ def test_ortho_random_configurations(seed):
             mosaic.process(sc.poses[lo:hi], sc.frames[lo:hi], m)
         got = {n: m.get(n) for n in ORTHO_LAYERS}
     S.assert_layers_equal(got, layers, ORTHO_LAYERS)
+
+
+def test_dsm_sparse_calls_on_a_large_map_use_the_tile_list():
+    # > 8192 gather tiles and far fewer points than cells: the gather walks the
+    # list of occupied tiles with a fixed grid (incremental mapping: one stereo
+    # pair at a time onto a big map).  Two successive clouds, the second partly
+    # over the first; everything else keeps its previous value.
+    A = _A()
+    g = O.make_grid(752.0, 752.0, 0.25)
+    assert (g.rows // 64 + 1) * (g.cols // 16) > 8192
+    a = synth.make_points(160000, 70.0, 97, center=(-250.0, 180.0))
+    b = synth.make_points(120000, 60.0, 98, center=(-190.0, 150.0))
+    rc, want, _ = O.dsm_process(a, g)
+    assert rc == O.OK
+    rc, want, _ = O.dsm_process(b, g, elevation=want)
+    assert rc == O.OK
+    st = A.GridMapSettings(0.0, 0.0, 752.0, 752.0, 0.25)
+    with A.AerialGridMap(st) as m:
+        m.get("elevation")                      # materialize: the very first call is sparse too
+        A.Dsm(A.DsmSettings(), m).process(a, m)
+        A.Dsm(A.DsmSettings(), m).process(b, m)
+        got = m.get("elevation")
+    S.assert_dsm_close(got, want)
+    assert 0.01 < (~np.isnan(want)).mean() < 0.2
