@@ -657,6 +657,8 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
       e = hipMalloc(reinterpret_cast<void**>(&c->layers[l]), c->cells * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_err), 4 * sizeof(unsigned));
     if (e == hipSuccess)
+      e = hipMalloc(reinterpret_cast<void**>(&c->dev_zrange), 2 * sizeof(unsigned long long));
+    if (e == hipSuccess)
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_err), sizeof(unsigned), 0);
     if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
     if (e != hipSuccess) {
@@ -687,7 +689,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -727,6 +729,11 @@ int amhip_layers_reset(amhip_ctx* h) {
   // first (materialize()).  Layers whose device pointer was handed out are
   // refilled eagerly.  AMHIP_EAGER_RESET=1 restores the plain fills.
   static const bool eager = std::getenv("AMHIP_EAGER_RESET") != nullptr;
+  {  // every elevation is NaN again: empty height range
+    static const unsigned long long empty[2] = {0xFFF0000000000000ull, 0x000FFFFFFFFFFFFFull};
+    AMHIP_TRY(hipMemcpyAsync(c->dev_zrange, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
+    c->zrange_valid = true;
+  }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l) {
     unsigned char& st = c->layer_state[l];
     if (st == 0 || st == 3) continue;
@@ -761,6 +768,7 @@ static int touch(Ctx* c, int layer) {
 // full overwrite (upload): no need to fill first
 static void overwrite(Ctx* c, int layer) {
   if (c->layer_state[layer] != 2) c->layer_state[layer] = 1;
+  if (layer == AMHIP_LAYER_ELEVATION) c->zrange_valid = false;  // heights from outside
 }
 
 int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
@@ -792,6 +800,7 @@ void* amhip_layer_device_ptr(amhip_ctx* h, int layer) {
   Ctx* c = &h->impl;
   if (use_device(c) != AMHIP_OK || materialize(c, layer) != AMHIP_OK) return nullptr;
   c->layer_state[layer] = 2;  // the caller may write through the pointer at any time
+  if (layer == AMHIP_LAYER_ELEVATION) c->zrange_valid = false;
   return c->layers[layer];
 }
 
@@ -820,7 +829,8 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
     return rc;
   return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr,
-                 fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION));
+                 fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION),
+                 c->zrange_valid ? c->dev_zrange : nullptr);
 }
 
 int amhip_dsm_process(amhip_ctx* h, const double* host_xyz, size_t n,
@@ -1068,6 +1078,8 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
     else if ((rc = touch(c, outs[k])))
       return rc;
   }
+  // small batches on a big map: most tiles are out of every frame's sight
+  p.coarse = (p.cull && c->zrange_valid && F <= 64 && !std::getenv("AMHIP_NO_COARSE_CULL")) ? 1 : 0;
   p.virt_nobs = c->layer_state[AMHIP_LAYER_NUM_OBSERVATIONS] == 3 ? 1 : 0;
   if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
   return ortho_run(c, p, c->frame_poses, dev_frames);

@@ -100,6 +100,9 @@ struct OrthoParams {
   // read them, and write the initial values into every cell no view is
   // accepted for; same for num_observations (initial 0: `+= itself` keeps it)
   int virt_out, virt_nobs;
+  // the global elevation range is available: pre-cull the frames with it and
+  // leave the tile before touching its elevation when nothing can see it
+  int coarse;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
@@ -129,6 +132,14 @@ struct Ctx {
   // may write at any time: always refilled); 3: logically initial, memory not
   // filled (lazy reset: the next producer kernel fuses the fill)
   unsigned char layer_state[AMHIP_NUM_LAYERS] = {1, 1, 1, 1, 1, 1};
+  // [min, max] of the heights every DSM call since the last reset could have
+  // written (ordered 64-bit keys, amhip_device.h); lets the mosaic kernel drop
+  // tiles no frame of a small batch can see before it reads their elevation.
+  // Not valid once the elevation layer was written from outside.
+  unsigned long long* dev_zrange = nullptr;
+  bool zrange_valid = false;
+  double* zpart = nullptr;       // per-workgroup partials of one call
+  size_t zpart_cap = 0;
   unsigned* dev_err = nullptr;   // device error word
   unsigned* host_err = nullptr;  // pinned mirror
 
@@ -224,10 +235,11 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-             const DsmParams& p);
+             const DsmParams& p, unsigned long long* zrange);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
-            bool fill_untouched = false, float init_value = 0.0f);
+            bool fill_untouched = false, float init_value = 0.0f,
+            unsigned long long* zrange = nullptr);
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
               const uint8_t* dev_frames);
 

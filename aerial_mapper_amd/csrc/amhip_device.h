@@ -46,6 +46,40 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, unsigned* total,
   return base + incl - v;
 }
 
+// ---------------------------------------------------------------------------
+// running [min, max] of doubles in global memory (atomicMin / atomicMax on an
+// order-preserving 64-bit key); NaN never enters
+// ---------------------------------------------------------------------------
+constexpr unsigned long long kOrderedPlusInf = 0xFFF0000000000000ull;   // key(+inf)
+constexpr unsigned long long kOrderedMinusInf = 0x000FFFFFFFFFFFFFull;  // key(-inf)
+
+__device__ __forceinline__ unsigned long long ordered_key(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double from_ordered_key(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+// Every lane brings its own [lo, hi] (lo = +inf, hi = -inf when it has
+// nothing); each WAVE stores its result to part[2 * wave_index .. +1] with plain
+// stores (no barrier; thousands of same-address atomics would serialize) and
+// k_range_reduce folds the partials into the running range.
+__device__ __forceinline__ void range_commit_wave(double lo, double hi, double* __restrict__ part,
+                                                  size_t wave_index) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, d, 64));
+    hi = fmax(hi, __shfl_xor(hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    part[2 * wave_index] = lo;
+    part[2 * wave_index + 1] = hi;
+  }
+}
+
 }  // namespace amhip
 
 #endif  // AMHIP_DEVICE_H_

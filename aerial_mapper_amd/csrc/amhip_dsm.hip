@@ -605,10 +605,10 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
 // ---------------------------------------------------------------------------
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
-            bool fill_untouched, float init_value) {
+            bool fill_untouched, float init_value, unsigned long long* zrange) {
   const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value};
   {
-    const int rc = dsm_sort(c, dev_xyz, dev_values, n, p);
+    const int rc = dsm_sort(c, dev_xyz, dev_values, n, p, zrange);
     if (rc) return rc;
   }
   {

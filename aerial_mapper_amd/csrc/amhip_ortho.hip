@@ -21,6 +21,7 @@
 // minkindr transform of the landmark, aslam pinhole project3 (+ radtan /
 // equidistant distortion), asin(|z| / ||p||).
 #include "amhip_common.h"
+#include "amhip_device.h"
 
 namespace amhip {
 
@@ -130,6 +131,21 @@ __device__ __forceinline__ float wave_max_f(float v) {
   return v;
 }
 
+// Can the frame with pose T (= T_C_G) see any point of the sphere?  Conservative:
+// false only if the sphere lies entirely behind the camera or outside one of
+// the four side planes of the view pyramid.
+__device__ __forceinline__ bool frame_may_see(const OrthoParams& p, const FramePose& T,
+                                              const V3& centre, double radius) {
+  const V3 cc = transform_point(T, centre);
+  bool keep = !(cc.z < -radius);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double d = p.pl[k][0] * cc.x + p.pl[k][1] * cc.y + p.pl[k][2] * cc.z;
+    if (d < -radius) keep = false;
+  }
+  return keep;
+}
+
 // aerial-mapper-grid-map.cc:40-48: elevation_angle 0, observation_index NaN,
 // ortho 255 / colored_ortho NaN
 __device__ __forceinline__ void write_initial(const OrthoParams& p, float* __restrict__ angle,
@@ -148,7 +164,8 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
                  float* __restrict__ elevation_angle,
                  float* __restrict__ observation_index,
                  float* __restrict__ num_observations,
-                 float* __restrict__ out_layer, unsigned* __restrict__ dev_err) {
+                 float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
+                 const unsigned long long* __restrict__ zrange) {
   __shared__ float s_red[2 * (kOrthoThreads / 64)];
   __shared__ int s_cand[kChunk];
   __shared__ int s_wave_cnt[kOrthoThreads / 64];
@@ -158,6 +175,40 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   const int i = blockIdx.x * kTileI + lane;
   const int j0 = blockIdx.y * kTileJ;
   const bool i_ok = i < p.rows;
+
+  // tile extents (cell centres)
+  const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
+  const int j_hi = min(j0 + kTileJ, p.cols) - 1;
+  const double xa = p.base_x + p.res * (-(double)((int)(blockIdx.x * kTileI) + p.i_off));
+  const double xb = p.base_x + p.res * (-(double)(i_hi + p.i_off));
+  const double ya = p.base_y + p.res * (-(double)(j0 + p.j_off));
+  const double yb = p.base_y + p.res * (-(double)(j_hi + p.j_off));
+  const double hx = 0.5 * fabs(xa - xb), hy = 0.5 * fabs(ya - yb);
+
+  // ---- phase 0 (small batches): can ANY frame see this tile at all, given the
+  // range of heights the DSM has ever written?  If not, leave before touching
+  // the tile's elevation.  (Incremental mapping: a few frames, a huge map.)
+  if (p.coarse) {
+    const double glo = from_ordered_key(zrange[0]), ghi = from_ordered_key(zrange[1]);
+    bool any = false;
+    if (glo <= ghi) {
+      const double ghz = 0.5 * (ghi - glo) * (1.0 + 1e-6) + 1e-3;  // float-rounded heights
+      const V3 gc = {0.5 * (xa + xb), 0.5 * (ya + yb), 0.5 * (glo + ghi)};
+      const double gr = sqrt(hx * hx + hy * hy + ghz * ghz) * (1.0 + 1e-9) + 1e-6;
+      for (int f = threadIdx.x; f < p.num_frames; f += kOrthoThreads)
+        any = any || frame_may_see(p, poses[f], gc, gr);
+    }
+    if (!__syncthreads_or(any)) {
+      if (p.virt_out && i_ok) {
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c) {
+          const int j = j0 + wid + c * (kOrthoThreads / 64);
+          if (j < p.cols) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+        }
+      }
+      return;
+    }
+  }
 
   // ---- phase A: this lane's cells + tile elevation range -------------------
   float elev[kCellsPerLane];
@@ -199,16 +250,9 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   }
 
   // bounding sphere of the tile's landmarks (cell centres x elevation range)
-  const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
-  const int j_hi = min(j0 + kTileJ, p.cols) - 1;
-  const double xa = p.base_x + p.res * (-(double)((int)(blockIdx.x * kTileI) + p.i_off));
-  const double xb = p.base_x + p.res * (-(double)(i_hi + p.i_off));
-  const double ya = p.base_y + p.res * (-(double)(j0 + p.j_off));
-  const double yb = p.base_y + p.res * (-(double)(j_hi + p.j_off));
   const V3 centre = {0.5 * (xa + xb), 0.5 * (ya + yb),
                      0.5 * ((double)zmin + (double)zmax)};
-  const double hx = 0.5 * fabs(xa - xb), hy = 0.5 * fabs(ya - yb),
-               hz = 0.5 * ((double)zmax - (double)zmin);
+  const double hz = 0.5 * ((double)zmax - (double)zmin);
   // generous slack: the cull only has to be conservative
   const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6;
 
@@ -260,17 +304,7 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
       bool keep = false;
       if (f < chunk0 + chunk_n) {
         keep = true;
-        if (p.cull) {
-          const FramePose T = poses[f];
-          const V3 cc = transform_point(T, centre);
-          if (cc.z < -radius) keep = false;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const double d =
-                p.pl[k][0] * cc.x + p.pl[k][1] * cc.y + p.pl[k][2] * cc.z;
-            if (d < -radius) keep = false;
-          }
-        }
+        if (p.cull) keep = frame_may_see(p, poses[f], centre, radius);
       }
       const unsigned long long m = __ballot(keep);
       const int before = __popcll(m & ((1ull << lane) - 1ull));
@@ -394,7 +428,8 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
                      c->layers[AMHIP_LAYER_ELEVATION],
                      c->layers[AMHIP_LAYER_ELEVATION_ANGLE],
                      c->layers[AMHIP_LAYER_OBSERVATION_INDEX],
-                     c->layers[AMHIP_LAYER_NUM_OBSERVATIONS], out, c->dev_err);
+                     c->layers[AMHIP_LAYER_NUM_OBSERVATIONS], out, c->dev_err,
+                     p.coarse ? c->dev_zrange : nullptr);
   AMHIP_TRY(hipGetLastError());
   return AMHIP_OK;
 }

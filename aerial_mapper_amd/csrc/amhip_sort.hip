@@ -12,6 +12,7 @@
 //                   one-level counting sort with global atomics (very wide
 //                   grids; fallback)
 // plus k_halo_select, the multi-GPU halo compaction (same streaming shape).
+#include <algorithm>
 #include <cstdlib>
 
 #include "amhip_common.h"
@@ -65,8 +66,10 @@ k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
 __global__ void __launch_bounds__(256)
 k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values, size_t n,
               DsmParams p, const uint32_t* __restrict__ start,
-              const uint32_t* __restrict__ rank, double* __restrict__ sorted) {
+              const uint32_t* __restrict__ rank, double* __restrict__ sorted,
+              double* __restrict__ zpart) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += stride) {
     const uint32_t r = rank[idx];
@@ -82,7 +85,10 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
     sorted[3 * slot + 0] = px;
     sorted[3 * slot + 1] = py;
     sorted[3 * slot + 2] = z;
+    zlo = fmin(zlo, z);
+    zhi = fmax(zhi, z);
   }
+  if (zpart) range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
 // ---------------------------------------------------------------------------
@@ -166,8 +172,9 @@ k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
 __global__ void __launch_bounds__(kL1Threads)
 k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values,
                      size_t n, size_t chunk, DsmParams p, uint32_t* __restrict__ cursor,
-                     double* __restrict__ tmp) {
+                     double* __restrict__ tmp, double* __restrict__ zpart) {
   extern __shared__ uint32_t s_mem[];
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
   uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
   const size_t c0 = (size_t)blockIdx.x * chunk;
@@ -194,11 +201,17 @@ k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__
     if (point_bin_xy(p, px, py, &bx, &by)) {
       const int st = by / p.stripe_rows;
       const size_t slot = (size_t)s_base[st] + atomicAdd(&s_cnt[st], 1u);
+      const double z = values ? (double)values[idx] : xyz[3 * idx + 2];
       tmp[3 * slot + 0] = px;
       tmp[3 * slot + 1] = py;
-      tmp[3 * slot + 2] = values ? (double)values[idx] : xyz[3 * idx + 2];
+      tmp[3 * slot + 2] = z;
+      zlo = fmin(zlo, z);
+      zhi = fmax(zhi, z);
     }
   }
+  if (zpart)
+    range_commit_wave(zlo, zhi, zpart,
+                      (size_t)blockIdx.x * (kL1Threads / 64) + (threadIdx.x >> 6));
 }
 
 __global__ void __launch_bounds__(kL2Threads)
@@ -381,7 +394,7 @@ __global__ void __launch_bounds__(kP3Threads)
 k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ values, size_t n,
                  DsmParams p, const uint32_t* __restrict__ start1,
                  const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
-                 double* __restrict__ dst) {
+                 double* __restrict__ dst, double* __restrict__ zpart) {
   extern __shared__ double s_pts[];                                       // 3 * kP3Chunk
   uint32_t* s_dest = reinterpret_cast<uint32_t*>(s_pts + 3 * kP3Chunk);   // kP3Chunk
   uint32_t* s_cnt = s_dest + kP3Chunk;                                    // kP3MaxKeys
@@ -412,6 +425,7 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
   if (tid < kP3MaxKeys) s_cnt[tid] = 0;
   __syncthreads();
   double px[kP3PerThread], py[kP3PerThread], pz[kP3PerThread];
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   uint32_t slot[kP3PerThread];  // key << 13 | rank in the chunk's run of that key
 #pragma unroll
   for (int k = 0; k < kP3PerThread; ++k) {
@@ -434,9 +448,15 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
       if (p3_keys(p, x, y, &k1, &k2)) {
         const int key = kFirst ? k1 : k2;
         slot[k] = ((uint32_t)key << 13) | atomicAdd(&s_cnt[key], 1u);
+        if (kFirst) {
+          zlo = fmin(zlo, z);
+          zhi = fmax(zhi, z);
+        }
       }
     }
   }
+  if (kFirst && zpart)
+    range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * (kP3Threads / 64) + (tid >> 6));
   __syncthreads();
   {
     const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
@@ -699,11 +719,55 @@ k_scan_final(uint32_t* __restrict__ data, size_t n,
 }
 
 
+// fold the scatter waves' [min z, max z] partials into the context's range
+__global__ void __launch_bounds__(1024)
+k_range_reduce(const double* __restrict__ part, size_t nparts,
+               unsigned long long* __restrict__ range) {
+  __shared__ double s_pair[2 * 16];
+  double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+  const size_t stride = (size_t)gridDim.x * 1024;  // (a handful of workgroups: few atomics)
+  for (size_t k = (size_t)blockIdx.x * 1024 + threadIdx.x; k < nparts; k += stride) {
+    const double2 v = reinterpret_cast<const double2*>(part)[k];
+    lo = fmin(lo, v.x);
+    hi = fmax(hi, v.y);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, d, 64));
+    hi = fmax(hi, __shfl_xor(hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_pair[2 * (threadIdx.x >> 6)] = lo;
+    s_pair[2 * (threadIdx.x >> 6) + 1] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = fmin(lo, s_pair[2 * w]);
+      hi = fmax(hi, s_pair[2 * w + 1]);
+    }
+    if (lo <= hi) {
+      atomicMin(&range[0], ordered_key(lo));
+      atomicMax(&range[1], ordered_key(hi));
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-             const DsmParams& p) {
+             const DsmParams& p, unsigned long long* zrange) {
+  // [min z, max z] of the binned points (for the mosaic's coarse cull): every
+  // workgroup of the first scatter pass -- it loads z anyway -- writes a
+  // partial, k_range_reduce folds them into *zrange
+  double* zpart = nullptr;
+  if (zrange) {
+    const size_t max_waves = 8 * std::max<size_t>((n + 2047) / 2048 + 1, 256 * 16);
+    const int rc = ensure_capacity(&c->zpart, &c->zpart_cap, 2 * max_waves + 16);
+    if (rc) return rc;
+    zpart = c->zpart;
+  }
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   {
@@ -755,10 +819,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
       hipLaunchKernelGGL(k_dsm_p3_scatter<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
-                         c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted);
+                         c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted,
+                         zpart);
+      if (zpart)
+        hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
+                           (size_t)g1 * (kP3Threads / 64), zrange);
       hipLaunchKernelGGL(k_dsm_p3_scatter<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
                          lds, c->stream, c->sorted, (const int32_t*)nullptr, n, p, start1, blk2,
-                         cursor2, c->tmp_points);
+                         cursor2, c->tmp_points, (double*)nullptr);
       AMHIP_TRY(hipGetLastError());
     }
     {
@@ -800,7 +868,10 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const size_t grid = (n + chunk - 1) / chunk;
       hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
                          2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, dev_values, n,
-                         chunk, p, stripe_cursor, c->tmp_points);
+                         chunk, p, stripe_cursor, c->tmp_points, zpart);
+      if (zpart)
+        hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
+                           (size_t)grid * (kL1Threads / 64), zrange);
       AMHIP_TRY(hipGetLastError());
     }
     {
@@ -843,7 +914,10 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
       hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
-                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted);
+                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted, zpart);
+      if (zpart)
+        hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
+                           (size_t)grid_pts * 4, zrange);
       AMHIP_TRY(hipGetLastError());
     }
   }

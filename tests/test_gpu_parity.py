@@ -689,3 +689,34 @@ def test_dsm_sparse_calls_on_a_large_map_use_the_tile_list():
         got = m.get("elevation")
     S.assert_dsm_close(got, want)
     assert 0.01 < (~np.isnan(want)).mean() < 0.2
+
+
+def test_ortho_coarse_cull_with_the_tracked_height_range():
+    # Small batches: the mosaic kernel first asks whether ANY frame can see the
+    # tile given the range of heights the DSM calls have written (tracked on the
+    # device), and leaves without reading the tile's elevation if not.  Two
+    # clouds with very different heights (the range must be their union), frames
+    # all over the map, batches of 1..5 frames, then a reset and another round.
+    A = _A()
+    sc = S.Scene(300.0, 220.0, 0.5, 60000, seed=99, num_frames=18, altitude=470.0, tilt_deg=8.0)
+    lo = sc.points[sc.points[:, 0] < 20.0].copy()
+    hi = sc.points[sc.points[:, 0] > -20.0].copy()
+    hi[:, 2] += 90.0 * np.exp(-((hi[:, 0] - 80.0) ** 2 + hi[:, 1] ** 2) / 3000.0)   # a hill
+    ncam = A.NCamera(sc.cam.fu, sc.cam.fv, sc.cam.cu, sc.cam.cv, sc.cam.width, sc.cam.height)
+    with _map_for(sc, A) as m:
+        dsm = A.Dsm(A.DsmSettings(), m)
+        mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
+        for rnd in range(2):
+            layers = O.new_layers(sc.grid)
+            for cloud, cuts in ((lo, [0, 1, 4, 9]), (hi, [9, 14, 15, 18])):
+                dsm.process(cloud, m)
+                layers["elevation"] = m.get("elevation")       # both folds see the GPU's DSM
+                for a, b in zip(cuts[:-1], cuts[1:]):
+                    assert O.ortho_process(sc.grid, sc.cam, sc.poses[a:b], sc.T_C_B,
+                                           sc.frames[a:b], layers) == O.OK
+                    mosaic.process(sc.poses[a:b], sc.frames[a:b], m)
+            got = {n: m.get(n) for n in ORTHO_LAYERS}
+            S.assert_layers_equal(got, layers, ORTHO_LAYERS)
+            assert (~np.isnan(layers["observation_index"])).mean() > 0.3
+            assert np.nanmax(layers["elevation"]) > 460.0
+            m.reset()
