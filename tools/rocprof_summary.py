@@ -53,7 +53,36 @@ def main():
     ap.add_argument("--traffic-json", help="write the per-step HBM traffic of bench.py's kernel slots")
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--note", default="")
+    ap.add_argument("--sq", nargs="*", help="rocpd databases of SQ / GRBM counter passes")
+    ap.add_argument("--sq-json", help="write the per-kernel averages of the --sq passes")
+    ap.add_argument("--tag", default="")
     a = ap.parse_args()
+    if a.sq:
+        import json
+        db0 = sqlite3.connect(a.sq[0])
+        out = {}
+        for path in a.sq:
+            db = sqlite3.connect(path)
+            cols = [r[1] for r in db.execute("pragma table_info(pmc_events)")]
+            name_col = "counter_name" if "counter_name" in cols else "pmc_name"
+            names = [r[0] for r in db.execute("select distinct %s from pmc_events" % name_col)]
+            for c in names:
+                for k, (n, avg, mn, mx) in pmc_rows(path, c).items():
+                    out.setdefault(k, {})[c] = avg
+        text = {"_comment": "rocprofv3 PMC SQ / GRBM counters, average per launch summed over XCDs / SEs, "
+                            "cfg3, round 1 %s build (python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
+                            "--no-host-path; separate --pmc passes with --kernel-trace only). SQ_* cycle "
+                            "counters tick every 4 clocks." % a.tag, "kernels": out}
+        if a.sq_json:
+            json.dump(text, open(a.sq_json, "w"), indent=1)
+        for k, v in out.items():
+            if "GRBM_GUI_ACTIVE" in v and "SQ_INSTS_VALU" in v and v["GRBM_GUI_ACTIVE"] > 0:
+                g = v["GRBM_GUI_ACTIVE"] / 8
+                print("%-45s VALU insts %.3g  issue util %.2f  lanes %.2f  waves/SIMD %.2f" % (
+                    k, v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU"] / 1024 * 4 / g,
+                    v.get("SQ_THREAD_CYCLES_VALU", 0) / max(v["SQ_INSTS_VALU"], 1) / 64,
+                    v.get("SQ_WAVE_CYCLES", 0) * 4 / 1024 / g))
+        return
     lines = ["# " + a.title, ""]
     if a.trace:
         rows, tot = kernel_rows(a.trace)
