@@ -1041,11 +1041,18 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
-  if ((rc = ensure_capacity(&c->frame_poses, &c->frame_pose_cap, F))) return rc;
+  // one buffer, one upload: FramePose[F], then FrameFast[F + 1] (two FramePose
+  // slots each; the extra entry carries the camera for exact_view())
+  const size_t slots = F + 2 * (F + 1);
+  if ((rc = ensure_capacity(&c->frame_poses, &c->frame_pose_cap, slots))) return rc;
 
   // T_C_G[f] = T_G_C[f].inverse()  (ortho-backward-grid.cc:157-158; the
   // reference recomputes it per cell and frame, the value is the same)
-  std::vector<FramePose> inv(F);
+  static_assert(sizeof(FrameFast) == 2 * sizeof(FramePose), "frame table layout");
+  std::vector<FramePose> inv(slots);
+  FrameFast* fast = reinterpret_cast<FrameFast*>(inv.data() + F);
+  bool fast_ok = cam->distortion == AMHIP_DIST_NONE && cam->fu > 0.0 && cam->fv > 0.0 &&
+                 !std::getenv("AMHIP_ORTHO_EXACT_FOLD");
   for (size_t f = 0; f < F; ++f) {
     const HPose T = hpose_inverse(hpose_from7(host_T_G_C + 7 * f));
     inv[f].qw = T.qw;
@@ -1056,9 +1063,21 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
     inv[f].ty = T.ty;
     inv[f].tz = T.tz;
     inv[f]._pad = 0.0;
+    // (non-unit quaternion / non-finite pose: the whole call takes the exact kernel)
+    if (!make_frame_fast(inv[f], &fast[f])) fast_ok = false;
+  }
+  {
+    double* camd = reinterpret_cast<double*>(&fast[F]);
+    std::memset(camd, 0, sizeof(FrameFast));
+    camd[0] = cam->fu;
+    camd[1] = cam->fv;
+    camd[2] = cam->cu;
+    camd[3] = cam->cv;
+    camd[4] = (double)cam->width;
+    camd[5] = (double)cam->height;
   }
   // pageable source: hipMemcpyAsync returns once it has been staged
-  AMHIP_TRY(hipMemcpyAsync(c->frame_poses, inv.data(), F * sizeof(FramePose),
+  AMHIP_TRY(hipMemcpyAsync(c->frame_poses, inv.data(), slots * sizeof(FramePose),
                            hipMemcpyHostToDevice, c->stream));
 
   OrthoParams p;
@@ -1082,7 +1101,10 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   p.coarse = (p.cull && c->zrange_valid && F <= 64 && !std::getenv("AMHIP_NO_COARSE_CULL")) ? 1 : 0;
   p.virt_nobs = c->layer_state[AMHIP_LAYER_NUM_OBSERVATIONS] == 3 ? 1 : 0;
   if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
-  return ortho_run(c, p, c->frame_poses, dev_frames);
+  p.fast = fast_ok ? 1 : 0;
+  p.fold = make_fold_cam(cam->fu, cam->fv, cam->cu, cam->cv, cam->width, cam->height);
+  return ortho_run(c, p, c->frame_poses, reinterpret_cast<const FrameFast*>(c->frame_poses + F),
+                   dev_frames);
 }
 
 int amhip_ortho_backward_process(

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "aerial_mapper_hip.h"
+#include "amhip_ortho_fold.h"
 
 namespace amhip {
 
@@ -72,12 +73,7 @@ struct DsmParams {
   unsigned lds_bytes;
 };
 
-// Per-frame inverse pose T_C_G = T_G_C^-1 (minkindr inverse()).
-struct FramePose {
-  double qw, qx, qy, qz;
-  double tx, ty, tz;
-  double _pad;
-};
+// FramePose / FrameFast (per-frame inverse pose T_C_G = T_G_C^-1): amhip_ortho_fold.h
 
 struct OrthoParams {
   double base_x, base_y, res;
@@ -103,6 +99,10 @@ struct OrthoParams {
   // the global elevation range is available: pre-cull the frames with it and
   // leave the tile before touching its elevation when nothing can see it
   int coarse;
+  // margin-guarded fold (amhip_ortho_fold.h): undistorted pinhole, unit
+  // quaternions; the frame table follows the poses in the same buffer
+  int fast;
+  FoldCam fold;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
@@ -240,7 +240,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
             bool fill_untouched = false, float init_value = 0.0f,
             unsigned long long* zrange = nullptr);
-int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
+// dev_fast: FrameFast[num_frames] followed by one entry holding the camera
+// (fu fv cu cv W H) for exact_view(); only read when p.fast
+int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
               const uint8_t* dev_frames);
 
 // host-side restatements of the external pose math (minkindr), used to build

@@ -20,6 +20,8 @@
 // for operation, in double without fused multiply-add (-ffp-contract=off):
 // minkindr transform of the landmark, aslam pinhole project3 (+ radtan /
 // equidistant distortion), asin(|z| / ||p||).
+#include <cstdlib>
+
 #include "amhip_common.h"
 #include "amhip_device.h"
 
@@ -31,36 +33,7 @@ constexpr int kOrthoThreads = 256;
 constexpr int kCellsPerLane = kTileJ / (kOrthoThreads / 64);  // 4
 constexpr int kChunk = 1024;  // frames culled per pass
 
-struct V3 {
-  double x, y, z;
-};
-
-__device__ __forceinline__ V3 cross3(const V3& a, const V3& b) {
-  V3 r;
-  r.x = a.y * b.z - a.z * b.y;
-  r.y = a.z * b.x - a.x * b.z;
-  r.z = a.x * b.y - a.y * b.x;
-  return r;
-}
-
-// Eigen::Quaternion::_transformVector followed by the translation
-// (kindr::minimal::QuatTransformation::transform).
-__device__ __forceinline__ V3 transform_point(const FramePose& T, const V3& v) {
-  const V3 qv = {T.qx, T.qy, T.qz};
-  V3 uv = cross3(qv, v);
-  uv.x = uv.x + uv.x;
-  uv.y = uv.y + uv.y;
-  uv.z = uv.z + uv.z;
-  const V3 c2 = cross3(qv, uv);
-  V3 r;
-  r.x = (v.x + T.qw * uv.x) + c2.x;
-  r.y = (v.y + T.qw * uv.y) + c2.y;
-  r.z = (v.z + T.qw * uv.z) + c2.z;
-  r.x = r.x + T.tx;
-  r.y = r.y + T.ty;
-  r.z = r.z + T.tz;
-  return r;
-}
+// V3, cross3, transform_point, exact_view_inline, fold_init / fold_pair / fold_finish: amhip_ortho_fold.h
 
 __device__ __forceinline__ void distort_point(const OrthoParams& p, double* px,
                                               double* py) {
@@ -120,6 +93,28 @@ __device__ __noinline__ double view_angle(double abs_z, double n2) {
   return asin(abs_z / norm);
 }
 
+// The reference's arithmetic for one (cell, frame) pair of the margin-guarded
+// fold: needed once per cell (the winner's keypoint and angle) and for the rare
+// pairs whose decision falls inside a margin.  Out of line for the same reason
+// as view_angle().
+__device__ __noinline__ ExactView exact_view(const double* __restrict__ cam,
+                                             const FramePose* __restrict__ pose, double lx,
+                                             double ly, double lz) {
+  return exact_view_inline(cam, *pose, lx, ly, lz);
+}
+
+struct DeviceExact {
+  const double* cam;
+  const FramePose* poses;
+  double lx, ly, lz;
+  __device__ __forceinline__ ExactView view(int f) const {
+    return exact_view(cam, poses + f, lx, ly, lz);
+  }
+  __device__ __forceinline__ double angle(double absz, double n2) const {
+    return view_angle(absz, n2);
+  }
+};
+
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v = fminf(v, __shfl_xor(v, d, 64));
@@ -157,18 +152,84 @@ __device__ __forceinline__ void write_initial(const OrthoParams& p, float* __res
   out[at] = p.colored ? __builtin_nanf("") : 255.0f;
 }
 
-__global__ void __launch_bounds__(kOrthoThreads)
-k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
-                 const uint8_t* __restrict__ frames,
-                 const float* __restrict__ elevation,
-                 float* __restrict__ elevation_angle,
-                 float* __restrict__ observation_index,
-                 float* __restrict__ num_observations,
-                 float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
-                 const unsigned long long* __restrict__ zrange) {
-  __shared__ float s_red[2 * (kOrthoThreads / 64)];
-  __shared__ int s_cand[kChunk];
-  __shared__ int s_wave_cnt[kOrthoThreads / 64];
+// Phase B: cull one chunk of frames against the tile's bounding sphere, keep
+// the survivors in ascending order in s_cand.  Returns their number (the same
+// value in every thread of the block); ends with a barrier.
+__device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose* __restrict__ poses,
+                                          const V3& centre, double radius, int chunk0, int chunk_n,
+                                          int* s_cand, int* s_wave_cnt) {
+  const int lane = threadIdx.x & 63;
+  const int wid = threadIdx.x >> 6;
+  int ncand = 0;
+  for (int r = 0; r < chunk_n; r += kOrthoThreads) {
+    const int f = chunk0 + r + (int)threadIdx.x;
+    bool keep = false;
+    if (f < chunk0 + chunk_n) {
+      keep = true;
+      if (p.cull) keep = frame_may_see(p, poses[f], centre, radius);
+    }
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();  // previous round's readers of s_wave_cnt are done
+    if (lane == 0) s_wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int base = ncand, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kOrthoThreads / 64; ++w) {
+      const int cw = s_wave_cnt[w];
+      if (w < wid) base += cw;
+      tot += cw;
+    }
+    if (keep) s_cand[base + before] = f;
+    ncand += tot;
+  }
+  __syncthreads();  // s_cand complete
+  return ncand;
+}
+
+// One cell's results (ortho-backward-grid.cc:181-208): angle, frame index, the
+// `num_observations += itself` updates and the sampled pixel.
+__device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* __restrict__ frames,
+                                           float* __restrict__ elevation_angle,
+                                           float* __restrict__ observation_index,
+                                           float* __restrict__ num_observations,
+                                           float* __restrict__ out_layer, int i, int j, float angle,
+                                           int frame, int accepted, int kp_x, int kp_y) {
+  const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+  elevation_angle[at] = angle;
+  observation_index[at] = (float)frame;
+  // layer_num_observations(x, y) += layer_num_observations(x, y), once per
+  // accepted update (ortho-backward-grid.cc:183): doubles the stored value.
+  if (!p.virt_nobs) {
+    float nobs = num_observations[at];
+    if (nobs != 0.0f) {
+      for (int n = 0; n < accepted; ++n) nobs += nobs;
+      num_observations[at] = nobs;
+    }
+  }
+  const uint8_t* px = frames + (size_t)frame * p.frame_stride + (size_t)kp_y * p.row_step;
+  if (p.colored) {
+    // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B
+    px += (size_t)kp_x * 3u;
+    const unsigned bits = ((unsigned)px[2] << 16) | ((unsigned)px[1] << 8) | (unsigned)px[0];
+    out_layer[at] = __uint_as_float(bits);
+  } else {
+    out_layer[at] = (float)px[kp_x];
+  }
+}
+
+// kFast: the margin-guarded fold of amhip_ortho_fold.h (undistorted pinhole,
+// unit quaternions) -- ~30 FP64 operations per pair instead of ~85, the
+// reference's own arithmetic once per cell for the winner and for the pairs a
+// margin cannot decide.  !kFast: every pair in the reference's arithmetic.
+template <bool kFast>
+__device__ __forceinline__ void ortho_backward_tile(
+    const OrthoParams& p, const FramePose* __restrict__ poses,
+    const FrameFast* __restrict__ fast_tab, const uint8_t* __restrict__ frames,
+    const float* __restrict__ elevation, float* __restrict__ elevation_angle,
+    float* __restrict__ observation_index, float* __restrict__ num_observations,
+    float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
+    const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt) {
 
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
@@ -256,8 +317,74 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   // generous slack: the cull only has to be conservative
   const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6;
 
-  // ---- per-lane fold state ---------------------------------------------------
   const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
+  if constexpr (kFast) {
+    // ---- margin-guarded fold (amhip_ortho_fold.h) -----------------------------
+    const double* cam_tab = reinterpret_cast<const double*>(fast_tab + p.num_frames);
+    CellFold st[kCellsPerLane];
+    double ly[kCellsPerLane], lz[kCellsPerLane];
+    bool valid[kCellsPerLane];
+    double magL = 0.0;  // >= |lx| + |ly| + |lz| of every cell of the lane
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = j0 + wid + c * (kOrthoThreads / 64);
+      float a0 = 0.0f;
+      if (i_ok && j < p.cols && !p.virt_out)
+        a0 = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
+      fold_init(&st[c], a0);
+      ly[c] = p.base_y + p.res * (-(double)(j + p.j_off));
+      lz[c] = (double)elev[c];
+      valid[c] = elev[c] == elev[c];  // NaN elevation (or no such cell) is never visible
+      // an infinite elevation makes mag infinite: every pair of the lane then
+      // goes through exact_view()
+      if (valid[c]) magL = fmax(magL, fabs(ly[c]) + fabs(lz[c]));
+    }
+    magL += fabs(lx);
+    bool bad_alpha = false;
+
+    for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
+      const int chunk_n = min(kChunk, p.num_frames - chunk0);
+      const int ncand = cull_chunk(p, poses, centre, radius, chunk0, chunk_n, s_cand, s_wave_cnt);
+      if (i_ok) {
+        for (int k = 0; k < ncand; ++k) {
+          const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
+          const FrameFast& Q = fast_tab[f];
+          const double mag = magL + Q.tmag;
+          const double zthr = fma(0x1p-22, mag, 1e-10);
+          const double muv = p.fold.kuv * mag;
+          const double bx = fma(Q.m[0], lx, Q.t[0]);
+          const double by = fma(Q.m[3], lx, Q.t[1]);
+          const double bz = fma(Q.m[6], lx, Q.t[2]);
+#pragma unroll
+          for (int c = 0; c < kCellsPerLane; ++c) {
+            const double cx = fma(Q.m[2], lz[c], fma(Q.m[1], ly[c], bx));
+            const double cy = fma(Q.m[5], lz[c], fma(Q.m[4], ly[c], by));
+            const double cz = fma(Q.m[8], lz[c], fma(Q.m[7], ly[c], bz));
+            const DeviceExact ex = {cam_tab, poses, lx, ly[c], lz[c]};
+            fold_pair(&st[c], f, p.fold, valid[c], cx, cy, cz, zthr, muv, ex, &bad_alpha);
+          }
+        }
+      }
+      __syncthreads();  // everyone is done with s_cand before the next chunk
+    }
+
+    // ---- write back: the winner's angle and keypoint in the reference's arithmetic
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = j0 + wid + c * (kOrthoThreads / 64);
+      if (!(i_ok && j < p.cols)) continue;
+      const DeviceExact ex = {cam_tab, poses, lx, ly[c], lz[c]};
+      int ku = 0, kv = 0;
+      if (!fold_finish(&st[c], ex, p.width, p.height, &ku, &kv, &bad_alpha)) {
+        if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+        continue;
+      }
+      write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
+                 st[c].best, st[c].best_f, st[c].accepted, ku, kv);
+    }
+    if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
+  } else {
+  // ---- per-lane fold state ---------------------------------------------------
   // Running best view per cell.  The reference keeps (float)asin(|z|/||p||) and
   // accepts a view iff its asin exceeds that float (widened to double).  asin is
   // monotonic, so unless the two sines are within 2.5e-6 (relative, squared) of
@@ -283,7 +410,9 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
       best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
     have_f[c] = true;
     n2b[c] = 1.0;
-    if (best[c] > 0.0f)
+    if (best[c] >= 1.5707964f)
+      zb[c] = __builtin_huge_val();  // no asin exceeds (float)(pi/2)
+    else if (best[c] > 0.0f)
       zb[c] = sin((double)best[c]);  // incremental mode: angle left by earlier batches
     else if (best[c] == best[c])
       zb[c] = 0.0;                   // fresh layer: every visible view wins (alpha > 0)
@@ -296,32 +425,8 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
   }
 
   for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
-    // ---- phase B: cull this chunk of frames, keep ascending order -----------
     const int chunk_n = min(kChunk, p.num_frames - chunk0);
-    int ncand = 0;  // same value in every thread of the block
-    for (int r = 0; r < chunk_n; r += kOrthoThreads) {
-      const int f = chunk0 + r + (int)threadIdx.x;
-      bool keep = false;
-      if (f < chunk0 + chunk_n) {
-        keep = true;
-        if (p.cull) keep = frame_may_see(p, poses[f], centre, radius);
-      }
-      const unsigned long long m = __ballot(keep);
-      const int before = __popcll(m & ((1ull << lane) - 1ull));
-      __syncthreads();  // previous round's readers of s_wave_cnt are done
-      if (lane == 0) s_wave_cnt[wid] = __popcll(m);
-      __syncthreads();
-      int base = ncand, tot = 0;
-#pragma unroll
-      for (int w = 0; w < kOrthoThreads / 64; ++w) {
-        const int cw = s_wave_cnt[w];
-        if (w < wid) base += cw;
-        tot += cw;
-      }
-      if (keep) s_cand[base + before] = f;
-      ncand += tot;
-    }
-    __syncthreads();  // s_cand complete
+    const int ncand = cull_chunk(p, poses, centre, radius, chunk0, chunk_n, s_cand, s_wave_cnt);
 
     // ---- phase C: fold the candidates, ascending -----------------------------
     if (i_ok) {
@@ -384,47 +489,59 @@ k_ortho_backward(OrthoParams p, const FramePose* __restrict__ poses,
       if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
       continue;
     }
-    const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
     if (!have_f[c]) {
       // the winning view's angle, evaluated exactly like the reference does
       const double alpha = view_angle(zb[c], n2b[c]);
       if (!(alpha > 0.0)) atomicOr(dev_err, kDevErrAlphaNonPos);  // CHECK(alpha > 0.0)
       best[c] = (float)alpha;
     }
-    elevation_angle[at] = best[c];
-    observation_index[at] = (float)best_f[c];
-    // layer_num_observations(x, y) += layer_num_observations(x, y), once per
-    // accepted update (ortho-backward-grid.cc:183): doubles the stored value.
-    if (!p.virt_nobs) {
-      float nobs = num_observations[at];
-      if (nobs != 0.0f) {
-        for (int n = 0; n < accepted[c]; ++n) nobs += nobs;
-        num_observations[at] = nobs;
-      }
-    }
-    const uint8_t* px = frames + (size_t)best_f[c] * p.frame_stride +
-                        (size_t)best_v[c] * p.row_step;
-    if (p.colored) {
-      // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B
-      px += (size_t)best_u[c] * 3u;
-      const unsigned bits = ((unsigned)px[2] << 16) | ((unsigned)px[1] << 8) |
-                            (unsigned)px[0];
-      out_layer[at] = __uint_as_float(bits);
-    } else {
-      out_layer[at] = (float)px[best_u[c]];
-    }
+    write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
+               best[c], best_f[c], accepted[c], best_u[c], best_v[c]);
+  }
   }
 }
 
-int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses,
+#define AMHIP_ORTHO_KERNEL_ARGS                                                              \
+  OrthoParams p, const FramePose *__restrict__ poses, const FrameFast *__restrict__ fast_tab, \
+      const uint8_t *__restrict__ frames, const float *__restrict__ elevation,               \
+      float *__restrict__ elevation_angle, float *__restrict__ observation_index,            \
+      float *__restrict__ num_observations, float *__restrict__ out_layer,                   \
+      unsigned *__restrict__ dev_err, const unsigned long long *__restrict__ zrange
+#define AMHIP_ORTHO_KERNEL_BODY(FAST)                                                        \
+  __shared__ float s_red[2 * (kOrthoThreads / 64)];                                          \
+  __shared__ int s_cand[kChunk];                                                             \
+  __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
+  ortho_backward_tile<FAST>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
+                            observation_index, num_observations, out_layer, dev_err, zrange, \
+                            s_red, s_cand, s_wave_cnt);
+
+// every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
+__global__ void __launch_bounds__(kOrthoThreads) k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
+  AMHIP_ORTHO_KERNEL_BODY(false)
+}
+// margin-guarded fold, registers as they come (3 waves per SIMD)
+__global__ void __launch_bounds__(kOrthoThreads) k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
+  AMHIP_ORTHO_KERNEL_BODY(true)
+}
+// the same held to 128 VGPRs (4 waves per SIMD); AMHIP_ORTHO_FAST_WAVES picks
+__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_ortho_backward_fast4(AMHIP_ORTHO_KERNEL_ARGS) {
+  AMHIP_ORTHO_KERNEL_BODY(true)
+}
+
+int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
               const uint8_t* dev_frames) {
   ScopedTimer t(c, AMHIP_K_ORTHO);
   dim3 grid((unsigned)((p.rows + kTileI - 1) / kTileI),
             (unsigned)((p.cols + kTileJ - 1) / kTileJ));
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
-  hipLaunchKernelGGL(k_ortho_backward, grid, dim3(kOrthoThreads), 0, c->stream,
-                     p, dev_poses, dev_frames,
+  const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 7
+  const int fast_waves = fw ? std::atoi(fw) : 4;
+  auto kernel = !p.fast ? k_ortho_backward
+                        : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
+  hipLaunchKernelGGL(kernel, grid, dim3(kOrthoThreads), 0, c->stream,
+                     p, dev_poses, dev_fast, dev_frames,
                      c->layers[AMHIP_LAYER_ELEVATION],
                      c->layers[AMHIP_LAYER_ELEVATION_ANGLE],
                      c->layers[AMHIP_LAYER_OBSERVATION_INDEX],

@@ -1,0 +1,133 @@
+"""GPU: the three builds of the backward-grid kernel -- k_ortho_backward (every pair in
+the reference's arithmetic), k_ortho_backward_fast and k_ortho_backward_fast4 (the
+margin-guarded fold of amhip_ortho_fold.h at 3 / 4 waves per SIMD) -- must all give the
+oracle's layers, bit for bit, on the scenes that stress the margins: engineered exact
+ties, image-border hits, grazing / backward views, UTM magnitudes, incremental batches
+replayed onto their own result, NaN / infinite elevations, non-zero num_observations.
+(The default build is exercised by every other ortho test of the suite.)"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = ["elevation_angle", "observation_index", "num_observations", "ortho", "colored_ortho"]
+VARIANTS = [{"AMHIP_ORTHO_EXACT_FOLD": "1"}, {"AMHIP_ORTHO_FAST_WAVES": "3"},
+            {"AMHIP_ORTHO_FAST_WAVES": "4"}]
+IDS = ["exact", "fast3", "fast4"]
+
+
+def run_gpu(g, cam, batches, elevation, nobs0=None, angle0=None):
+    """batches: list of (poses, frames).  -> (GPU layers, oracle layers)"""
+    import aerial_mapper_amd as A
+    want = O.new_layers(g)
+    want["elevation"][...] = elevation
+    if nobs0 is not None:
+        want["num_observations"][...] = nobs0
+    if angle0 is not None:
+        want["elevation_angle"][...] = angle0
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    with A.AerialGridMap(st) as m:
+        assert (m.rows, m.cols) == (g.rows, g.cols)
+        m.set("elevation", want["elevation"])
+        if nobs0 is not None:
+            m.set("num_observations", want["num_observations"])
+        if angle0 is not None:
+            m.set("elevation_angle", want["elevation_angle"])
+        nc = A.NCamera(cam.fu, cam.fv, cam.cu, cam.cv, cam.width, cam.height)
+        mosaic = A.OrthoBackwardGrid(nc, A.OrthoSettings(), m)
+        for poses, frames in batches:
+            assert O.ortho_process(g, cam, poses, synth.IDENTITY_POSE, frames, want) == O.OK
+            mosaic.process(poses, frames, m)
+        got = {n: m.get(n) for n in LAYERS}
+    return got, want
+
+
+def terrain(g, seed, nan_frac=0.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    j, i = np.meshgrid(np.arange(g.cols), np.arange(g.rows), indexing="ij")
+    x = g.pos_x + g.length_x / 2 - g.resolution * (i + 0.5)
+    y = g.pos_y + g.length_y / 2 - g.resolution * (j + 0.5)
+    z = (synth.terrain_height(x, y) + rng.uniform(-0.5, 0.5, size=x.shape)).astype(np.float32)
+    if nan_frac:
+        z[rng.uniform(size=z.shape) < nan_frac] = np.nan
+    return z
+
+
+def frames_for(F, cam, salt):
+    return [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=salt)]
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=IDS)
+def test_ties_borders_and_odd_elevations(monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+    # (1) duplicate and minutely perturbed poses: exact and near ties
+    g = O.make_grid(100.0, 70.0, 0.5)
+    cam = S.camera()
+    base = synth.make_lawnmower_poses(3, 10.0, 500.0, 77, tilt_deg=6.0)
+    poses = [base[0], base[0].copy(), base[1], base[1].copy()]
+    for k, eps in enumerate([1e-9, 3e-8, 1e-7, 4e-7, 1e-6, 3e-6]):
+        p = base[2].copy()
+        p[2] += eps * 500.0 * (1 if k % 2 else -1)
+        poses.append(p)
+    poses.append(base[0].copy())
+    poses = np.array(poses)
+    z = terrain(g, 5, nan_frac=0.03)
+    z[3, 5] = np.inf
+    z[7, 11] = -np.inf
+    z[9, 2] = 3.0e38
+    got, want = run_gpu(g, cam, [(poses, frames_for(len(poses), cam, 3))], z,
+                        nobs0=np.full((g.cols, g.rows), 0.75, np.float32))
+    S.assert_layers_equal(got, want, LAYERS)
+    assert (want["num_observations"] > 0.75).any()
+
+    # (2) flat ground, level camera whose pixel grid puts whole rows / columns of cell
+    # centres exactly on u = 0, u = W, v = 0, v = H; sideways and upward looking cameras
+    res = 0.5
+    g = O.make_grid(160.0 * res, 96.0 * res, res)
+    cam = O.Camera()
+    cam.fu = cam.fv = 100.0
+    cam.cu, cam.cv = 32.0, 24.0
+    cam.width, cam.height = 64, 48
+    cam.distortion = O.DIST_NONE
+    q_down = synth._qmul(synth._axis_angle((0, 0, 1.0), 0.0), synth._axis_angle((1.0, 0, 0), math.pi))
+    q_side = synth._qmul(q_down, synth._axis_angle((1.0, 0, 0), math.pi / 2))
+    q_up = synth._qmul(q_down, synth._axis_angle((1.0, 0, 0), math.pi))
+    poses = [[x, y, 50.0] + list(q_down) for (x, y) in [(0.25, 0.25), (0.0, 0.0), (3.25, -2.25), (0.25, 0.25)]]
+    poses += [[0.0, 0.0, 0.0] + list(q_side), [5.0, 5.0, 50.0] + list(q_side), [0.0, 0.0, 50.0] + list(q_up)]
+    poses = np.array(poses, np.float64)
+    got, want = run_gpu(g, cam, [(poses, frames_for(len(poses), cam, 1))],
+                        np.zeros((g.cols, g.rows), np.float32))
+    S.assert_layers_equal(got, want, LAYERS)
+    assert (~np.isnan(want["observation_index"])).mean() > 0.05
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=IDS)
+def test_utm_flight_in_batches_and_replay(monkeypatch, env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = (464980.25, 5272690.5)
+    g = O.make_grid(150.0, 110.0, 0.5, c[0], c[1])
+    cam = S.camera()
+    F = 15
+    poses = synth.make_lawnmower_poses(F, 50.0, 640.0, 21, tilt_deg=12.0, center=c)
+    fr = frames_for(F, cam, 4)
+    z = terrain(g, 8, nan_frac=0.01)
+    cuts = [(0, 4), (4, 5), (5, 11), (11, 15), (5, 11)]       # the last batch replays an earlier one
+    got, want = run_gpu(g, cam, [(poses[a:b], fr[a:b]) for a, b in cuts], z)
+    S.assert_layers_equal(got, want, LAYERS)
+    assert (~np.isnan(want["observation_index"])).mean() > 0.5
+    # layer angles no asin can beat, NaN in the layer
+    weird = want["elevation_angle"].copy()
+    weird[::3, ::2] = np.float32(1.5707964)
+    weird[1::3, ::2] = np.float32(2.0)
+    weird[2::3, 1::2] = np.nan
+    got, want = run_gpu(g, cam, [(poses[0:6], fr[0:6])], z, angle0=weird)
+    S.assert_layers_equal(got, want, LAYERS)

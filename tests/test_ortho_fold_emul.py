@@ -1,0 +1,232 @@
+"""CPU: the margin-guarded fold of k_ortho_backward<true> (amhip_ortho_fold.h), emulated
+on the host by tests/cpp/ortho_fold_emul.cc, must take the oracle's decisions for
+every (cell, frame) pair: same observation_index, same float angle bits, same sampled
+pixel, same number of accepted updates.  Covers ordinary flights, UTM-scale
+coordinates, engineered exact ties (duplicate poses), image-border hits, grazing and
+behind-the-camera views, NaN / infinite elevations and incremental batches."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    O.build()
+    out = str(tmp_path_factory.mktemp("fold") / "libfold_emul.so")
+    subprocess.check_call([
+        "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+        "-I" + os.path.join(ROOT, "aerial_mapper_amd", "csrc"),
+        os.path.join(ROOT, "tests", "cpp", "ortho_fold_emul.cc"), "-o", out])
+    lib = C.CDLL(out)
+    lib.emul_ortho_fold.restype = C.c_int
+    return lib
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def run_both(emul, g, cam, T_G_B, elevation, frames, angle0=None, T_C_B=None):
+    """-> (oracle layers, emulated layers, stats)"""
+    T_C_B = synth.IDENTITY_POSE if T_C_B is None else T_C_B
+    F = len(frames)
+    want = O.new_layers(g)
+    want["elevation"][...] = elevation
+    if angle0 is not None:
+        want["elevation_angle"][...] = angle0
+    got = {k: v.copy() for k, v in want.items()}
+    rc_o = O.ortho_process(g, cam, T_G_B, T_C_B, frames, want, multi_thread=True)
+
+    T_G_C = O.compose_T_G_C(T_G_B, T_C_B)
+    half_x = g.length_x / 2.0 - g.resolution / 2.0
+    half_y = g.length_y / 2.0 - g.resolution / 2.0
+    base_x = g.pos_x + half_x
+    base_y = g.pos_y + half_y
+    camv = np.array([cam.fu, cam.fv, cam.cu, cam.cv, cam.width, cam.height], np.float64)
+    n = g.rows * g.cols
+    kx = np.zeros(n, np.int32)
+    ky = np.zeros(n, np.int32)
+    acc = np.zeros(n, np.int32)
+    stats = np.zeros(8, np.int64)
+    rc_e = emul.emul_ortho_fold(
+        C.c_int(g.rows), C.c_int(g.cols), C.c_double(base_x), C.c_double(base_y),
+        C.c_double(g.resolution), _ptr(camv, C.c_double),
+        _ptr(np.ascontiguousarray(T_G_C), C.c_double), C.c_int(F),
+        _ptr(got["elevation"], C.c_float), _ptr(got["elevation_angle"], C.c_float),
+        _ptr(got["observation_index"], C.c_float), _ptr(kx, C.c_int32), _ptr(ky, C.c_int32),
+        _ptr(acc, C.c_int32), _ptr(stats, C.c_longlong))
+    assert rc_e != -1, "fast path refused the poses"
+    assert (rc_e == 3) == (rc_o == 3)
+    # sample like ortho-backward-grid.cc:195 for the cells the emulation accepted
+    shape = (g.cols, g.rows)
+    kx, ky, acc = kx.reshape(shape), ky.reshape(shape), acc.reshape(shape)
+    hit = acc > 0
+    fidx = got["observation_index"][hit].astype(np.int64)
+    stack = np.stack(frames)
+    got["ortho"][hit] = stack[fidx, ky[hit], kx[hit]].astype(np.float32)
+    return want, got, dict(pairs=int(stats[0]), vis_exact=int(stats[1]), ties=int(stats[2]),
+                           exact_views=int(stats[3]), asins=int(stats[4])), acc
+
+
+def check(want, got):
+    S.assert_layers_equal(got, want, ["observation_index", "elevation_angle", "ortho"])
+
+
+def terrain(g, seed, nan_frac=0.0):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    j, i = np.meshgrid(np.arange(g.cols), np.arange(g.rows), indexing="ij")
+    x = g.pos_x + g.length_x / 2 - g.resolution * (i + 0.5)
+    y = g.pos_y + g.length_y / 2 - g.resolution * (j + 0.5)
+    z = synth.terrain_height(x, y) + rng.uniform(-0.5, 0.5, size=x.shape)
+    z = z.astype(np.float32)
+    if nan_frac:
+        z[rng.uniform(size=z.shape) < nan_frac] = np.nan
+    return z
+
+
+@pytest.mark.parametrize("seed,center,alt,tilt", [
+    (1, (0.0, 0.0), 700.0, 5.0),
+    (2, (0.0, 0.0), 460.0, 25.0),               # low, strongly tilted: many border crossings
+    (3, (464980.0, 5272190.0), 900.0, 8.0),     # UTM-scale coordinates
+    (4, (-1.0e7, 3.0e7), 650.0, 3.0),           # far larger than any projected CRS
+])
+def test_fold_matches_oracle_on_flights(emul, seed, center, alt, tilt):
+    g = O.make_grid(120.0, 90.0, 0.5, center[0], center[1])
+    cam = S.camera()
+    F = 14
+    poses = synth.make_lawnmower_poses(F, 40.0, alt, seed + 10, tilt_deg=tilt, center=center)
+    frames = [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=seed)]
+    want, got, st, _ = run_both(emul, g, cam, poses, terrain(g, seed, nan_frac=0.02), frames)
+    check(want, got)
+    assert st["pairs"] > 0
+    # the margins are tight: hardly any pair needs the reference's arithmetic
+    cells = g.rows * g.cols
+    assert st["vis_exact"] + st["ties"] < 1e-3 * st["pairs"] + 8
+    assert st["exact_views"] <= cells + 3 * (st["vis_exact"] + st["ties"]) + 8
+
+
+def test_duplicate_and_near_duplicate_poses_tie_exactly(emul):
+    """The same pose twice: equal alphas, `alpha > (double)(float)alpha` decides by the
+    float rounding direction; tiny perturbations of the pose produce genuine near ties."""
+    g = O.make_grid(60.0, 60.0, 0.5)
+    cam = S.camera()
+    base = synth.make_lawnmower_poses(3, 10.0, 500.0, 77, tilt_deg=6.0)
+    poses = [base[0], base[0].copy(), base[1], base[1].copy()]
+    for k, eps in enumerate([1e-9, 3e-8, 1e-7, 4e-7, 1e-6, 3e-6]):
+        p = base[2].copy()
+        p[2] += eps * 500.0 * (1 if k % 2 else -1)
+        poses.append(p)
+    poses.append(base[0].copy())
+    poses = np.array(poses)
+    F = len(poses)
+    frames = [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=3)]
+    want, got, st, _ = run_both(emul, g, cam, poses, terrain(g, 5), frames)
+    check(want, got)
+    assert st["ties"] > 1000  # the exact route really ran
+
+
+def test_image_border_hits_and_grazing_views(emul):
+    """Level camera whose pixel grid maps cell centres exactly onto u = 0, u = W, v = 0,
+    v = H (flat ground): the box test sits on its decision boundary for whole rows and
+    columns of cells; plus cameras looking sideways / away (z ~ 0, z < 0)."""
+    res = 0.5
+    g = O.make_grid(100.0 * res, 80.0 * res, res)
+    cam = O.Camera()
+    W, H = 64, 48
+    cam.fu = cam.fv = 100.0
+    cam.cu, cam.cv = 32.0, 24.0
+    cam.width, cam.height = W, H
+    cam.distortion = O.DIST_NONE
+    alt = 50.0                                  # ground sampling: 0.5 m per pixel at z = 0
+    elev = np.zeros((g.cols, g.rows), np.float32)
+    q_down = synth._qmul(synth._axis_angle((0, 0, 1.0), 0.0), synth._axis_angle((1.0, 0, 0), math.pi))
+    poses = []
+    for (x, y) in [(0.25, 0.25), (0.0, 0.0), (3.25, -2.25), (0.25, 0.25)]:
+        poses.append([x, y, alt] + list(q_down))
+    # sideways (optical axis horizontal) and upward looking cameras
+    q_side = synth._qmul(q_down, synth._axis_angle((1.0, 0, 0), math.pi / 2))
+    q_up = synth._qmul(q_down, synth._axis_angle((1.0, 0, 0), math.pi))
+    poses.append([0.0, 0.0, 0.0] + list(q_side))     # camera ON the ground plane: z_c ~ 0 for a row
+    poses.append([5.0, 5.0, alt] + list(q_side))
+    poses.append([0.0, 0.0, alt] + list(q_up))
+    poses = np.array(poses, np.float64)
+    F = len(poses)
+    frames = [np.ascontiguousarray(f) for f in synth.make_frames(F, H, W, 1, salt=1)]
+    want, got, st, _ = run_both(emul, g, cam, poses, elev, frames)
+    check(want, got)
+    assert st["vis_exact"] > 50   # border cells went through exact_view
+
+
+def test_nan_and_infinite_elevations(emul):
+    g = O.make_grid(40.0, 30.0, 0.5)
+    cam = S.camera()
+    F = 6
+    poses = synth.make_lawnmower_poses(F, 12.0, 600.0, 9, tilt_deg=4.0)
+    frames = [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=2)]
+    z = terrain(g, 12, nan_frac=0.3)
+    z[3, 5] = np.inf
+    z[7, 11] = -np.inf
+    z[9, 2] = 3.0e38
+    want, got, st, _ = run_both(emul, g, cam, poses, z, frames)
+    check(want, got)
+
+
+def test_incremental_batches_continue_from_the_layer(emul):
+    g = O.make_grid(80.0, 60.0, 0.5)
+    cam = S.camera()
+    F = 12
+    poses = synth.make_lawnmower_poses(F, 25.0, 650.0, 21, tilt_deg=7.0)
+    fr = [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=4)]
+    z = terrain(g, 8)
+    angle_o = np.zeros((g.cols, g.rows), np.float32)
+    angle_e = angle_o.copy()
+    for lo in (0, 4, 8):
+        want, got, st, _ = run_both(emul, g, cam, poses[lo:lo + 4], z, fr[lo:lo + 4], angle0=angle_o)
+        # both start from the ORACLE's running angle; the emulation's must be identical anyway
+        assert np.array_equal(angle_o.view(np.uint32), angle_e.view(np.uint32))
+        check(want, got)
+        angle_o = want["elevation_angle"].copy()
+        angle_e = got["elevation_angle"].copy()
+    # a batch replayed onto its own result: every view ties with the stored float
+    want, got, st, _ = run_both(emul, g, cam, poses[8:12], z, fr[8:12], angle0=angle_o)
+    check(want, got)
+    assert st["ties"] > 100
+    # layer values no asin can beat / NaN in the layer
+    weird = angle_o.copy()
+    weird[::3, ::2] = np.float32(1.5707964)
+    weird[1::3, ::2] = np.float32(2.0)
+    weird[2::3, 1::2] = np.nan
+    want, got, st, _ = run_both(emul, g, cam, poses[0:4], z, fr[0:4], angle0=weird)
+    check(want, got)
+
+
+def test_accept_counts_match_a_python_fold(emul):
+    """accepted[] drives `num_observations += num_observations`; count the oracle's accepts
+    by folding frame by frame."""
+    g = O.make_grid(30.0, 20.0, 0.5)
+    cam = S.camera()
+    F = 7
+    poses = synth.make_lawnmower_poses(F, 8.0, 500.0, 31, tilt_deg=10.0)
+    fr = [np.ascontiguousarray(f) for f in synth.make_frames(F, cam.height, cam.width, 1, salt=5)]
+    z = terrain(g, 3)
+    lay = O.new_layers(g)
+    lay["elevation"][...] = z
+    count = np.zeros((g.cols, g.rows), np.int32)
+    for f in range(F):
+        before = lay["elevation_angle"].copy()
+        O.ortho_process(g, cam, poses[f:f + 1], synth.IDENTITY_POSE, fr[f:f + 1], lay)
+        count += (lay["elevation_angle"].view(np.uint32) != before.view(np.uint32))
+    want, got, st, acc = run_both(emul, g, cam, poses, z, fr)
+    check(want, got)
+    # an accept always raises the float angle (alpha > stored float), so changes == accepts
+    assert np.array_equal(acc, count)
