@@ -1041,9 +1041,10 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   Ctx* c = &h->impl;
   int rc = use_device(c);
   if (rc) return rc;
-  // one buffer, one upload: FramePose[F], then FrameFast[F + 1] (two FramePose
-  // slots each; the extra entry carries the camera for exact_view())
-  const size_t slots = F + 2 * (F + 1);
+  // one buffer, one upload: FramePose[F], then FrameFast[F + 2] (two FramePose
+  // slots each; the two extra entries carry the camera for exact_view(),
+  // doubles 0..5, and the atan table of fold_angle(), doubles 8..24)
+  const size_t slots = F + 2 * (F + 2);
   if ((rc = ensure_capacity(&c->frame_poses, &c->frame_pose_cap, slots))) return rc;
 
   // T_C_G[f] = T_G_C[f].inverse()  (ortho-backward-grid.cc:157-158; the
@@ -1051,6 +1052,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   static_assert(sizeof(FrameFast) == 2 * sizeof(FramePose), "frame table layout");
   std::vector<FramePose> inv(slots);
   FrameFast* fast = reinterpret_cast<FrameFast*>(inv.data() + F);
+  double qdev = 0.0;  // max | |q|^2 - 1 |
   bool fast_ok = cam->distortion == AMHIP_DIST_NONE && cam->fu > 0.0 && cam->fv > 0.0 &&
                  !std::getenv("AMHIP_ORTHO_EXACT_FOLD");
   for (size_t f = 0; f < F; ++f) {
@@ -1065,10 +1067,13 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
     inv[f]._pad = 0.0;
     // (non-unit quaternion / non-finite pose: the whole call takes the exact kernel)
     if (!make_frame_fast(inv[f], &fast[f])) fast_ok = false;
+    const double dev = std::fabs(T.qw * T.qw + T.qx * T.qx + T.qy * T.qy + T.qz * T.qz - 1.0);
+    if (!(dev <= qdev)) qdev = dev;  // (NaN sticks)
   }
   {
     double* camd = reinterpret_cast<double*>(&fast[F]);
-    std::memset(camd, 0, sizeof(FrameFast));
+    std::memset(camd, 0, 2 * sizeof(FrameFast));
+    make_atan_table(camd + 8);
     camd[0] = cam->fu;
     camd[1] = cam->fv;
     camd[2] = cam->cu;
@@ -1097,11 +1102,22 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
     else if ((rc = touch(c, outs[k])))
       return rc;
   }
+  p.radius_scale = 1.0 + 2.0 * qdev;
+  if (!(qdev < 0.25)) p.cull = 0;  // not a rotation at all (or NaN): every frame is tested
   // small batches on a big map: most tiles are out of every frame's sight
   p.coarse = (p.cull && c->zrange_valid && F <= 64 && !std::getenv("AMHIP_NO_COARSE_CULL")) ? 1 : 0;
-  p.virt_nobs = c->layer_state[AMHIP_LAYER_NUM_OBSERVATIONS] == 3 ? 1 : 0;
+  // num_observations is zero everywhere while it holds its initial value,
+  // filled (0) or not (3): `+= itself` keeps it zero, the kernel neither reads
+  // nor writes it and the layer stays in that state
+  {
+    const unsigned char st = c->layer_state[AMHIP_LAYER_NUM_OBSERVATIONS];
+    p.virt_nobs = (st == 3 || st == 0) ? 1 : 0;
+  }
   if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
+  p.prune = (p.cull && cam->distortion == AMHIP_DIST_NONE && p.virt_nobs &&
+             !std::getenv("AMHIP_ORTHO_NO_PRUNE")) ? 1 : 0;
   p.fast = fast_ok ? 1 : 0;
+  p.dbg_stop = std::getenv("AMHIP_ORTHO_STOP") ? std::atoi(std::getenv("AMHIP_ORTHO_STOP")) : 0;
   p.fold = make_fold_cam(cam->fu, cam->fv, cam->cu, cam->cv, cam->width, cam->height);
   return ortho_run(c, p, c->frame_poses, reinterpret_cast<const FrameFast*>(c->frame_poses + F),
                    dev_frames);

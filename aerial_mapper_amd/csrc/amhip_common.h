@@ -103,6 +103,13 @@ struct OrthoParams {
   // quaternions; the frame table follows the poses in the same buffer
   int fast;
   FoldCam fold;
+  // dominance pruning of a tile's frame list (frame_bounds / dominated):
+  // undistorted pinhole, num_observations logically zero
+  int prune;
+  // the bounding spheres assume rigid poses; |q|^2 = 1 + dev scales distances
+  // by that much: radii are multiplied by 1 + 2 max|dev|
+  double radius_scale;
+  int dbg_stop;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).

@@ -28,9 +28,10 @@
 namespace amhip {
 
 constexpr int kTileI = 64;
-constexpr int kTileJ = 16;
+constexpr int kTileJ = 64;   // a workgroup's tile ...
+constexpr int kSlabJ = 16;   // ... is folded in slabs of this many cell columns
 constexpr int kOrthoThreads = 256;
-constexpr int kCellsPerLane = kTileJ / (kOrthoThreads / 64);  // 4
+constexpr int kCellsPerLane = kSlabJ / (kOrthoThreads / 64);  // 4 per slab
 constexpr int kChunk = 1024;  // frames culled per pass
 
 // V3, cross3, transform_point, exact_view_inline, fold_init / fold_pair / fold_finish: amhip_ortho_fold.h
@@ -93,27 +94,21 @@ __device__ __noinline__ double view_angle(double abs_z, double n2) {
   return asin(abs_z / norm);
 }
 
-// The reference's arithmetic for one (cell, frame) pair of the margin-guarded
-// fold: needed once per cell (the winner's keypoint and angle) and for the rare
-// pairs whose decision falls inside a margin.  Out of line for the same reason
-// as view_angle().
-__device__ __noinline__ ExactView exact_view(const double* __restrict__ cam,
-                                             const FramePose* __restrict__ pose, double lx,
-                                             double ly, double lz) {
-  return exact_view_inline(cam, *pose, lx, ly, lz);
+// The reference's arithmetic for the cells the margin-guarded fold could not
+// settle (amhip_ortho_fold.h).  Out of line, called after the hot loop with
+// almost nothing live: their registers do not add to the loop's.
+__device__ __noinline__ FoldResult slow_finish(const double* __restrict__ cam,
+                                               const FramePose* __restrict__ pose, double lx,
+                                               double ly, double lz, int best_f, int accepted) {
+  return exact_finish(cam, *pose, lx, ly, lz, best_f, accepted);
 }
 
-struct DeviceExact {
-  const double* cam;
-  const FramePose* poses;
-  double lx, ly, lz;
-  __device__ __forceinline__ ExactView view(int f) const {
-    return exact_view(cam, poses + f, lx, ly, lz);
-  }
-  __device__ __forceinline__ double angle(double absz, double n2) const {
-    return view_angle(absz, n2);
-  }
-};
+__device__ __noinline__ FoldResult slow_refold(const double* __restrict__ cam,
+                                               const FramePose* __restrict__ poses,
+                                               const int* cand, int n, double lx, double ly,
+                                               double lz, float layer_angle) {
+  return exact_refold(cam, poses, cand, n, lx, ly, lz, layer_angle);
+}
 
 __device__ __forceinline__ float wave_min_f(float v) {
 #pragma unroll
@@ -152,21 +147,67 @@ __device__ __forceinline__ void write_initial(const OrthoParams& p, float* __res
   out[at] = p.colored ? __builtin_nanf("") : 255.0f;
 }
 
-// Phase B: cull one chunk of frames against the tile's bounding sphere, keep
-// the survivors in ascending order in s_cand.  Returns their number (the same
-// value in every thread of the block); ends with a barrier.
+// a wave-uniform double, moved to scalar registers
+__device__ __forceinline__ double uniform_d(double v) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_min_d(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// The same test with the pose as a matrix (FrameFast): 21 FP64 operations
+// instead of 45.  The fma chain is within 2^-46 (|centre|_1 + |t|_1) of the
+// exact transform (amhip_ortho_fold.h); the radius grows by 2^-40 of that.
+__device__ __forceinline__ bool frame_may_see_fast(const OrthoParams& p, const FrameFast& Q,
+                                                   const V3& centre, double cmag, double radius) {
+  const double r = fma(0x1p-40, cmag + Q.tmag, radius);
+  const double cx = fma(Q.m[2], centre.z, fma(Q.m[1], centre.y, fma(Q.m[0], centre.x, Q.t[0])));
+  const double cy = fma(Q.m[5], centre.z, fma(Q.m[4], centre.y, fma(Q.m[3], centre.x, Q.t[1])));
+  const double cz = fma(Q.m[8], centre.z, fma(Q.m[7], centre.y, fma(Q.m[6], centre.x, Q.t[2])));
+  bool keep = !(cz < -r);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double d = fma(p.pl[k][2], cz, fma(p.pl[k][1], cy, p.pl[k][0] * cx));
+    if (d < -r) keep = false;
+  }
+  return keep;
+}
+
+// Phase B: the tile's frame list for one chunk of frames, ascending, in s_cand.
+//   stage 1  one thread per frame: bounding sphere of the tile's landmarks
+//            against the view pyramid (conservative: a dropped frame is
+//            invisible from every cell of the tile), ballot compaction;
+//   stage 2  (p.prune) one thread per SURVIVOR: frame_bounds() -> drop the
+//            frames that a frame fully visible over the tile beats at every
+//            landmark (amhip_ortho_fold.h: dominated), second compaction.
+// Returns the number of frames left (the same value in every thread of the
+// block); ends with a barrier.
+template <bool kFast>
 __device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose* __restrict__ poses,
-                                          const V3& centre, double radius, int chunk0, int chunk_n,
-                                          int* s_cand, int* s_wave_cnt) {
+                                          const FrameFast* __restrict__ fast_tab,
+                                          const V3& centre, double radius, double slack,
+                                          int chunk0, int chunk_n, int* s_cand, int* s_wave_cnt,
+                                          double* s_best) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
+  const double cmag = fabs(centre.x) + fabs(centre.y) + fabs(centre.z);
   int ncand = 0;
   for (int r = 0; r < chunk_n; r += kOrthoThreads) {
     const int f = chunk0 + r + (int)threadIdx.x;
     bool keep = false;
     if (f < chunk0 + chunk_n) {
       keep = true;
-      if (p.cull) keep = frame_may_see(p, poses[f], centre, radius);
+      if (p.cull) {
+        if constexpr (kFast)
+          keep = frame_may_see_fast(p, fast_tab[f], centre, cmag, radius);
+        else
+          keep = frame_may_see(p, poses[f], centre, radius);
+      }
     }
     const unsigned long long m = __ballot(keep);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
@@ -184,7 +225,43 @@ __device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose*
     ncand += tot;
   }
   __syncthreads();  // s_cand complete
-  return ncand;
+  // more survivors than threads (a frame list that long is not worth pruning)
+  if (!p.prune || ncand <= 1 || ncand > kOrthoThreads) return ncand;
+
+  // ---- stage 2 ---------------------------------------------------------------
+  const bool mine = (int)threadIdx.x < ncand;
+  int f = 0;
+  double tmin = 0.0, tmax_full = __builtin_huge_val();
+  if (mine) {
+    f = s_cand[threadIdx.x];
+    const FrameBounds b = frame_bounds(p.pl, poses[f], centre, radius, slack);
+    tmin = b.tmin;
+    if (b.full) tmax_full = b.tmax;
+  }
+  // smallest tmax of a fully visible frame (survivors sit in the first waves)
+  const int nw = (ncand + 63) >> 6;
+  if (wid < nw) {
+    const double wmin = wave_min_d(tmax_full);
+    if (lane == 0) s_best[wid] = wmin;
+  }
+  __syncthreads();  // s_best written, everyone has read its s_cand entry
+  double best = s_best[0];
+  for (int w = 1; w < nw; ++w) best = fmin(best, s_best[w]);
+  const bool keep = mine && !dominated(tmin, best);
+  const unsigned long long m = __ballot(keep);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave_cnt[wid] = __popcll(m);
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kOrthoThreads / 64; ++w) {
+    const int cw = s_wave_cnt[w];
+    if (w < wid) base += cw;
+    tot += cw;
+  }
+  if (keep) s_cand[base + before] = f;
+  __syncthreads();  // s_cand complete
+  return tot;
 }
 
 // One cell's results (ortho-backward-grid.cc:181-208): angle, frame index, the
@@ -218,10 +295,272 @@ __device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* 
   }
 }
 
+// One slab (64 x kSlabJ cells, kCellsPerLane per lane) of the block's tile: fold
+// the tile's frame list into the slab's cells and write them back.
+//
 // kFast: the margin-guarded fold of amhip_ortho_fold.h (undistorted pinhole,
 // unit quaternions) -- ~30 FP64 operations per pair instead of ~85, the
 // reference's own arithmetic once per cell for the winner and for the pairs a
 // margin cannot decide.  !kFast: every pair in the reference's arithmetic.
+//
+// single: the whole frame list fits one cull chunk and is already in s_cand
+// (ncand0 entries); otherwise the chunks are culled here, per slab.
+template <bool kFast>
+__device__ __forceinline__ void ortho_slab(
+    const OrthoParams& p, const FramePose* __restrict__ poses,
+    const FrameFast* __restrict__ fast_tab, const uint8_t* __restrict__ frames,
+    const float* __restrict__ elevation, float* __restrict__ elevation_angle,
+    float* __restrict__ observation_index, float* __restrict__ num_observations,
+    float* __restrict__ out_layer, unsigned* __restrict__ dev_err, int* s_cand, int* s_wave_cnt,
+    double* s_best, const V3& centre, double radius, double slack, int i, bool i_ok, int js,
+    bool single, int ncand0) {
+  const int wid = threadIdx.x >> 6;
+  const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
+  float elev[kCellsPerLane];
+#pragma unroll
+  for (int c = 0; c < kCellsPerLane; ++c) {
+    const int j = js + wid + c * (kOrthoThreads / 64);
+    float e = __builtin_nanf("");
+    if (i_ok && j < p.cols) e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
+    elev[c] = e;
+  }
+
+  if constexpr (kFast) {
+    // ---- margin-guarded fold (amhip_ortho_fold.h) -----------------------------
+    const double* cam_tab = reinterpret_cast<const double*>(fast_tab + p.num_frames);
+    CellFold st[kCellsPerLane];
+    double lz[kCellsPerLane];
+    bool valid[kCellsPerLane];
+    const double ly0 = p.base_y + p.res * (-(double)(js + wid + p.j_off));
+    const double dly = p.res * (-(double)(kOrthoThreads / 64));
+    double magL = 0.0;  // >= |lx| + |ly| + |lz| of every cell of the lane
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = js + wid + c * (kOrthoThreads / 64);
+      float a0 = 0.0f;
+      if (i_ok && j < p.cols && !p.virt_out)
+        a0 = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
+      fold_init(&st[c], a0);
+      lz[c] = (double)elev[c];
+      valid[c] = elev[c] == elev[c];  // NaN elevation (or no such cell) is never visible
+      // an infinite elevation makes mag infinite: every pair of the lane is then
+      // inside the margins and the cells are replayed by slow_refold()
+      if (valid[c]) magL = fmax(magL, fabs(lz[c]));
+    }
+    // (the fma chain's ly differs from the grid's by an ulp at most: the 2x
+    // headroom of the error budget covers it; the slow routines use the grid's)
+    magL += fabs(lx) + fmax(fabs(ly0), fabs(ly0 + dly * (double)(kCellsPerLane - 1)));
+    double tmag_max = 0.0;  // over the frames folded (same value in every lane)
+
+    for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
+      int ncand = ncand0;
+      if (!single) {
+        const int chunk_n = min(kChunk, p.num_frames - chunk0);
+        ncand = cull_chunk<kFast>(p, poses, fast_tab, centre, radius, slack, chunk0, chunk_n, s_cand,
+                                  s_wave_cnt, s_best);
+      }
+      if (i_ok) {
+        for (int k = 0; k < ncand; ++k) {
+          const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
+          const FrameFast& Q = fast_tab[f];
+          const double mag = magL + Q.tmag;
+          tmag_max = fmax(tmag_max, Q.tmag);
+          const double zthr = fma(0x1p-22, mag, 1e-10);
+          const double muv = p.fold.kuv * mag;
+          const double bx = fma(Q.m[1], ly0, fma(Q.m[0], lx, Q.t[0]));
+          const double by = fma(Q.m[4], ly0, fma(Q.m[3], lx, Q.t[1]));
+          const double bz = fma(Q.m[7], ly0, fma(Q.m[6], lx, Q.t[2]));
+          const double sx = Q.m[1] * dly, sy = Q.m[4] * dly, sz = Q.m[7] * dly;
+#pragma unroll
+          for (int c = 0; c < kCellsPerLane; ++c) {
+            const double cx = fma(Q.m[2], lz[c], fma(sx, (double)c, bx));
+            const double cy = fma(Q.m[5], lz[c], fma(sy, (double)c, by));
+            const double cz = fma(Q.m[8], lz[c], fma(sz, (double)c, bz));
+            fold_pair(&st[c], f, p.fold, valid[c], cx, cy, cz, zthr, muv);
+          }
+        }
+      }
+      if (single) break;
+      __syncthreads();  // everyone is done with s_cand before the next chunk
+    }
+
+    // ---- write back, pass 1: the winner's keypoint and stored angle from the
+    // approximate point wherever that is provably the reference's result --------
+    int pending = 0;  // 2 bits per cell: kFoldFinish / kFoldRedo
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = js + wid + c * (kOrthoThreads / 64);
+      if (!(i_ok && j < p.cols)) continue;
+      int ku = 0, kv = 0;
+      float angle = 0.0f;
+      const int what = fold_finish(&st[c], p.fold, cam_tab + 8, magL + tmag_max, p.width, p.height,
+                                   &ku, &kv, &angle);
+      if (what == kFoldNone) {
+        if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+      } else if (what == kFoldDone) {
+        write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
+                   angle, st[c].best_f, st[c].accepted, ku, kv);
+      } else {
+        pending |= what << (2 * c);
+        // (what slow_finish needs survives in two registers per cell)
+      }
+    }
+    // ---- pass 2 (rare): the reference's arithmetic -------------------------------
+    if (pending) {
+      const bool whole_list = single;  // else: every frame, like the reference itself
+      bool bad_alpha = false;
+#pragma unroll
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int what = (pending >> (2 * c)) & 3;
+        if (what == 0) continue;
+        const int j = js + wid + c * (kOrthoThreads / 64);
+        const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+        const double ly = p.base_y + p.res * (-(double)(j + p.j_off));
+        const double lzc = (double)elevation[at];
+        FoldResult r;
+        if (what == kFoldFinish) {
+          r = slow_finish(cam_tab, poses + st[c].best_f, lx, ly, lzc, st[c].best_f, st[c].accepted);
+        } else {
+          const float a0 = p.virt_out ? 0.0f : elevation_angle[at];
+          r = slow_refold(cam_tab, poses, whole_list ? s_cand : nullptr,
+                          whole_list ? ncand0 : p.num_frames, lx, ly, lzc, a0);
+        }
+        if (r.bad_alpha) bad_alpha = true;
+        if (r.best_f < 0) {
+          if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+        } else {
+          write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i,
+                     j, r.best, r.best_f, r.accepted, r.kp_x, r.kp_y);
+        }
+      }
+      if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
+    }
+  } else {
+    // ---- per-lane fold state -------------------------------------------------
+    // Running best view per cell.  The reference keeps (float)asin(|z|/||p||) and
+    // accepts a view iff its asin exceeds that float (widened to double).  asin is
+    // monotonic, so unless the two sines are within 2.5e-6 (relative, squared) of
+    // each other the outcome is decided by comparing |z|^2/||p||^2 -- no sqrt, no
+    // division, no asin.  Only near ties (where the float rounding of the stored
+    // angle matters) take the exact route; the winning angle itself is evaluated
+    // once per cell at the end.  Margin: d(asin)/ds >= 1 and asin(s) <= (pi/2) s,
+    // so a relative gap of 1e-6 in s is > 10x the 6e-8 float rounding of the angle.
+    float best[kCellsPerLane];    // stored angle (valid iff have_f)
+    bool have_f[kCellsPerLane];
+    double zb[kCellsPerLane];     // |z| and ||p||^2 of the current best view
+    double n2b[kCellsPerLane];
+    int best_f[kCellsPerLane];
+    int best_u[kCellsPerLane];
+    int best_v[kCellsPerLane];
+    int accepted[kCellsPerLane];
+    bool bad_alpha = false;
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = js + wid + c * (kOrthoThreads / 64);
+      best[c] = 0.0f;
+      if (i_ok && j < p.cols && !p.virt_out)
+        best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
+      have_f[c] = true;
+      n2b[c] = 1.0;
+      if (best[c] >= 1.5707964f)
+        zb[c] = __builtin_huge_val();  // no asin exceeds (float)(pi/2)
+      else if (best[c] > 0.0f)
+        zb[c] = sin((double)best[c]);  // incremental mode: angle left by earlier batches
+      else if (best[c] == best[c])
+        zb[c] = 0.0;                   // fresh layer: every visible view wins (alpha > 0)
+      else
+        zb[c] = __builtin_huge_val();  // NaN in the layer: `alpha > NaN` never holds
+      best_f[c] = -1;
+      best_u[c] = 0;
+      best_v[c] = 0;
+      accepted[c] = 0;
+    }
+
+    for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
+      int ncand = ncand0;
+      if (!single) {
+        const int chunk_n = min(kChunk, p.num_frames - chunk0);
+        ncand = cull_chunk<kFast>(p, poses, fast_tab, centre, radius, slack, chunk0, chunk_n, s_cand,
+                                  s_wave_cnt, s_best);
+      }
+      // ---- fold the candidates, ascending --------------------------------------
+      if (i_ok) {
+        for (int k = 0; k < ncand; ++k) {
+          const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
+          const FramePose T = poses[f];
+#pragma unroll
+          for (int c = 0; c < kCellsPerLane; ++c) {
+            const int j = js + wid + c * (kOrthoThreads / 64);
+            const double ly = p.base_y + p.res * (-(double)(j + p.j_off));
+            const V3 landmark = {lx, ly, (double)elev[c]};
+            const V3 cp = transform_point(T, landmark);
+            double u, v;
+            if (!project_visible(p, cp, &u, &v)) continue;
+            const double zz = cp.z * cp.z;
+            const double n2 = cp.x * cp.x + cp.y * cp.y + zz;
+            const double lhs = zz * n2b[c];
+            const double rhs = (zb[c] * zb[c]) * n2;
+            bool accept = lhs > rhs * (1.0 + 2.5e-6);
+            const bool reject = lhs < rhs * (1.0 - 2.5e-6);
+            bool exact = false;
+            if (!accept && !reject) {
+              // near tie: the reference's own arithmetic decides
+              asm volatile("" ::: "memory");
+              if (!have_f[c]) {
+                best[c] = (float)view_angle(zb[c], n2b[c]);
+                have_f[c] = true;
+              }
+              const double alpha = view_angle(fabs(cp.z), n2);
+              if (!(alpha > 0.0)) bad_alpha = true;  // CHECK(alpha > 0.0)
+              if (alpha > (double)best[c]) {
+                best[c] = (float)alpha;
+                accept = true;
+                exact = true;
+              }
+            }
+            if (accept) {
+              have_f[c] = exact;
+              zb[c] = fabs(cp.z);
+              n2b[c] = n2;
+              best_f[c] = f;
+              accepted[c]++;
+              best_v[c] = min((int)round(v), p.height - 1);
+              best_u[c] = min((int)round(u), p.width - 1);
+            }
+          }
+        }
+      }
+      if (single) break;
+      __syncthreads();  // everyone is done with s_cand before the next chunk
+    }
+
+    if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
+
+    // ---- write back ------------------------------------------------------------
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = js + wid + c * (kOrthoThreads / 64);
+      if (!(i_ok && j < p.cols)) continue;
+      if (accepted[c] == 0) {
+        if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+        continue;
+      }
+      if (!have_f[c]) {
+        // the winning view's angle, evaluated exactly like the reference does
+        const double alpha = view_angle(zb[c], n2b[c]);
+        if (!(alpha > 0.0)) atomicOr(dev_err, kDevErrAlphaNonPos);  // CHECK(alpha > 0.0)
+        best[c] = (float)alpha;
+      }
+      write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
+                 best[c], best_f[c], accepted[c], best_u[c], best_v[c]);
+    }
+  }
+}
+
+// One workgroup owns a tile of 64 x kTileJ cells = kTileJ / kSlabJ slabs.  The
+// frame list is built ONCE per tile (elevation range -> bounding sphere -> cull
+// + dominance pruning, one thread per frame: that is 250 transforms, a sqrt and
+// two divisions per tile, as much work as folding a slab) and every slab folds it.
 template <bool kFast>
 __device__ __forceinline__ void ortho_backward_tile(
     const OrthoParams& p, const FramePose* __restrict__ poses,
@@ -229,8 +568,8 @@ __device__ __forceinline__ void ortho_backward_tile(
     const float* __restrict__ elevation, float* __restrict__ elevation_angle,
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
-    const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt) {
-
+    const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt,
+    double* s_best) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int i = blockIdx.x * kTileI + lane;
@@ -249,64 +588,53 @@ __device__ __forceinline__ void ortho_backward_tile(
   // ---- phase 0 (small batches): can ANY frame see this tile at all, given the
   // range of heights the DSM has ever written?  If not, leave before touching
   // the tile's elevation.  (Incremental mapping: a few frames, a huge map.)
+  bool nothing = false;
   if (p.coarse) {
     const double glo = from_ordered_key(zrange[0]), ghi = from_ordered_key(zrange[1]);
     bool any = false;
     if (glo <= ghi) {
       const double ghz = 0.5 * (ghi - glo) * (1.0 + 1e-6) + 1e-3;  // float-rounded heights
       const V3 gc = {0.5 * (xa + xb), 0.5 * (ya + yb), 0.5 * (glo + ghi)};
-      const double gr = sqrt(hx * hx + hy * hy + ghz * ghz) * (1.0 + 1e-9) + 1e-6;
+      const double gr =
+          (sqrt(hx * hx + hy * hy + ghz * ghz) * (1.0 + 1e-9) + 1e-6) * p.radius_scale;
       for (int f = threadIdx.x; f < p.num_frames; f += kOrthoThreads)
         any = any || frame_may_see(p, poses[f], gc, gr);
     }
-    if (!__syncthreads_or(any)) {
-      if (p.virt_out && i_ok) {
-#pragma unroll
-        for (int c = 0; c < kCellsPerLane; ++c) {
-          const int j = j0 + wid + c * (kOrthoThreads / 64);
-          if (j < p.cols) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
-        }
-      }
-      return;
-    }
+    nothing = !__syncthreads_or(any);
   }
 
-  // ---- phase A: this lane's cells + tile elevation range -------------------
-  float elev[kCellsPerLane];
+  // ---- phase A: the tile's elevation range ----------------------------------
   float zmin = __builtin_huge_valf(), zmax = -__builtin_huge_valf();
-#pragma unroll
-  for (int c = 0; c < kCellsPerLane; ++c) {
-    const int j = j0 + wid + c * (kOrthoThreads / 64);
-    float e = __builtin_nanf("");
-    if (i_ok && j < p.cols) e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
-    elev[c] = e;
-    if (e == e) {  // NaN elevation can never be visible
-      zmin = fminf(zmin, e);
-      zmax = fmaxf(zmax, e);
-    }
-  }
-  zmin = wave_min_f(zmin);
-  zmax = wave_max_f(zmax);
-  if (lane == 0) {
-    s_red[wid] = zmin;
-    s_red[kOrthoThreads / 64 + wid] = zmax;
-  }
-  __syncthreads();
-  zmin = s_red[0];
-  zmax = s_red[kOrthoThreads / 64];
-#pragma unroll
-  for (int w = 1; w < kOrthoThreads / 64; ++w) {
-    zmin = fminf(zmin, s_red[w]);
-    zmax = fmaxf(zmax, s_red[kOrthoThreads / 64 + w]);
-  }
-  if (!(zmin <= zmax)) {  // no finite elevation in this tile: every cell keeps its values
-    if (p.virt_out && i_ok) {
-#pragma unroll
-      for (int c = 0; c < kCellsPerLane; ++c) {
-        const int j = j0 + wid + c * (kOrthoThreads / 64);
-        if (j < p.cols) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+  if (!nothing) {
+    if (i_ok) {
+      for (int j = j0 + wid; j <= j_hi; j += kOrthoThreads / 64) {
+        const float e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
+        if (e == e) {  // NaN elevation can never be visible
+          zmin = fminf(zmin, e);
+          zmax = fmaxf(zmax, e);
+        }
       }
     }
+    zmin = wave_min_f(zmin);
+    zmax = wave_max_f(zmax);
+    if (lane == 0) {
+      s_red[wid] = zmin;
+      s_red[kOrthoThreads / 64 + wid] = zmax;
+    }
+    __syncthreads();
+    zmin = s_red[0];
+    zmax = s_red[kOrthoThreads / 64];
+#pragma unroll
+    for (int w = 1; w < kOrthoThreads / 64; ++w) {
+      zmin = fminf(zmin, s_red[w]);
+      zmax = fmaxf(zmax, s_red[kOrthoThreads / 64 + w]);
+    }
+  }
+  if (!(zmin <= zmax)) {
+    // nothing can see the tile / no finite elevation in it: every cell keeps its values
+    if (p.virt_out && i_ok)
+      for (int j = j0 + wid; j <= j_hi; j += kOrthoThreads / 64)
+        write_initial(p, elevation_angle, observation_index, out_layer, i, j);
     return;
   }
 
@@ -315,189 +643,32 @@ __device__ __forceinline__ void ortho_backward_tile(
                      0.5 * ((double)zmin + (double)zmax)};
   const double hz = 0.5 * ((double)zmax - (double)zmin);
   // generous slack: the cull only has to be conservative
-  const double radius = sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6;
+  const double radius =
+      (sqrt(hx * hx + hy * hy + hz * hz) * (1.0 + 1e-9) + 1e-6) * p.radius_scale;
+  // "fully visible" margin of frame_bounds(): 1e-6 m + 2^-40 of the coordinate
+  // magnitudes (the pose translations are of the same order as the map's)
+  const double slack =
+      1e-6 + 0x1p-40 * (fabs(centre.x) + fabs(centre.y) + fabs(centre.z) + radius) * 2.0;
 
-  const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
-  if constexpr (kFast) {
-    // ---- margin-guarded fold (amhip_ortho_fold.h) -----------------------------
-    const double* cam_tab = reinterpret_cast<const double*>(fast_tab + p.num_frames);
-    CellFold st[kCellsPerLane];
-    double ly[kCellsPerLane], lz[kCellsPerLane];
-    bool valid[kCellsPerLane];
-    double magL = 0.0;  // >= |lx| + |ly| + |lz| of every cell of the lane
-#pragma unroll
-    for (int c = 0; c < kCellsPerLane; ++c) {
-      const int j = j0 + wid + c * (kOrthoThreads / 64);
-      float a0 = 0.0f;
-      if (i_ok && j < p.cols && !p.virt_out)
-        a0 = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
-      fold_init(&st[c], a0);
-      ly[c] = p.base_y + p.res * (-(double)(j + p.j_off));
-      lz[c] = (double)elev[c];
-      valid[c] = elev[c] == elev[c];  // NaN elevation (or no such cell) is never visible
-      // an infinite elevation makes mag infinite: every pair of the lane then
-      // goes through exact_view()
-      if (valid[c]) magL = fmax(magL, fabs(ly[c]) + fabs(lz[c]));
-    }
-    magL += fabs(lx);
-    bool bad_alpha = false;
-
-    for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
-      const int chunk_n = min(kChunk, p.num_frames - chunk0);
-      const int ncand = cull_chunk(p, poses, centre, radius, chunk0, chunk_n, s_cand, s_wave_cnt);
-      if (i_ok) {
-        for (int k = 0; k < ncand; ++k) {
-          const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
-          const FrameFast& Q = fast_tab[f];
-          const double mag = magL + Q.tmag;
-          const double zthr = fma(0x1p-22, mag, 1e-10);
-          const double muv = p.fold.kuv * mag;
-          const double bx = fma(Q.m[0], lx, Q.t[0]);
-          const double by = fma(Q.m[3], lx, Q.t[1]);
-          const double bz = fma(Q.m[6], lx, Q.t[2]);
-#pragma unroll
-          for (int c = 0; c < kCellsPerLane; ++c) {
-            const double cx = fma(Q.m[2], lz[c], fma(Q.m[1], ly[c], bx));
-            const double cy = fma(Q.m[5], lz[c], fma(Q.m[4], ly[c], by));
-            const double cz = fma(Q.m[8], lz[c], fma(Q.m[7], ly[c], bz));
-            const DeviceExact ex = {cam_tab, poses, lx, ly[c], lz[c]};
-            fold_pair(&st[c], f, p.fold, valid[c], cx, cy, cz, zthr, muv, ex, &bad_alpha);
-          }
-        }
-      }
-      __syncthreads();  // everyone is done with s_cand before the next chunk
-    }
-
-    // ---- write back: the winner's angle and keypoint in the reference's arithmetic
-#pragma unroll
-    for (int c = 0; c < kCellsPerLane; ++c) {
-      const int j = j0 + wid + c * (kOrthoThreads / 64);
-      if (!(i_ok && j < p.cols)) continue;
-      const DeviceExact ex = {cam_tab, poses, lx, ly[c], lz[c]};
-      int ku = 0, kv = 0;
-      if (!fold_finish(&st[c], ex, p.width, p.height, &ku, &kv, &bad_alpha)) {
-        if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
-        continue;
-      }
-      write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
-                 st[c].best, st[c].best_f, st[c].accepted, ku, kv);
-    }
-    if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
+  // (block-uniform values the slabs need: keep them in scalar registers)
+  const V3 ucentre = {uniform_d(centre.x), uniform_d(centre.y), uniform_d(centre.z)};
+  const double uradius = uniform_d(radius), uslack = uniform_d(slack);
+  const bool single = p.num_frames <= kChunk;
+  int ncand0 = 0;
+  if (single)
+    ncand0 = cull_chunk<kFast>(p, poses, fast_tab, ucentre, uradius, uslack, 0, p.num_frames, s_cand,
+                                   s_wave_cnt, s_best);
+  if (p.dbg_stop == 2) return;
+  if constexpr (kTileJ == kSlabJ) {
+    ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
+                      num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,
+                      uradius, uslack, i, i_ok, j0, single, ncand0);
   } else {
-  // ---- per-lane fold state ---------------------------------------------------
-  // Running best view per cell.  The reference keeps (float)asin(|z|/||p||) and
-  // accepts a view iff its asin exceeds that float (widened to double).  asin is
-  // monotonic, so unless the two sines are within 2.5e-6 (relative, squared) of
-  // each other the outcome is decided by comparing |z|^2/||p||^2 -- no sqrt, no
-  // division, no asin.  Only near ties (where the float rounding of the stored
-  // angle matters) take the exact route; the winning angle itself is evaluated
-  // once per cell at the end.  Margin: d(asin)/ds >= 1 and asin(s) <= (pi/2) s,
-  // so a relative gap of 1e-6 in s is > 10x the 6e-8 float rounding of the angle.
-  float best[kCellsPerLane];    // stored angle (valid iff have_f)
-  bool have_f[kCellsPerLane];
-  double zb[kCellsPerLane];     // |z| and ||p||^2 of the current best view
-  double n2b[kCellsPerLane];
-  int best_f[kCellsPerLane];
-  int best_u[kCellsPerLane];
-  int best_v[kCellsPerLane];
-  int accepted[kCellsPerLane];
-  bool bad_alpha = false;
-#pragma unroll
-  for (int c = 0; c < kCellsPerLane; ++c) {
-    const int j = j0 + wid + c * (kOrthoThreads / 64);
-    best[c] = 0.0f;
-    if (i_ok && j < p.cols && !p.virt_out)
-      best[c] = elevation_angle[(size_t)i + (size_t)j * (size_t)p.rows];
-    have_f[c] = true;
-    n2b[c] = 1.0;
-    if (best[c] >= 1.5707964f)
-      zb[c] = __builtin_huge_val();  // no asin exceeds (float)(pi/2)
-    else if (best[c] > 0.0f)
-      zb[c] = sin((double)best[c]);  // incremental mode: angle left by earlier batches
-    else if (best[c] == best[c])
-      zb[c] = 0.0;                   // fresh layer: every visible view wins (alpha > 0)
-    else
-      zb[c] = __builtin_huge_val();  // NaN in the layer: `alpha > NaN` never holds
-    best_f[c] = -1;
-    best_u[c] = 0;
-    best_v[c] = 0;
-    accepted[c] = 0;
-  }
-
-  for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
-    const int chunk_n = min(kChunk, p.num_frames - chunk0);
-    const int ncand = cull_chunk(p, poses, centre, radius, chunk0, chunk_n, s_cand, s_wave_cnt);
-
-    // ---- phase C: fold the candidates, ascending -----------------------------
-    if (i_ok) {
-      for (int k = 0; k < ncand; ++k) {
-        const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
-        const FramePose T = poses[f];
-#pragma unroll
-        for (int c = 0; c < kCellsPerLane; ++c) {
-          const int j = j0 + wid + c * (kOrthoThreads / 64);
-          const double ly = p.base_y + p.res * (-(double)(j + p.j_off));
-          const V3 landmark = {lx, ly, (double)elev[c]};
-          const V3 cp = transform_point(T, landmark);
-          double u, v;
-          if (!project_visible(p, cp, &u, &v)) continue;
-          const double zz = cp.z * cp.z;
-          const double n2 = cp.x * cp.x + cp.y * cp.y + zz;
-          const double lhs = zz * n2b[c];
-          const double rhs = (zb[c] * zb[c]) * n2;
-          bool accept = lhs > rhs * (1.0 + 2.5e-6);
-          const bool reject = lhs < rhs * (1.0 - 2.5e-6);
-          bool exact = false;
-          if (!accept && !reject) {
-            // near tie: the reference's own arithmetic decides
-            asm volatile("" ::: "memory");
-            if (!have_f[c]) {
-              best[c] = (float)view_angle(zb[c], n2b[c]);
-              have_f[c] = true;
-            }
-            const double alpha = view_angle(fabs(cp.z), n2);
-            if (!(alpha > 0.0)) bad_alpha = true;  // CHECK(alpha > 0.0)
-            if (alpha > (double)best[c]) {
-              best[c] = (float)alpha;
-              accept = true;
-              exact = true;
-            }
-          }
-          if (accept) {
-            have_f[c] = exact;
-            zb[c] = fabs(cp.z);
-            n2b[c] = n2;
-            best_f[c] = f;
-            accepted[c]++;
-            best_v[c] = min((int)round(v), p.height - 1);
-            best_u[c] = min((int)round(u), p.width - 1);
-          }
-        }
-      }
-    }
-    __syncthreads();  // everyone is done with s_cand before the next chunk
-  }
-
-  if (bad_alpha) atomicOr(dev_err, kDevErrAlphaNonPos);
-
-  // ---- write back ------------------------------------------------------------
-#pragma unroll
-  for (int c = 0; c < kCellsPerLane; ++c) {
-    const int j = j0 + wid + c * (kOrthoThreads / 64);
-    if (!(i_ok && j < p.cols)) continue;
-    if (accepted[c] == 0) {
-      if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
-      continue;
-    }
-    if (!have_f[c]) {
-      // the winning view's angle, evaluated exactly like the reference does
-      const double alpha = view_angle(zb[c], n2b[c]);
-      if (!(alpha > 0.0)) atomicOr(dev_err, kDevErrAlphaNonPos);  // CHECK(alpha > 0.0)
-      best[c] = (float)alpha;
-    }
-    write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
-               best[c], best_f[c], accepted[c], best_u[c], best_v[c]);
-  }
+#pragma unroll 1
+    for (int js = j0; js <= j_hi; js += kSlabJ)
+      ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
+                        num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,
+                        uradius, uslack, i, i_ok, js, single, ncand0);
   }
 }
 
@@ -511,16 +682,19 @@ __device__ __forceinline__ void ortho_backward_tile(
   __shared__ float s_red[2 * (kOrthoThreads / 64)];                                          \
   __shared__ int s_cand[kChunk];                                                             \
   __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
+  __shared__ double s_best[kOrthoThreads / 64];                                              \
   ortho_backward_tile<FAST>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
                             observation_index, num_observations, out_layer, dev_err, zrange, \
-                            s_red, s_cand, s_wave_cnt);
+                            s_red, s_cand, s_wave_cnt, s_best);
 
 // every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
-__global__ void __launch_bounds__(kOrthoThreads) k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
+__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
+k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(false)
 }
 // margin-guarded fold, registers as they come (3 waves per SIMD)
-__global__ void __launch_bounds__(kOrthoThreads) k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
+__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
+k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(true)
 }
 // the same held to 128 VGPRs (4 waves per SIMD); AMHIP_ORTHO_FAST_WAVES picks
@@ -537,7 +711,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
   const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 7
-  const int fast_waves = fw ? std::atoi(fw) : 4;
+  const int fast_waves = fw ? std::atoi(fw) : 3;
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
   hipLaunchKernelGGL(kernel, grid, dim3(kOrthoThreads), 0, c->stream,

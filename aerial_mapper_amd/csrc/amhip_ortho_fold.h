@@ -7,8 +7,8 @@
 //   fast_*         a bounded-error evaluation (pose as a 3x4 matrix, box test
 //                  without the division) whose every DECISION carries a margin
 //                  that covers the worst-case distance to the reference's
-//                  doubles; a pair whose decision falls inside the margin is
-//                  handed to exact_view().  Outcomes are therefore the
+//                  doubles; a cell with a decision inside a margin is replayed in
+//                  the reference's arithmetic (exact_refold / exact_finish).  Outcomes are therefore the
 //                  reference's, the cost is ~30 instead of ~85 FP64 operations
 //                  for almost every pair.
 //
@@ -104,12 +104,67 @@ inline bool make_frame_fast(const FramePose& T, FrameFast* o) {
   return std::fabs(n - 1.0) < 1e-6 && o->tmag < 1e300;
 }
 
+// One frame against the bounding sphere (centre, radius) of a tile's landmarks.
+//   keep   false only if no landmark of the sphere can be visible (entirely
+//          behind the camera or outside one side plane of the view pyramid)
+//   full   every landmark of the sphere is visible, by a clear margin, in the
+//          reference's arithmetic (undistorted pinhole only)
+//   tmin, tmax   bounds of tan(theta), theta = angle between the optical axis
+//          and the ray to a landmark (= pi/2 - the view angle), over the
+//          landmarks of the sphere in front of the camera
+// pl: unit inward normals of the four side planes through the optical centre.
+struct FrameBounds {
+  bool keep, full;
+  double tmin, tmax;
+};
+
+AMHIP_HD FrameBounds frame_bounds(const double (*pl)[3], const FramePose& T, const V3& centre,
+                                  double radius, double slack) {
+  const V3 cc = transform_point(T, centre);
+  FrameBounds b;
+  b.keep = !(cc.z < -radius);
+  double dmin = HUGE_VAL;
+  for (int k = 0; k < 4; ++k) {
+    const double d = pl[k][0] * cc.x + pl[k][1] * cc.y + pl[k][2] * cc.z;
+    if (d < -radius) b.keep = false;
+    dmin = fmin(dmin, d);
+  }
+  // inside every plane by `slack` metres and at least that far in front:
+  // u = d * |n| / z >= slack * |n| / z pixels inside the box, orders of
+  // magnitude above the rounding of the reference's u (callers scale slack
+  // with the coordinate magnitudes)
+  const double zlo = cc.z - radius;
+  b.full = b.keep && (dmin - radius > slack) && (zlo > slack) && (zlo > 1e-3);
+  const double rxy = sqrt(cc.x * cc.x + cc.y * cc.y);
+  const double zhi = cc.z + radius;
+  // directed rounding by hand: 1e-12 relative dwarfs the few ulps of the
+  // sqrt / divisions (whatever their implementation)
+  b.tmin = zhi > 0.0 ? (fmax(rxy - radius, 0.0) / zhi) * (1.0 - 1e-12) : HUGE_VAL;
+  b.tmax = zlo > 0.0 ? ((rxy + radius) / zlo) * (1.0 + 1e-12) : HUGE_VAL;
+  return b;
+}
+
+// Frame f can be left out of a tile's fold when some frame g that is fully
+// visible over the tile beats it at every landmark by a clear margin:
+//   tan(theta_f) >= tmin_f > tmax_g + 1e-5 (1 + tmin_f^2) >= tan(theta_g) + ...
+// i.e. theta_f - theta_g > ~1e-5 rad, 80x the float spacing of the stored
+// angle: f is never the view the fold ends on, whatever the order of the
+// frames and whatever the layer held before (g is accepted over f or blocks
+// it; any third frame that matters beats f by the same margin).  Only the
+// COUNT of accepted updates changes, so callers prune only while
+// num_observations is known to be zero everywhere (`+= itself` keeps it zero).
+AMHIP_HD bool dominated(double tmin_f, double best_tmax) {
+  return tmin_f - best_tmax > 1e-5 * (1.0 + tmin_f * tmin_f);
+}
+
 // Camera constants of the fast path.  cam[] layout of the device table entry
 // that follows the frames: fu, fv, cu, cv, W, H.
 struct FoldCam {
   double fu, fv, cu, cv;
   double wcu, hcv;  // W - cu, H - cv
   double kuv;       // box-test margin per unit of mag
+  double kround;    // keypoint error per unit of mag / z (fold_finish)
+  double uv_abs;    // its absolute part
 };
 
 inline FoldCam make_fold_cam(double fu, double fv, double cu, double cv, int width, int height) {
@@ -129,6 +184,14 @@ inline FoldCam make_fold_cam(double fu, double fv, double cu, double cv, int wid
   // u < W adds W u z_r.  kuv = 2^-44 * (sum of all of them): > 4x that.
   k.kuv = 0x1p-44 * (std::fabs(fu) + std::fabs(fv) + std::fabs(cu) + std::fabs(cv) +
                      (double)width + (double)height);
+  // Keypoint of the winning view from the approximate point (fold_finish):
+  //   |kx_a - kx_r| <= (eps / z) (1 + |kx|) + 4u |kx|,  eps = 2^-46 mag
+  //   |u_a - u_ref| <= |fu| |kx_a - kx_r| + 2u (|fu kx| + |cu|)
+  // kround = 2^-44 (|fu| + |fv|) is 4x the first part per (mag / z) (1 + |kx| + |ky|);
+  // uv_abs = 2^-46 (everything) covers the roundings (|u| < W, |v| < H there).
+  k.kround = 0x1p-44 * (std::fabs(fu) + std::fabs(fv));
+  k.uv_abs = 0x1p-46 * (std::fabs(fu) + std::fabs(fv) + std::fabs(cu) + std::fabs(cv) +
+                        (double)width + (double)height);
   return k;
 }
 
@@ -169,11 +232,66 @@ AMHIP_HD ExactView exact_view_inline(const double* cam, const FramePose& T, doub
 // (their relative error is <= 7e-7 in the worst admissible geometry).
 constexpr double kSineBand = 4e-6;
 
-// Fold state of one cell.  sin^2 of the best view so far = zb2 / n2b.
+// ---- small numeric helpers (device: hardware seed + Newton; host: libm) -------
+AMHIP_HD double fold_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;  // ~1 ulp
+#else
+  return 1.0 / x;
+#endif
+}
+
+AMHIP_HD double fold_sqrt(double x) {  // x > 0, normal
+#if defined(__HIP_DEVICE_COMPILE__)
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  return g;  // ~1 ulp
+#else
+  return std::sqrt(x);
+#endif
+}
+
+// atan(i / 8), i = 0 .. 16, correctly rounded; lives behind the camera in the
+// device frame table (doubles 8 .. 24 of the slots that follow the frames).
+constexpr int kAtanTabSize = 17;
+inline void make_atan_table(double* tab) {
+  for (int i = 0; i < kAtanTabSize; ++i) tab[i] = std::atan((double)i / 8.0);
+}
+
+// pi/2 - atan(r) for r in [1e-3, 2], absolute error < 1e-15 (table + 6 terms
+// on |y| <= 1/16: truncation y^13 / 13 < 2e-17).  false: r out of range.
+AMHIP_HD bool fold_angle(const double* atan_tab, double r, double* alpha) {
+  if (!(r >= 1e-3 && r <= 2.0)) return false;
+  const double fi = rint(r * 8.0);
+  const double c = fi * 0.125;
+  const double y = (r - c) * fold_rcp(fma(r, c, 1.0));
+  const double y2 = y * y;
+  double q = fma(y2, -1.0 / 11.0, 1.0 / 9.0);
+  q = fma(y2, q, -1.0 / 7.0);
+  q = fma(y2, q, 1.0 / 5.0);
+  q = fma(y2, q, -1.0 / 3.0);
+  const double at = fma(y * y2, q, y);
+  const double theta = atan_tab[(int)fi] + at;
+  *alpha = (1.5707963267948966 - theta) + 6.123233995736766e-17;
+  return true;
+}
+
+// Fold state of one cell.
 struct CellFold {
-  double zb2, n2b;
-  float best;    // its angle as the layer stores it; valid iff have_f
-  bool have_f;
+  // Camera-frame point of the best view so far, within eps of the reference's
+  // (sin^2 of its angle = bz^2 / |b|^2); for the angle `a` a layer held before
+  // this call: (cos a, 0, sin a).
+  double bx, by, bz;
+  bool redo;     // some decision fell inside a margin: the cell is folded again
+                 // in the reference's arithmetic (exact_refold)
   int best_f;    // frame of the best view accepted in THIS call (-1: none)
   int accepted;  // accepted updates (num_observations += itself, :183)
 };
@@ -181,18 +299,19 @@ struct CellFold {
 // Start from the layer's current angle (0 on a fresh map; the maximum left by
 // earlier batches in incremental mode).
 AMHIP_HD void fold_init(CellFold* s, float layer_angle) {
-  s->best = layer_angle;
-  s->have_f = true;
-  s->n2b = 1.0;
-  if (layer_angle >= 1.5707964f) {
-    s->zb2 = HUGE_VAL;  // no asin can exceed (float)(pi/2): nothing is accepted
+  s->redo = false;
+  s->by = 0.0;
+  if (layer_angle >= 1.5707964f || layer_angle != layer_angle) {
+    // no asin exceeds (float)(pi/2), `alpha > NaN` never holds: sin^2 = 1 sends
+    // every view that is not clearly lower to the reference's comparison
+    s->bx = 0.0;
+    s->bz = 1.0;
   } else if (layer_angle > 0.0f) {
-    const double sn = sin((double)layer_angle);
-    s->zb2 = sn * sn;
-  } else if (layer_angle == layer_angle) {
-    s->zb2 = 0.0;       // every visible view wins (alpha > 0)
+    s->bx = cos((double)layer_angle);
+    s->bz = sin((double)layer_angle);
   } else {
-    s->zb2 = HUGE_VAL;  // NaN in the layer: `alpha > NaN` never holds
+    s->bx = 1.0;  // every visible view wins (alpha > 0)
+    s->bz = 0.0;
   }
   s->best_f = -1;
   s->accepted = 0;
@@ -201,16 +320,16 @@ AMHIP_HD void fold_init(CellFold* s, float layer_angle) {
 // One frame folded into one cell.  (cx, cy, cz) is the camera-frame point from
 // the fma chain over FrameFast, mag >= |L|_1 + |t|_1 of the pair,
 //   zthr = 1e-10 + 2^-22 mag,  muv = kuv * mag;
-// `valid` false: the cell has no (finite-or-not) elevation at all -- NaN, never
-// visible.  `ex` supplies the reference's arithmetic for this cell:
-//   ExactView ex.view(int frame);   double ex.angle(double absz, double n2);
-// The steps follow ortho-backward-grid.cc:164-208; *bad_alpha <=> CHECK(alpha > 0).
+// `valid` false: the cell has no elevation (NaN): never visible.
+// The steps follow ortho-backward-grid.cc:164-208.  A pair whose visibility or
+// whose comparison with the running best falls inside a margin (or involves
+// non-finite numbers) marks the cell `redo`; nothing else happens for it then
+// -- exact_refold() replays the cell later, out of the hot loop.
 // Written with predicates rather than early exits: almost every pair that
 // survives the tile's frame cull is visible, and the wave executes all of it
 // anyway.
-template <class Exact>
 AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double cx, double cy,
-                        double cz, double zthr, double muv, const Exact& ex, bool* bad_alpha) {
+                        double cz, double zthr, double muv) {
   // box test without the division: for z > 0
   //   u >= 0 <=> fu x + cu z >= 0,   u < W <=> (W - cu) z - fu x > 0   (same for v)
   const double a = k.fu * cx;
@@ -222,73 +341,138 @@ AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double
   // (all four are finite whenever zok: a non-finite elevation makes mag, hence
   // zthr, infinite; poses with non-finite entries never reach the fast path)
   const double g = fmin(fmin(d1, d2), fmin(e1, e2));
-  double zz = cz * cz;
-  double n2 = fma(cx, cx, fma(cy, cy, zz));
+  const double zz = cz * cz;
+  const double n2 = fma(cx, cx, fma(cy, cy, zz));
   // z_r > 1e-10 is certain above zthr (eps = 2^-46 mag) and the relative error
   // of cz there is <= 2^-24; below -zthr it is certainly false
   const bool zok = cz > zthr;
-  bool vis = valid & zok & (g > muv);
+  const bool vis = valid & zok & (g > muv);
   const bool invis = !valid | (cz < -zthr) | (zok & (g < -muv));
-  ExactView e;
-  bool have_e = false;
-  if (!(vis | invis)) {
-    // inside a margin (or NaN somewhere): the reference's arithmetic decides
-    e = ex.view(f);
-    have_e = true;
-    vis = e.n2 >= 0.0;
-    zz = e.absz * e.absz;
-    n2 = e.n2;
-  }
-  const double lhs = zz * s->n2b;
-  const double rhs = s->zb2 * n2;
-  bool accept = vis & (lhs > rhs * (1.0 + kSineBand));
+  const double zzb = s->bz * s->bz;
+  const double n2b = fma(s->bx, s->bx, fma(s->by, s->by, zzb));
+  const double lhs = zz * n2b;
+  const double rhs = zzb * n2;
+  const bool accept = vis & (lhs > rhs * (1.0 + kSineBand));
   const bool tie = vis & !accept & !(lhs < rhs * (1.0 - kSineBand));
-  bool exact = false;
-  if (tie) {
-    // near tie: compare the angles like ortho-backward-grid.cc:180 does
-    if (!s->have_f) {
-      const ExactView w = ex.view(s->best_f);
-      s->best = (float)ex.angle(w.absz, w.n2);
-      s->have_f = true;
-    }
-    if (!have_e) e = ex.view(f);
-    const double alpha = ex.angle(e.absz, e.n2);
-    if (!(alpha > 0.0)) *bad_alpha = true;
-    if (alpha > (double)s->best) {
-      s->best = (float)alpha;
-      zz = e.absz * e.absz;
-      n2 = e.n2;
-      accept = true;
-      exact = true;
-    }
-  }
+  if (!(vis | invis) | tie) s->redo = true;
   if (accept) {
-    s->have_f = exact;
-    s->zb2 = zz;
-    s->n2b = n2;
+    s->bx = cx;
+    s->by = cy;
+    s->bz = cz;
     s->best_f = f;
     s->accepted++;
   }
 }
 
-// After the last frame: the winner's angle and keypoint, evaluated exactly like
-// the reference does (:181, :186-193).  false: no view was accepted.
-template <class Exact>
-AMHIP_HD bool fold_finish(CellFold* s, const Exact& ex, int width, int height, int* kp_x,
-                          int* kp_y, bool* bad_alpha) {
-  if (s->accepted == 0) return false;
-  const ExactView e = ex.view(s->best_f);
-  if (!s->have_f) {
-    const double alpha = ex.angle(e.absz, e.n2);
-    if (!(alpha > 0.0)) *bad_alpha = true;
-    s->best = (float)alpha;
-    s->have_f = true;
+// After the last frame: the winner's keypoint (:186-193) and its angle as the
+// layer stores it (:181), from the approximate point when that provably gives
+// the reference's result:
+//   keypoint  round(u) is safe when u is farther from k + 1/2 than its error
+//   angle     (float)alpha is safe when alpha is farther from the float
+//             rounding boundaries than its error:  |alpha_a - alpha_ref| <=
+//             eps / z (direction of the ray) + 2u / tan(theta) (the rounding of
+//             |z| / ||p|| under the reference's asin) + 1e-14 (everything else)
+// magmax >= mag of every pair of this cell.  Returns
+//   kFoldNone    no view was accepted: the cell keeps its values
+//   kFoldDone    *kp_x, *kp_y, *angle are the reference's
+//   kFoldFinish  the winner (s->best_f) is right, keypoint / angle need
+//                exact_finish()
+//   kFoldRedo    the whole cell needs exact_refold()
+enum { kFoldNone = 0, kFoldDone = 1, kFoldFinish = 2, kFoldRedo = 3 };
+
+AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan_tab,
+                         double magmax, int width, int height, int* kp_x, int* kp_y,
+                         float* angle) {
+  if (s->redo) return kFoldRedo;
+  if (s->accepted == 0) return kFoldNone;
+  const double rcz = fold_rcp(s->bz);
+  const double kx = s->bx * rcz;
+  const double ky = s->by * rcz;
+  const double u = fma(k.fu, kx, k.cu);
+  const double v = fma(k.fv, ky, k.cv);
+  const double mz = magmax * rcz;
+  const double duv = fma(k.kround * mz, 1.0 + fabs(kx) + fabs(ky), k.uv_abs);
+  // std::round of a non-negative number = floor(x + 1/2) away from the ties
+  const double tu = u + 0.5, tv = v + 0.5;
+  const double fu_ = floor(tu), fv_ = floor(tv);
+  const double ru = tu - fu_, rv = tv - fv_;
+  bool ok = (ru > duv) & (ru < 1.0 - duv) & (rv > duv) & (rv < 1.0 - duv);
+  const int kx_i = (int)fu_, ky_i = (int)fv_;
+  *kp_y = ky_i < height - 1 ? ky_i : height - 1;
+  *kp_x = kx_i < width - 1 ? kx_i : width - 1;
+  const double r = fold_sqrt(fma(kx, kx, ky * ky));
+  double alpha = 0.0;
+  ok = ok & fold_angle(atan_tab, r, &alpha);
+  const double da = 0x1p-45 * mz + 0x1p-49 * fold_rcp(r) + 1e-14;
+  const float fl = (float)alpha;
+  const double e = alpha - (double)fl;
+  // alpha in [0.46, 1.57]: float spacing 2^-23 (>= 1), 2^-24 ([0.5, 1)), 2^-25
+  const double half = fl >= 1.0f ? 0x1p-24 : (fl >= 0.5f ? 0x1p-25 : 0x1p-26);
+  // (just below a power of two the spacing halves: stay clear of those floats)
+  ok = ok & (fabs(e) < half - da) & (fl != 1.0f) & (fl != 0.5f) & (fl > 0.26f);
+  *angle = fl;
+  return ok ? kFoldDone : kFoldFinish;
+}
+
+// ---- the reference's arithmetic, for the cells the margins could not settle ----
+struct FoldResult {
+  float best;   // elevation_angle
+  int best_f;   // observation_index (-1: no view accepted, the cell keeps its values)
+  int accepted;
+  int kp_x, kp_y;
+  int bad_alpha;  // CHECK(alpha > 0.0) would have fired
+};
+
+AMHIP_HD double exact_angle(double absz, double n2) {
+  const double norm = sqrt(n2);
+  return asin(absz / norm);
+}
+
+// keypoint and stored angle of the known winner `pose`
+AMHIP_HD FoldResult exact_finish(const double* cam, const FramePose& pose, double lx, double ly,
+                                 double lz, int best_f, int accepted) {
+  FoldResult r;
+  const ExactView e = exact_view_inline(cam, pose, lx, ly, lz);
+  const double alpha = exact_angle(e.absz, e.n2);
+  r.bad_alpha = !(alpha > 0.0);
+  r.best = (float)alpha;
+  r.best_f = best_f;
+  r.accepted = accepted;
+  const int ky = (int)round(e.v), kx = (int)round(e.u);
+  const int w = (int)cam[4], h = (int)cam[5];
+  r.kp_y = ky < h - 1 ? ky : h - 1;
+  r.kp_x = kx < w - 1 ? kx : w - 1;
+  return r;
+}
+
+// ortho-backward-grid.cc:144-208 for one cell, literally, over the frames
+// cand[0 .. n) (ascending; cand == nullptr: frames 0 .. n-1).  layer_angle:
+// what the elevation_angle layer held before this call.
+AMHIP_HD FoldResult exact_refold(const double* cam, const FramePose* poses, const int* cand, int n,
+                                 double lx, double ly, double lz, float layer_angle) {
+  FoldResult r;
+  r.best = layer_angle;
+  r.best_f = -1;
+  r.accepted = 0;
+  r.kp_x = r.kp_y = 0;
+  r.bad_alpha = 0;
+  const int w = (int)cam[4], h = (int)cam[5];
+  for (int k = 0; k < n; ++k) {
+    const int f = cand ? cand[k] : k;
+    const ExactView e = exact_view_inline(cam, poses[f], lx, ly, lz);
+    if (e.n2 < 0.0) continue;
+    const double alpha = exact_angle(e.absz, e.n2);
+    if (!(alpha > 0.0)) r.bad_alpha = 1;
+    if (alpha > (double)r.best) {
+      r.best = (float)alpha;
+      r.best_f = f;
+      r.accepted++;
+      const int ky = (int)round(e.v), kx = (int)round(e.u);
+      r.kp_y = ky < h - 1 ? ky : h - 1;
+      r.kp_x = kx < w - 1 ? kx : w - 1;
+    }
   }
-  const int ky = (int)round(e.v);
-  const int kx = (int)round(e.u);
-  *kp_y = ky < height - 1 ? ky : height - 1;
-  *kp_x = kx < width - 1 ? kx : width - 1;
-  return true;
+  return r;
 }
 
 }  // namespace amhip
