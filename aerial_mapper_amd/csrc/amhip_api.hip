@@ -1117,7 +1117,6 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   p.prune = (p.cull && cam->distortion == AMHIP_DIST_NONE && p.virt_nobs &&
              !std::getenv("AMHIP_ORTHO_NO_PRUNE")) ? 1 : 0;
   p.fast = fast_ok ? 1 : 0;
-  p.dbg_stop = std::getenv("AMHIP_ORTHO_STOP") ? std::atoi(std::getenv("AMHIP_ORTHO_STOP")) : 0;
   p.fold = make_fold_cam(cam->fu, cam->fv, cam->cu, cam->cv, cam->width, cam->height);
   return ortho_run(c, p, c->frame_poses, reinterpret_cast<const FrameFast*>(c->frame_poses + F),
                    dev_frames);

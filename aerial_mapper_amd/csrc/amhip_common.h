@@ -109,7 +109,6 @@ struct OrthoParams {
   // the bounding spheres assume rigid poses; |q|^2 = 1 + dev scales distances
   // by that much: radii are multiplied by 1 + 2 max|dev|
   double radius_scale;
-  int dbg_stop;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).

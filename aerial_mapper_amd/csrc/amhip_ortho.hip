@@ -160,15 +160,16 @@ __device__ __forceinline__ double wave_min_d(double v) {
   return v;
 }
 
-// The same test with the pose as a matrix (FrameFast): 21 FP64 operations
-// instead of 45.  The fma chain is within 2^-46 (|centre|_1 + |t|_1) of the
-// exact transform (amhip_ortho_fold.h); the radius grows by 2^-40 of that.
+// The same test with the pose as a matrix around the camera centre (FrameFast):
+// 24 FP64 operations instead of 45, and within ~1e-15 (|centre| + distance) of
+// the exact transform (amhip_ortho_fold.h); the radius grows by 2^-40 of that.
 __device__ __forceinline__ bool frame_may_see_fast(const OrthoParams& p, const FrameFast& Q,
                                                    const V3& centre, double cmag, double radius) {
-  const double r = fma(0x1p-40, cmag + Q.tmag, radius);
-  const double cx = fma(Q.m[2], centre.z, fma(Q.m[1], centre.y, fma(Q.m[0], centre.x, Q.t[0])));
-  const double cy = fma(Q.m[5], centre.z, fma(Q.m[4], centre.y, fma(Q.m[3], centre.x, Q.t[1])));
-  const double cz = fma(Q.m[8], centre.z, fma(Q.m[7], centre.y, fma(Q.m[6], centre.x, Q.t[2])));
+  const double dx = centre.x - Q.p[0], dy = centre.y - Q.p[1], dz = centre.z - Q.p[2];
+  const double r = fma(0x1p-40, cmag + (fabs(dx) + fabs(dy) + fabs(dz)), radius);
+  const double cx = fma(Q.m[2], dz, fma(Q.m[1], dy, Q.m[0] * dx));
+  const double cy = fma(Q.m[5], dz, fma(Q.m[4], dy, Q.m[3] * dx));
+  const double cz = fma(Q.m[8], dz, fma(Q.m[7], dy, Q.m[6] * dx));
   bool keep = !(cz < -r);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -347,10 +348,10 @@ __device__ __forceinline__ void ortho_slab(
       // inside the margins and the cells are replayed by slow_refold()
       if (valid[c]) magL = fmax(magL, fabs(lz[c]));
     }
-    // (the fma chain's ly differs from the grid's by an ulp at most: the 2x
-    // headroom of the error budget covers it; the slow routines use the grid's)
+    // (the fma chain steps ly through the slab as ly0 + c * dly: within 1.5 ulp of
+    // the grid's value, a term of the error budget; the slow routines use the grid's)
     magL += fabs(lx) + fmax(fabs(ly0), fabs(ly0 + dly * (double)(kCellsPerLane - 1)));
-    double tmag_max = 0.0;  // over the frames folded (same value in every lane)
+    const double epsL = 0x1p-48 * magL;
 
     for (int chunk0 = 0; chunk0 < p.num_frames; chunk0 += kChunk) {
       int ncand = ncand0;
@@ -363,20 +364,19 @@ __device__ __forceinline__ void ortho_slab(
         for (int k = 0; k < ncand; ++k) {
           const int f = __builtin_amdgcn_readfirstlane(s_cand[k]);
           const FrameFast& Q = fast_tab[f];
-          const double mag = magL + Q.tmag;
-          tmag_max = fmax(tmag_max, Q.tmag);
-          const double zthr = fma(0x1p-22, mag, 1e-10);
-          const double muv = p.fold.kuv * mag;
-          const double bx = fma(Q.m[1], ly0, fma(Q.m[0], lx, Q.t[0]));
-          const double by = fma(Q.m[4], ly0, fma(Q.m[3], lx, Q.t[1]));
-          const double bz = fma(Q.m[7], ly0, fma(Q.m[6], lx, Q.t[2]));
+          // c = M (L - p): the large coordinates cancel in the differences
+          const double dx = lx - Q.p[0], dy0 = ly0 - Q.p[1];
+          const double bx = fma(Q.m[1], dy0, Q.m[0] * dx);
+          const double by = fma(Q.m[4], dy0, Q.m[3] * dx);
+          const double bz = fma(Q.m[7], dy0, Q.m[6] * dx);
           const double sx = Q.m[1] * dly, sy = Q.m[4] * dly, sz = Q.m[7] * dly;
 #pragma unroll
           for (int c = 0; c < kCellsPerLane; ++c) {
-            const double cx = fma(Q.m[2], lz[c], fma(sx, (double)c, bx));
-            const double cy = fma(Q.m[5], lz[c], fma(sy, (double)c, by));
-            const double cz = fma(Q.m[8], lz[c], fma(sz, (double)c, bz));
-            fold_pair(&st[c], f, p.fold, valid[c], cx, cy, cz, zthr, muv);
+            const double dz = lz[c] - Q.p[2];
+            const double cx = fma(Q.m[2], dz, fma(sx, (double)c, bx));
+            const double cy = fma(Q.m[5], dz, fma(sy, (double)c, by));
+            const double cz = fma(Q.m[8], dz, fma(sz, (double)c, bz));
+            fold_pair(&st[c], f, p.fold, valid[c], cx, cy, cz, epsL);
           }
         }
       }
@@ -393,8 +393,8 @@ __device__ __forceinline__ void ortho_slab(
       if (!(i_ok && j < p.cols)) continue;
       int ku = 0, kv = 0;
       float angle = 0.0f;
-      const int what = fold_finish(&st[c], p.fold, cam_tab + 8, magL + tmag_max, p.width, p.height,
-                                   &ku, &kv, &angle);
+      const int what = fold_finish(&st[c], p.fold, cam_tab + 8, epsL, p.width, p.height, &ku, &kv,
+                                   &angle);
       if (what == kFoldNone) {
         if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
       } else if (what == kFoldDone) {
@@ -658,7 +658,6 @@ __device__ __forceinline__ void ortho_backward_tile(
   if (single)
     ncand0 = cull_chunk<kFast>(p, poses, fast_tab, ucentre, uradius, uslack, 0, p.num_frames, s_cand,
                                    s_wave_cnt, s_best);
-  if (p.dbg_stop == 2) return;
   if constexpr (kTileJ == kSlabJ) {
     ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
                       num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,

@@ -15,16 +15,27 @@
 // Host + device: the kernel (amhip_ortho.hip) and the CPU emulation the unit
 // tests drive (tests/cpp/ortho_fold_emul.cc) compile the same functions.
 //
-// Error budget (u = 2^-53, |q| = 1 within 1e-6, S = |L|_1, mag = S + |t|_1):
-//   reference   c_r = fl(q (x) L + t): 33 operations, |c_r - c*| <= 49 u mag
-//   here        c_a = fma chain over M(q), |M - M*| <= 8u per entry:
-//               |c_a - c*| <= 11 u mag
-//   => |c_a - c_r| <= 60 u mag; every margin below assumes eps = 128 u mag
-//      = 2^-46 mag and then doubles again.
+// Error budget (u = 2^-53; |q|^2 = 1 within 1e-6; V = |L|_2, D = |L - p|_2 with
+// p the camera centre in the ground frame; per component of the camera-frame
+// point c):
+//   reference   c_r = fl(q (x) L) + t, Eigen's _transformVector order:
+//                 cross      2 u V          (two products + the difference)
+//                 doubling   exact          -> |d(uv)| <= 4 u V, |uv| <= 2 V
+//                 w * uv     4 u V + 2 u V
+//                 v + w uv   3 u V
+//                 cross 2    sqrt(2) 4 u V + 4 u V
+//                 + cross 2  u V            -> |c_r - c*| <= 19.7 u V  (+ u |c| for + t)
+//   here        c_a = M (L - p): M and p from long double (<= 0.5 u each after
+//               rounding), three fma:  |c_a - c*| <= 0.5 u (V + D) + 9.7 u D
+//               (+ 1.5 u V where a caller steps L.y through a slab as
+//               ly0 + c * dly instead of taking the grid's rounded value)
+//   => |c_a - c_r| <= 21.7 u V + 10.2 u D;  eps = 32 u V1 + 16 u D1  with the
+//      1-norms V1 >= V, D1 >= D  (2^-48 V1 + 2^-49 D1): 1.5x headroom.
 #ifndef AMHIP_ORTHO_FOLD_H_
 #define AMHIP_ORTHO_FOLD_H_
 
 #include <cmath>
+#include <limits>
 
 #if defined(__HIPCC__)
 #define AMHIP_HD __host__ __device__ __forceinline__
@@ -44,12 +55,14 @@ struct FramePose {
 // The same pose as the linear map of Eigen's _transformVector formula
 //   v + w (2 q x v) + q x (2 q x v)  =  M v,
 //   M = (1 - 2|q_v|^2) I + 2 q_v q_v^T + 2 w [q_v]x
-// (which is what that formula computes for ANY quaternion, unit or not).
+// (which is what that formula computes for ANY quaternion, unit or not), around
+// the camera centre:  M L + t = M (L - p).  Both correctly rounded from a long
+// double evaluation, so that the large coordinates cancel BEFORE anything is
+// rounded at their magnitude.
 struct FrameFast {
   double m[9];  // row-major
-  double t[3];
-  double tmag;  // |tx| + |ty| + |tz|
-  double _pad[3];
+  double p[3];  // camera centre in the ground frame: M p + t = 0
+  double _pad[4];
 };
 
 struct V3 {
@@ -84,24 +97,43 @@ AMHIP_HD V3 transform_point(const FramePose& T, const V3& v) {
 }
 
 inline bool make_frame_fast(const FramePose& T, FrameFast* o) {
-  const double w = T.qw, x = T.qx, y = T.qy, z = T.qz;
-  o->m[0] = 1.0 - 2.0 * (y * y + z * z);
-  o->m[1] = 2.0 * (x * y - w * z);
-  o->m[2] = 2.0 * (x * z + w * y);
-  o->m[3] = 2.0 * (x * y + w * z);
-  o->m[4] = 1.0 - 2.0 * (x * x + z * z);
-  o->m[5] = 2.0 * (y * z - w * x);
-  o->m[6] = 2.0 * (x * z - w * y);
-  o->m[7] = 2.0 * (y * z + w * x);
-  o->m[8] = 1.0 - 2.0 * (x * x + y * y);
-  o->t[0] = T.tx;
-  o->t[1] = T.ty;
-  o->t[2] = T.tz;
-  o->tmag = std::fabs(T.tx) + std::fabs(T.ty) + std::fabs(T.tz);
-  o->_pad[0] = o->_pad[1] = o->_pad[2] = 0.0;
-  const double n = w * w + x * x + y * y + z * z;
-  // the error budget above assumes a unit quaternion and finite numbers
-  return std::fabs(n - 1.0) < 1e-6 && o->tmag < 1e300;
+  typedef long double ld;
+  static_assert(sizeof(FrameFast) == 128, "frame table layout");
+  const ld w = T.qw, x = T.qx, y = T.qy, z = T.qz;
+  ld m[9];
+  m[0] = 1.0L - 2.0L * (y * y + z * z);
+  m[1] = 2.0L * (x * y - w * z);
+  m[2] = 2.0L * (x * z + w * y);
+  m[3] = 2.0L * (x * y + w * z);
+  m[4] = 1.0L - 2.0L * (x * x + z * z);
+  m[5] = 2.0L * (y * z - w * x);
+  m[6] = 2.0L * (x * z - w * y);
+  m[7] = 2.0L * (y * z + w * x);
+  m[8] = 1.0L - 2.0L * (x * x + y * y);
+  // p = -M^-1 t by cofactors (M is a rotation up to 1e-6: well conditioned)
+  const ld c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8],
+           c02 = m[3] * m[7] - m[4] * m[6];
+  const ld det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const ld c10 = m[2] * m[7] - m[1] * m[8], c11 = m[0] * m[8] - m[2] * m[6],
+           c12 = m[1] * m[6] - m[0] * m[7];
+  const ld c20 = m[1] * m[5] - m[2] * m[4], c21 = m[2] * m[3] - m[0] * m[5],
+           c22 = m[0] * m[4] - m[1] * m[3];
+  const ld tx = T.tx, ty = T.ty, tz = T.tz;
+  const ld px = -(c00 * tx + c10 * ty + c20 * tz) / det;
+  const ld py = -(c01 * tx + c11 * ty + c21 * tz) / det;
+  const ld pz = -(c02 * tx + c12 * ty + c22 * tz) / det;
+  for (int k = 0; k < 9; ++k) o->m[k] = (double)m[k];
+  o->p[0] = (double)px;
+  o->p[1] = (double)py;
+  o->p[2] = (double)pz;
+  o->_pad[0] = o->_pad[1] = o->_pad[2] = o->_pad[3] = 0.0;
+  const ld n = w * w + x * x + y * y + z * z;
+  // the error budget above assumes a unit quaternion, finite numbers and a
+  // 64-bit significand for this function
+  const bool finite = std::fabs(o->p[0]) < 1e300 && std::fabs(o->p[1]) < 1e300 &&
+                      std::fabs(o->p[2]) < 1e300;
+  return std::numeric_limits<long double>::digits >= 64 && std::fabs((double)(n - 1.0L)) < 1e-6 &&
+         finite;
 }
 
 // One frame against the bounding sphere (centre, radius) of a tile's landmarks.
@@ -162,8 +194,8 @@ AMHIP_HD bool dominated(double tmin_f, double best_tmax) {
 struct FoldCam {
   double fu, fv, cu, cv;
   double wcu, hcv;  // W - cu, H - cv
-  double kuv;       // box-test margin per unit of mag
-  double kround;    // keypoint error per unit of mag / z (fold_finish)
+  double kuv;       // box-test margin per unit of eps
+  double kround;    // keypoint error per unit of eps / z (fold_finish)
   double uv_abs;    // its absolute part
 };
 
@@ -180,16 +212,16 @@ inline FoldCam make_fold_cam(double fu, double fv, double cu, double cv, int wid
   //   <=>  fu x_r (1 + th) + cu z_r >= 0,  |th| <= 3.01 u
   // and ours  s = fu x_a + cu z_a  differs from that by at most
   //   (|fu| + |cu|) eps + 3.01 u |fu| |x_r| + 2 u (|fu x_a| + |cu z_a|)
-  //   <= (|fu| + |cu|) (2^-46 + 2^-50) mag ;
-  // u < W adds W u z_r.  kuv = 2^-44 * (sum of all of them): > 4x that.
-  k.kuv = 0x1p-44 * (std::fabs(fu) + std::fabs(fv) + std::fabs(cu) + std::fabs(cv) +
-                     (double)width + (double)height);
+  //   <= (|fu| + |cu|) (eps + 5.1 u D) <= 1.4 (|fu| + |cu|) eps      (eps >= 16 u D);
+  // u < W adds W u z_r.  kuv = 4 * (sum of all of them): ~3x that.
+  k.kuv = 4.0 * (std::fabs(fu) + std::fabs(fv) + std::fabs(cu) + std::fabs(cv) + (double)width +
+                 (double)height);
   // Keypoint of the winning view from the approximate point (fold_finish):
-  //   |kx_a - kx_r| <= (eps / z) (1 + |kx|) + 4u |kx|,  eps = 2^-46 mag
+  //   |kx_a - kx_r| <= (eps / z) (1 + |kx|) + 4u |kx|
   //   |u_a - u_ref| <= |fu| |kx_a - kx_r| + 2u (|fu kx| + |cu|)
-  // kround = 2^-44 (|fu| + |fv|) is 4x the first part per (mag / z) (1 + |kx| + |ky|);
-  // uv_abs = 2^-46 (everything) covers the roundings (|u| < W, |v| < H there).
-  k.kround = 0x1p-44 * (std::fabs(fu) + std::fabs(fv));
+  // kround = 4 (|fu| + |fv|) per (eps / z) (1 + |kx| + |ky|); uv_abs = 2^-46
+  // (everything) covers the roundings (|u| < W, |v| < H there).
+  k.kround = 4.0 * (std::fabs(fu) + std::fabs(fv));
   k.uv_abs = 0x1p-46 * (std::fabs(fu) + std::fabs(fv) + std::fabs(cu) + std::fabs(cv) +
                         (double)width + (double)height);
   return k;
@@ -317,9 +349,9 @@ AMHIP_HD void fold_init(CellFold* s, float layer_angle) {
   s->accepted = 0;
 }
 
-// One frame folded into one cell.  (cx, cy, cz) is the camera-frame point from
-// the fma chain over FrameFast, mag >= |L|_1 + |t|_1 of the pair,
-//   zthr = 1e-10 + 2^-22 mag,  muv = kuv * mag;
+// One frame folded into one cell.  (cx, cy, cz) = M (L - p) from the fma chain
+// over FrameFast; epsL = 2^-48 V1 with V1 >= |L|_1 (the D part of eps is added
+// here from the point itself).
 // `valid` false: the cell has no elevation (NaN): never visible.
 // The steps follow ortho-backward-grid.cc:164-208.  A pair whose visibility or
 // whose comparison with the running best falls inside a margin (or involves
@@ -329,7 +361,11 @@ AMHIP_HD void fold_init(CellFold* s, float layer_angle) {
 // survives the tile's frame cull is visible, and the wave executes all of it
 // anyway.
 AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double cx, double cy,
-                        double cz, double zthr, double muv) {
+                        double cz, double epsL) {
+  const double eps = fma(0x1p-49, fabs(cx) + fabs(cy) + fabs(cz), epsL);
+  // z_r > 1e-10 is certain above zthr, where the relative error of cz is <= 2^-24
+  const double zthr = fma(0x1p+24, eps, 1e-10);
+  const double muv = k.kuv * eps;
   // box test without the division: for z > 0
   //   u >= 0 <=> fu x + cu z >= 0,   u < W <=> (W - cu) z - fu x > 0   (same for v)
   const double a = k.fu * cx;
@@ -338,13 +374,12 @@ AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double
   const double d2 = fma(k.wcu, cz, -a);
   const double e1 = fma(k.cv, cz, b);
   const double e2 = fma(k.hcv, cz, -b);
-  // (all four are finite whenever zok: a non-finite elevation makes mag, hence
-  // zthr, infinite; poses with non-finite entries never reach the fast path)
+  // (all four are finite whenever zok: a non-finite elevation makes eps, hence
+  // zthr, infinite or NaN; poses with non-finite entries never reach the fast path)
   const double g = fmin(fmin(d1, d2), fmin(e1, e2));
   const double zz = cz * cz;
   const double n2 = fma(cx, cx, fma(cy, cy, zz));
-  // z_r > 1e-10 is certain above zthr (eps = 2^-46 mag) and the relative error
-  // of cz there is <= 2^-24; below -zthr it is certainly false
+  // (below -zthr it is certainly false)
   const bool zok = cz > zthr;
   const bool vis = valid & zok & (g > muv);
   const bool invis = !valid | (cz < -zthr) | (zok & (g < -muv));
@@ -372,7 +407,7 @@ AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double
 //             rounding boundaries than its error:  |alpha_a - alpha_ref| <=
 //             eps / z (direction of the ray) + 2u / tan(theta) (the rounding of
 //             |z| / ||p|| under the reference's asin) + 1e-14 (everything else)
-// magmax >= mag of every pair of this cell.  Returns
+// epsL: as in fold_pair.  Returns
 //   kFoldNone    no view was accepted: the cell keeps its values
 //   kFoldDone    *kp_x, *kp_y, *angle are the reference's
 //   kFoldFinish  the winner (s->best_f) is right, keypoint / angle need
@@ -381,7 +416,7 @@ AMHIP_HD void fold_pair(CellFold* s, int f, const FoldCam& k, bool valid, double
 enum { kFoldNone = 0, kFoldDone = 1, kFoldFinish = 2, kFoldRedo = 3 };
 
 AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan_tab,
-                         double magmax, int width, int height, int* kp_x, int* kp_y,
+                         double epsL, int width, int height, int* kp_x, int* kp_y,
                          float* angle) {
   if (s->redo) return kFoldRedo;
   if (s->accepted == 0) return kFoldNone;
@@ -390,8 +425,9 @@ AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan
   const double ky = s->by * rcz;
   const double u = fma(k.fu, kx, k.cu);
   const double v = fma(k.fv, ky, k.cv);
-  const double mz = magmax * rcz;
-  const double duv = fma(k.kround * mz, 1.0 + fabs(kx) + fabs(ky), k.uv_abs);
+  const double eps = fma(0x1p-49, fabs(s->bx) + fabs(s->by) + fabs(s->bz), epsL);
+  const double ez = eps * rcz;  // the direction of the ray is known to within this
+  const double duv = fma(k.kround * ez, 1.0 + fabs(kx) + fabs(ky), k.uv_abs);
   // std::round of a non-negative number = floor(x + 1/2) away from the ties
   const double tu = u + 0.5, tv = v + 0.5;
   const double fu_ = floor(tu), fv_ = floor(tv);
@@ -403,7 +439,8 @@ AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan
   const double r = fold_sqrt(fma(kx, kx, ky * ky));
   double alpha = 0.0;
   ok = ok & fold_angle(atan_tab, r, &alpha);
-  const double da = 0x1p-45 * mz + 0x1p-49 * fold_rcp(r) + 1e-14;
+  // (2u / tan(theta) <= 2^-49 / r; r >= 1e-3 in fold_angle's range)
+  const double da = 2.0 * ez + 2e-12;
   const float fl = (float)alpha;
   const double e = alpha - (double)fl;
   // alpha in [0.46, 1.57]: float spacing 2^-23 (>= 1), 2^-24 ([0.5, 1)), 2^-25

@@ -64,6 +64,9 @@ def parse():
                          "entry points, PCIe transfers included (reported as pcie_inclusive, never "
                          "as value)")
     ap.add_argument("--no-host-path", dest="host_path", action="store_false")
+    ap.add_argument("--map-origin", default="0,0",
+                    help="easting,northing of the map centre (default 0,0; e.g. 464980.25,5272690.5 "
+                         "puts the same workload at UTM magnitudes)")
     return ap.parse_args()
 
 
@@ -165,13 +168,14 @@ def main():
     L = side * res
     # ONE survey map of world x 1 tiles (weak scaling: every rank owns a
     # side x side window of it, cell positions are those of the full map)
-    st = A.GridMapSettings(0.0, 0.0, world * L, L, res)
+    ox, oy = (float(v) for v in args.map_origin.split(","))
+    st = A.GridMapSettings(ox, oy, world * L, L, res)
     layout = tiling.TileLayout(world * side, side, world, 1)
     win = layout.window(rank)
     m = A.AerialGridMap(st, device=local_rank, window=win)
     m.set_stream(stream.cuda_stream)
     # centre of this rank's window in map coordinates (x decreases with i)
-    tile_center = (world * L / 2.0 - (win[0] + win[2] / 2.0) * res, 0.0)
+    tile_center = (ox + world * L / 2.0 - (win[0] + win[2] / 2.0) * res, oy)
 
     # inputs, generated in HBM (synthetic, seeded).  N = 1: the tile's points
     # plus a 4 m apron.  N > 1: each rank holds exactly the points of ITS

@@ -65,8 +65,6 @@ int emul_ortho_fold(int rows, int cols, double base_x, double base_y, double res
                                   (int)camera[5]);
   double atan_tab[kAtanTabSize];
   make_atan_table(atan_tab);
-  double tmag_max = 0.0;
-  for (int f = 0; f < F; ++f) tmag_max = std::fmax(tmag_max, fast[f].tmag);
   bool bad = false;
   // side planes of the undistorted view pyramid, unit inward normals
   // (amhip_api.hip: make_ortho_params)
@@ -135,27 +133,25 @@ int emul_ortho_fold(int rows, int cols, double base_x, double base_y, double res
           const double ly = base_y + res * (-(double)j);
           const double lz = (double)e;
           const double magL = std::fabs(lx) + std::fabs(ly) + std::fabs(lz);
+          const double epsL = 0x1p-48 * magL;
           const float a0 = elevation_angle[at];
           CellFold s;
           fold_init(&s, a0);
           for (int f : cand) {
             const FrameFast& Q = fast[f];
-            const double mag = magL + Q.tmag;
-            const double zthr = fma(0x1p-22, mag, 1e-10);
-            const double muv = k.kuv * mag;
-            const double bx = fma(Q.m[0], lx, Q.t[0]);
-            const double by = fma(Q.m[3], lx, Q.t[1]);
-            const double bz = fma(Q.m[6], lx, Q.t[2]);
-            const double cx = fma(Q.m[2], lz, fma(Q.m[1], ly, bx));
-            const double cy = fma(Q.m[5], lz, fma(Q.m[4], ly, by));
-            const double cz = fma(Q.m[8], lz, fma(Q.m[7], ly, bz));
+            // (the kernel steps ly through a slab as ly0 + c * dly; the error
+            // budget carries that term, the emulation takes the grid's value)
+            const double dx = lx - Q.p[0], dy = ly - Q.p[1], dz = lz - Q.p[2];
+            const double cx = fma(Q.m[2], dz, fma(Q.m[1], dy, Q.m[0] * dx));
+            const double cy = fma(Q.m[5], dz, fma(Q.m[4], dy, Q.m[3] * dx));
+            const double cz = fma(Q.m[8], dz, fma(Q.m[7], dy, Q.m[6] * dx));
             stats[0]++;
-            fold_pair(&s, f, k, true, cx, cy, cz, zthr, muv);
+            fold_pair(&s, f, k, true, cx, cy, cz, epsL);
           }
           int ku = 0, kv = 0;
           float angle = 0.0f;
-          const int what = fold_finish(&s, k, atan_tab, magL + tmag_max, (int)camera[4],
-                                       (int)camera[5], &ku, &kv, &angle);
+          const int what = fold_finish(&s, k, atan_tab, epsL, (int)camera[4], (int)camera[5], &ku,
+                                       &kv, &angle);
           FoldResult r;
           r.best_f = -1;
           if (what == kFoldDone) {

@@ -7,13 +7,12 @@ O=/tmp/sq_ortho_$$
 rm -rf "$OUT" "$O"; mkdir -p "$OUT" "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"
-for v in stop2 fast3 fast4 exact; do
+for v in stop3 stop4 stop5; do
   unset AMHIP_ORTHO_EXACT_FOLD AMHIP_ORTHO_FAST_WAVES AMHIP_ORTHO_NO_PRUNE AMHIP_ORTHO_STOP
   case $v in
-    stop2) export AMHIP_ORTHO_FAST_WAVES=3 AMHIP_ORTHO_STOP=2;;
-    fast3) export AMHIP_ORTHO_FAST_WAVES=3;;
-    fast4) export AMHIP_ORTHO_FAST_WAVES=4;;
-    exact) export AMHIP_ORTHO_EXACT_FOLD=1;;
+    stop3) export AMHIP_ORTHO_STOP=3;;
+    stop4) export AMHIP_ORTHO_STOP=4;;
+    stop5) export AMHIP_ORTHO_STOP=5;;
   esac
   timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$O/$v-a" -o s -- $B > /dev/null 2> "$O/$v-a.err"
   timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d "$O/$v-b" -o s -- $B > /dev/null 2> "$O/$v-b.err"
