@@ -107,7 +107,8 @@ def main():
         import json
         slot = lambda k: ("k_dsm_gather" if k.startswith("k_dsm_gather") else
                           "k_dsm_p3_scatter" if k.startswith("k_dsm_p3_scatter") else
-                          "k_dsm_p3_count" if k.startswith(("k_dsm_p3_count", "k_dsm_p3_reduce", "k_dsm_p3_scan")) else k)
+                          "k_dsm_p3_count" if k.startswith(("k_dsm_p3_count", "k_dsm_p3_reduce", "k_dsm_p3_scan")) else
+                          "k_ortho_backward" if k.startswith("k_ortho_backward") else k)
         fetch, write = pmc_rows(a.fetch, "FETCH_SIZE"), pmc_rows(a.write, "WRITE_SIZE")
         steps = max(c for k, (c, *_r) in fetch.items() if k.startswith("k_dsm_gather"))
         out = {}
