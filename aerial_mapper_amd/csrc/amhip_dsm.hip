@@ -27,6 +27,10 @@
 #include "amhip_common.h"
 #include "amhip_device.h"
 
+#ifndef AMHIP_GATHER_UNROLL
+#define AMHIP_GATHER_UNROLL 2
+#endif
+
 namespace amhip {
 
 __global__ void k_fill_f32(float* __restrict__ dst, size_t n, float value) {
@@ -457,7 +461,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
         const uint32_t kb = orow[-2 * w];
         const uint32_t ke = orow[2 * w + 2];
         orow += RW2;
-        for (uint32_t k = kb; k < ke; ++k) {
+        auto candidate = [&](uint32_t k) __attribute__((always_inline)) {
           const double2 xy = s_xy[k];
           const double z = s_z[k];
           // L2_Adaptor, size == 2 (nanoflann.hpp:319-322): 0 + dx*dx, + dy*dy
@@ -491,7 +495,19 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
                 : "+v"(NB), "+v"(DB), "+v"(PB), "=&v"(t)
                 : "v"(z), "v"(d2B));
           }
+        };
+#if AMHIP_GATHER_UNROLL > 1
+        // (unrolled by hand: the loop bookkeeping is a quarter of the loop's
+        // instructions otherwise)
+        uint32_t k = kb;
+        for (; k + (AMHIP_GATHER_UNROLL - 1) < ke; k += AMHIP_GATHER_UNROLL) {
+#pragma unroll
+          for (uint32_t q = 0; q < AMHIP_GATHER_UNROLL; ++q) candidate(k + q);
         }
+        for (; k < ke; ++k) candidate(k);
+#else
+        for (uint32_t k = kb; k < ke; ++k) candidate(k);
+#endif
         // keep the running products inside the double range (exact scaling by
         // powers of two; N, D, P share the factor so N/D is unaffected).  The
         // test looks at the exponent field only: outside 2^-332 .. 2^332
