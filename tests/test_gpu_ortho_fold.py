@@ -131,3 +131,44 @@ def test_utm_flight_in_batches_and_replay(monkeypatch, env):
     weird[2::3, 1::2] = np.nan
     got, want = run_gpu(g, cam, [(poses[0:6], fr[0:6])], z, angle0=weird)
     S.assert_layers_equal(got, want, LAYERS)
+
+
+@pytest.mark.parametrize("origin", [(0.0, 0.0), (464980.25, 5272690.5), (-2.1e7, 3.3e7)],
+                         ids=["local", "utm", "3e7"])
+def test_fast_and_exact_kernels_agree_on_a_large_map(monkeypatch, origin):
+    """Differential test at a scale the CPU oracle cannot reach in a unit test: 16 M cells x
+    249 frames (the bench geometry), random terrain with holes, three coordinate magnitudes;
+    the margin-guarded kernel (with and without frame-list pruning) against the kernel that
+    does every pair in the reference's arithmetic -- itself oracle-checked above and in
+    tests/test_gpu_parity.py."""
+    import torch
+    import aerial_mapper_amd as A
+    side, res, F, W, H = 4000, 0.25, 249, 1920, 1080
+    L = side * res
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    elev = 400.0 + 10.0 * torch.rand((side, side), device=dev, generator=g)
+    elev += 30.0 * torch.sin(torch.arange(side, device=dev) * 0.01)[None, :]
+    elev[torch.rand((side, side), device=dev, generator=g) < 0.01] = float("nan")
+    elev = elev.float().cpu().numpy()
+    frames = synth.make_frames_torch(F, H, W, 1, 78, dev)
+    poses = synth.make_lawnmower_poses(F, L / 2.0 * 1.3, 700.0, 79, tilt_deg=7.0, center=origin)
+    ncam = A.NCamera(1400.0, 1400.0, (W - 1) / 2.0, (H - 1) / 2.0, W, H)
+    results = {}
+    for name, env in (("exact", {"AMHIP_ORTHO_EXACT_FOLD": "1", "AMHIP_ORTHO_NO_PRUNE": "1"}),
+                      ("fast", {}), ("fast_noprune", {"AMHIP_ORTHO_NO_PRUNE": "1"})):
+        for k in ("AMHIP_ORTHO_EXACT_FOLD", "AMHIP_ORTHO_NO_PRUNE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with A.AerialGridMap(A.GridMapSettings(origin[0], origin[1], L, L, res)) as m:
+            m.set("elevation", elev)
+            mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
+            mosaic.process(poses[:100], frames[:100], m)        # two batches: the second one
+            mosaic.process(poses[100:], frames[100:], m)        # continues from the layers
+            results[name] = {n: m.get(n) for n in LAYERS}
+    want = results["exact"]
+    assert (~np.isnan(want["observation_index"])).mean() > 0.9
+    for name in ("fast", "fast_noprune"):
+        S.assert_layers_equal(results[name], want, LAYERS)
