@@ -270,3 +270,25 @@ def test_dominance_pruning_drops_frames_but_not_results(emul, order):
                               prune=1)
     check(w2, g2)
     assert st2["dropped"] > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cameras_anisotropic_focal_lengths(emul, seed):
+    """fu != fv, principal point far off-centre, wide and narrow lenses, any tilt; with and
+    without frame-list pruning."""
+    rng = np.random.default_rng(500 + seed)
+    center = (float(rng.uniform(-5e5, 5e5)), float(rng.uniform(-5e6, 5e6))) if seed % 2 else (0.0, 0.0)
+    g = O.make_grid(float(rng.uniform(40, 100)), float(rng.uniform(40, 100)),
+                    float(rng.choice([0.25, 0.5, 0.3])), center[0], center[1])
+    W, H = int(rng.integers(40, 220)), int(rng.integers(30, 140))
+    cam = S.camera(W, H, f=float(rng.uniform(30, 320)))
+    cam.fv = cam.fu * float(rng.uniform(0.6, 1.7))
+    cam.cu = float(rng.uniform(0.1 * W, 0.9 * W))
+    cam.cv = float(rng.uniform(0.1 * H, 0.9 * H))
+    F = int(rng.integers(2, 26))
+    poses = synth.make_lawnmower_poses(F, float(rng.uniform(5, 60)), float(rng.uniform(430, 1500)),
+                                       seed + 900, tilt_deg=float(rng.uniform(0, 40)), center=center)
+    frames = [np.ascontiguousarray(f) for f in synth.make_frames(F, H, W, 1, salt=seed % 5)]
+    want, got, st, _ = run_both(emul, g, cam, poses, terrain(g, seed, nan_frac=0.03), frames,
+                                prune=seed % 2)
+    check(want, got)
