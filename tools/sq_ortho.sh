@@ -1,5 +1,6 @@
 #!/bin/bash
-# SQ instruction counters of the backward-grid kernel builds (one gpurun call).
+# SQ instruction counters of the backward-grid kernel builds (one gpurun call):
+#   gpurun --timeout 1200 -- 'bash tools/sq_ortho.sh'   -> gpurun_out/sq_ortho/sq_<variant>.json
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/sq_ortho
@@ -7,12 +8,13 @@ O=/tmp/sq_ortho_$$
 rm -rf "$OUT" "$O"; mkdir -p "$OUT" "$O"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-path"
-for v in stop3 stop4 stop5; do
-  unset AMHIP_ORTHO_EXACT_FOLD AMHIP_ORTHO_FAST_WAVES AMHIP_ORTHO_NO_PRUNE AMHIP_ORTHO_STOP
+for v in exact exact_noprune fast fast_noprune; do
+  unset AMHIP_ORTHO_EXACT_FOLD AMHIP_ORTHO_FAST_WAVES AMHIP_ORTHO_NO_PRUNE
   case $v in
-    stop3) export AMHIP_ORTHO_STOP=3;;
-    stop4) export AMHIP_ORTHO_STOP=4;;
-    stop5) export AMHIP_ORTHO_STOP=5;;
+    exact) export AMHIP_ORTHO_EXACT_FOLD=1;;
+    exact_noprune) export AMHIP_ORTHO_EXACT_FOLD=1 AMHIP_ORTHO_NO_PRUNE=1;;
+    fast) ;;
+    fast_noprune) export AMHIP_ORTHO_NO_PRUNE=1;;
   esac
   timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$O/$v-a" -o s -- $B > /dev/null 2> "$O/$v-a.err"
   timeout 300 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d "$O/$v-b" -o s -- $B > /dev/null 2> "$O/$v-b.err"
