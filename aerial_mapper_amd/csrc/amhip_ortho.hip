@@ -709,7 +709,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
             (unsigned)((p.cols + kTileJ - 1) / kTileJ));
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
-  const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 7
+  const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 8
   const int fast_waves = fw ? std::atoi(fw) : 3;
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
