@@ -7,19 +7,29 @@
 // running maximum, which makes the fold order dependent) and the nearest
 // pixel of the winning frame is sampled.
 //
-// One workgroup owns a tile of 64 x kTileJ cells.  It first reduces the
-// tile's elevation range, then culls the frames against the tile's bounding
-// sphere with the four side planes of the (undistorted pinhole) frustum --
-// conservative, so a culled frame can not be visible from any cell of the
-// tile and skipping it does not change the fold -- and finally every lane
-// folds the surviving frames, in ascending order, for its cells.  The
-// reference brute-forces all F frames per cell; with ~4x overlap only a
-// handful survive per tile.
+// One workgroup owns a tile of 64 x 64 cells.  It reduces the tile's elevation
+// range, builds the tile's frame list ONCE -- cull against the bounding sphere
+// of the tile's landmarks with the four side planes of the view pyramid
+// (conservative: a culled frame is invisible from every cell of the tile, so
+// skipping it does not change the fold), then dominance pruning of the
+// survivors (amhip_ortho_fold.h) -- and folds the list, in ascending order,
+// into the tile's cells, one slab of 64 x 16 cells (4 per lane) at a time.  The
+// reference brute-forces all F frames per cell; with ~4x overlap one or two
+// frames are left per tile.
 //
-// All per-pair arithmetic is the oracle's (oracle/amo_compat.h), operation
-// for operation, in double without fused multiply-add (-ffp-contract=off):
-// minkindr transform of the landmark, aslam pinhole project3 (+ radtan /
-// equidistant distortion), asin(|z| / ||p||).
+// Two builds of the fold:
+//   k_ortho_backward        every pair in the reference's arithmetic
+//                           (oracle/amo_compat.h), operation for operation, in
+//                           double without fused multiply-add
+//                           (-ffp-contract=off): minkindr transform of the
+//                           landmark, aslam pinhole project3 (+ radtan /
+//                           equidistant distortion), asin(|z| / ||p||);
+//   k_ortho_backward_fast   undistorted pinhole + unit quaternions: a
+//                           bounded-error evaluation whose every decision
+//                           carries a margin, the reference's arithmetic only
+//                           for the cells a margin cannot settle
+//                           (amhip_ortho_fold.h).
+// Both give the reference's layers bit for bit.
 #include <cstdlib>
 
 #include "amhip_common.h"
