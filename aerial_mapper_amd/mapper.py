@@ -109,12 +109,38 @@ class AerialGridMap(object):
                                                out.ctypes.data))
         return out
 
+    def host_mirror(self, layer):
+        """The layer's persistent host-side matrix (the GridMap's own matrix in the
+        C++ shim), brought up to date with the device copy if something may have
+        changed that since the last synchronisation."""
+        if not hasattr(self, "_mirrors"):
+            self._mirrors, self._mirror_fresh = {}, set()
+        buf = self._mirrors.get(layer)
+        if buf is None:
+            buf = self._mirrors[layer] = np.zeros((self.cols, self.rows), np.float32)
+            buf.fill(0.0)  # touch the pages once
+        if layer not in self._mirror_fresh:
+            self.get(layer, out=buf)
+            self._mirror_fresh.add(layer)
+        return buf
+
+    def _touched(self, *layers):
+        """The device copy of these layers (all, if none is named) may have changed."""
+        if hasattr(self, "_mirror_fresh"):
+            if layers:
+                self._mirror_fresh.difference_update(layers)
+            else:
+                self._mirror_fresh.clear()
+
     def set(self, layer, values):
+        self._touched(layer)
         a = np.ascontiguousarray(values, np.float32)
         assert a.shape == (self.cols, self.rows), a.shape
         L.check(self._lib.amhip_layer_upload(self._h, self._layer_id(layer), a.ctypes.data))
 
     def device_ptr(self, layer):
+        self._touched(layer)
+        self._external = getattr(self, "_external", set()) | {layer}
         return self._lib.amhip_layer_device_ptr(self._h, self._layer_id(layer))
 
     def as_torch(self, layer):
@@ -136,6 +162,7 @@ class AerialGridMap(object):
 
     def reset(self):
         """AerialGridMap::initialize() constants."""
+        self._touched()
         L.check(self._lib.amhip_layers_reset(self._h))
 
     # -- stream / sync / timing ------------------------------------------
@@ -216,6 +243,7 @@ class Dsm(object):
             assert point_cloud.element_size() == 8 and point_cloud.is_contiguous()
             n = point_cloud.numel() // 3
             map.wait_for_torch(point_cloud)
+            map._touched("elevation")
             L.check(lib.amhip_dsm_process_dev(
                 map.handle, C.c_void_p(point_cloud.data_ptr()), n,
                 s.interpolation_radius, s.center_easting, s.center_northing))
@@ -225,7 +253,14 @@ class Dsm(object):
         pts = np.ascontiguousarray(point_cloud, np.float64).reshape(-1, 3)
         if pts.shape[0] == 0:
             return  # "Passed empty point cloud to DSM module" (dsm.cc:189-192)
-        elev = map.get("elevation")
+        # The host-buffer entry point works on the caller's elevation matrix like
+        # the C++ drop-in does on the GridMap's: uploaded, updated, downloaded.
+        # The matrix is the map's persistent host mirror (allocated and touched
+        # once -- a fresh 400 MB array per call would cost more in page faults
+        # than the transfers).
+        if "elevation" in getattr(map, "_external", ()):
+            map._touched("elevation")  # someone holds the device pointer: always refresh
+        elev = map.host_mirror("elevation")
         L.check(lib.amhip_dsm_process(map.handle, pts.ctypes.data, pts.shape[0],
                                       s.interpolation_radius, s.center_easting,
                                       s.center_northing, elev.ctypes.data))
@@ -301,6 +336,8 @@ class OrthoBackwardGrid(object):
         if map is None:
             raise L.AmhipError(L.ERR_ARG, "CHECK(map)")
         lib = L.load()
+        map._touched("elevation_angle", "observation_index", "num_observations", "ortho",
+                     "colored_ortho")
         cam = self.ncameras.camera
         colored = bool(self.settings.colored_ortho)
         T_G_C = compose_T_G_C(T_G_Bs, self.ncameras.T_C_B)
@@ -373,6 +410,7 @@ class OrthoFromPcl(object):
             if n == 0 or intensities.numel() < n:
                 raise L.AmhipError(L.ERR_ARG, "CHECK(!pointcloud.empty()) / CHECK(i < intensities.size())")
             map.wait_for_torch(pointcloud)
+            map._touched("ortho")
             L.check(lib.amhip_ortho_from_pcl_process_dev(
                 map.handle, C.c_void_p(pointcloud.data_ptr()), C.c_void_p(intensities.data_ptr()),
                 n, s.interpolation_radius, int(bool(s.use_adaptive_interpolation))))
@@ -383,7 +421,9 @@ class OrthoFromPcl(object):
         inten = np.ascontiguousarray(intensities, np.int32).reshape(-1)
         if pts.shape[0] == 0 or inten.shape[0] < pts.shape[0]:
             raise L.AmhipError(L.ERR_ARG, "CHECK(!pointcloud.empty()) / CHECK(i < intensities.size())")
-        ortho = map.get("ortho")
+        if "ortho" in getattr(map, "_external", ()):
+            map._touched("ortho")
+        ortho = map.host_mirror("ortho")
         L.check(lib.amhip_ortho_from_pcl_process(
             map.handle, pts.ctypes.data, inten.ctypes.data, pts.shape[0],
             s.interpolation_radius, int(bool(s.use_adaptive_interpolation)), ortho.ctypes.data))

@@ -304,7 +304,8 @@ def main():
             out_names = ["elevation"] + (["elevation_angle", "observation_index", "ortho"] if F else [])
             # the caller's layer matrices exist (and are touched) before the call,
             # like the GridMap's in the C++ shim
-            h_layers = {n: np.zeros((m.cols, m.rows), np.float32) for n in out_names}
+            h_layers = {n: np.full((m.cols, m.rows), -1.0, np.float32) for n in out_names}
+            dsm.process(h_pts[:1024], m)  # (allocates the host mirror of the elevation layer)
             m.reset()
             m.synchronize()
             t0h = time.perf_counter()
