@@ -232,14 +232,24 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 
-// One lane per gather tile: does any binned point lie within the LAST fallback
-// radius of the tile?  (Tile numbering: ti + tj * tiles_i, as in the gather.)
+// One lane per gather tile (tile numbering: ti + tj * tiles_i, as in the gather):
+//   occ[tile] = 0          no binned point within the LAST fallback radius of the tile
+//             = 1 + class  otherwise; class = which LDS capacity the points of the
+//                          tile's first-level region (the `np` gather_tile stages)
+//                          fit: 0: cap0 (the launch's own), 1: <= cap1, 2: more
+// Clouds are not uniform (overlapping strips, partial coverage): the capacity of
+// the main launch follows the MEAN density, denser tiles go to launches with more
+// LDS per workgroup instead of falling back to the global-memory path.
+//   lists (may be null): [4 counters] then three arrays of ntiles ids:
+//     list 0  occupied class-0 tiles (only filled when `list0` -- sparse calls)
+//     list 1  class-1 tiles,  list 2  class-2 tiles
 __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
-                     uint8_t* __restrict__ occ, int* __restrict__ list,
-                     unsigned* __restrict__ count) {
+                     uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
+                     int cap1) {
+  const int ntiles = p.tiles_i * p.tiles_j;
   const int tile = blockIdx.x * 256 + threadIdx.x;
-  if (tile >= p.tiles_i * p.tiles_j) return;
+  if (tile >= ntiles) return;
   const int ti = tile % p.tiles_i, tj = tile / p.tiles_i;
   const int i0 = ti * kTileI, j0 = tj * tile_j;
   const int i_hi = min(i0 + kTileI, p.rows) - 1;
@@ -252,8 +262,25 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
     const uint32_t* row = start + (size_t)by * p.nbx;
     tot += row[ex1 + 1] - row[ex0];
   }
-  occ[tile] = tot ? 1 : 0;
-  if (list && tot) list[atomicAdd(count, 1u)] = tile;  // (order is irrelevant)
+  if (tot == 0) {
+    occ[tile] = 0;
+    return;
+  }
+  // the first-level region, exactly as gather_tile() sums it
+  const int w0 = p.w[0];
+  const int rbx0 = (i0 - w0 + p.M) / p.B, rbx1 = (i_hi + w0 + p.M) / p.B;
+  const int rby0 = (j0 - w0 + p.M) / p.B, rby1 = (j_hi + w0 + p.M) / p.B;
+  uint32_t np = 0;
+  for (int by = rby0; by <= rby1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    np += row[rbx1 + 1] - row[rbx0];
+  }
+  const int cls = np <= (uint32_t)cap0 ? 0 : (np <= (uint32_t)cap1 ? 1 : 2);
+  occ[tile] = (uint8_t)(1 + cls);
+  if (lists && (cls > 0 || list0)) {
+    unsigned* cnt = reinterpret_cast<unsigned*>(lists);
+    lists[4 + (size_t)cls * ntiles + atomicAdd(&cnt[cls], 1u)] = tile;  // (order is irrelevant)
+  }
 }
 
 // |v| outside [2^-960, 2^960] (within ~1e19 of the ends of the double range)
@@ -272,7 +299,7 @@ template <int NT, int kTileJ, int kCap>
 __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* __restrict__ start,
                                             const double* __restrict__ sorted,
                                             const uint8_t* __restrict__ tile_occ, const CellOut& o,
-                                            const int tile, unsigned char* smem) {
+                                            const int tile, unsigned char* smem, int my_class) {
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
   // [xy: cap+1 double2][z: cap+1 double (+pad)][cell offsets][rows][ctl][flags]
@@ -300,7 +327,10 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   // No point within the LAST fallback radius of the tile (k_dsm_tile_occupancy):
   // every cell stays untouched.  In incremental mapping this is most of the map,
   // so the test is one byte, read before anything else.
-  if (tile_occ[tile] == 0) {
+  const int occ = tile_occ[tile];
+  // (dense launch: tiles of another capacity class belong to another launch)
+  if (my_class >= 0 && occ != 0 && occ - 1 != my_class) return;
+  if (occ == 0) {
     if (o.unfilled && tid == 0)
       atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
     if (o.fill_untouched) {
@@ -369,7 +399,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   __syncthreads();
   static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
   constexpr int kMaxK = (kCap + NT - 1) / NT;  // p.lds_cap == kCap
-  uint32_t pslot[kMaxK];                       // cell << 12 | rank  (rank < 4096)
+  uint32_t pslot[kMaxK];                       // cell << 13 | rank  (rank < kCap <= 8192)
   double ppx[kMaxK], ppy[kMaxK], ppz[kMaxK];   // the thread's points (placed after the scan)
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
@@ -395,7 +425,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       iy = min(max(iy, 0), RH - 1);
       iy += sh;
       const uint32_t cell = (uint32_t)((iy >> 1) * RW2 + 2 * ix + (iy & 1));
-      pslot[k] = (cell << 12) | atomicAdd(&s_off[cell], 1u);
+      pslot[k] = (cell << 13) | atomicAdd(&s_off[cell], 1u);
     }
   }
   __syncthreads();
@@ -420,7 +450,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     if (pslot[k] != 0xFFFFFFFFu) {
-      const uint32_t pos = s_off[pslot[k] >> 12] + (pslot[k] & 0xFFFu);
+      const uint32_t pos = s_off[pslot[k] >> 13] + (pslot[k] & 0x1FFFu);
       s_xy[pos] = make_double2(ppx[k], ppy[k]);
       s_z[pos] = ppz[k];
     }
@@ -597,11 +627,12 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const int xcd = b & 7, k = b >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem);
+  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, 0);
 }
 
-// Sparse launch (a small cloud on a large map, e.g. one stereo pair of an
-// incremental mapping run): a fixed grid walks the list of occupied tiles.
+// List launch: a fixed grid walks a list of tiles -- the occupied tiles of a
+// sparse call (a small cloud on a large map, e.g. one stereo pair of an
+// incremental mapping run) or the tiles of one capacity class.
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
@@ -611,7 +642,7 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned count = *tile_count;
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-    gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem);
+    gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem, -1);
     __syncthreads();
   }
 }
@@ -639,50 +670,74 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // only the occupied tiles are visited, by a fixed grid walking their list.
       const bool sparse = !fill_untouched && ntiles > 8192 &&
                           (double)n * 16.0 < (double)p.rows * (double)p.cols;
-      int* tile_list = nullptr;
-      unsigned* tile_count = nullptr;
-      if (sparse) {
+      // Capacity classes (k_dsm_tile_occupancy): tiles whose first-level region
+      // holds more points than the main launch's LDS image go to list launches
+      // with 2x / 4x the capacity (fewer workgroups per CU, still LDS-resident);
+      // beyond that gather_tile() takes the global-memory path, as before.
+      // Capacities follow the workgroups a CU's 160 KB of LDS can hold: 1024
+      // points -> 4 per CU; class 1 = the most that still leaves two per CU;
+      // class 2 = everything one workgroup can take.
+      const int cap0 = p.lds_cap;
+      const int cap1 = p.tile_j == 16 ? 2752 : 2432;
+      {
         int rc;
-        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, (size_t)ntiles + 4))) return rc;
-        tile_count = reinterpret_cast<unsigned*>(c->tile_list);
-        tile_list = c->tile_list + 4;
-        AMHIP_TRY(hipMemsetAsync(tile_count, 0, sizeof(unsigned), c->stream));
+        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, 3 * (size_t)ntiles + 4))) return rc;
       }
+      unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
+      int* const lists = c->tile_list;
+      AMHIP_TRY(hipMemsetAsync(tile_count, 0, 4 * sizeof(unsigned), c->stream));
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
-                         p, p.tile_j, c->bin_start, c->tile_occ, tile_list, tile_count);
+                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, cap0, cap1);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
-#define AMHIP_LAUNCH_TILED(NT_, TJ_, CAP_)                                                    \
+      auto with_cap = [&](int cap) {
+        DsmParams q = p;
+        q.lds_cap = cap;
+        q.lds_bytes = p.lds_bytes + (unsigned)(cap - cap0) * 24u;
+        return q;
+      };
+#define AMHIP_LAUNCH_DENSE(NT_, TJ_, CAP_)                                                    \
   do {                                                                                        \
-    if (sparse) {                                                                             \
-      AMHIP_TRY(hipFuncSetAttribute(                                                          \
-          reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),           \
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                     \
-      hipLaunchKernelGGL((k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>), dim3(8192), dim3(NT_),  \
-                         p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,     \
-                         tile_list, tile_count, cell_out);                                    \
-    } else {                                                                                  \
-      AMHIP_TRY(hipFuncSetAttribute(                                                          \
-          reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                  \
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                     \
-      hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),       \
-                         p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,     \
-                         cell_out);                                                           \
-    }                                                                                         \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                    \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
+    hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
+                       p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,       \
+                       cell_out);                                                             \
+  } while (0)
+#define AMHIP_LAUNCH_LIST(NT_, TJ_, CAP_, CLS_, GRID_)                                        \
+  do {                                                                                        \
+    const DsmParams q = with_cap(CAP_);                                                       \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),             \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
+    hipLaunchKernelGGL((k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>), dim3(GRID_), dim3(NT_),   \
+                       q.lds_bytes, c->stream, q, c->bin_start, c->sorted, c->tile_occ,       \
+                       lists + 4 + (size_t)(CLS_) * ntiles, tile_count + (CLS_), cell_out);   \
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
-      if (p.tile_j == 16 && p.lds_cap == 1024) {
-        if (nt == 256) AMHIP_LAUNCH_TILED(256, 16, 1024);
-        else AMHIP_LAUNCH_TILED(512, 16, 1024);
+      if (p.tile_j == 16 && cap0 == 1024) {
+        if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
+        else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 16, 1024);
+        else AMHIP_LAUNCH_DENSE(512, 16, 1024);
+        AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
+        AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else if (p.tile_j == 16) {
-        AMHIP_LAUNCH_TILED(512, 16, 2048);
+        if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
+        else AMHIP_LAUNCH_DENSE(512, 16, 2048);
+        AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
+        AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else {
-        if (nt == 256) AMHIP_LAUNCH_TILED(256, 32, 2048);
-        else if (nt == 1024) AMHIP_LAUNCH_TILED(1024, 32, 2048);
-        else AMHIP_LAUNCH_TILED(512, 32, 2048);
+        if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
+        else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
+        else if (nt == 1024) AMHIP_LAUNCH_DENSE(1024, 32, 2048);
+        else AMHIP_LAUNCH_DENSE(512, 32, 2048);
+        AMHIP_LAUNCH_LIST(512, 32, 2432, 1, 2048);
+        AMHIP_LAUNCH_LIST(512, 32, 5200, 2, 1024);
       }
-#undef AMHIP_LAUNCH_TILED
+#undef AMHIP_LAUNCH_DENSE
+#undef AMHIP_LAUNCH_LIST
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,

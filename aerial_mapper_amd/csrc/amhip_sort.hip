@@ -298,6 +298,9 @@ constexpr int kP3MaxKeys = 256;
 constexpr int kP3PlaceThreads = 256;
 constexpr int kP3PlaceMaxCap = 2048;  // LDS capacity (points) the register-resident path handles
 constexpr int kP3PlacePer = kP3PlaceMaxCap / kP3PlaceThreads;
+constexpr int kP3BigThreads = 1024;
+constexpr int kP3BigPer = 6;
+constexpr int kP3BigCap = kP3BigThreads * kP3BigPer;  // 6144 points = 147 KB of LDS
 
 __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
                                         int* k2) {
@@ -350,14 +353,20 @@ __global__ void __launch_bounds__(1024)
 k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
               uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
-              uint32_t* __restrict__ blk2) {
+              uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
+              uint32_t* __restrict__ big_list) {
   __shared__ unsigned lds[1024 / 64 + 1];
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
   unsigned carry = 0;
+  if (threadIdx.x == 0) big_list[0] = 0;
+  __syncthreads();
   for (int base = 0; base < nk; base += 1024) {
     const int i = base + threadIdx.x;
     const unsigned v = (i < nk) ? cnt[i] : 0u;
+    // sub-partitions too full for k_dsm_p3_place's registers but not for a whole
+    // CU's LDS (denser parts of a non-uniform cloud): k_dsm_p3_place_big's list
+    if (v > cap_small && v <= cap_big) big_list[1 + atomicAdd(&big_list[0], 1u)] = (uint32_t)i;
     unsigned total;
     const unsigned ex = block_excl_scan<1024>(v, &total, lds);
     if (i < nk) {
@@ -489,15 +498,16 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
 }
 
 // Pass 3: one workgroup per (k1, k2) sub-partition.
-__global__ void __launch_bounds__(kP3PlaceThreads)
-k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
-               const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
-               double* __restrict__ sorted) {
+template <int THREADS, int PER>
+__device__ __forceinline__ void place_subpartition(const double* __restrict__ src, const DsmParams& p,
+                                                   int cap, const uint32_t* __restrict__ start2,
+                                                   uint32_t* __restrict__ bin_start,
+                                                   double* __restrict__ sorted, int sp,
+                                                   unsigned skip_lo, unsigned skip_hi) {
   extern __shared__ double s_pts[];                                  // 3 * cap
   uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
   uint32_t* s_scan = s_bins + p.p3_w;                                // 24
   const int tid = threadIdx.x;
-  const int sp = blockIdx.x;
   const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
   const int rr = k2 / p.p3_c;
   const int row = k1 * p.p3_r1 + rr;
@@ -507,17 +517,19 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
     bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
   if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
-  for (int k = tid; k < nbw; k += kP3PlaceThreads) s_bins[k] = 0;
+  for (int k = tid; k < nbw; k += THREADS) s_bins[k] = 0;
   __syncthreads();
-  const bool in_lds = (int)(g1 - g0) <= cap && cap <= kP3PlaceMaxCap;
+  // (skip_lo, skip_hi]: sub-partitions the other launch takes
+  if ((g1 - g0) > skip_lo && (g1 - g0) <= skip_hi) return;
+  const bool in_lds = (int)(g1 - g0) <= cap && cap <= THREADS * PER;
   // the sub-partition is read ONCE: a thread keeps its points (<= 8) in
   // registers between the count and the placement
-  double px[kP3PlacePer], py[kP3PlacePer], pz[kP3PlacePer];
-  int pb[kP3PlacePer];
+  double px[PER], py[PER], pz[PER];
+  int pb[PER];
   if (in_lds) {
 #pragma unroll
-    for (int k = 0; k < kP3PlacePer; ++k) {
-      const uint32_t idx = g0 + tid + (uint32_t)k * kP3PlaceThreads;
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
       pb[k] = -1;
       if (idx < g1) {
         px[k] = src[3 * (size_t)idx + 0];
@@ -530,7 +542,7 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
       }
     }
   } else {
-    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
       int bx, by;
       point_bin_xy(p, src[3 * (size_t)idx + 0], src[3 * (size_t)idx + 1], &bx, &by);
       atomicAdd(&s_bins[bx - bx0], 1u);
@@ -538,13 +550,13 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
   }
   __syncthreads();
   {
-    const int per = (nbw + kP3PlaceThreads - 1) / kP3PlaceThreads;
+    const int per = (nbw + THREADS - 1) / THREADS;
     const int lo = tid * per;
     const int hi = min(lo + per, nbw);
     unsigned sum = 0;
     for (int k = lo; k < hi; ++k) sum += s_bins[k];
     unsigned total;
-    unsigned run = block_excl_scan<kP3PlaceThreads>(sum, &total, s_scan);
+    unsigned run = block_excl_scan<THREADS>(sum, &total, s_scan);
     for (int k = lo; k < hi; ++k) {
       const unsigned t = s_bins[k];
       s_bins[k] = run;
@@ -553,11 +565,11 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
   }
   __syncthreads();
   uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
-  for (int k = tid; k < nbw; k += kP3PlaceThreads) out_start[k] = g0 + s_bins[k];
+  for (int k = tid; k < nbw; k += THREADS) out_start[k] = g0 + s_bins[k];
   __syncthreads();
   if (!in_lds) {
     // over-full sub-partition (clustered cloud): second read, direct placement
-    for (uint32_t idx = g0 + tid; idx < g1; idx += kP3PlaceThreads) {
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
       const double x = src[3 * (size_t)idx + 0];
       const double y = src[3 * (size_t)idx + 1];
       const double z = src[3 * (size_t)idx + 2];
@@ -571,7 +583,7 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
     return;
   }
 #pragma unroll
-  for (int k = 0; k < kP3PlacePer; ++k) {
+  for (int k = 0; k < PER; ++k) {
     if (pb[k] >= 0) {
       const uint32_t q = atomicAdd(&s_bins[pb[k]], 1u);
       s_pts[3 * q + 0] = px[k];
@@ -582,7 +594,32 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
   __syncthreads();
   const uint32_t ne = 3u * (g1 - g0);
   double* out = sorted + 3 * (size_t)g0;
-  for (uint32_t e = tid; e < ne; e += kP3PlaceThreads) out[e] = s_pts[e];
+  for (uint32_t e = tid; e < ne; e += THREADS) out[e] = s_pts[e];
+}
+
+// cap points in LDS, <= kP3PlacePer per thread in registers; fuller
+// sub-partitions are left to k_dsm_p3_place_big (skip_lo < count <= skip_hi) or,
+// beyond a CU's LDS, placed directly with a second read.
+__global__ void __launch_bounds__(kP3PlaceThreads)
+k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
+               const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+               double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi) {
+  place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted,
+                                                   (int)blockIdx.x, skip_lo, skip_hi);
+}
+
+// The same with 1024 threads and a whole CU's LDS (kP3BigCap points), walking
+// the list k_dsm_p3_scan made of the sub-partitions in (skip_lo, skip_hi].
+__global__ void __launch_bounds__(kP3BigThreads)
+k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
+                   const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+                   double* __restrict__ sorted, const uint32_t* __restrict__ big_list) {
+  const unsigned count = big_list[0];
+  for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+    place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted,
+                                                 (int)big_list[1 + k], 0u, 0u);
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -788,7 +825,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     if (gcount < 1) gcount = 1;
     int rc;
     if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
-    const size_t ws_words = gcount * (size_t)nk + 3 * (size_t)nk + 3 * (size_t)n1 + 16;
+    const size_t ws_words = gcount * (size_t)nk + 4 * (size_t)nk + 3 * (size_t)n1 + 24;
     if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, ws_words))) return rc;
     uint32_t* hist_rows = c->stripe_ws;
     uint32_t* cnt = hist_rows + gcount * (size_t)nk;
@@ -797,6 +834,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     uint32_t* start1 = cursor2 + nk;   // n1 + 1
     uint32_t* cursor1 = start1 + n1 + 1;
     uint32_t* blk2 = cursor1 + n1;     // n1 + 1
+    uint32_t* big_list = blk2 + n1 + 1;  // [count] + up to nk sub-partition ids
     {
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
       const size_t lds = (size_t)nk * sizeof(uint32_t);
@@ -807,7 +845,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
-                         cursor2, start1, cursor1, blk2);
+                         cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
+                         big_list);
       AMHIP_TRY(hipGetLastError());
     }
     {
@@ -835,7 +874,13 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
-                         c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted);
+                         c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
+                         (unsigned)p.p3_cap, (unsigned)kP3BigCap);
+      const size_t lds_big = (size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+      hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
+                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list);
       AMHIP_TRY(hipGetLastError());
     }
   } else if (p.nstripes > 0 && !force_one_level) {

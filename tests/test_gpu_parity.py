@@ -326,6 +326,44 @@ def test_dsm_clustered_cloud_overflows_lds_tiles():
     S.assert_dsm_close(got, want)
 
 
+def test_dsm_uneven_density_takes_every_capacity_class():
+    # Real clouds are not uniform (overlapping strips, partial coverage).  The gather's
+    # main launch sizes its LDS image for the MEAN density; denser tiles go to list launches
+    # with more LDS per workgroup (<= 2752 and <= 5600 points per tile region), denser still
+    # to the global-memory path.  Same for the sort's placement pass (sub-partitions beyond
+    # 2048 points: 6144-point workgroups, beyond that direct placement).  ~1.6 M points, so
+    # the three-pass sort runs: base 0.4 pts/cell + patches of 1.2, 2.5, 5 and 12 pts/cell.
+    rng = np.random.default_rng(17)
+    lx, ly, res = 520.0, 380.0, 0.25
+    g = O.make_grid(lx, ly, res)
+    n0 = int(0.4 * g.rows * g.cols)
+    parts = [np.c_[rng.uniform(-lx / 2 - 2, lx / 2 + 2, n0), rng.uniform(-ly / 2 - 2, ly / 2 + 2, n0)]]
+    for k, dens in enumerate([1.2, 2.5, 5.0, 12.0]):
+        side = 60.0 if dens < 6 else 30.0
+        cx0, cy0 = -200.0 + 110.0 * k, -100.0 + 50.0 * k
+        nk = int(dens * (side / res) ** 2)
+        parts.append(np.c_[rng.uniform(cx0, cx0 + side, nk), rng.uniform(cy0, cy0 + side, nk)])
+    xy = np.concatenate(parts)
+    pts = np.empty((xy.shape[0], 3))
+    pts[:, :2] = xy
+    pts[:, 2] = synth.terrain_height(xy[:, 0], xy[:, 1]) + rng.uniform(-0.3, 0.3, xy.shape[0])
+    assert pts.shape[0] > (1 << 20)
+    A = _A()
+    rc, want, _ = O.dsm_process(pts, g)
+    assert rc == O.OK
+    with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, lx, ly, res)) as m:
+        A.Dsm(A.DsmSettings(), m).process(pts, m)
+        got = m.get("elevation")
+        # the same cloud as a sparse call onto the materialized layer (list launches only)
+        few = np.ascontiguousarray(pts[-int(12.0 * (30.0 / res) ** 2):])
+        A.Dsm(A.DsmSettings(), m).process(few, m)
+        got2 = m.get("elevation")
+    S.assert_dsm_close(got, want)
+    rc, want2, _ = O.dsm_process(few, g, elevation=want.copy())
+    assert rc == O.OK
+    S.assert_dsm_close(got2, want2)
+
+
 @pytest.mark.parametrize("knobs", [
     {"AMHIP_SORT_ONE_LEVEL": "1"},
     {"AMHIP_SORT_TWO_LEVEL": "1"},
