@@ -208,6 +208,68 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
   }
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// One WAVE per cell, the lanes over the candidates: for tiles denser than any
+// LDS image can hold (dense stereo clouds: tens of points per cell, hundreds of
+// neighbours per cell).  The window's bin rows are contiguous spans of the
+// sorted cloud, read coalesced; every lane keeps partial inverse-distance sums,
+// one butterfly reduction per cell.  Same neighbour set as cell_global(), the
+// order of the double sums differs (as it does from the kd-tree's anyway).
+// Must be called by all 64 lanes of a wave with the same (i, j).
+__device__ __forceinline__ void cell_wave(const DsmParams& p, const uint32_t* __restrict__ start,
+                                          const double* __restrict__ sorted, int i, int j,
+                                          const CellOut& o) {
+  const int lane = threadIdx.x & 63;
+  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
+  const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
+  const int w = p.w[0];
+  const double T = p.T[0];
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
+  double num = 0.0, den = 0.0;
+  unsigned cnt = 0;
+  bool exact = false;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    for (uint32_t k = s0 + lane; k < e0; k += 64) {
+      const double px = sorted[3 * (size_t)k + 0];
+      const double py = sorted[3 * (size_t)k + 1];
+      const double dx = qx - px;
+      const double dy = qy - py;
+      double d2 = dx * dx;
+      d2 = d2 + dy * dy;  // L2_Adaptor, size == 2 (nanoflann.hpp:319-322)
+      if (d2 < T) {       // strict (nanoflann.hpp:157)
+        if (d2 > 0.0)
+          idw_add(d2, sorted[3 * (size_t)k + 2], &num, &den);
+        else
+          exact = true;
+        cnt++;
+      }
+    }
+  }
+  const bool any_exact = __ballot(exact) != 0ull;
+  num = wave_sum_d(num);
+  den = wave_sum_d(den);
+  unsigned total = cnt;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
+  if (lane != 0) return;
+  if (any_exact || total == 0) {
+    // exact hit (CHECK failure / OrthoFromPcl's perfect match, which depends on
+    // the scan order) or an empty first search (the ladder): the scalar routine
+    cell_global(p, start, sorted, i, j, o);
+    return;
+  }
+  emit_value(p, o, i, j, num / den);
+}
+
 // Pure global-memory gather: used when the first-level window is too wide for
 // the LDS image (very fine grids) and by the adaptive OrthoFromPcl passes.
 __global__ void __launch_bounds__(256)
@@ -236,17 +298,18 @@ constexpr int kMaxRegionRows = 96;  // bin rows of a region
 //   occ[tile] = 0          no binned point within the LAST fallback radius of the tile
 //             = 1 + class  otherwise; class = which LDS capacity the points of the
 //                          tile's first-level region (the `np` gather_tile stages)
-//                          fit: 0: cap0 (the launch's own), 1: <= cap1, 2: more
+//                          fit: 0: cap0 (the launch's own), 1: <= cap1, 2: <= cap2,
+//                          3: more than any LDS image holds (wave-per-cell path)
 // Clouds are not uniform (overlapping strips, partial coverage): the capacity of
 // the main launch follows the MEAN density, denser tiles go to launches with more
 // LDS per workgroup instead of falling back to the global-memory path.
-//   lists (may be null): [4 counters] then three arrays of ntiles ids:
+//   lists (may be null): [4 counters] then four arrays of ntiles ids:
 //     list 0  occupied class-0 tiles (only filled when `list0` -- sparse calls)
-//     list 1  class-1 tiles,  list 2  class-2 tiles
+//     list k  class-k tiles
 __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
-                     int cap1) {
+                     int cap1, int cap2) {
   const int ntiles = p.tiles_i * p.tiles_j;
   const int tile = blockIdx.x * 256 + threadIdx.x;
   if (tile >= ntiles) return;
@@ -275,7 +338,7 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
     const uint32_t* row = start + (size_t)by * p.nbx;
     np += row[rbx1 + 1] - row[rbx0];
   }
-  const int cls = np <= (uint32_t)cap0 ? 0 : (np <= (uint32_t)cap1 ? 1 : 2);
+  const int cls = np <= (uint32_t)cap0 ? 0 : (np <= (uint32_t)cap1 ? 1 : (np <= (uint32_t)cap2 ? 2 : 3));
   occ[tile] = (uint8_t)(1 + cls);
   if (lists && (cls > 0 || list0)) {
     unsigned* cnt = reinterpret_cast<unsigned*>(lists);
@@ -385,7 +448,17 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   const int np = (int)s_ctl[0];
   const bool use_lds = geom_ok && np <= p.lds_cap;
   if (!use_lds) {
-    // over-full tile (very dense / clustered cloud): global path for all cells
+    if (geom_ok) {
+      // more points than any LDS image holds (dense stereo clouds): one wave per
+      // cell over the global bins, lanes over the candidates
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int j = j0 + wid * kCellsPerLane + c;
+        if (j > j_hi) break;
+        for (int i = i0; i <= i_hi; ++i) cell_wave(p, start, sorted, i, j, o);
+      }
+      return;
+    }
+    // region too tall for the row tables (very fine grids): one lane per cell
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
       if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
@@ -679,21 +752,22 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // class 2 = everything one workgroup can take.
       const int cap0 = p.lds_cap;
       const int cap1 = p.tile_j == 16 ? 2752 : 2432;
+      const int cap2 = p.tile_j == 16 ? 5600 : 5200;
       {
         int rc;
-        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, 3 * (size_t)ntiles + 4))) return rc;
+        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, 4 * (size_t)ntiles + 4))) return rc;
       }
       unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
       int* const lists = c->tile_list;
       AMHIP_TRY(hipMemsetAsync(tile_count, 0, 4 * sizeof(unsigned), c->stream));
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
-                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, cap0, cap1);
+                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, cap0, cap1, cap2);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
       auto with_cap = [&](int cap) {
         DsmParams q = p;
         q.lds_cap = cap;
-        q.lds_bytes = p.lds_bytes + (unsigned)(cap - cap0) * 24u;
+        q.lds_bytes = (unsigned)((int)p.lds_bytes + (cap - cap0) * 24);
         return q;
       };
 #define AMHIP_LAUNCH_DENSE(NT_, TJ_, CAP_)                                                    \
@@ -723,11 +797,13 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
+        AMHIP_LAUNCH_LIST(512, 16, 1024, 3, 4096);  // (small LDS image: full occupancy)
       } else if (p.tile_j == 16) {
         if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
         else AMHIP_LAUNCH_DENSE(512, 16, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
+        AMHIP_LAUNCH_LIST(512, 16, 1024, 3, 4096);
       } else {
         if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
@@ -735,6 +811,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
         AMHIP_LAUNCH_LIST(512, 32, 2432, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 32, 5200, 2, 1024);
+        AMHIP_LAUNCH_LIST(512, 32, 2048, 3, 4096);
       }
 #undef AMHIP_LAUNCH_DENSE
 #undef AMHIP_LAUNCH_LIST

@@ -364,6 +364,30 @@ def test_dsm_uneven_density_takes_every_capacity_class():
     S.assert_dsm_close(got2, want2)
 
 
+@pytest.mark.parametrize("dens", [4.0, 9.0, 30.0])
+def test_dsm_dense_clouds_take_the_wave_per_cell_path(dens):
+    # Dense stereo clouds put tens of points into a 0.25 m cell and hundreds of neighbours
+    # into a search disc: more than any LDS image of a tile holds.  Those tiles run one WAVE
+    # per cell over the global bins (lanes over the candidates, butterfly reduction).
+    rng = np.random.default_rng(int(dens))
+    lx, ly, res = 72.0, 44.0, 0.25
+    g = O.make_grid(lx, ly, res)
+    n = int(dens * g.rows * g.cols)
+    pts = np.empty((n, 3))
+    pts[:, 0] = rng.uniform(-lx / 2 - 1.5, lx / 2 + 1.5, n)
+    pts[:, 1] = rng.uniform(-ly / 2 - 1.5, ly / 2 + 1.5, n)
+    pts[:, 2] = synth.terrain_height(pts[:, 0], pts[:, 1]) + rng.uniform(-2.0, 2.0, n)
+    pts = pts[~((pts[:, 0] > 5.0) & (pts[:, 0] < 12.0) & (pts[:, 1] > -3.0) & (pts[:, 1] < 4.0))]  # a hole: ladder
+    A = _A()
+    rc, want, _ = O.dsm_process(pts, g)
+    assert rc == O.OK
+    with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, lx, ly, res)) as m:
+        A.Dsm(A.DsmSettings(), m).process(pts, m)
+        got = m.get("elevation")
+    assert np.isnan(want).any() and (~np.isnan(want)).mean() > 0.9
+    S.assert_dsm_close(got, want)
+
+
 @pytest.mark.parametrize("knobs", [
     {"AMHIP_SORT_ONE_LEVEL": "1"},
     {"AMHIP_SORT_TWO_LEVEL": "1"},

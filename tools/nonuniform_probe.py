@@ -37,3 +37,12 @@ strip = torch.empty_like(uni)
 strip[:] = synth.make_points_torch(N, L / 2 + 4, 46, dev)
 strip[:, 1] = strip[:, 1] * 0.5           # everything squeezed into the middle half: 1 pt/cell there
 run("all points in half of the map", strip)
+
+# spatially ORDERED clouds (scan lines, raster order of a stereo densifier, pre-tiled data):
+# every chunk of the sort then holds one or two partitions
+order = torch.argsort(uni[:, 1])
+run("uniform, sorted by northing", uni[order].contiguous())
+key = (torch.floor(uni[:, 1] / 4.0) * 100000.0 + uni[:, 0])
+order = torch.argsort(key)
+run("uniform, sorted in 4 m strips", uni[order].contiguous())
+del order, key
