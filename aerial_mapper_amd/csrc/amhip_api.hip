@@ -462,6 +462,89 @@ static bool distorted_view_cone(const amhip_camera& cam, double* cone) {
   return false;
 }
 
+// Tighter bounds for cameras with a distortion model, given the view cone
+// `cone` of distorted_view_cone() (every visible landmark has |p| <= cone * z):
+//   ax, ay  outer rectangle: visible => |x| <= ax z and |y| <= ay z.  From
+//           x_d = x s(r) + t_x with |t_x| <= c r^2 (radtan; s = the radial
+//           factor, t = the tangential terms) resp. x_d = x s(r) (equidistant)
+//           and |x_d| <= Bx for a visible landmark:  |x| <= (Bx + c cone^2) / min s.
+//   rin     inner cone: |p| <= rin z  =>  visible by a clear margin.  The
+//           distorted point of such a landmark has |x_d|, |y_d| <= r |s(r)| + c r^2
+//           =: g(r); rin = the largest r with g <= (smallest distance of the
+//           principal point to an image edge, normalised) on [0, r].
+// Both scans carry a Lipschitz margin per step.  Values of 0 mean "no bound".
+static void distorted_rectangle_and_inner_cone(const amhip_camera& cam, double cone, double* ax,
+                                               double* ay, double* rin) {
+  *ax = *ay = cone;
+  *rin = 0.0;
+  const double W = cam.width, H = cam.height;
+  // (the same one-pixel allowance as distorted_view_cone)
+  const double Bx = std::max(std::fabs(-1.0 - cam.cu), std::fabs(W - cam.cu)) / cam.fu;
+  const double By = std::max(std::fabs(-1.0 - cam.cv), std::fabs(H - cam.cv)) / cam.fv;
+  const double bmin = std::min(std::min(cam.cu / cam.fu, (W - cam.cu) / cam.fu),
+                               std::min(cam.cv / cam.fv, (H - cam.cv) / cam.fv));
+  double c = 0.0;
+  // s(r): radial factor; ds: an upper bound of |s'| that grows with r
+  auto s_of = [&](double r) {
+    if (cam.distortion == AMHIP_DIST_RADTAN) {
+      const double r2 = r * r;
+      return 1.0 + cam.dist[0] * r2 + cam.dist[1] * r2 * r2;
+    }
+    if (r < 1e-8) return 1.0;
+    const double th = std::atan(r);
+    const double t2 = th * th, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    return th * (1.0 + cam.dist[0] * t2 + cam.dist[1] * t4 + cam.dist[2] * t6 + cam.dist[3] * t8) / r;
+  };
+  auto ds_of = [&](double r) {
+    if (cam.distortion == AMHIP_DIST_RADTAN)
+      return 2.0 * std::fabs(cam.dist[0]) * r + 4.0 * std::fabs(cam.dist[1]) * r * r * r;
+    // s = theta_d(theta) / r, theta = atan r, theta_d = theta P(theta^2):
+    //   s' = [P (r / (1 + r^2) - theta) + 2 theta^2 P' r / (1 + r^2)] / r^2
+    // |theta_d'| <= L, |theta_d| <= L theta <= L r            =>  |s'| <= 2 L / r
+    // |r / (1 + r^2) - atan r| <= r^3, theta <= r, |P| <= L   =>  |s'| <= (L + 2 Lp) r
+    const double hp = 1.5707963267948966, t2 = hp * hp, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double L = 1.0 + 3.0 * std::fabs(cam.dist[0]) * t2 + 5.0 * std::fabs(cam.dist[1]) * t4 +
+                     7.0 * std::fabs(cam.dist[2]) * t6 + 9.0 * std::fabs(cam.dist[3]) * t8;
+    const double Lp = std::fabs(cam.dist[0]) + 2.0 * std::fabs(cam.dist[1]) * t2 +
+                      3.0 * std::fabs(cam.dist[2]) * t4 + 4.0 * std::fabs(cam.dist[3]) * t6;
+    return std::min(2.0 * L / std::max(r, 1e-12), (L + 2.0 * Lp) * r);
+  };
+  if (cam.distortion == AMHIP_DIST_RADTAN)
+    c = 4.5 * (std::fabs(cam.dist[2]) + std::fabs(cam.dist[3]));
+  if (!(cone > 0.0) || !(cone < 1e3)) return;
+  // ---- outer rectangle: min |s| on [0, cone]
+  {
+    const int n = 20000;
+    const double h = cone / n;
+    double smin = 1e300;
+    for (int k = 0; k <= n; ++k) {
+      const double r = k * h;
+      smin = std::min(smin, std::fabs(s_of(r)) - h * ds_of(r + h));
+    }
+    if (smin > 0.05) {
+      const double tx = c * cone * cone;
+      *ax = std::min(cone, ((Bx + tx) / smin) * (1.0 + 1e-6) + 1e-6);
+      *ay = std::min(cone, ((By + tx) / smin) * (1.0 + 1e-6) + 1e-6);
+    }
+  }
+  // ---- inner cone
+  if (bmin > 0.0) {
+    const double bound = bmin * (1.0 - 1e-6) - 1e-9;
+    const double h = 2e-5;
+    double r = 0.0, best = 0.0;
+    while (r < cone) {
+      const double rn = r + h;
+      // g(r) = r |s(r)| + c r^2;  |g'| <= |s| + r |s'| + 2 c r
+      const double g = r * std::fabs(s_of(r)) + c * r * r;
+      const double lip = std::fabs(s_of(rn)) + h * ds_of(rn) + rn * ds_of(rn) + 2.0 * c * rn;
+      if (!(g + h * lip <= bound)) break;
+      best = rn;
+      r = rn;
+    }
+    *rin = best;
+  }
+}
+
 static void make_ortho_params(Ctx& c, const amhip_camera& cam,
                               size_t F, size_t frame_stride, size_t row_step,
                               int channels, int colored, OrthoParams* out) {
@@ -499,15 +582,29 @@ static void make_ortho_params(Ctx& c, const amhip_camera& cam,
     if (c.cone_state == 0 || std::memcmp(&c.cone_cam, &cam, sizeof(cam)) != 0) {
       c.cone_cam = cam;
       c.cone_state = distorted_view_cone(cam, &c.cone) ? 1 : 2;
+      c.cone_state_rect = 0;
     }
     have_cone = c.cone_state == 1;
     cone = c.cone;
   }
+  double ax = cone, ay = cone;
+  p.r_in = 0.0;
   if (have_cone) {
-    // every visible landmark has |x| <= cone * z and |y| <= cone * z
+    if (c.cone_state_rect != 1 || c.cone_rect_cone != cone) {
+      distorted_rectangle_and_inner_cone(cam, cone, &c.cone_ax, &c.cone_ay, &c.cone_rin);
+      c.cone_state_rect = 1;
+      c.cone_rect_cone = cone;
+    }
+    ax = c.cone_ax;
+    ay = c.cone_ay;
+    if (!std::getenv("AMHIP_NO_DISTORTED_PRUNE")) p.r_in = c.cone_rin;
+    if (std::getenv("AMHIP_DISTORTED_SQUARE_CULL")) ax = ay = cone;  // (A/B: the circumscribed square)
+  }
+  if (have_cone) {
+    // every visible landmark has |x| <= ax * z and |y| <= ay * z
     p.cull = 1;
-    double l[3] = {1.0, 0.0, cone}, r[3] = {-1.0, 0.0, cone};
-    double t[3] = {0.0, 1.0, cone}, b[3] = {0.0, -1.0, cone};
+    double l[3] = {1.0, 0.0, ax}, r[3] = {-1.0, 0.0, ax};
+    double t[3] = {0.0, 1.0, ay}, b[3] = {0.0, -1.0, ay};
     normalize3(l);
     normalize3(r);
     normalize3(t);
@@ -1114,7 +1211,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
     p.virt_nobs = (st == 3 || st == 0) ? 1 : 0;
   }
   if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
-  p.prune = (p.cull && cam->distortion == AMHIP_DIST_NONE && p.virt_nobs &&
+  p.prune = (p.cull && (cam->distortion == AMHIP_DIST_NONE || p.r_in > 0.0) && p.virt_nobs &&
              !std::getenv("AMHIP_ORTHO_NO_PRUNE")) ? 1 : 0;
   p.fast = fast_ok ? 1 : 0;
   p.fold = make_fold_cam(cam->fu, cam->fv, cam->cu, cam->cv, cam->width, cam->height);

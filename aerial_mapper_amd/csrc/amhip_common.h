@@ -109,6 +109,9 @@ struct OrthoParams {
   // the bounding spheres assume rigid poses; |q|^2 = 1 + dev scales distances
   // by that much: radii are multiplied by 1 + 2 max|dev|
   double radius_scale;
+  // cameras with a distortion model: |p| <= r_in z  =>  visible by a clear
+  // margin (0: unknown); lets frame_bounds() call a frame fully visible
+  double r_in;
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
@@ -177,6 +180,8 @@ struct Ctx {
   amhip_camera cone_cam = {};    // camera the cached view cone belongs to
   double cone = 0.0;             // distorted_view_cone() result
   int cone_state = 0;            // 0: none cached, 1: usable bound, 2: no bound
+  int cone_state_rect = 0;       // distorted_rectangle_and_inner_cone() cached for `cone_rect_cone`
+  double cone_rect_cone = 0.0, cone_ax = 0.0, cone_ay = 0.0, cone_rin = 0.0;
   FramePose* frame_poses = nullptr;
   size_t frame_pose_cap = 0;
   uint8_t* stage_frames = nullptr;

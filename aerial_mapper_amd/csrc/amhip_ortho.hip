@@ -245,7 +245,7 @@ __device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose*
   double tmin = 0.0, tmax_full = __builtin_huge_val();
   if (mine) {
     f = s_cand[threadIdx.x];
-    const FrameBounds b = frame_bounds(p.pl, poses[f], centre, radius, slack);
+    const FrameBounds b = frame_bounds(p.pl, poses[f], centre, radius, slack, p.r_in);
     tmin = b.tmin;
     if (b.full) tmax_full = b.tmax;
   }

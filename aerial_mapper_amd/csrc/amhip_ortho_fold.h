@@ -150,8 +150,11 @@ struct FrameBounds {
   double tmin, tmax;
 };
 
+// r_in > 0 (cameras with a distortion model): `full` <=> the whole sphere lies
+// inside the inner cone |p| <= r_in z instead of inside the four planes (which
+// are only an OUTER bound of the view then).
 AMHIP_HD FrameBounds frame_bounds(const double (*pl)[3], const FramePose& T, const V3& centre,
-                                  double radius, double slack) {
+                                  double radius, double slack, double r_in = 0.0) {
   const V3 cc = transform_point(T, centre);
   FrameBounds b;
   b.keep = !(cc.z < -radius);
@@ -173,6 +176,7 @@ AMHIP_HD FrameBounds frame_bounds(const double (*pl)[3], const FramePose& T, con
   // sqrt / divisions (whatever their implementation)
   b.tmin = zhi > 0.0 ? (fmax(rxy - radius, 0.0) / zhi) * (1.0 - 1e-12) : HUGE_VAL;
   b.tmax = zlo > 0.0 ? ((rxy + radius) / zlo) * (1.0 + 1e-12) : HUGE_VAL;
+  if (r_in > 0.0) b.full = b.keep && (zlo > slack) && (zlo > 1e-3) && (b.tmax <= r_in * (1.0 - 1e-9));
   return b;
 }
 

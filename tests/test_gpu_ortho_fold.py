@@ -172,3 +172,50 @@ def test_fast_and_exact_kernels_agree_on_a_large_map(monkeypatch, origin):
     assert (~np.isnan(want["observation_index"])).mean() > 0.9
     for name in ("fast", "fast_noprune"):
         S.assert_layers_equal(results[name], want, LAYERS)
+
+
+@pytest.mark.parametrize("kind,dist", [
+    ("radtan", (-0.28, 0.07, 2e-4, -1e-4)),
+    ("radtan", (0.12, -0.02, -8e-4, 6e-4)),            # pincushion
+    ("radtan", (-0.45, 0.0, 0.0, 0.0)),                # folds back inside the cone
+    ("equidistant", (-0.01, 0.02, -0.005, 0.001)),
+    ("equidistant", (0.08, -0.03, 0.0, 0.0)),
+])
+def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(monkeypatch, kind, dist):
+    """Cameras with a distortion model on a 9 M-cell rough map, 120 frames: the frame-list
+    pruning (inner cone = 'fully visible') and the rectangular outer cull against the plain
+    circumscribed-square cull without pruning -- which tests/test_gpu_parity.py checks
+    against the oracle.  All layers must be identical."""
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import hip_lib as L
+    side, res, F, W, H = 3000, 0.25, 120, 960, 540
+    Lm = side * res
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    elev = 400.0 + 8.0 * torch.rand((side, side), device=dev, generator=g)
+    elev += 25.0 * torch.sin(torch.arange(side, device=dev) * 0.013)[:, None]
+    elev[torch.rand((side, side), device=dev, generator=g) < 0.005] = float("nan")
+    elev = elev.float().cpu().numpy()
+    frames = synth.make_frames_torch(F, H, W, 1, 6, dev)
+    poses = synth.make_lawnmower_poses(F, Lm / 2.0 * 1.2, 650.0, 7, tilt_deg=9.0)
+    model = L.DIST_RADTAN if kind == "radtan" else L.DIST_EQUIDISTANT
+    ncam = A.NCamera(700.0, 690.0, 470.0, 280.0, W, H, model, dist)
+    results = {}
+    for name, env in (("plain", {"AMHIP_NO_DISTORTED_PRUNE": "1", "AMHIP_DISTORTED_SQUARE_CULL": "1"}),
+                      ("rect", {"AMHIP_NO_DISTORTED_PRUNE": "1"}), ("pruned", {})):
+        for k in ("AMHIP_NO_DISTORTED_PRUNE", "AMHIP_DISTORTED_SQUARE_CULL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, Lm, Lm, res)) as m:
+            m.set("elevation", elev)
+            mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
+            mosaic.process(poses[:50], frames[:50], m)
+            mosaic.process(poses[50:], frames[50:], m)
+            results[name] = {n: m.get(n) for n in LAYERS}
+    want = results["plain"]
+    assert (~np.isnan(want["observation_index"])).mean() > 0.5
+    for name in ("rect", "pruned"):
+        S.assert_layers_equal(results[name], want, LAYERS)
