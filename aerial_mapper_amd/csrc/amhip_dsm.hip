@@ -214,60 +214,90 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
-// One WAVE per cell, the lanes over the candidates: for tiles denser than any
-// LDS image can hold (dense stereo clouds: tens of points per cell, hundreds of
-// neighbours per cell).  The window's bin rows are contiguous spans of the
-// sorted cloud, read coalesced; every lane keeps partial inverse-distance sums,
-// one butterfly reduction per cell.  Same neighbour set as cell_global(), the
-// order of the double sums differs (as it does from the kd-tree's anyway).
-// Must be called by all 64 lanes of a wave with the same (i, j).
-__device__ __forceinline__ void cell_wave(const DsmParams& p, const uint32_t* __restrict__ start,
-                                          const double* __restrict__ sorted, int i, int j,
-                                          const CellOut& o) {
+// A block of up to 4 x 4 cells per WAVE, the lanes over the candidates: for tiles
+// denser than any LDS image can hold (dense stereo clouds: tens of points per
+// cell, hundreds of neighbours per search disc).  The cells of a block lie in
+// one bin, so they share the window of bins; the window's bin rows are
+// contiguous spans of the sorted cloud, read coalesced -- every lane loads a
+// candidate once and tests it against all 16 cells, keeping partial
+// inverse-distance sums per cell; one butterfly reduction per block.  Same
+// neighbour sets as cell_global(), the order of the double sums differs (as it
+// does from the kd-tree's anyway).  Must be called by all 64 lanes of a wave
+// with the same block; bi0..bi1 x bj0..bj1 inclusive, <= 4 each way.
+__device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* __restrict__ start,
+                                           const double* __restrict__ sorted, int bi0, int bi1,
+                                           int bj0, int bj1, const CellOut& o) {
   const int lane = threadIdx.x & 63;
-  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
-  const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
-  const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
   const int w = p.w[0];
   const double T = p.T[0];
-  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
-  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
-  double num = 0.0, den = 0.0;
-  unsigned cnt = 0;
-  bool exact = false;
+  double qx[4], qy[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    // (cells beyond the block repeat its last one: computed, never written)
+    qx[a] = p.base_x + p.res * (-(double)(min(bi0 + a, bi1) + p.i_off));
+    qy[a] = p.base_y + p.res * (-(double)(min(bj0 + a, bj1) + p.j_off));
+  }
+  const int bx0 = (bi0 - w + p.M) / p.B, bx1 = (bi1 + w + p.M) / p.B;
+  const int by0 = (bj0 - w + p.M) / p.B, by1 = (bj1 + w + p.M) / p.B;
+  double num[16], den[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0;
+  unsigned exact = 0;  // bit c: some neighbour of cell c at distance 0
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
       const double px = sorted[3 * (size_t)k + 0];
       const double py = sorted[3 * (size_t)k + 1];
-      const double dx = qx - px;
-      const double dy = qy - py;
-      double d2 = dx * dx;
-      d2 = d2 + dy * dy;  // L2_Adaptor, size == 2 (nanoflann.hpp:319-322)
-      if (d2 < T) {       // strict (nanoflann.hpp:157)
-        if (d2 > 0.0)
-          idw_add(d2, sorted[3 * (size_t)k + 2], &num, &den);
-        else
-          exact = true;
-        cnt++;
+      const double pz = sorted[3 * (size_t)k + 2];
+      double dx2[4], dy2[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const double dx = qx[a] - px, dy = qy[a] - py;
+        dx2[a] = dx * dx;
+        dy2[a] = dy * dy;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double d2 = dx2[c & 3] + dy2[c >> 2];  // L2_Adaptor (nanoflann.hpp:319-322)
+        const bool in = d2 < T;                      // strict (nanoflann.hpp:157)
+        // 1 / d2 for every candidate (no branch per cell), kept only for the hits
+        double r = __builtin_amdgcn_rcp(d2);
+        double e = fma(-d2, r, 1.0);
+        r = fma(r, e, r);
+        e = fma(-d2, r, 1.0);
+        r = fma(r, e, r);
+        const bool hit = in & (d2 > 0.0);
+        r = hit ? r : 0.0;
+        num[c] = fma(pz, r, num[c]);
+        den[c] += r;
+        exact |= (in & !hit) ? (1u << c) : 0u;
       }
     }
   }
-  const bool any_exact = __ballot(exact) != 0ull;
-  num = wave_sum_d(num);
-  den = wave_sum_d(den);
-  unsigned total = cnt;
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) total += __shfl_xor(total, d, 64);
-  if (lane != 0) return;
-  if (any_exact || total == 0) {
+  for (int d = 32; d > 0; d >>= 1) exact |= __shfl_xor(exact, d, 64);
+  // lane c finishes cell c
+  double my_num = 0.0, my_den = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    const double sn = wave_sum_d(num[c]), sd = wave_sum_d(den[c]);
+    if (lane == c) {
+      my_num = sn;
+      my_den = sd;
+    }
+  }
+  const int a = lane & 3, bq = lane >> 2;
+  if (lane >= 16 || bi0 + a > bi1 || bj0 + bq > bj1) return;
+  const int i = bi0 + a, j = bj0 + bq;
+  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  if (((exact >> lane) & 1u) || !(my_den > 0.0)) {
     // exact hit (CHECK failure / OrthoFromPcl's perfect match, which depends on
     // the scan order) or an empty first search (the ladder): the scalar routine
     cell_global(p, start, sorted, i, j, o);
     return;
   }
-  emit_value(p, o, i, j, num / den);
+  emit_value(p, o, i, j, my_num / my_den);
 }
 
 // Pure global-memory gather: used when the first-level window is too wide for
@@ -448,17 +478,8 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   const int np = (int)s_ctl[0];
   const bool use_lds = geom_ok && np <= p.lds_cap;
   if (!use_lds) {
-    if (geom_ok) {
-      // more points than any LDS image holds (dense stereo clouds): one wave per
-      // cell over the global bins, lanes over the candidates
-      for (int c = 0; c < kCellsPerLane; ++c) {
-        const int j = j0 + wid * kCellsPerLane + c;
-        if (j > j_hi) break;
-        for (int i = i0; i <= i_hi; ++i) cell_wave(p, start, sorted, i, j, o);
-      }
-      return;
-    }
-    // region too tall for the row tables (very fine grids): one lane per cell
+    // region too tall for the row tables (very fine grids) or a tile that does
+    // not fit this launch's LDS image: one lane per cell on the global bins
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
       if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
@@ -720,6 +741,40 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
   }
 }
 
+// Class-3 tiles (more points than any LDS image holds): a fixed grid walks their
+// list; the four waves of a workgroup share a tile's blocks of 4 x 4 cells
+// (block_wave).  No LDS, its own register budget.
+__global__ void __launch_bounds__(256)
+k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
+                   const double* __restrict__ sorted, const int* __restrict__ tile_list,
+                   const unsigned* __restrict__ tile_count, CellOut o) {
+  const unsigned count = *tile_count;
+  const int wid = threadIdx.x >> 6;
+  for (unsigned t = blockIdx.x; t < count; t += gridDim.x) {
+    const int tile = tile_list[t];
+    const int ti = tile % p.tiles_i, tj = tile / p.tiles_i;
+    const int i0 = ti * kTileI, j0 = tj * tile_j;
+    const int i_hi = min(i0 + kTileI, p.rows) - 1;
+    const int j_hi = min(j0 + tile_j, p.cols) - 1;
+    // blocks = cells of one bin, cut into pieces of <= 4 x 4, clipped to the tile
+    const int gb = min(p.B, 4);
+    const int nbi = (i_hi - i0) / gb + 2, nbj = (j_hi - j0) / gb + 2;  // (upper bounds)
+    int idx = 0;
+    for (int bj = ((j0 + p.M) / p.B) * p.B - p.M; bj <= j_hi; bj += p.B)
+      for (int sj = 0; sj < p.B; sj += gb)
+        for (int bi = ((i0 + p.M) / p.B) * p.B - p.M; bi <= i_hi; bi += p.B)
+          for (int si = 0; si < p.B; si += gb, ++idx) {
+            if ((idx & 3) != wid) continue;
+            const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + p.B - 1), i_hi);
+            const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + p.B - 1), j_hi);
+            if (a0 > a1 || b0 > b1) continue;
+            block_wave(p, start, sorted, a0, a1, b0, b1, o);
+          }
+    (void)nbi;
+    (void)nbj;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
@@ -797,13 +852,11 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
-        AMHIP_LAUNCH_LIST(512, 16, 1024, 3, 4096);  // (small LDS image: full occupancy)
       } else if (p.tile_j == 16) {
         if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
         else AMHIP_LAUNCH_DENSE(512, 16, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
-        AMHIP_LAUNCH_LIST(512, 16, 1024, 3, 4096);
       } else {
         if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
@@ -811,10 +864,12 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
         AMHIP_LAUNCH_LIST(512, 32, 2432, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 32, 5200, 2, 1024);
-        AMHIP_LAUNCH_LIST(512, 32, 2048, 3, 4096);
       }
 #undef AMHIP_LAUNCH_DENSE
 #undef AMHIP_LAUNCH_LIST
+      hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
+                         c->bin_start, c->sorted, lists + 4 + (size_t)3 * ntiles, tile_count + 3,
+                         cell_out);
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,
