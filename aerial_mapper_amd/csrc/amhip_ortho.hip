@@ -232,47 +232,64 @@ __device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose*
       if (w < wid) base += cw;
       tot += cw;
     }
-    if (keep) s_cand[base + before] = f;
+    if (keep && base + before < kChunk) s_cand[base + before] = f;
     ncand += tot;
   }
   __syncthreads();  // s_cand complete
-  // more survivors than threads (a frame list that long is not worth pruning)
-  if (!p.prune || ncand <= 1 || ncand > kOrthoThreads) return ncand;
+  // more survivors than the list holds: the caller splits the frames into chunks
+  if (ncand > kChunk) return -1;
+  if (!p.prune || ncand <= 1) return ncand;
 
-  // ---- stage 2 ---------------------------------------------------------------
-  const bool mine = (int)threadIdx.x < ncand;
-  int f = 0;
-  double tmin = 0.0, tmax_full = __builtin_huge_val();
-  if (mine) {
-    f = s_cand[threadIdx.x];
-    const FrameBounds b = frame_bounds(p.pl, poses[f], centre, radius, slack, p.r_in);
-    tmin = b.tmin;
-    if (b.full) tmax_full = b.tmax;
+  // ---- stage 2: every thread takes up to kChunk / kOrthoThreads survivors -------
+  constexpr int kPer = kChunk / kOrthoThreads;
+  int f[kPer];
+  double tmin[kPer];
+  double tmax_full = __builtin_huge_val();
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    const int k = q * kOrthoThreads + (int)threadIdx.x;
+    f[q] = -1;
+    tmin[q] = 0.0;
+    if (k < ncand) {
+      f[q] = s_cand[k];
+      const FrameBounds b = frame_bounds(p.pl, poses[f[q]], centre, radius, slack, p.r_in);
+      tmin[q] = b.tmin;
+      if (b.full) tmax_full = fmin(tmax_full, b.tmax);
+    }
   }
-  // smallest tmax of a fully visible frame (survivors sit in the first waves)
-  const int nw = (ncand + 63) >> 6;
-  if (wid < nw) {
+  // smallest tmax of a fully visible frame
+  {
     const double wmin = wave_min_d(tmax_full);
     if (lane == 0) s_best[wid] = wmin;
   }
-  __syncthreads();  // s_best written, everyone has read its s_cand entry
+  __syncthreads();  // s_best written, everyone has read its s_cand entries
   double best = s_best[0];
-  for (int w = 1; w < nw; ++w) best = fmin(best, s_best[w]);
-  const bool keep = mine && !dominated(tmin, best);
-  const unsigned long long m = __ballot(keep);
-  const int before = __popcll(m & ((1ull << lane) - 1ull));
-  if (lane == 0) s_wave_cnt[wid] = __popcll(m);
-  __syncthreads();
-  int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kOrthoThreads / 64; ++w) {
-    const int cw = s_wave_cnt[w];
-    if (w < wid) base += cw;
-    tot += cw;
+  for (int w = 1; w < kOrthoThreads / 64; ++w) best = fmin(best, s_best[w]);
+  int kept = 0;
+#pragma unroll
+  for (int q = 0; q < kPer; ++q) {
+    if (q * kOrthoThreads >= ncand) break;  // (uniform)
+    const bool keep = f[q] >= 0 && !dominated(tmin[q], best);
+    const unsigned long long m = __ballot(keep);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();  // previous round's readers of s_wave_cnt are done
+    if (lane == 0) s_wave_cnt[wid] = __popcll(m);
+    __syncthreads();
+    int base = kept, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kOrthoThreads / 64; ++w) {
+      const int cw = s_wave_cnt[w];
+      if (w < wid) base += cw;
+      tot += cw;
+    }
+    // (in place: entry `base + before` <= the entry read, and every thread has
+    // read all of its entries before the first barrier above)
+    if (keep) s_cand[base + before] = f[q];
+    kept += tot;
   }
-  if (keep) s_cand[base + before] = f;
   __syncthreads();  // s_cand complete
-  return tot;
+  return kept;
 }
 
 // One cell's results (ortho-backward-grid.cc:181-208): angle, frame index, the
@@ -663,11 +680,13 @@ __device__ __forceinline__ void ortho_backward_tile(
   // (block-uniform values the slabs need: keep them in scalar registers)
   const V3 ucentre = {uniform_d(centre.x), uniform_d(centre.y), uniform_d(centre.z)};
   const double uradius = uniform_d(radius), uslack = uniform_d(slack);
-  const bool single = p.num_frames <= kChunk;
-  int ncand0 = 0;
-  if (single)
-    ncand0 = cull_chunk<kFast>(p, poses, fast_tab, ucentre, uradius, uslack, 0, p.num_frames, s_cand,
-                                   s_wave_cnt, s_best);
+  // The whole frame list in one go: the survivors of the sphere cull are what
+  // the list holds, not the frames; only if more than kChunk frames can see the
+  // tile the slabs split the frames into chunks (and cull per slab and chunk).
+  int ncand0 = cull_chunk<kFast>(p, poses, fast_tab, ucentre, uradius, uslack, 0, p.num_frames,
+                                 s_cand, s_wave_cnt, s_best);
+  const bool single = ncand0 >= 0;
+  if (!single) ncand0 = 0;
   if constexpr (kTileJ == kSlabJ) {
     ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
                       num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,
