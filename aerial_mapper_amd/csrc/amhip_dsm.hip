@@ -744,7 +744,10 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
 // Class-3 tiles (more points than any LDS image holds): a fixed grid walks their
 // list; the four waves of a workgroup share a tile's blocks of 4 x 4 cells
 // (block_wave).  No LDS, its own register budget.
-__global__ void __launch_bounds__(256)
+#ifndef AMHIP_DENSE_WAVES
+#define AMHIP_DENSE_WAVES 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AMHIP_DENSE_WAVES)))
 k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                    const double* __restrict__ sorted, const int* __restrict__ tile_list,
                    const unsigned* __restrict__ tile_count, CellOut o) {
