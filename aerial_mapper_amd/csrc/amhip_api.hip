@@ -1120,6 +1120,23 @@ void amhip_compose_T_G_C(const double* T_G_B, const double* T_C_B, size_t F,
   }
 }
 
+int amhip_camera_view_bounds(const amhip_camera* cam, double* out4) {
+  if (!cam || !out4) return arg_fail("amhip_camera_view_bounds: null argument");
+  if (!(cam->fu > 0.0) || !(cam->fv > 0.0) || cam->width <= 0 || cam->height <= 0)
+    return arg_fail("amhip_camera_view_bounds: bad camera");
+  out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+  if (cam->distortion == AMHIP_DIST_NONE) {
+    out4[1] = std::max(cam->cu, (double)cam->width - cam->cu) / cam->fu;
+    out4[2] = std::max(cam->cv, (double)cam->height - cam->cv) / cam->fv;
+    return AMHIP_OK;
+  }
+  double cone = 0.0;
+  if (!distorted_view_cone(*cam, &cone)) return AMHIP_OK;
+  out4[0] = cone;
+  distorted_rectangle_and_inner_cone(*cam, cone, &out4[1], &out4[2], &out4[3]);
+  return AMHIP_OK;
+}
+
 int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
                                      const double* host_T_G_C, size_t F,
                                      const uint8_t* dev_frames,

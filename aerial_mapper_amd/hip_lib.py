@@ -46,6 +46,7 @@ EXPORTS = [
     "amhip_mosaic_synchronize", "amhip_mosaic_reset", "amhip_mosaic_batch",
     "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
     "amhip_mosaic_download", "amhip_mosaic_device_ptr", "amhip_mosaic_homography",
+    "amhip_camera_view_bounds",
     "amhip_io_parse_point_cloud_text", "amhip_io_download_point_cloud", "amhip_io_free",
 ]
 
@@ -159,6 +160,7 @@ def load():
     lib.amhip_mosaic_download.argtypes = [vp, vp, vp]
     lib.amhip_mosaic_device_ptr.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     lib.amhip_mosaic_homography.argtypes = [mp, cp, f64p, C.c_int, f64p]
+    lib.amhip_camera_view_bounds.argtypes = [cp, f64p]
     lib.amhip_io_parse_point_cloud_text.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.POINTER(vp),
                                                     C.POINTER(vp), C.POINTER(C.c_size_t),
                                                     C.POINTER(C.c_size_t)]

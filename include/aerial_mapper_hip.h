@@ -332,6 +332,16 @@ int amhip_mosaic_device_ptr(amhip_mosaic* mosaic, void** result_16sc3, void** re
 int amhip_mosaic_homography(const amhip_mosaic_desc* desc, const amhip_camera* cam,
                             const double* T_G_C7, int batch_quirk, double* M9);
 
+/* The conservative view bounds the backward-grid mosaic derives from a camera
+ * (host arithmetic only; diagnostics / tests), in normalised camera coordinates
+ * (x / z, y / z):
+ *   out[0] cone   every visible landmark has |p| <= cone            (0: no bound)
+ *   out[1], out[2]  ax, ay: every visible landmark has |x| <= ax, |y| <= ay
+ *   out[3] rin    |p| <= rin  =>  the landmark is visible             (0: unknown)
+ * "visible" = aslam project3's image-box test (ortho-backward-grid.cc:164-171);
+ * for an undistorted camera cone = rin = 0 and ax, ay describe the image box. */
+int amhip_camera_view_bounds(const amhip_camera* cam, double* out4);
+
 /* ---- io::AerialMapperIO::loadPointCloudFromFile
  *      (aerial_mapper_io/src/aerial-mapper-io.cc:309-347) --
  * The text point-cloud format in front of the DSM: whitespace separated
