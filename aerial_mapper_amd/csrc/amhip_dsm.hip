@@ -277,21 +277,35 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) exact |= __shfl_xor(exact, d, 64);
-  // lane c finishes cell c
-  double my_num = 0.0, my_den = 0.0;
+  // Butterfly with halving: 32 partial sums per lane (16 x num, 16 x den) -> after
+  // the exchange over lane bit 5 a lane keeps 16 of them, then 8, 4, 2, 1; the
+  // last exchange over bit 0 completes the sums.  Lane l ends with the total of
+  // value l >> 1 (num of cell c at lane 2c, den at lane 32 + 2c).
+  double v[32];
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
-    const double sn = wave_sum_d(num[c]), sd = wave_sum_d(den[c]);
-    if (lane == c) {
-      my_num = sn;
-      my_den = sd;
+    v[c] = num[c];
+    v[16 + c] = den[c];
+  }
+#pragma unroll
+  for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const double send = up ? v[k] : v[k + half];
+      const double keep = up ? v[k + half] : v[k];
+      v[k] = keep + __shfl_xor(send, bit, 64);
     }
   }
-  const int a = lane & 3, bq = lane >> 2;
-  if (lane >= 16 || bi0 + a > bi1 || bj0 + bq > bj1) return;
+  v[0] += __shfl_xor(v[0], 1, 64);
+  const double my_num = v[0];
+  const double my_den = __shfl(v[0], (lane & 31) | 32, 64);
+  const int cidx = (lane & 31) >> 1;
+  const int a = cidx & 3, bq = cidx >> 2;
+  if (lane >= 32 || (lane & 1) || bi0 + a > bi1 || bj0 + bq > bj1) return;
   const int i = bi0 + a, j = bj0 + bq;
   if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
-  if (((exact >> lane) & 1u) || !(my_den > 0.0)) {
+  if (((exact >> cidx) & 1u) || !(my_den > 0.0)) {
     // exact hit (CHECK failure / OrthoFromPcl's perfect match, which depends on
     // the scan order) or an empty first search (the ladder): the scalar routine
     cell_global(p, start, sorted, i, j, o);
