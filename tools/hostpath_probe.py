@@ -1,5 +1,8 @@
+#!/usr/bin/env python3
+"""Probe: where the time of one pass through the host-buffer entry points goes (DSM call,
+mosaic call, layer downloads), cold and warm."""
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import aerial_mapper_amd as A
 from aerial_mapper_amd import synth
