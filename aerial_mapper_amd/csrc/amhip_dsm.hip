@@ -22,6 +22,7 @@
 //                        finer than 16 cells per radius and the adaptive
 //                        OrthoFromPcl passes)
 // (integer / FP64 streaming work, no MFMA)
+#include <algorithm>
 #include <cstdlib>
 
 #include "amhip_common.h"
@@ -823,8 +824,13 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // points -> 4 per CU; class 1 = the most that still leaves two per CU;
       // class 2 = everything one workgroup can take.
       const int cap0 = p.lds_cap;
-      const int cap1 = p.tile_j == 16 ? 2752 : 2432;
-      const int cap2 = p.tile_j == 16 ? 5600 : 5200;
+      // (the rest of the LDS image -- cell table, row tables, flags -- grows with the
+      // search window: wide radii / coarse grids leave less room for points; a class
+      // that cannot hold more than the one below it stays empty)
+      const long fixed_bytes = (long)p.lds_bytes - ((long)cap0 + 2) * 24;
+      auto cap_fit = [&](long limit) { return (int)((limit - fixed_bytes) / 24 - 2); };
+      const int cap1 = std::max(cap0, std::min(p.tile_j == 16 ? 2752 : 2432, cap_fit(80 * 1024)));
+      const int cap2 = std::max(cap1, std::min(p.tile_j == 16 ? 5600 : 5200, cap_fit(150 * 1024)));
       {
         int rc;
         if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, 4 * (size_t)ntiles + 4))) return rc;
@@ -853,7 +859,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   } while (0)
 #define AMHIP_LAUNCH_LIST(NT_, TJ_, CAP_, CLS_, GRID_)                                        \
   do {                                                                                        \
-    const DsmParams q = with_cap(CAP_);                                                       \
+    /* CAP_ sizes the instance's registers; the LDS image holds what fits */                  \
+    const DsmParams q = with_cap((CLS_) == 0 ? cap0 : std::min((int)(CAP_), (CLS_) == 1 ? cap1 : cap2)); \
     AMHIP_TRY(hipFuncSetAttribute(                                                            \
         reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),             \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
