@@ -23,6 +23,7 @@
 //                        OrthoFromPcl passes)
 // (integer / FP64 streaming work, no MFMA)
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "amhip_common.h"
@@ -338,6 +339,8 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 // in LDS and finished by the fallback path on the global bins.
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
+// s_setreg operand: HW_REG_MODE (id 1), offset 6, width 2 = FP_DENORM for f64 / f16
+constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 
 // One lane per gather tile (tile numbering: ti + tj * tiles_i, as in the gather):
 //   occ[tile] = 0          no binned point within the LAST fallback radius of the tile
@@ -595,6 +598,15 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       // pair = one contiguous span per trip (lanes wait for each other per
       // trip, and the spread of a two-row candidate count is relatively smaller).
       const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * RW2 + 2 * ci;
+      // FP64 denormals are FLUSHED while the products run (MODE.FP_DENORM[7:6] = 0):
+      // a product that dips below 2^-1022 inside one trip -- hundreds of points
+      // within centimetres of a centre, in a tile of a dense capacity class -- then
+      // becomes exactly 0, stays 0 and sends the cell to the reciprocal-weight
+      // routine below, instead of silently losing bits as a denormal and climbing
+      // back into the normal range before the end of the trip.  (Overflow is
+      // sticky anyway.  A d2 itself is never denormal: coordinates are doubles of
+      // magnitude >= 1e-3, their differences multiples of ~1e-19.)
+      __builtin_amdgcn_s_setreg(kHwRegModeFpDenormF64, 0);
       for (int r = 0; r <= w0; ++r) {
         const int w = p.wrp[r];
         const uint32_t kb = orow[-2 * w];
@@ -669,6 +681,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           PB *= sc;
         }
       }
+      __builtin_amdgcn_s_setreg(kHwRegModeFpDenormF64, 3);  // denormals allowed again
       // P == 0 <=> a hit with d2 == 0 -- or a product that underflowed inside
       // one trip.  Either way (and whenever the running values came close to
       // the ends of the double range) the cell is re-done by the global
@@ -838,8 +851,11 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
       int* const lists = c->tile_list;
       AMHIP_TRY(hipMemsetAsync(tile_count, 0, 4 * sizeof(unsigned), c->stream));
+      int ccap0 = cap0, ccap1 = cap1, ccap2 = cap2;  // classification thresholds
+      if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
+        sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
-                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, cap0, cap1, cap2);
+                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
       auto with_cap = [&](int cap) {
