@@ -130,6 +130,8 @@ def make_points_torch(n, half_extent, seed, device, noise=0.05, center=(0.0, 0.0
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     pts = torch.empty((n, 3), dtype=torch.float64, device=device)
+    if isinstance(half_extent, (tuple, list)):     # (half extent in x, in y)
+        half_extent = torch.tensor(half_extent, dtype=torch.float64, device=device)
     xy = (torch.rand((n, 2), dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0) * half_extent
     z = 400.0 + 10.0 * torch.sin(0.01 * xy[:, 0]) * torch.cos(0.01 * xy[:, 1])
     z += (torch.rand(n, dtype=torch.float64, device=device, generator=g) * 2.0 - 1.0) * noise

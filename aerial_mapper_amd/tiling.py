@@ -159,20 +159,36 @@ def select_for_windows(points, grid, windows, margin_m, center_easting=0.0,
 
 class TorchComm(object):
     """The two collectives route_points() needs, over torch.distributed
-    (backend nccl = RCCL on the GPUs, gloo in the CPU tests)."""
+    (backend nccl = RCCL on the GPUs, gloo in the CPU tests).  via_host=True
+    stages device tensors through host memory: only for rehearsing the N > 1
+    code path with several ranks on ONE GPU over gloo (bench.py,
+    AMHIP_BENCH_ONE_GPU=1) -- RCCL refuses two ranks on one device."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, via_host=False):
         self.group = group
+        self.via_host = via_host
 
     def exchange_counts(self, send_counts_tensor):
         import torch
         import torch.distributed as dist
+        if self.via_host:
+            src = send_counts_tensor.cpu()
+            recv = torch.empty_like(src)
+            dist.all_to_all_single(recv, src, group=self.group)
+            return recv.to(send_counts_tensor.device)
         recv = torch.empty_like(send_counts_tensor)
         dist.all_to_all_single(recv, send_counts_tensor, group=self.group)
         return recv
 
     def exchange_rows(self, out_rows, in_rows, recv_counts, send_counts):
+        import torch
         import torch.distributed as dist
+        if self.via_host:
+            tmp = torch.empty(out_rows.shape, dtype=out_rows.dtype)
+            dist.all_to_all_single(tmp, in_rows.cpu(), output_split_sizes=recv_counts,
+                                   input_split_sizes=send_counts, group=self.group)
+            out_rows.copy_(tmp)
+            return
         dist.all_to_all_single(out_rows, in_rows, output_split_sizes=recv_counts,
                                input_split_sizes=send_counts, group=self.group)
 

@@ -147,6 +147,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    # AMHIP_BENCH_ONE_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box -- every rank
+    # on device 0, gloo instead of RCCL (which refuses two ranks per device), the halo rows
+    # staged through host memory.  Its numbers mean nothing; the line says so.
+    one_gpu = world > 1 and os.environ.get("AMHIP_BENCH_ONE_GPU", "0") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # ONE explicit HIP stream for everything in the timed region: torch's
@@ -157,7 +163,10 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import aerial_mapper_amd as A
     from aerial_mapper_amd import synth
@@ -186,8 +195,10 @@ def main():
     if world > 1:
         halo_cap = int(4.0 * (2 * (L + L)) * tiling.halo_margin(1, res) * n_pts / (L * L)) + 4096
     pts_buf = torch.empty((n_pts + halo_cap, 3), dtype=torch.float64, device=dev)
-    pts_buf[:n_pts] = synth.make_points_torch(n_pts, L / 2.0 + apron, 43 + rank, dev,
-                                              center=tile_center)
+    # (N > 1: window edges are multiples of 64 cells, so a window is not exactly L wide;
+    # its points cover exactly its own extent, no strip of the map is left without points)
+    half = L / 2.0 + apron if world == 1 else (win[2] * res / 2.0, L / 2.0)
+    pts_buf[:n_pts] = synth.make_points_torch(n_pts, half, 43 + rank, dev, center=tile_center)
     if world > 1:
         # keep only points whose cell is inside the window (a point exactly on
         # the upper edge belongs to the neighbour)
@@ -210,13 +221,15 @@ def main():
         mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=args.colored), m)
     dsm = A.Dsm(A.DsmSettings(interpolation_radius=1), m)
 
+    comm = tiling.TorchComm(via_host=True) if one_gpu else None
+
     def step():
         m.reset()
         cloud = pts
         if world > 1:
             cloud = tiling.route_points(pts, m.grid, layout, rank, radius_sq=1, map_=m,
                                         assume_owned=True, cap=halo_cap // 2,
-                                        workspace=pts_buf)
+                                        workspace=pts_buf, comm=comm)
         dsm.process(cloud, m, sync=False)
         if F:
             mosaic.process(poses, frames, m, sync=False)
@@ -240,7 +253,7 @@ def main():
     dt = time.perf_counter() - t0
     m.synchronize()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if one_gpu else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ktimes = m.kernel_times()
@@ -277,7 +290,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": "synthetic" if not one_gpu else
+            "synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a measurement" % world,
             "config": {"workload": args.workload + ": " + wl["desc"],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "

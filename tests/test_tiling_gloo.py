@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, tiles, assume_owned, ret):
+def _worker(rank, world, port, tiles, assume_owned, via_host, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, ROOT)
@@ -43,7 +43,8 @@ def _worker(rank, world, port, tiles, assume_owned, ret):
         else:
             mine = cloud[rank::world]  # partitioned by source, not by tile
         got = tiling.route_points(torch.from_numpy(np.ascontiguousarray(mine)), g, layout, rank,
-                                  radius_sq=1, assume_owned=assume_owned).numpy()
+                                  radius_sq=1, assume_owned=assume_owned,
+                                  comm=tiling.TorchComm(via_host=via_host)).numpy()
         margin = tiling.halo_margin(1, g.resolution)
         want_mask = tiling.in_window(cx, cy, layout.window(rank), margin / g.resolution)
         if assume_owned:
@@ -72,14 +73,15 @@ def _worker(rank, world, port, tiles, assume_owned, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tiles,assume_owned", [(2, (2, 1), True), (2, (1, 2), False),
-                                                       (4, (2, 2), True)])
-def test_route_points_gloo(world, tiles, assume_owned):
+@pytest.mark.parametrize("world,tiles,assume_owned,via_host",
+                         [(2, (2, 1), True, False), (2, (1, 2), False, False), (4, (2, 2), True, False),
+                          (2, (2, 1), True, True)])
+def test_route_points_gloo(world, tiles, assume_owned, via_host):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tiles, assume_owned, ret))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tiles, assume_owned, via_host, ret))
              for r in range(world)]
     for p in procs:
         p.start()
