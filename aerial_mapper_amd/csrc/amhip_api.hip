@@ -1069,6 +1069,44 @@ int amhip_densify_dev(amhip_ctx* h, const float* dev_disparity, size_t disp_step
 
 // ---- multi-GPU halo ----------------------------------------------------------
 
+static int make_halo_params(const Ctx& c, double center_easting, double center_northing,
+                            const int32_t* dest_windows, int nd, double margin_m,
+                            size_t cap_per_dest, HaloParams* out) {
+  HaloParams hp;
+  std::memset(&hp, 0, sizeof(hp));
+  grid_bases(c.grid, &hp.base_x, &hp.base_y);
+  hp.inv_res = 1.0 / c.grid.resolution;
+  hp.sub_x = center_northing;  // dsm.cc:42
+  hp.sub_y = center_easting;   // dsm.cc:43
+  hp.nd = nd;
+  hp.cap = cap_per_dest;
+  const double mc = margin_m / c.grid.resolution;  // margin in cells
+  for (int d = 0; d < nd; ++d) {
+    const int32_t* w = dest_windows + 4 * d;
+    if (w[2] <= 0 || w[3] <= 0) return arg_fail("halo selection: empty window");
+    hp.lo_i[d] = (double)w[0] - 0.5 - mc;
+    hp.hi_i[d] = (double)(w[0] + w[2]) - 0.5 + mc;
+    hp.lo_j[d] = (double)w[1] - 0.5 - mc;
+    hp.hi_j[d] = (double)(w[1] + w[3]) - 0.5 + mc;
+  }
+  // the context's own window shrunk by the margin, if no destination reaches into it
+  // (windows of one tiling never do)
+  hp.in_lo_i = (double)c.win_i0 - 0.5 + mc + 1.0;
+  hp.in_hi_i = (double)(c.win_i0 + c.win_rows) - 0.5 - mc - 1.0;
+  hp.in_lo_j = (double)c.win_j0 - 0.5 + mc + 1.0;
+  hp.in_hi_j = (double)(c.win_j0 + c.win_cols) - 0.5 - mc - 1.0;
+  bool clear = hp.in_lo_i < hp.in_hi_i && hp.in_lo_j < hp.in_hi_j;
+  for (int d = 0; d < nd && clear; ++d)
+    clear = hp.hi_i[d] < hp.in_lo_i || hp.lo_i[d] > hp.in_hi_i || hp.hi_j[d] < hp.in_lo_j ||
+            hp.lo_j[d] > hp.in_hi_j;
+  if (!clear) {
+    hp.in_lo_i = hp.in_lo_j = 1.0;
+    hp.in_hi_i = hp.in_hi_j = 0.0;
+  }
+  *out = hp;
+  return AMHIP_OK;
+}
+
 int amhip_halo_select_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
                           double center_easting, double center_northing,
                           const int32_t* dest_windows, int nd, double margin_m,
@@ -1082,24 +1120,77 @@ int amhip_halo_select_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   HaloParams hp;
-  std::memset(&hp, 0, sizeof(hp));
-  grid_bases(c->grid, &hp.base_x, &hp.base_y);
-  hp.inv_res = 1.0 / c->grid.resolution;
-  hp.sub_x = center_northing;  // dsm.cc:42
-  hp.sub_y = center_easting;   // dsm.cc:43
-  hp.nd = nd;
-  hp.cap = cap_per_dest;
-  const double mc = margin_m / c->grid.resolution;  // margin in cells
-  for (int d = 0; d < nd; ++d) {
-    const int32_t* w = dest_windows + 4 * d;
-    if (w[2] <= 0 || w[3] <= 0) return arg_fail("amhip_halo_select_dev: empty window");
-    hp.lo_i[d] = (double)w[0] - 0.5 - mc;
-    hp.hi_i[d] = (double)(w[0] + w[2]) - 0.5 + mc;
-    hp.lo_j[d] = (double)w[1] - 0.5 - mc;
-    hp.hi_j[d] = (double)(w[1] + w[3]) - 0.5 + mc;
-  }
+  if ((rc = make_halo_params(*c, center_easting, center_northing, dest_windows, nd, margin_m,
+                             cap_per_dest, &hp)))
+    return rc;
   return halo_select_run(c, dev_xyz, n, hp, dev_out,
                          reinterpret_cast<unsigned long long*>(dev_counts));
+}
+
+int amhip_dsm_tiled_begin_dev(amhip_ctx* h, const double* dev_xyz, size_t n_owned,
+                              size_t n_total, int radius_sq, double center_easting,
+                              double center_northing, const int32_t* dest_windows, int nd,
+                              double margin_m, double* dev_out, size_t cap_per_dest,
+                              int64_t* dev_counts) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  c->tiled_pending = false;
+  if (!dev_xyz || n_total == 0 || n_owned > n_total)
+    return arg_fail("amhip_dsm_tiled_begin_dev: bad point arguments");
+  if (radius_sq <= 0) return arg_fail("interpolation_radius must be >= 1");
+  if (n_total >= 0x7FFFFFFFull) return arg_fail("more than 2^31-1 points");
+  if (nd < 1 || nd > kMaxHaloDests || !dest_windows || !dev_out || !dev_counts ||
+      !(margin_m >= 0.0) || cap_per_dest == 0)
+    return arg_fail("amhip_dsm_tiled_begin_dev: bad halo arguments (1..8 destinations)");
+  int rc = use_device(c);
+  if (rc) return rc;
+  SortSplit sp;
+  std::memset(&sp, 0, sizeof(sp));
+  sp.phase = 1;
+  sp.n_prefix = n_owned;
+  if ((rc = make_halo_params(*c, center_easting, center_northing, dest_windows, nd, margin_m,
+                             cap_per_dest, &sp.hp)))
+    return rc;
+  sp.halo_out = dev_out;
+  sp.halo_counts = reinterpret_cast<unsigned long long*>(dev_counts);
+  DsmParams p;
+  if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n_total)))
+    return rc;
+  if ((rc = dsm_run(c, dev_xyz, nullptr, n_total, p, nullptr, nullptr, nullptr, false, 0.0f,
+                    nullptr, &sp)))
+    return rc;
+  c->tiled_pending = true;
+  c->tiled_xyz = dev_xyz;
+  c->tiled_n = n_total;
+  c->tiled_radius_sq = radius_sq;
+  c->tiled_ce = center_easting;
+  c->tiled_cn = center_northing;
+  c->tiled_split = sp;
+  return AMHIP_OK;
+}
+
+int amhip_dsm_tiled_finish_dev(amhip_ctx* h) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  if (!c->tiled_pending)
+    return arg_fail("amhip_dsm_tiled_finish_dev without amhip_dsm_tiled_begin_dev");
+  c->tiled_pending = false;
+  int rc = use_device(c);
+  if (rc) return rc;
+  DsmParams p;
+  if ((rc = make_dsm_params(*c, c->tiled_radius_sq, c->tiled_ce, c->tiled_cn, &p, 0, 1,
+                            c->tiled_n)))
+    return rc;
+  SortSplit sp = c->tiled_split;
+  sp.phase = 2;
+  const bool fused_fill = c->layer_state[AMHIP_LAYER_ELEVATION] == 3;
+  if (fused_fill)
+    c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
+  else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
+    return rc;
+  return dsm_run(c, c->tiled_xyz, nullptr, c->tiled_n, p, c->layers[AMHIP_LAYER_ELEVATION],
+                 nullptr, nullptr, fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION),
+                 c->zrange_valid ? c->dev_zrange : nullptr, &sp);
 }
 
 // ---- ortho ----------------------------------------------------------------

@@ -120,6 +120,28 @@ enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u };
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+constexpr int kMaxHaloDests = 8;
+struct HaloParams {
+  double base_x, base_y, inv_res, sub_x, sub_y;
+  int nd;
+  double lo_i[kMaxHaloDests], hi_i[kMaxHaloDests], lo_j[kMaxHaloDests], hi_j[kMaxHaloDests];
+  unsigned long long cap;
+  // a box (open) no destination reaches into -- the inside of the context's own window --
+  // or an empty one: a point in it is done after four comparisons
+  double in_lo_i, in_hi_i, in_lo_j, in_hi_j;
+};
+// Multi-GPU tiling (amhip_dsm_tiled_begin_dev / _finish_dev): the sort's count pass in two
+// parts around the caller's halo exchange.  phase 1: count rows [0, n_prefix) of the cloud
+// and copy the points other windows need into their send rows, then stop; phase 2: count
+// rows [n_prefix, n) (what the exchange delivered) and carry on.
+struct SortSplit {
+  int phase;
+  size_t n_prefix;
+  HaloParams hp;
+  double* halo_out;
+  unsigned long long* halo_counts;
+};
+
 struct TimedRegion {
   hipEvent_t a, b;
   int slot;
@@ -187,6 +209,14 @@ struct Ctx {
   uint8_t* stage_frames = nullptr;
   size_t stage_frames_cap = 0;
 
+  // amhip_dsm_tiled_begin_dev .. amhip_dsm_tiled_finish_dev
+  bool tiled_pending = false;
+  const double* tiled_xyz = nullptr;
+  size_t tiled_n = 0;
+  int tiled_radius_sq = 0;
+  double tiled_ce = 0.0, tiled_cn = 0.0;
+  SortSplit tiled_split = {};
+
   // stats of the last DSM call
   int64_t last_points_binned = 0;
   int64_t last_num_bins = 0;
@@ -231,13 +261,6 @@ int densify_run(Ctx* c, const DensifyParams& p, const float* dev_disparity,
                 size_t capacity, long long* dev_count);
 
 // multi-GPU halo selection
-constexpr int kMaxHaloDests = 8;
-struct HaloParams {
-  double base_x, base_y, inv_res, sub_x, sub_y;
-  int nd;
-  double lo_i[kMaxHaloDests], hi_i[kMaxHaloDests], lo_j[kMaxHaloDests], hi_j[kMaxHaloDests];
-  unsigned long long cap;
-};
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
                     double* dev_out, unsigned long long* dev_counts);
 // values: nullptr -> interpolate the points' z; else one int per point
@@ -246,11 +269,11 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-             const DsmParams& p, unsigned long long* zrange);
+             const DsmParams& p, unsigned long long* zrange, const SortSplit* split = nullptr);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
             bool fill_untouched = false, float init_value = 0.0f,
-            unsigned long long* zrange = nullptr);
+            unsigned long long* zrange = nullptr, const SortSplit* split = nullptr);
 // dev_fast: FrameFast[num_frames] followed by one entry holding the camera
 // (fu fv cu cv W H) for exact_view(); only read when p.fast
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,

@@ -811,12 +811,14 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
 // ---------------------------------------------------------------------------
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
-            bool fill_untouched, float init_value, unsigned long long* zrange) {
+            bool fill_untouched, float init_value, unsigned long long* zrange,
+            const SortSplit* split) {
   const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value};
   {
-    const int rc = dsm_sort(c, dev_xyz, dev_values, n, p, zrange);
+    const int rc = dsm_sort(c, dev_xyz, dev_values, n, p, zrange, split);
     if (rc) return rc;
   }
+  if (split && split->phase == 1) return AMHIP_OK;  // (tiled call: the rest follows the exchange)
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
     if (p.lds_ok) {

@@ -105,8 +105,7 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
 //            placed; a stripe is ~1 MB, so the second read and the random
 //            placement stay inside the XCD's L2.
 // Stripes are whole bin rows, so the final order is still row-major by bin.
-constexpr int kMaxStripes = 8192;
-constexpr int kMaxStripeBins = 8192;
+// (make_dsm_params keeps to <= 8192 stripes of <= 8192 bins: the LDS histograms' sizes)
 constexpr int kL1Threads = 256;
 constexpr int kL1Chunk = 65536;  // points per workgroup in the level-1 scatter (A/B: 16K..128K)
 constexpr int kL2Threads = 512;
@@ -312,20 +311,146 @@ __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py
   return true;
 }
 
+// Halo selection (multi-GPU tiling): the windows a point has to travel to.  Shared by
+// k_halo_select and the count pass that selects on the way (k_dsm_p3_count<true>), so both
+// pick the same points.  A workgroup stages what it selects in LDS and reserves its rows
+// with ONE global atomic per destination at the end: tens of thousands of returning
+// atomics on the same counter serialise in L2 (0.45 ms for the 57 K points of a 2.5 km
+// edge, more than the pass itself).
+constexpr unsigned kHaloStage = 2048;  // staged selections per workgroup; more go direct
+struct HaloStage {
+  unsigned n;                            // selections so far (those past kHaloStage went direct)
+  unsigned cnt[kMaxHaloDests];           // staged per destination
+  unsigned long long base[kMaxHaloDests];
+  // the destinations' bounds: read here by the few points outside the own window's inside,
+  // so that 64 SGPRs of kernel arguments are not kept alive (spilled) across the hot loop
+  double lo_i[kMaxHaloDests], hi_i[kMaxHaloDests], lo_j[kMaxHaloDests], hi_j[kMaxHaloDests];
+  unsigned long long entry[kHaloStage];  // point index | destination << 32 | local slot << 36
+};
+
+__device__ __forceinline__ void halo_stage_init(HaloStage* st, const HaloParams& hp) {
+  if (threadIdx.x == 0) {
+    st->n = 0;
+#pragma unroll
+    for (int d = 0; d < kMaxHaloDests; ++d) {
+      st->cnt[d] = 0;
+      st->lo_i[d] = hp.lo_i[d];
+      st->hi_i[d] = hp.hi_i[d];
+      st->lo_j[d] = hp.lo_j[d];
+      st->hi_j[d] = hp.hi_j[d];
+    }
+  }
+}
+
+__device__ __forceinline__ void halo_write(const HaloParams& hp, const double* __restrict__ xyz,
+                                           size_t idx, int d, unsigned long long slot,
+                                           double* __restrict__ out) {
+  if (slot < hp.cap) {
+    double* o = out + ((size_t)d * hp.cap + slot) * 3;
+    o[0] = xyz[3 * idx + 0];
+    o[1] = xyz[3 * idx + 1];
+    o[2] = xyz[3 * idx + 2];
+  }
+}
+
+// true: the point lies outside the inside of the own window, halo_emit() has to look at it
+__device__ __forceinline__ bool halo_candidate(const HaloParams& hp, double x, double y) {
+  // continuous cell coordinates in the full map (same frame as point_bin)
+  const double cx = (hp.base_x - (x - hp.sub_x)) * hp.inv_res;
+  const double cy = (hp.base_y - (y - hp.sub_y)) * hp.inv_res;
+  return !(cx > hp.in_lo_i && cx < hp.in_hi_i && cy > hp.in_lo_j && cy < hp.in_hi_j);
+}
+
+// (the rare path: kept compact -- a rolled loop over the destinations, bounds from LDS)
+__device__ __forceinline__ void halo_emit(HaloStage* st, const HaloParams& hp,
+                                          const double* __restrict__ xyz, size_t idx,
+                                          double* __restrict__ out,
+                                          unsigned long long* __restrict__ counts) {
+  const double x = xyz[3 * idx + 0], y = xyz[3 * idx + 1];
+  const double cx = (hp.base_x - (x - hp.sub_x)) * hp.inv_res;
+  const double cy = (hp.base_y - (y - hp.sub_y)) * hp.inv_res;
+#pragma nounroll
+  for (int d = 0; d < hp.nd; ++d) {
+    if (cx >= st->lo_i[d] && cx <= st->hi_i[d] && cy >= st->lo_j[d] && cy <= st->hi_j[d]) {
+      const unsigned pos = atomicAdd(&st->n, 1u);
+      if (pos < kHaloStage) {
+        const unsigned ls = atomicAdd(&st->cnt[d], 1u);
+        st->entry[pos] = (unsigned long long)idx | ((unsigned long long)d << 32) |
+                         ((unsigned long long)ls << 36);
+      } else {
+        halo_write(hp, xyz, idx, d, atomicAdd(&counts[d], 1ull), out);
+      }
+    }
+  }
+}
+
+// all threads of the workgroup, after their last halo_emit
+__device__ __forceinline__ void halo_flush(HaloStage* st, const HaloParams& hp,
+                                           const double* __restrict__ xyz,
+                                           double* __restrict__ out,
+                                           unsigned long long* __restrict__ counts) {
+  __syncthreads();
+  if ((int)threadIdx.x < hp.nd && st->cnt[threadIdx.x])
+    st->base[threadIdx.x] = atomicAdd(&counts[threadIdx.x], (unsigned long long)st->cnt[threadIdx.x]);
+  __syncthreads();
+  const unsigned m = min(st->n, kHaloStage);
+  for (unsigned e = threadIdx.x; e < m; e += blockDim.x) {
+    const unsigned long long v = st->entry[e];
+    const int d = (int)((v >> 32) & 15u);
+    halo_write(hp, xyz, (size_t)(v & 0xFFFFFFFFull), d, st->base[d] + (v >> 36), out);
+  }
+}
+
+// kHalo: the pass also copies the points other windows need into their send rows -- it
+// reads every point anyway (amhip_dsm_tiled_begin_dev).
+template <bool kHalo>
 __global__ void __launch_bounds__(kP3CountThreads)
 k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
-               uint32_t* __restrict__ hist_rows) {
+               uint32_t* __restrict__ hist_rows, HaloParams hp, double* __restrict__ halo_out,
+               unsigned long long* __restrict__ halo_counts) {
   extern __shared__ uint32_t s_hist[];
   const int nk = p.p3_n1 * p.p3_n2;
+  // (kHalo: the staging area follows the histogram, 8-byte aligned)
+  HaloStage* const stage = reinterpret_cast<HaloStage*>(s_hist + ((nk + 1) & ~1));
   for (int k = threadIdx.x; k < nk; k += kP3CountThreads) s_hist[k] = 0;
+  if (kHalo) halo_stage_init(stage, hp);
   __syncthreads();
   const size_t stride = (size_t)gridDim.x * kP3CountThreads;
-  for (size_t idx = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; idx < n; idx += stride) {
-    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
-    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
-    int k1, k2;
-    if (p3_keys(p, px, py, &k1, &k2)) atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+  // four points' loads in flight per lane before any of the (branchy) bookkeeping
+  constexpr int kU = 4;
+  for (size_t base = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; base < n;
+       base += kU * stride) {
+    double x[kU], y[kU];
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const size_t idx = base + u * stride;
+      if (idx < n) {
+        x[u] = xyz[3 * idx + 0];
+        y[u] = xyz[3 * idx + 1];
+      }
+    }
+    unsigned look = 0;  // kHalo: which of the four may have to travel
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const size_t idx = base + u * stride;
+      if (idx < n) {
+        const double px = x[u] - p.sub_x;  // dsm.cc:42
+        const double py = y[u] - p.sub_y;  // dsm.cc:43
+        int k1, k2;
+        if (p3_keys(p, px, py, &k1, &k2)) atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+        if (kHalo && halo_candidate(hp, x[u], y[u])) look |= 1u << u;
+      }
+    }
+    if (kHalo) {
+#pragma nounroll
+      while (look) {
+        const int u = __builtin_ctz(look);
+        look &= look - 1;
+        halo_emit(stage, hp, xyz, base + (size_t)u * stride, halo_out, halo_counts);
+      }
+    }
   }
+  if (kHalo) halo_flush(stage, hp, xyz, halo_out, halo_counts);
   __syncthreads();
   uint32_t* row = hist_rows + (size_t)blockIdx.x * nk;
   for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
@@ -628,28 +753,16 @@ k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
 __global__ void __launch_bounds__(256)
 k_halo_select(const double* __restrict__ xyz, size_t n, HaloParams hp,
               double* __restrict__ out, unsigned long long* __restrict__ counts) {
+  __shared__ HaloStage stage;
+  halo_stage_init(&stage, hp);
+  __syncthreads();
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += stride) {
-    const double x = xyz[3 * idx + 0];
-    const double y = xyz[3 * idx + 1];
-    // continuous cell coordinates in the full map (same frame as point_bin)
-    const double cx = (hp.base_x - (x - hp.sub_x)) * hp.inv_res;
-    const double cy = (hp.base_y - (y - hp.sub_y)) * hp.inv_res;
-#pragma unroll
-    for (int d = 0; d < kMaxHaloDests; ++d) {
-      if (d < hp.nd && cx >= hp.lo_i[d] && cx <= hp.hi_i[d] && cy >= hp.lo_j[d] &&
-          cy <= hp.hi_j[d]) {
-        const unsigned long long slot = atomicAdd(&counts[d], 1ull);
-        if (slot < hp.cap) {
-          double* o = out + ((size_t)d * hp.cap + slot) * 3;
-          o[0] = x;
-          o[1] = y;
-          o[2] = xyz[3 * idx + 2];
-        }
-      }
-    }
+    if (halo_candidate(hp, xyz[3 * idx + 0], xyz[3 * idx + 1]))
+      halo_emit(&stage, hp, xyz, idx, out, counts);
   }
+  halo_flush(&stage, hp, xyz, out, counts);
 }
 
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
@@ -658,7 +771,7 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
   AMHIP_TRY(hipMemsetAsync(dev_counts, 0, sizeof(unsigned long long) * hp.nd, c->stream));
   if (n == 0) return AMHIP_OK;
   size_t grid = (n + 255) / 256;
-  if (grid > 256 * 16) grid = 256 * 16;
+  if (grid > 256 * 8) grid = 256 * 8;
   hipLaunchKernelGGL(k_halo_select, dim3((unsigned)grid), dim3(256), 0, c->stream,
                      dev_xyz, n, hp, dev_out, dev_counts);
   AMHIP_TRY(hipGetLastError());
@@ -794,7 +907,7 @@ k_range_reduce(const double* __restrict__ part, size_t nparts,
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
-             const DsmParams& p, unsigned long long* zrange) {
+             const DsmParams& p, unsigned long long* zrange, const SortSplit* split) {
   // [min z, max z] of the binned points (for the mosaic's coarse cull): every
   // workgroup of the first scatter pass -- it loads z anyway -- writes a
   // partial, k_range_reduce folds them into *zrange
@@ -817,12 +930,22 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
   static const bool force_two_level = getenv("AMHIP_SORT_TWO_LEVEL") != nullptr;
-  if (p.p3_n1 > 0 && !force_one_level && !force_two_level) {
+  const bool three_pass = p.p3_n1 > 0 && !force_one_level && !force_two_level;
+  if (split && split->phase == 1 && !three_pass)  // small clouds: selection in a pass of its own
+    return halo_select_run(c, dev_xyz, split->n_prefix, split->hp, split->halo_out,
+                           split->halo_counts);
+  if (split && !three_pass) split = nullptr;
+  if (three_pass) {
     // ---- three-pass partition sort ---------------------------------------------
     const int n1 = p.p3_n1, n2 = p.p3_n2, nk = n1 * n2;
-    size_t gcount = (n + 8191) / 8192;
-    if (gcount > 256) gcount = 256;
-    if (gcount < 1) gcount = 1;
+    auto count_grid = [](size_t len) {
+      return std::min<size_t>(std::max<size_t>((len + 8191) / 8192, 1), 256);
+    };
+    // (tiled call: the prefix is counted -- and its halo selected -- before the caller's
+    // exchange, the received rows after it; each part writes its own histogram rows)
+    const size_t n_a = split ? split->n_prefix : n;
+    const size_t g_a = count_grid(n_a), g_b = n > n_a ? count_grid(n - n_a) : 0;
+    const size_t gcount = g_a + g_b;
     int rc;
     if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
     const size_t ws_words = gcount * (size_t)nk + 4 * (size_t)nk + 3 * (size_t)n1 + 24;
@@ -838,10 +961,29 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     {
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
       const size_t lds = (size_t)nk * sizeof(uint32_t);
-      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count),
+      const size_t lds_halo = (size_t)((nk + 1) & ~1) * sizeof(uint32_t) + sizeof(HaloStage);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_dsm_p3_count, dim3((unsigned)gcount), dim3(kP3CountThreads), lds,
-                         c->stream, dev_xyz, n, p, hist_rows);
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_halo));
+      const HaloParams no_halo = {};
+      if (split && split->phase == 1) {
+        AMHIP_TRY(hipMemsetAsync(split->halo_counts, 0,
+                                 sizeof(unsigned long long) * split->hp.nd, c->stream));
+        hipLaunchKernelGGL(k_dsm_p3_count<true>, dim3((unsigned)g_a), dim3(kP3CountThreads),
+                           lds_halo, c->stream, dev_xyz, n_a, p, hist_rows, split->hp, split->halo_out,
+                           split->halo_counts);
+        AMHIP_TRY(hipGetLastError());
+        return AMHIP_OK;  // amhip_dsm_tiled_finish_dev comes back with phase 2
+      }
+      if (!split)
+        hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds,
+                           c->stream, dev_xyz, n_a, p, hist_rows, no_halo, (double*)nullptr,
+                           (unsigned long long*)nullptr);
+      else if (g_b)
+        hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_b), dim3(kP3CountThreads), lds,
+                           c->stream, dev_xyz + 3 * n_a, n - n_a, p, hist_rows + g_a * (size_t)nk,
+                           no_halo, (double*)nullptr, (unsigned long long*)nullptr);
       hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,

@@ -39,7 +39,8 @@ EXPORTS = [
     "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
     "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
     "amhip_ortho_from_pcl_process_dev", "amhip_ortho_from_pcl_process",
-    "amhip_densify_dev", "amhip_halo_select_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
+    "amhip_densify_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
+    "amhip_dsm_tiled_finish_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
     "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
     "amhip_mosaic_create", "amhip_mosaic_destroy", "amhip_mosaic_set_stream",
@@ -131,6 +132,10 @@ def load():
     lib.amhip_halo_select_dev.argtypes = [vp, vp, C.c_size_t, C.c_double, C.c_double,
                                           C.POINTER(C.c_int32), C.c_int, C.c_double, vp,
                                           C.c_size_t, vp]
+    lib.amhip_dsm_tiled_begin_dev.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_double,
+                                              C.c_double, C.POINTER(C.c_int32), C.c_int,
+                                              C.c_double, vp, C.c_size_t, vp]
+    lib.amhip_dsm_tiled_finish_dev.argtypes = [vp]
     lib.amhip_compose_T_G_C.restype = None
     lib.amhip_compose_T_G_C.argtypes = [f64p, f64p, C.c_size_t, f64p]
     lib.amhip_ortho_backward_process_dev.argtypes = [

@@ -180,6 +180,14 @@ class AerialGridMap(object):
         if int(cur.cuda_stream) == 0 or int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
             cur.synchronize()
 
+    def torch_waits(self):
+        """The reverse of wait_for_torch: what this context's kernels wrote must be
+        complete before torch work on ANOTHER stream reads it."""
+        import torch
+        cur = torch.cuda.current_stream(torch.device("cuda", self.device))
+        if int(cur.cuda_stream) == 0 or int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
+            self.synchronize()
+
     def synchronize(self):
         """Waits for the GPU and raises if a device-side CHECK fired."""
         L.check(self._lib.amhip_ctx_synchronize(self._h))

@@ -180,6 +180,17 @@ class TorchComm(object):
         dist.all_to_all_single(recv, send_counts_tensor, group=self.group)
         return recv
 
+    def exchange_equal(self, out_rows, in_rows):
+        """all_to_all of equal splits (TiledDsm): block r of in_rows goes to rank r."""
+        import torch
+        import torch.distributed as dist
+        if self.via_host:
+            tmp = torch.empty(out_rows.shape, dtype=out_rows.dtype)
+            dist.all_to_all_single(tmp, in_rows.cpu(), group=self.group)
+            out_rows.copy_(tmp)
+            return
+        dist.all_to_all_single(out_rows, in_rows, group=self.group)
+
     def exchange_rows(self, out_rows, in_rows, recv_counts, send_counts):
         import torch
         import torch.distributed as dist
@@ -248,3 +259,70 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
     recv_view = out[nk:]
     comm.exchange_rows(recv_view, send_buf.contiguous(), recv_counts, send_counts)
     return out
+
+
+class TiledDsm(object):
+    """dsm::Dsm::process of one window of a tiled map, the halo exchange folded in
+    (amhip_dsm_tiled_begin_dev / _finish_dev): the DSM's binning pass selects the
+    points the other windows need on the way, ONE all_to_all of equal splits ships
+    them (unused rows are NaN and dropped by the receiver's binning), and nothing
+    synchronises with the host -- the counts stay on the device until
+    `check_overflow()` is asked, e.g. once after a run of steps.
+
+    workspace  (n_owned + world * cap, 3) float64 CUDA tensor whose first n_owned
+               rows are this rank's own points; the received rows land behind them
+    cap        rows per (source, destination) pair: a few times edge x margin x
+               density (halo_strip_rows())
+    """
+
+    def __init__(self, settings, map_, layout, rank, cap, comm=None):
+        import torch
+        if layout.world > MAX_DESTS:
+            raise ValueError("at most %d windows per exchange" % MAX_DESTS)
+        self.settings, self.map, self.layout, self.rank = settings, map_, layout, rank
+        self.cap = int(cap)
+        self.comm = comm or TorchComm()
+        dev = torch.device("cuda", map_.device)
+        world = layout.world
+        self.send = torch.empty((world * self.cap, 3), dtype=torch.float64, device=dev)
+        self.counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        wins = layout.windows()
+        wins[rank] = (-(1 << 28), -(1 << 28), 1, 1)   # placeholder: nothing travels to oneself
+        self._wins = (C.c_int32 * (4 * world))(*[int(v) for w in wins for v in w])
+        self._margin = halo_margin(settings.interpolation_radius, map_.grid.resolution)
+
+    def process(self, workspace, n_owned, sync=True):
+        import torch
+        from . import hip_lib as L
+        lib = L.load()
+        world, cap, m, s = self.layout.world, self.cap, self.map, self.settings
+        n_total = n_owned + world * cap
+        assert workspace.is_cuda and workspace.dtype == torch.float64 and workspace.is_contiguous()
+        assert workspace.shape[0] >= n_total and workspace.shape[1] == 3
+        self.send.fill_(float("nan"))
+        m.wait_for_torch(workspace)
+        m._touched("elevation")
+        L.check(lib.amhip_dsm_tiled_begin_dev(
+            m.handle, C.c_void_p(workspace.data_ptr()), n_owned, n_total, s.interpolation_radius,
+            s.center_easting, s.center_northing, self._wins, world, float(self._margin),
+            C.c_void_p(self.send.data_ptr()), cap, C.c_void_p(self.counts.data_ptr())))
+        m.torch_waits()
+        self.comm.exchange_equal(workspace[n_owned:n_total], self.send)
+        m.wait_for_torch(workspace)
+        L.check(lib.amhip_dsm_tiled_finish_dev(m.handle))
+        if sync:
+            m.synchronize()
+            self.check_overflow()
+
+    def check_overflow(self):
+        """Raises if the last process() had more halo points for some window than `cap`
+        rows (the excess was not shipped: the result near that edge is incomplete)."""
+        worst = int(self.counts.max().item())
+        if worst > self.cap:
+            raise RuntimeError("halo rows: %d points for one window, capacity %d" % (worst, self.cap))
+
+
+def halo_strip_rows(points_per_m2, edge_m, radius_sq, resolution, slack=1.5):
+    """Rows to reserve per (source, destination) pair of TiledDsm: the points of a strip
+    one halo margin deep along the longest shared edge, with slack."""
+    return int(slack * points_per_m2 * edge_m * halo_margin(radius_sq, resolution)) + 4096

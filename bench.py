@@ -188,13 +188,13 @@ def main():
 
     # inputs, generated in HBM (synthetic, seeded).  N = 1: the tile's points
     # plus a 4 m apron.  N > 1: each rank holds exactly the points of ITS
-    # window; the halo strips are exchanged over RCCL inside every step.
+    # window; the halo strips are exchanged over RCCL inside every step (tiling.TiledDsm).
     apron = 4.0 if world == 1 else 0.0
     n_pts = wl["points"]
-    halo_cap = 0
+    halo_cap = 0       # rows per (source, destination) pair of the halo exchange
     if world > 1:
-        halo_cap = int(4.0 * (2 * (L + L)) * tiling.halo_margin(1, res) * n_pts / (L * L)) + 4096
-    pts_buf = torch.empty((n_pts + halo_cap, 3), dtype=torch.float64, device=dev)
+        halo_cap = tiling.halo_strip_rows(n_pts / (L * L), L, 1, res)
+    pts_buf = torch.empty((n_pts + world * halo_cap, 3), dtype=torch.float64, device=dev)
     # (N > 1: window edges are multiples of 64 cells, so a window is not exactly L wide;
     # its points cover exactly its own extent, no strip of the map is left without points)
     half = L / 2.0 + apron if world == 1 else (win[2] * res / 2.0, L / 2.0)
@@ -221,16 +221,19 @@ def main():
         mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=args.colored), m)
     dsm = A.Dsm(A.DsmSettings(interpolation_radius=1), m)
 
-    comm = tiling.TorchComm(via_host=True) if one_gpu else None
+    tiled = None
+    if world > 1:
+        # the DSM's binning pass selects the halo points on its way, one all_to_all of equal
+        # splits ships them, nothing synchronises with the host inside a step
+        tiled = tiling.TiledDsm(dsm.settings, m, layout, rank, halo_cap,
+                                comm=tiling.TorchComm(via_host=True) if one_gpu else None)
 
     def step():
         m.reset()
-        cloud = pts
-        if world > 1:
-            cloud = tiling.route_points(pts, m.grid, layout, rank, radius_sq=1, map_=m,
-                                        assume_owned=True, cap=halo_cap // 2,
-                                        workspace=pts_buf, comm=comm)
-        dsm.process(cloud, m, sync=False)
+        if tiled is not None:
+            tiled.process(pts_buf, n_pts, sync=False)
+        else:
+            dsm.process(pts, m, sync=False)
         if F:
             mosaic.process(poses, frames, m, sync=False)
 
@@ -258,6 +261,8 @@ def main():
         dt = float(tmax.item())
     ktimes = m.kernel_times()
     m.enable_timing(False)
+    if tiled is not None:
+        tiled.check_overflow()
 
     cells = side * side
     value = world * cells * args.steps / dt / 1e6

@@ -245,6 +245,28 @@ int amhip_halo_select_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
                           double* dev_out, size_t cap_per_dest,
                           int64_t* dev_counts);
 
+/* The same selection folded into dsm::Dsm::process (dsm.cc:182-217) of a window, around the
+ * caller's exchange -- the DSM's binning pass reads every point anyway:
+ *   1. amhip_dsm_tiled_begin_dev: bins the rank's own points dev_xyz[0, n_owned) and, in the
+ *      same pass, copies the ones the `nd` windows in dest_windows need into dev_out /
+ *      dev_counts exactly like amhip_halo_select_dev (a placeholder window far outside the
+ *      map for the rank itself keeps the rows indexed by rank).
+ *   2. the caller exchanges the rows (one all_to_all of equal splits, no count exchange, no
+ *      host synchronisation) into dev_xyz[n_owned, n_total); rows it does not fill must be
+ *      NaN -- the binning drops them like any point outside the map.
+ *   3. amhip_dsm_tiled_finish_dev: bins dev_xyz[n_owned, n_total) and runs the rest of
+ *      Dsm::process on all n_total rows; the ELEVATION layer is as after
+ *      amhip_dsm_process_dev(dev_xyz, n_total).
+ * Both asynchronous on the context's stream; dev_xyz must stay valid and rows [0, n_owned)
+ * unchanged in between; any other DSM call on the context in between is an error the
+ * library does not detect. */
+int amhip_dsm_tiled_begin_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n_owned,
+                              size_t n_total, int radius_sq, double center_easting,
+                              double center_northing, const int32_t* dest_windows, int nd,
+                              double margin_m, double* dev_out, size_t cap_per_dest,
+                              int64_t* dev_counts);
+int amhip_dsm_tiled_finish_dev(amhip_ctx* ctx);
+
 /* ---- Ortho: ortho::OrthoBackwardGrid::process
  *      (ortho-backward-grid.cc:223-239) ------------------------------------*/
 

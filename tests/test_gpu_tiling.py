@@ -113,6 +113,16 @@ class _ThreadComm(object):
                     pos += n
                 torch.cuda.synchronize()
                 parent.barrier.wait()
+            def exchange_equal(self, out_rows, in_rows):
+                import torch
+                torch.cuda.synchronize()
+                parent.rows[rank] = in_rows
+                parent.barrier.wait()
+                cap = in_rows.shape[0] // parent.world
+                for r in range(parent.world):
+                    out_rows[r * cap:(r + 1) * cap] = parent.rows[r][rank * cap:(rank + 1) * cap]
+                torch.cuda.synchronize()
+                parent.barrier.wait()
         return _C()
 
 
@@ -157,3 +167,108 @@ def test_route_points_cuda_path_two_ranks_one_gpu():
     for rank in range(2):
         (i0, j0, r, c), elev = out[rank]
         S.assert_dsm_close(elev, full[j0:j0 + c, i0:i0 + r], tol=1e-6)
+
+
+@pytest.mark.parametrize("npts,lx,ly,tiles", [(80000, 256.0, 96.0, (2, 1)), (90000, 200.0, 160.0, (2, 2)),
+                                                (2600000, 800.0, 500.0, (2, 1))])
+def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
+    """tiling.TiledDsm (amhip_dsm_tiled_begin_dev / _finish_dev): small clouds take a selection
+    pass of their own (two-level sort), the large one the three-pass sort whose count kernel
+    selects on the way; NaN padding rows are dropped; every window equals the full-map DSM."""
+    import threading
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import synth, tiling
+    res = 0.5
+    g = O.make_grid(lx, ly, res, 12.5, -40.0)
+    rng = np.random.default_rng(73)
+    pts = np.empty((npts, 3))
+    pts[:, 0] = rng.uniform(g.pos_x - lx / 2 - 3.0, g.pos_x + lx / 2 + 3.0, npts)
+    pts[:, 1] = rng.uniform(g.pos_y - ly / 2 - 3.0, g.pos_y + ly / 2 + 3.0, npts)
+    pts[:, 2] = synth.terrain_height(pts[:, 0], pts[:, 1]) + rng.uniform(-0.5, 0.5, npts)
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    layout = tiling.TileLayout(g.rows, g.cols, tiles[0], tiles[1])
+    world = layout.world
+    cx, cy = tiling.cell_coords(pts, g)
+    # (points beyond the map border have no owner in a tiled run)
+    inside_any = np.zeros(npts, bool)
+    for r in range(world):
+        inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
+    with A.AerialGridMap(st) as m:
+        A.Dsm(A.DsmSettings(), m).process(np.ascontiguousarray(pts[inside_any]), m)
+        full = m.get("elevation")
+    cap = tiling.halo_strip_rows(npts / ((lx + 6) * (ly + 6)), max(lx, ly), 1, res, slack=2.0)
+    comm = _ThreadComm(world)
+    out, errs = {}, []
+
+    def run(rank):
+        try:
+            win = layout.window(rank)
+            own = pts[tiling.owner_mask(cx, cy, win)]
+            n = own.shape[0]
+            buf = torch.full((n + world * cap, 3), 7.0, dtype=torch.float64, device="cuda")
+            buf[:n] = torch.from_numpy(np.ascontiguousarray(own)).cuda()
+            with A.AerialGridMap(st, window=win) as m:
+                m.enable_timing(True)
+                t = tiling.TiledDsm(A.DsmSettings(), m, layout, rank, cap, comm=comm.bind(rank))
+                for _ in range(2):                       # a second step re-uses every buffer
+                    m.reset()
+                    t.process(buf, n)
+                got = buf[n:]
+                got = got[~torch.isnan(got[:, 0])].cpu().numpy()
+                out[rank] = (win, m.get("elevation"), got, int(t.counts.sum().item()),
+                             m.kernel_times()["k_halo_select"][1])
+        except Exception as e:  # surface in the main thread
+            errs.append(e)
+            comm.barrier.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(180)
+    assert not errs, errs
+    margin = tiling.halo_margin(1, res)
+    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+    sent_total = recv_total = 0
+    for rank in range(world):
+        (i0, j0, r, c), elev, got, sent, select_launches = out[rank]
+        win = layout.window(rank)
+        want = pts[tiling.in_window(cx, cy, win, margin / res) & inside_any &
+                   ~tiling.owner_mask(cx, cy, win)]
+        assert want.shape[0] > 0
+        assert got.shape == want.shape and np.array_equal(key(got), key(want))
+        sent_total += sent
+        recv_total += got.shape[0]
+        # the big cloud: selected inside k_dsm_p3_count, no pass of its own
+        assert select_launches == (0 if npts > 1000000 else 2)
+        S.assert_dsm_close(elev, full[j0:j0 + c, i0:i0 + r], tol=1e-6)
+    assert sent_total == recv_total
+
+
+def test_tiled_dsm_reports_halo_overflow():
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import tiling
+    g = O.make_grid(128.0, 64.0, 0.5)
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    layout = tiling.TileLayout(g.rows, g.cols, 2, 1)
+    rng = np.random.default_rng(5)
+    pts = np.c_[rng.uniform(-3.0, 3.0, 5000), rng.uniform(-30.0, 30.0, 5000), np.full(5000, 400.0)]
+    cx, cy = tiling.cell_coords(pts, g)
+    win = layout.window(0)
+    own = np.ascontiguousarray(pts[tiling.owner_mask(cx, cy, win)])
+    n, cap = own.shape[0], 16
+
+    class _Alone(object):
+        def exchange_equal(self, out_rows, in_rows):
+            out_rows.fill_(float("nan"))
+
+    buf = torch.empty((n + 2 * cap, 3), dtype=torch.float64, device="cuda")
+    buf[:n] = torch.from_numpy(own).cuda()
+    with A.AerialGridMap(st, window=win) as m:
+        t = tiling.TiledDsm(A.DsmSettings(), m, layout, 0, cap, comm=_Alone())
+        with pytest.raises(RuntimeError, match="halo rows"):
+            t.process(buf, n)
+        with pytest.raises(A.AmhipError):
+            A.hip_lib.check(A.hip_lib.load().amhip_dsm_tiled_finish_dev(m.handle))
