@@ -170,7 +170,8 @@ def test_route_points_cuda_path_two_ranks_one_gpu():
 
 
 @pytest.mark.parametrize("npts,lx,ly,tiles", [(80000, 256.0, 96.0, (2, 1)), (90000, 200.0, 160.0, (2, 2)),
-                                                (2600000, 800.0, 500.0, (2, 1))])
+                                                (2600000, 800.0, 500.0, (2, 1)),
+                                                (150000, 768.0, 64.0, (8, 1))])   # a node's 8 GPUs
 def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
     """tiling.TiledDsm (amhip_dsm_tiled_begin_dev / _finish_dev): small clouds take a selection
     pass of their own (two-level sort), the large one the three-pass sort whose count kernel
