@@ -70,3 +70,37 @@ def test_from_pcl_adaptive_fills_every_cell():
     assert (plain == 255.0).sum() > 1000          # without the retries most cells stay untouched
     got = _run(pts, inten, g, 2, True)
     assert _check(got, want) > 0.99
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_from_pcl_random_configurations(seed):
+    """Random grids / radii / densities (incl. patches dense enough for the gather's higher
+    capacity classes and the wave-per-cell kernel), plain and adaptive."""
+    rng = np.random.default_rng(8800 + seed)
+    res = float(rng.choice([0.25, 0.5, 1.0, 2.0]))
+    cx, cy = int(rng.integers(40, 260)), int(rng.integers(40, 200))
+    lx, ly = cx * res, cy * res
+    g = O.make_grid(lx, ly, res, float(rng.uniform(-500, 500)), float(rng.uniform(-500, 500)))
+    radius = int(rng.choice([1, 2, 2, 4, 10]))
+    adaptive = bool(rng.integers(0, 2))
+    n0 = int(rng.integers(2000, 60000))
+    parts = [np.c_[rng.uniform(g.pos_x - lx / 2 - 2, g.pos_x + lx / 2 + 2, n0),
+                   rng.uniform(g.pos_y - ly / 2 - 2, g.pos_y + ly / 2 + 2, n0)]]
+    if seed % 2 == 0:        # a dense patch
+        w, h = rng.uniform(0.05, 0.2) * lx, rng.uniform(0.05, 0.2) * ly
+        x0 = rng.uniform(g.pos_x - lx / 2, g.pos_x + lx / 2 - w)
+        y0 = rng.uniform(g.pos_y - ly / 2, g.pos_y + ly / 2 - h)
+        nk = int(rng.integers(20000, 120000))
+        parts.append(np.c_[rng.uniform(x0, x0 + w, nk), rng.uniform(y0, y0 + h, nk)])
+    xy = np.concatenate(parts)
+    if seed % 3 == 0:        # a strip without points
+        xy = xy[np.abs(xy[:, 1] - g.pos_y) > 0.08 * ly]
+    n = xy.shape[0]
+    pts = np.empty((n, 3))
+    pts[:, :2] = xy
+    pts[:, 2] = synth.terrain_height(xy[:, 0], xy[:, 1])
+    inten = rng.integers(0, 256, n).astype(np.int32)
+    rc, want = O.ortho_from_pcl(pts, inten, g, radius, adaptive)
+    assert rc == O.OK
+    got = _run(pts, inten, g, radius, adaptive, device=bool(seed % 2))
+    assert _check(got, want) > 0.98

@@ -12,9 +12,11 @@ first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 bad = []
 t0 = time.time()
+import test_gpu_ortho_from_pcl as P
 for seed in range(first, first + count):
     for name, fn in (("dsm", T.test_dsm_random_configurations), ("ortho", T.test_ortho_random_configurations),
-                     ("fwd", getattr(T, "test_forward_random_configurations", None))):
+                     ("fwd", getattr(T, "test_forward_random_configurations", None)),
+                     ("from_pcl", P.test_from_pcl_random_configurations)):
         if fn is None:
             continue
         try:
