@@ -71,13 +71,17 @@ def parse():
 
 
 def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
-    """Time the CPU oracle (oracle/_ref = vendored nanoflann, else the port) on a
-    corner sub-tile of this rank's workload and check GPU parity on it."""
+    """Time the CPU side on a corner sub-tile of this rank's workload and check GPU parity
+    on it.  In order of preference: the reference's OWN dsm::Dsm::process and
+    ortho::OrthoBackwardGrid::process (oracle/_ref/libref_loops_*.so: dsm.cc and
+    ortho-backward-grid.cc compiled unchanged against oracle/refkit/), the restated loops
+    over the reference's vendored nanoflann (oracle/_ref/liboracle_ref.so), the port."""
     import numpy as np
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
-    which = "ref" if O.have_ref() else "port"
+    which = "loops" if O.have_loops() else ("ref" if O.have_ref() else "port")
+    gwhich = "port" if which == "loops" else which
     side, res = wl["side"], wl["res"]
     s = min(args.cpu_sample_side, side)
     L = side * res
@@ -86,7 +90,7 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
     sub_len = s * res
     sub_cx = tile_center[0] + L / 2.0 - sub_len / 2.0
     sub_cy = tile_center[1] + L / 2.0 - sub_len / 2.0
-    g = O.make_grid(sub_len, sub_len, res, sub_cx, sub_cy, which=which)
+    g = O.make_grid(sub_len, sub_len, res, sub_cx, sub_cy, which=gwhich)
     assert g.rows == s and g.cols == s
     halo = 3.0
     x, y = pts_dev[:, 0], pts_dev[:, 1]
@@ -107,8 +111,9 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
         cam.fu, cam.fv, cam.cu, cam.cv = ncam.camera.fu, ncam.camera.fv, ncam.camera.cu, ncam.camera.cv
         cam.width, cam.height = ncam.camera.width, ncam.camera.height
         t0 = time.time()
+        t_mosaic = np.zeros(2)
         rc = O.ortho_process(g, cam, poses, ncam.T_C_B, frames_host, layers,
-                             colored=args.colored, which=which)
+                             colored=args.colored, which=which, timing=t_mosaic)
         assert rc == 0
         t_ortho = time.time() - t0
     # parity of the GPU result on the same cells
@@ -124,14 +129,29 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
             b = layers[name]
             eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
             parity[name + "_mismatch_cells"] = int((~eq).sum())
-    total = t_dsm + t_ortho
     cores = os.cpu_count() or 1
+    if which == "loops":
+        # the two process() calls alone; the constructors' one-sample-per-cell tables
+        # (dsm.cc:20-34, ortho-backward-grid.cc:22-40) are set-up, reported beside them
+        t_ctor = t_build + (t_mosaic[0] if F else 0.0)
+        t_dsm, t_ortho = t_cells, (t_mosaic[1] if F else 0.0)
+        sample = ("%dx%d-cell corner sub-tile of the workload (%d pts incl. 3 m halo, all %d "
+                  "frames): the reference's own Dsm::process %.2fs + OrthoBackwardGrid::process "
+                  "%.2fs (dsm.cc / ortho-backward-grid.cc compiled unchanged against "
+                  "oracle/refkit, use_multi_threads, std::thread x hardware_concurrency); "
+                  "constructors %.2fs not counted" % (s, s, sub_pts.shape[0], F, t_dsm, t_ortho, t_ctor))
+    else:
+        sample = ("%dx%d-cell corner sub-tile of the workload (%d pts incl. 3 m halo, "
+                  "all %d frames brute force); kd-tree build %.2fs (1 thread) + cell loop "
+                  "%.2fs + ortho %.2fs, std::thread x hardware_concurrency like "
+                  "utils::parFor" % (s, s, sub_pts.shape[0], F, t_build, t_cells, t_ortho))
+    total = t_dsm + t_ortho
     return {"value": round(s * s / total / 1e6, 4), "unit": "Mcells/s", "cores": cores,
-            "kind": "reference" if which == "ref" else "port",
-            "sample": "%dx%d-cell corner sub-tile of the workload (%d pts incl. 3 m halo, "
-                      "all %d frames brute force); kd-tree build %.2fs (1 thread) + cell loop "
-                      "%.2fs + ortho %.2fs, std::thread x hardware_concurrency like "
-                      "utils::parFor" % (s, s, sub_pts.shape[0], F, t_build, t_cells, t_ortho),
+            "kind": "port" if which == "port" else "reference",
+            "reference_code": {"loops": "dsm.cc + ortho-backward-grid.cc unchanged (oracle/refkit)",
+                               "ref": "vendored nanoflann under restated loops",
+                               "port": "none (restated loops, own kd-tree)"}[which],
+            "sample": sample,
             "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}, parity
 
 

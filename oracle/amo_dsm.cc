@@ -19,8 +19,13 @@
  *
  * Pinning: the reference has NO tests / golden vectors.
  * The kd-tree arithmetic is pinned by the vendored header (the _ref build IS
- * that code); the cell loop and grid_map_core's getPosition are restated
- * (amo_compat.h) -- PARITY UNPINNED for those.
+ * that code).  The loops of this file are pinned against the reference's OWN
+ * dsm.cc / ortho-from-pcl.cc, compiled unchanged from /root/reference against
+ * the stand-in headers of oracle/refkit/ (_ref/libref_loops_*.so;
+ * tests/test_reference_loops.py: every layer bit for bit, both thread
+ * variants, the exact-hit CHECK, the golden vectors).  What stays a definition
+ * is grid_map_core's arithmetic behind setGeometry / getPosition
+ * (amo_compat.h) -- PARITY UNPINNED for that.
  */
 #include <chrono>
 #include <cmath>

@@ -14,10 +14,15 @@
  * every comparison, so the fold is order dependent and float-rounded exactly
  * like the reference's  `if (alpha > layer_elevation_angle(x, y))`.
  *
- * PARITY UNPINNED: the reference has no tests or golden vectors, and the
- * projection / pose / grid arithmetic lives in un-vendored dependencies
- * (aslam_cv2, minkindr, grid_map_core, OpenCV Mat::at) restated in
- * amo_compat.h.  Results of this file DEFINE parity for the ortho path.
+ * Pinning: the reference has no tests or golden vectors.  The fold of this file
+ * is pinned against the reference's OWN ortho-backward-grid.cc, compiled
+ * unchanged from /root/reference against the stand-in headers of oracle/refkit/
+ * (_ref/libref_loops_ortho_backward.so; tests/test_reference_loops.py: every
+ * layer bit for bit -- gray and colour, pinhole / radtan / equidistant, both
+ * thread variants, batches appended onto existing layers, the golden vectors).
+ * PARITY UNPINNED for what lives in the un-vendored dependencies: the
+ * projection / pose / grid arithmetic of aslam_cv2, minkindr and grid_map_core,
+ * restated in amo_compat.h (the stand-ins forward to the same formulas).
  */
 #include <algorithm>
 #include <cmath>

@@ -7,6 +7,9 @@ container: oracle/_ref/liboracle_ref.so = the reference's VENDORED nanoflann
 (kd-tree build + radius search, compiled from /root/reference where it lies)
 driven by the restated dsm.cc / ortho-backward-grid.cc loops.  The fixtures
 travel to the GPU box, where /root/reference does not exist.
+tests/test_reference_loops.py checks that the reference's OWN loops (dsm.cc,
+ortho-backward-grid.cc, ortho-from-pcl.cc compiled unchanged against
+oracle/refkit/) reproduce every dsm_ / ortho_ / pcl_ fixture bit for bit.
 
     python tests/golden/make_golden.py        (needs /root/reference)
 

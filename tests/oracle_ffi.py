@@ -1,4 +1,5 @@
-"""ctypes binding of the CPU oracle (oracle/liboracle.so, oracle/_ref/liboracle_ref.so).
+"""ctypes binding of the CPU oracle (oracle/liboracle.so, oracle/_ref/liboracle_ref.so,
+oracle/_ref/libref_loops_*.so).
 
 TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and the
 cpu_baseline leg of bench.py -- never by the product package aerial_mapper_amd.
@@ -122,6 +123,41 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
+# ---- the reference's OWN loops (oracle/_ref/libref_loops_*.so: dsm.cc, ortho-backward-grid.cc,
+# ortho-from-pcl.cc compiled unchanged against oracle/refkit/; `which="loops"` below) ----------
+LOOPS_SO = {name: os.path.join(ORACLE_DIR, "_ref", "libref_loops_%s.so" % name)
+            for name in ("dsm", "ortho_backward", "ortho_from_pcl")}
+_loops_libs = {}
+
+
+def have_loops():
+    return all(os.path.exists(p) for p in LOOPS_SO.values())
+
+
+def _loops(name):
+    if name not in _loops_libs:
+        if not os.path.exists(LOOPS_SO[name]):
+            raise FileNotFoundError(LOOPS_SO[name])
+        f64p, f32p = C.POINTER(C.c_double), C.POINTER(C.c_float)
+        so = C.CDLL(LOOPS_SO[name])
+        if name == "dsm":
+            so.amr_dsm_process.restype = C.c_int
+            so.amr_dsm_process.argtypes = [f64p, C.c_size_t, C.POINTER(Grid), C.c_int, C.c_double,
+                                           C.c_double, C.c_int, f32p, f64p]
+        elif name == "ortho_backward":
+            so.amr_ortho_backward_process.restype = C.c_int
+            so.amr_ortho_backward_process.argtypes = [
+                C.POINTER(Grid), C.POINTER(Camera), f64p, f64p, C.POINTER(C.c_void_p),
+                C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_int, C.c_int,
+                f32p, f32p, f32p, f32p, f32p, f32p, f64p]
+        else:
+            so.amr_ortho_from_pcl_process.restype = C.c_int
+            so.amr_ortho_from_pcl_process.argtypes = [f64p, C.POINTER(C.c_int32), C.c_size_t,
+                                                      C.POINTER(Grid), C.c_int, C.c_int, f32p]
+        _loops_libs[name] = so
+    return _loops_libs[name]
+
+
 def _f64(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
@@ -165,6 +201,13 @@ def dsm_process(xyz, g, radius_sq=1, center_easting=0.0, center_northing=0.0,
         elevation = np.full((g.cols, g.rows), np.nan, np.float32)
     assert elevation.dtype == np.float32 and elevation.flags.c_contiguous
     t = np.zeros(2)
+    if which == "loops":
+        rc = _loops("dsm").amr_dsm_process(_f64(xyz), xyz.shape[0], C.byref(g), int(radius_sq),
+                                           center_easting, center_northing,
+                                           int(bool(multi_thread)), _f32(elevation), _f64(t))
+        # (t[0] = the constructor's one-sample-per-cell table, t[1] = Dsm::process: kd-tree
+        # build + cell loop together)
+        return rc, elevation, (t[0], t[1])
     rc = lib(which).amo_dsm_process(
         _f64(xyz), xyz.shape[0], C.byref(g), int(radius_sq),
         center_easting, center_northing, int(bool(multi_thread)),
@@ -179,6 +222,11 @@ def ortho_from_pcl(xyz, intensities, g, radius_sq=2, adaptive=False, ortho=None,
     assert inten.shape[0] == xyz.shape[0]
     if ortho is None:
         ortho = np.full((g.cols, g.rows), 255.0, np.float32)
+    if which == "loops":
+        rc = _loops("ortho_from_pcl").amr_ortho_from_pcl_process(
+            _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)), xyz.shape[0], C.byref(g),
+            int(radius_sq), int(bool(adaptive)), _f32(ortho))
+        return rc, ortho
     rc = lib(which).amo_ortho_from_pcl_process(
         _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)), xyz.shape[0], C.byref(g),
         int(radius_sq), int(bool(adaptive)), _f32(ortho))
@@ -214,7 +262,7 @@ def radius_probe(xyz, qx, qy, radius_sq, cap=4096, which="port"):
 
 
 def ortho_process(g, cam, T_G_B, T_C_B, images, layers, colored=False,
-                  multi_thread=True, num_threads=0, which="port"):
+                  multi_thread=True, num_threads=0, which="port", timing=None):
     """images: list of uint8 arrays (H,W) or (H,W,3 BGR). layers updated in place."""
     T_G_B = np.ascontiguousarray(T_G_B, np.float64).reshape(-1, 7)
     T_C_B = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
@@ -230,6 +278,14 @@ def ortho_process(g, cam, T_G_B, T_C_B, images, layers, colored=False,
         keep.append(im)
         ptrs[k] = im.ctypes.data
         steps[k] = im.strides[0]
+    if which == "loops":
+        return _loops("ortho_backward").amr_ortho_backward_process(
+            C.byref(g), C.byref(cam), _f64(T_G_B), _f64(T_C_B), ptrs, steps, ch, F,
+            int(bool(colored)), int(bool(multi_thread)),
+            _f32(layers["elevation"]), _f32(layers["elevation_angle"]),
+            _f32(layers["observation_index"]), _f32(layers["num_observations"]),
+            _f32(layers["ortho"]), _f32(layers["colored_ortho"]),
+            _f64(timing) if timing is not None else None)
     rc = lib(which).amo_ortho_backward_process(
         C.byref(g), C.byref(cam), _f64(T_G_B), _f64(T_C_B), ptrs, steps, ch, F,
         int(bool(colored)), int(bool(multi_thread)), int(num_threads),

@@ -1,0 +1,171 @@
+"""The restated oracle (oracle/amo_*.cc) against the reference's OWN loops: dsm.cc,
+ortho-backward-grid.cc and ortho-from-pcl.cc compiled unchanged from /root/reference against
+the stand-in headers of oracle/refkit/ (oracle/Makefile target `loops`,
+oracle/_ref/libref_loops_*.so).  Everything the reference's own code does is pinned by
+these comparisons -- bit for bit, every layer; what stays a definition is the arithmetic
+inside the external libraries' calls (oracle/refkit/refkit.h)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+pytestmark = pytest.mark.skipif(not O.have_loops(),
+                                reason="oracle/_ref/libref_loops_*.so not built (needs /root/reference)")
+
+
+def _same(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+@pytest.mark.parametrize("multi_thread", [True, False])
+@pytest.mark.parametrize("seed,res,radius,ce,cn", [(5, 0.5, 1, 0.0, 0.0), (6, 0.25, 1, 0.0, 0.0),
+                                                  (7, 1.0, 4, 0.0, 0.0), (8, 0.5, 2, 3.5, -1.25),
+                                                  (9, 2.0, 9, 0.0, 0.0)])
+def test_dsm_restatement_equals_the_reference_loops(seed, res, radius, ce, cn, multi_thread):
+    sc = S.Scene(70.0, 50.0, res, 9000, seed=seed, center=(ce * 10, cn * 10), point_extent=45.0)
+    pts = sc.points[np.abs(sc.points[:, 0] - ce * 10 - 8.0) > 4.0]      # a gap: ladder + NaN cells
+    g = sc.grid
+    rc_a, a, _ = O.dsm_process(pts, g, radius, ce, cn, multi_thread=multi_thread)
+    rc_b, b, _ = O.dsm_process(pts, g, radius, ce, cn, multi_thread=multi_thread, which="loops")
+    assert rc_a == rc_b == O.OK
+    assert _same(a, b)
+    assert np.isnan(a).any() and (~np.isnan(a)).mean() > 0.5
+    if O.have_ref():                                   # and the vendored-nanoflann driver
+        rc_c, c, _ = O.dsm_process(pts, g, radius, ce, cn, multi_thread=multi_thread, which="ref")
+        assert rc_c == O.OK and _same(a, c)
+
+
+def test_dsm_untouched_cells_and_second_cloud():
+    """Cells without neighbours keep what the layer held; a second process() overwrites."""
+    g = O.make_grid(40.0, 30.0, 1.0)
+    p1 = synth.make_points(500, 8.0, 11, center=(-10.0, -6.0))
+    p2 = synth.make_points(700, 9.0, 12, center=(9.0, 5.0))
+    layers = {}
+    for which in ("port", "loops"):
+        e = np.full((g.cols, g.rows), -7.0, np.float32)
+        assert O.dsm_process(p1, g, 1, elevation=e, which=which)[0] == O.OK
+        assert O.dsm_process(p2, g, 1, elevation=e, which=which)[0] == O.OK
+        layers[which] = e
+    assert _same(layers["port"], layers["loops"])
+    assert (layers["port"] == -7.0).any()
+
+
+def test_dsm_exact_hit_is_the_references_check():
+    g = O.make_grid(30.0, 20.0, 1.0)
+    pts = synth.make_points(900, 18.0, 95)
+    x, y = O.cell_position(g, 7, 5)
+    pts[13, :2] = (x, y)
+    assert O.dsm_process(pts, g, 1)[0] == O.ERR_EXACT_HIT
+    assert O.dsm_process(pts, g, 1, which="loops")[0] == O.ERR_EXACT_HIT   # CHECK(distances[i] > 0.0)
+
+
+def test_dsm_empty_cloud_is_a_no_op():
+    g = O.make_grid(10.0, 10.0, 1.0)
+    e = np.full((g.cols, g.rows), 3.0, np.float32)
+    assert O.dsm_process(np.zeros((0, 3)), g, 1, elevation=e, which="loops")[0] == O.OK
+    assert (e == 3.0).all()
+
+
+CAMERAS = [
+    ("pinhole", dict()),
+    ("radtan", dict(distortion=O.DIST_RADTAN, dist=(-0.12, 0.03, 0.002, -0.001))),
+    ("equidistant", dict(distortion=O.DIST_EQUIDISTANT, dist=(0.02, -0.01, 0.004, -0.001))),
+]
+
+
+@pytest.mark.parametrize("multi_thread", [True, False])
+@pytest.mark.parametrize("colored", [False, True])
+@pytest.mark.parametrize("name,kw", CAMERAS)
+def test_mosaic_restatement_equals_the_reference_loops(name, kw, colored, multi_thread):
+    sc = S.Scene(90.0, 70.0, 0.5, 30000, seed=46 + len(name), cam=S.camera(**kw), colored=colored,
+                 num_frames=10, tilt_deg=12.0)
+    g = sc.grid
+    rc, elev, _ = O.dsm_process(sc.points, g)
+    assert rc == O.OK
+    elev[3:9, 4:30] = np.nan                     # NaN elevation: never visible
+    T_C_B = np.array([0.3, -0.2, 0.1, 0.9987502603949663, 0.0, 0.049979169270678331, 0.0])
+    out = {}
+    for which in ("port", "loops"):
+        la = O.new_layers(g)
+        la["elevation"] = elev.copy()
+        la["num_observations"][:] = 1.0          # `+= itself` doubles per accepted view
+        assert O.ortho_process(g, sc.cam, sc.poses[:6], T_C_B, sc.frames[:6], la, colored=colored,
+                               multi_thread=multi_thread, which=which) == O.OK
+        # a second batch onto the same layers (incremental use)
+        assert O.ortho_process(g, sc.cam, sc.poses[6:], T_C_B, sc.frames[6:], la, colored=colored,
+                               multi_thread=multi_thread, which=which) == O.OK
+        out[which] = la
+    for layer in out["port"]:
+        assert _same(out["port"][layer], out["loops"][layer]), layer
+    seen = ~np.isnan(out["port"]["observation_index"])
+    assert 0.3 < seen.mean() < 1.0
+    assert (out["port"]["num_observations"][seen] >= 2.0).all()
+
+
+def test_mosaic_without_frames_fails_the_references_check():
+    sc = S.Scene(20.0, 16.0, 1.0, 1500, seed=3, num_frames=2)
+    g = sc.grid
+    for which in ("port", "loops"):                   # CHECK(!T_G_Bs.empty()), :225
+        la = O.new_layers(g)
+        la["elevation"][:] = 400.0
+        assert O.ortho_process(g, sc.cam, sc.poses[:0], sc.T_C_B, [], la, which=which) == O.ERR_ARG
+        assert np.isnan(la["observation_index"]).all()
+
+
+@pytest.mark.parametrize("res,n,radius,adaptive", [(1.0, 6000, 2, False), (0.5, 30000, 2, False),
+                                                   (1.0, 2500, 10, False), (1.0, 400, 2, True)])
+def test_from_pcl_restatement_equals_the_reference_loops(res, n, radius, adaptive):
+    g = O.make_grid(90.0, 70.0, res, 4.0, -3.0)
+    half = 12.0 if adaptive else 52.0
+    pts = synth.make_points(n, half, 90 + n % 7, center=(4.0, -3.0))
+    inten = ((np.arange(n) * 37) % 256).astype(np.int32)
+    x, y = O.cell_position(g, 40, 33)
+    pts[7, :2] = (x, y)                          # an exact hit takes the point's own value
+    rc_a, a = O.ortho_from_pcl(pts, inten, g, radius, adaptive)
+    rc_b, b = O.ortho_from_pcl(pts, inten, g, radius, adaptive, which="loops")
+    assert rc_a == rc_b == O.OK
+    assert _same(a, b)
+    assert a[33, 40] == float(inten[7])
+
+
+# ---------------------------------------------------------------------------
+# the committed golden vectors (tests/golden/*.npz) ARE outputs of the reference's own loops
+# ---------------------------------------------------------------------------
+import golden_io as G  # noqa: E402
+
+
+@pytest.mark.parametrize("name", G.names("dsm"))
+def test_reference_loops_reproduce_golden_dsm_bitwise(name):
+    d = G.load(name)
+    init = d["elevation_init"]
+    rc, elev, _ = O.dsm_process(d["points"], G.grid_of(d), int(d["radius_sq"]),
+                                float(d["center_easting"]), float(d["center_northing"]),
+                                elevation=init.copy() if init.size else None, which="loops")
+    assert rc == O.OK
+    assert G.bits_equal(elev, d["elevation"]).all()
+
+
+@pytest.mark.parametrize("name", G.names("ortho"))
+def test_reference_loops_reproduce_golden_ortho_bitwise(name):
+    d = G.load(name)
+    g, cam = G.grid_of(d), G.camera_of(d)
+    layers = O.new_layers(g)
+    layers["elevation"] = d["elevation"].copy()
+    layers["num_observations"][:] = float(d["num_observations_init"])
+    frames = [np.ascontiguousarray(f) for f in d["frames"]]
+    for lo, hi in d["batches"]:
+        assert O.ortho_process(g, cam, d["T_G_B"][lo:hi], d["T_C_B"], frames[lo:hi], layers,
+                               colored=bool(d["colored"]), which="loops") == O.OK
+    for n in G.ORTHO_LAYERS:
+        assert G.bits_equal(layers[n], d[n]).all(), n
+
+
+@pytest.mark.parametrize("name", G.names("pcl"))
+def test_reference_loops_reproduce_golden_from_pcl_bitwise(name):
+    d = G.load(name)
+    rc, ortho = O.ortho_from_pcl(d["points"], d["intensities"], G.grid_of(d), int(d["radius_sq"]),
+                                 bool(d["adaptive"]), which="loops")
+    assert rc == O.OK
+    assert G.bits_equal(ortho, d["ortho"]).all()
