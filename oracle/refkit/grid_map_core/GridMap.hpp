@@ -24,10 +24,17 @@ typedef Eigen::Array2i Size;
 
 class GridMap {
  public:
+  GridMap() { std::memset(&g_, 0, sizeof(g_)); }
   explicit GridMap(const std::vector<std::string>& layers) {
     for (const std::string& name : layers) data_[name] = Matrix();
     std::memset(&g_, 0, sizeof(g_));
   }
+  void setFrameId(const std::string& frame) { frame_ = frame; }
+  const std::string& getFrameId() const { return frame_; }
+  void setTimestamp(uint64_t) {}
+  Length getLength() const { return Length(g_.length_x, g_.length_y); }
+  Position getPosition() const { return Position(g_.pos_x, g_.pos_y); }
+  bool exists(const std::string& layer) const { return data_.count(layer) != 0; }
   void setGeometry(const Length& length, double resolution, const Position& position) {
     g_ = amo::make_grid(length(0), length(1), resolution, position(0), position(1));
     size_ = Size(g_.rows, g_.cols);
@@ -56,6 +63,7 @@ class GridMap {
 
  private:
   std::map<std::string, Matrix> data_;
+  std::string frame_;
   amo_grid g_;
   Size size_;
 };

@@ -3,7 +3,8 @@
  *
  * Build kit for compiling the reference's OWN translation units of the hot path --
  * aerial_mapper_dsm/src/dsm.cc, aerial_mapper_ortho/src/ortho-backward-grid.cc,
- * aerial_mapper_ortho/src/ortho-from-pcl.cc (+ aerial_mapper_utils/src/utils-common.cc) --
+ * aerial_mapper_ortho/src/ortho-from-pcl.cc, aerial_mapper_grid_map/src/aerial-mapper-grid-map.cc
+ * (+ aerial_mapper_utils/src/utils-common.cc) --
  * UNCHANGED, from where they lie under /root/reference, into oracle/_ref/ (oracle/Makefile,
  * target `loops`).  Those files need Eigen, glog, ROS, grid_map, aslam_cv2, minkindr and
  * OpenCV, none of which is in /root/reference or in this image; this directory holds

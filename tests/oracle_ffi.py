@@ -126,7 +126,7 @@ def have_ref():
 # ---- the reference's OWN loops (oracle/_ref/libref_loops_*.so: dsm.cc, ortho-backward-grid.cc,
 # ortho-from-pcl.cc compiled unchanged against oracle/refkit/; `which="loops"` below) ----------
 LOOPS_SO = {name: os.path.join(ORACLE_DIR, "_ref", "libref_loops_%s.so" % name)
-            for name in ("dsm", "ortho_backward", "ortho_from_pcl")}
+            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map")}
 _loops_libs = {}
 
 
@@ -150,12 +150,33 @@ def _loops(name):
                 C.POINTER(Grid), C.POINTER(Camera), f64p, f64p, C.POINTER(C.c_void_p),
                 C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_int, C.c_int,
                 f32p, f32p, f32p, f32p, f32p, f32p, f64p]
+        elif name == "grid_map":
+            so.amr_grid_map_initialize.restype = C.c_int
+            so.amr_grid_map_initialize.argtypes = [C.c_double] * 5 + [C.POINTER(Grid),
+                                                                      C.POINTER(C.c_void_p)]
         else:
             so.amr_ortho_from_pcl_process.restype = C.c_int
             so.amr_ortho_from_pcl_process.argtypes = [f64p, C.POINTER(C.c_int32), C.c_size_t,
                                                       C.POINTER(Grid), C.c_int, C.c_int, f32p]
         _loops_libs[name] = so
     return _loops_libs[name]
+
+
+LAYER_ORDER = ["ortho", "elevation", "elevation_angle", "num_observations", "observation_index",
+               "colored_ortho"]
+
+
+def reference_grid_map(center_easting, center_northing, delta_easting, delta_northing, resolution):
+    """The reference's own grid_map::AerialGridMap(settings) (aerial-mapper-grid-map.cc,
+    compiled unchanged): returns (Grid, {layer: initial values})."""
+    so = _loops("grid_map")
+    g = Grid()
+    args = (center_easting, center_northing, delta_easting, delta_northing, resolution)
+    assert so.amr_grid_map_initialize(*args, C.byref(g), None) == OK
+    layers = {n: np.empty((g.cols, g.rows), np.float32) for n in LAYER_ORDER}
+    ptrs = (C.c_void_p * 6)(*[layers[n].ctypes.data for n in LAYER_ORDER])
+    assert so.amr_grid_map_initialize(*args, C.byref(g), ptrs) == OK
+    return g, layers
 
 
 def _f64(a):

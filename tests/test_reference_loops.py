@@ -169,3 +169,17 @@ def test_reference_loops_reproduce_golden_from_pcl_bitwise(name):
                                  bool(d["adaptive"]), which="loops")
     assert rc == O.OK
     assert G.bits_equal(ortho, d["ortho"]).all()
+
+
+@pytest.mark.parametrize("ce,cn,de,dn,res", [(0.0, 0.0, 60.0, 40.0, 0.5), (464980.25, 5272690.5, 37.3, 81.9, 0.25),
+                                            (-12.5, 7.0, 10.0, 10.0, 0.3)])
+def test_map_creation_is_the_references(ce, cn, de, dn, res):
+    """grid_map::AerialGridMap::initialize (aerial-mapper-grid-map.cc:23-48): the geometry call's
+    argument order and the layers' initial values, from the reference's own code."""
+    g_ref, layers = O.reference_grid_map(ce, cn, de, dn, res)
+    g = O.make_grid(de, dn, res, ce, cn)
+    for f, _ in O.Grid._fields_:
+        assert getattr(g, f) == getattr(g_ref, f), f
+    want = O.new_layers(g)
+    for name in O.LAYER_ORDER:
+        assert G.bits_equal(layers[name], want[name]).all(), name
