@@ -17,7 +17,8 @@
  *               order they run in, the exact-hit CHECK, the per-frame fold with its
  *               float-rounded running maximum, the visibility test, round()/min() of the
  *               pixel, the colour packing call, `num_observations += itself`, the
- *               composition T_G_B * T_C_B^-1 -- compiled from the reference's source.
+ *               composition T_G_B * T_C_B^-1, the layers a map starts with and their
+ *               initial values -- compiled from the reference's source.
  *   NOT pinned  the arithmetic INSIDE the externals' calls (GridMap::getPosition,
  *               QuatTransformation::inverse/transform/operator*, Camera::project3,
  *               colorVectorToValue): the stand-ins forward to the same formulas the
