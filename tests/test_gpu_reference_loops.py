@@ -1,0 +1,84 @@
+"""GPU against the reference's OWN code: dsm.cc, ortho-backward-grid.cc and ortho-from-pcl.cc
+compiled unchanged against oracle/refkit/ (oracle/_ref/libref_loops_*.so -- built where
+/root/reference exists, they travel to the GPU box with the other built libraries).  The
+same bars as against the restated oracle: DSM heights within 1e-4 m with the same NaN
+pattern, mosaic layers bit for bit."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+from aerial_mapper_amd import synth
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not O.have_loops(), reason="oracle/_ref/libref_loops_*.so not built")]
+
+LAYERS = ["elevation_angle", "observation_index", "num_observations", "ortho", "colored_ortho"]
+
+
+def _settings(g):
+    import aerial_mapper_amd as A
+    return A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+
+
+@pytest.mark.parametrize("res,n,radius,ce,cn", [(0.5, 40000, 1, 0.0, 0.0), (0.25, 90000, 1, 2.5, -1.0),
+                                               (1.0, 9000, 4, 0.0, 0.0)])
+def test_dsm_equals_the_references_own_process(res, n, radius, ce, cn):
+    import aerial_mapper_amd as A
+    sc = S.Scene(110.0, 80.0, res, n, seed=300 + radius, point_extent=62.0)
+    pts = np.ascontiguousarray(sc.points[np.abs(sc.points[:, 1] - 11.0) > 3.5])   # a gap: ladder, NaN
+    g = sc.grid
+    rc, want, _ = O.dsm_process(pts, g, radius, ce, cn, which="loops")
+    assert rc == O.OK
+    with A.AerialGridMap(_settings(g)) as m:
+        A.Dsm(A.DsmSettings(radius, center_easting=ce, center_northing=cn), m).process(pts, m)
+        got = m.get("elevation")
+    S.assert_dsm_close(got, want)               # 1e-4 m, identical NaN pattern
+
+
+@pytest.mark.parametrize("colored,kw", [(False, dict()),
+                                        (True, dict(distortion=O.DIST_RADTAN, dist=(-0.12, 0.03, 0.002, -0.001))),
+                                        (False, dict(distortion=O.DIST_EQUIDISTANT, dist=(0.02, -0.01, 0.004, -0.001)))])
+def test_mosaic_equals_the_references_own_process(colored, kw):
+    import aerial_mapper_amd as A
+    sc = S.Scene(100.0, 80.0, 0.5, 36000, seed=310 + int(colored), cam=S.camera(**kw), colored=colored,
+                 num_frames=12, tilt_deg=10.0)
+    g = sc.grid
+    rc, elev, _ = O.dsm_process(sc.points, g, which="loops")
+    assert rc == O.OK
+    want = O.new_layers(g)
+    want["elevation"] = elev.copy()
+    cam = sc.cam
+    nc = A.NCamera(cam.fu, cam.fv, cam.cu, cam.cv, cam.width, cam.height,
+                   distortion=cam.distortion, dist=tuple(cam.dist))
+    with A.AerialGridMap(_settings(g)) as m:
+        m.set("elevation", elev)
+        mosaic = A.OrthoBackwardGrid(nc, A.OrthoSettings(colored_ortho=colored), m)
+        for lo, hi in ((0, 7), (7, 12)):        # a batch, then another appended
+            assert O.ortho_process(g, cam, sc.poses[lo:hi], sc.T_C_B, sc.frames[lo:hi], want,
+                                   colored=colored, which="loops") == O.OK
+            mosaic.process(sc.poses[lo:hi], sc.frames[lo:hi], m)
+        got = {n: m.get(n) for n in LAYERS}
+    names = [n for n in LAYERS if n != ("ortho" if colored else "colored_ortho")]
+    if kw.get("distortion") == O.DIST_EQUIDISTANT:
+        # atan from two libms: a couple of cells may sit on a rounding boundary
+        bad = sum(int((~((got[n].view(np.uint32) == want[n].view(np.uint32)) |
+                         (np.isnan(got[n]) & np.isnan(want[n])))).sum()) for n in names)
+        assert bad <= 2 * len(names)
+    else:
+        S.assert_layers_equal(got, want, names)
+    assert (~np.isnan(want["observation_index"])).mean() > 0.3
+
+
+def test_from_pcl_equals_the_references_own_process():
+    import aerial_mapper_amd as A
+    g = O.make_grid(90.0, 70.0, 0.5, 4.0, -3.0)
+    n = 30000
+    pts = synth.make_points(n, 52.0, 93, center=(4.0, -3.0))
+    inten = ((np.arange(n) * 37) % 256).astype(np.int32)
+    rc, want = O.ortho_from_pcl(pts, inten, g, 2, False, which="loops")
+    assert rc == O.OK
+    with A.AerialGridMap(_settings(g)) as m:
+        A.OrthoFromPcl(A.OrthoFromPclSettings(interpolation_radius=2)).process(pts, inten, m)
+        got = m.get("ortho")
+    assert np.abs(got.astype(np.float64) - want.astype(np.float64)).max() <= 1e-4
