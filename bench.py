@@ -299,6 +299,18 @@ def main():
                 traffic = {k: v["bytes"] for k, v in tj["kernels"].items()}
         except Exception:
             pass
+        # what actually bounds the dominant kernel when it is not HBM: the SQ counters of the
+        # committed PMC pass (same workload only) -- share of VALU issue slots used, lanes active
+        valu = None
+        try:
+            import glob
+            import re
+            sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_cfg3_pmc_sq.json")),
+                        key=lambda f: int(re.search(r"_v(\d+)_", f).group(1)))
+            if sq and args.workload in ("cfg3", "cfg2") and not args.colored:
+                valu = (os.path.basename(sq[-1]), json.load(open(sq[-1]))["kernels"])
+        except Exception:
+            pass
         kern = {}
         for name, (ms, n) in ktimes.items():
             if n:
@@ -336,6 +348,18 @@ def main():
             "kernels": kern,
             "dsm_stats": m.dsm_stats(),
         }
+        if valu is not None:
+            prefix = {"k_dsm_gather": "k_dsm_gather_tiled<", "k_ortho_backward": "k_ortho_backward"}[dom]
+            rows = [v for k, v in valu[1].items() if k.startswith(prefix) and v.get("GRBM_GUI_ACTIVE")]
+            if rows:
+                v = max(rows, key=lambda r: r.get("SQ_INSTS_VALU", 0))
+                busy = v["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
+                out["roofline"]["valu"] = {
+                    "note": "FP64 VALU-issue bound, not HBM bound (no MFMA-shaped work on this path)",
+                    "issue_slot_frac": round(v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / busy, 3),
+                    "lanes_active_frac": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) /
+                                               max(v["SQ_INSTS_VALU"], 1.0) / 64.0, 3),
+                    "source": "profiles/" + valu[0]}
         if world == 1 and args.host_path:
             # the reference-shaped call: cloud, frames and layers in host memory
             h_pts = pts.cpu().numpy()
