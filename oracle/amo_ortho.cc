@@ -237,8 +237,10 @@ float amo_color_value_bgr(uint8_t b, uint8_t g, uint8_t r) {
 // hands on, stereo.cpp:176-181); the ROS PointCloud2 fill is out of scope.
 //   K, R_G_C  row-major 3x3;  disparity  float32 rows of disp_step BYTES;
 //   image_left 8UC1 rows of img_step bytes.  Returns the number of points.
-// PARITY UNPINNED: no reference test pins these values; Eigen's fixed-size
-// 3x3 * 3x1 product is taken as ((r0*x + r1*y) + r2*z).
+// Pinned against the reference's OWN densifier.cpp compiled unchanged against
+// oracle/refkit/ (_ref/libref_loops_densify.so; tests/test_reference_loops.py: points
+// and intensities bit for bit, raster order).  PARITY UNPINNED for the one external
+// piece: Eigen's fixed-size 3x3 * 3x1 product is taken as ((r0*x + r1*y) + r2*z).
 // ---------------------------------------------------------------------------
 extern "C" long amo_densify(const float* disparity, size_t disp_step, const uint8_t* image_left,
                             size_t img_step, int width, int height, const double* K,

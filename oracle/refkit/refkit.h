@@ -3,12 +3,12 @@
  *
  * Build kit for compiling the reference's OWN translation units of the hot path --
  * aerial_mapper_dsm/src/dsm.cc, aerial_mapper_ortho/src/ortho-backward-grid.cc,
- * aerial_mapper_ortho/src/ortho-from-pcl.cc, aerial_mapper_grid_map/src/aerial-mapper-grid-map.cc
- * (+ aerial_mapper_utils/src/utils-common.cc) --
+ * aerial_mapper_ortho/src/ortho-from-pcl.cc, aerial_mapper_grid_map/src/aerial-mapper-grid-map.cc,
+ * aerial_mapper_dense_pcl/src/densifier.cpp (+ aerial_mapper_utils/src/utils-common.cc) --
  * UNCHANGED, from where they lie under /root/reference, into oracle/_ref/ (oracle/Makefile,
  * target `loops`).  Those files need Eigen, glog, ROS, grid_map, aslam_cv2, minkindr and
  * OpenCV, none of which is in /root/reference or in this image; this directory holds
- * minimal stand-ins with the names the three files mention, found by the compiler
+ * minimal stand-ins with the names those files mention, found by the compiler
  * under the externals' own include paths (<Eigen/Dense>, <glog/logging.h>, ...).
  *
  * What that pins and what it does not:
@@ -21,8 +21,9 @@
  *               initial values -- compiled from the reference's source.
  *   NOT pinned  the arithmetic INSIDE the externals' calls (GridMap::getPosition,
  *               QuatTransformation::inverse/transform/operator*, Camera::project3,
- *               colorVectorToValue): the stand-ins forward to the same formulas the
- *               restated oracle adopts (amo_compat.h).
+ *               colorVectorToValue, Eigen's 3x3 * 3x1 product in the densifier): the
+ *               stand-ins forward to / repeat the same formulas the restated oracle adopts
+ *               (amo_compat.h).
  * The stand-ins are written for this purpose only; nothing is copied from the
  * libraries they stand in for.
  */

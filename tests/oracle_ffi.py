@@ -126,7 +126,7 @@ def have_ref():
 # ---- the reference's OWN loops (oracle/_ref/libref_loops_*.so: dsm.cc, ortho-backward-grid.cc,
 # ortho-from-pcl.cc compiled unchanged against oracle/refkit/; `which="loops"` below) ----------
 LOOPS_SO = {name: os.path.join(ORACLE_DIR, "_ref", "libref_loops_%s.so" % name)
-            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map")}
+            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map", "densify")}
 _loops_libs = {}
 
 
@@ -150,6 +150,11 @@ def _loops(name):
                 C.POINTER(Grid), C.POINTER(Camera), f64p, f64p, C.POINTER(C.c_void_p),
                 C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_int, C.c_int,
                 f32p, f32p, f32p, f32p, f32p, f32p, f64p]
+        elif name == "densify":
+            so.amr_densify.restype = C.c_long
+            so.amr_densify.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_int,
+                                       C.c_int, f64p, C.c_double, f64p, f64p, f64p,
+                                       C.POINTER(C.c_int32)]
         elif name == "grid_map":
             so.amr_grid_map_initialize.restype = C.c_int
             so.amr_grid_map_initialize.argtypes = [C.c_double] * 5 + [C.POINTER(Grid),
@@ -265,7 +270,8 @@ def densify(disparity, image_left, K, baseline, R_G_C, t_G_C1, which="port"):
     t = np.ascontiguousarray(t_G_C1, np.float64).reshape(3)
     xyz = np.empty((h * w, 3), np.float64)
     inten = np.empty(h * w, np.int32)
-    n = lib(which).amo_densify(_f32(disp), disp.strides[0], img.ctypes.data_as(C.POINTER(C.c_uint8)),
+    fn = _loops("densify").amr_densify if which == "loops" else lib(which).amo_densify
+    n = fn(_f32(disp), disp.strides[0], img.ctypes.data_as(C.POINTER(C.c_uint8)),
                                img.strides[0], w, h, _f64(K), float(baseline), _f64(R), _f64(t),
                                _f64(xyz), inten.ctypes.data_as(C.POINTER(C.c_int32)))
     return xyz[:n].copy(), inten[:n].copy()

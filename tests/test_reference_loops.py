@@ -183,3 +183,28 @@ def test_map_creation_is_the_references(ce, cn, de, dn, res):
     want = O.new_layers(g)
     for name in O.LAYER_ORDER:
         assert G.bits_equal(layers[name], want[name]).all(), name
+
+
+@pytest.mark.parametrize("h,w,seed", [(48, 64, 1), (480, 752, 2), (333, 1021, 3)])
+def test_densifier_restatement_equals_the_reference_loop(h, w, seed):
+    """stereo::Densifier::computePointCloud (densifier.cpp:25-108, compiled unchanged): the
+    points it pushes and their intensities, in raster order."""
+    rng = np.random.default_rng(seed)
+    disp = rng.uniform(0.0, 80.0, (h, w)).astype(np.float32)
+    disp[rng.random((h, w)) < 0.2] = rng.choice(np.array([0.0, 1.0, -1.0, 0.5], np.float32))
+    disp[1, 2] = np.inf                       # 1/inf -> w = inf -> a point at t_G_C1, kept
+    disp[2, 3] = 1e-30 + 1.0000001            # just above kMaxInvalidDisparity
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    K = np.array([[520.0, 0, (w - 1) / 2.0], [0, 531.0, (h - 1) / 2.0], [0, 0, 1]])
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    qw, qx, qy, qz = q
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    t = np.array([12.5, -40.0, 430.0])
+    a_p, a_i = O.densify(disp, img, K, 0.83, R, t)
+    b_p, b_i = O.densify(disp, img, K, 0.83, R, t, which="loops")
+    assert a_p.shape == b_p.shape and a_p.shape[0] > 0.5 * h * w
+    assert np.array_equal(a_p.view(np.uint64), b_p.view(np.uint64))
+    assert np.array_equal(a_i, b_i)
