@@ -10,8 +10,9 @@
 #include <vector>
 
 #include <Eigen/Core>
+#include <glog/logging.h>  // (the real aslam headers bring glog in; the reference relies on it)
 
-#include "../../../amo_compat.h"
+#include "../../../amo_cvlike.h"
 
 namespace kindr {
 namespace minimal {
@@ -31,6 +32,15 @@ class QuatTransformation {
   }
   QuatTransformation operator*(const QuatTransformation& rhs) const {
     return QuatTransformation(amo::compose(p_, rhs.p_));
+  }
+  Eigen::Vector3d getPosition() const { return Eigen::Vector3d(p_.t.x, p_.t.y, p_.t.z); }
+  Eigen::Matrix3d getRotationMatrix() const {
+    double R[9];
+    amo::rotation_matrix(p_.q, R);
+    Eigen::Matrix3d m;
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) m(i, j) = R[3 * i + j];
+    return m;
   }
   const amo::Pose& pose() const { return p_; }
 
@@ -68,8 +78,17 @@ class Camera {
     const amo::ProjectionStatus st = amo::project3(c_, p, &(*keypoint)(0), &(*keypoint)(1));
     return ProjectionResult(static_cast<ProjectionResult::Status>(st));
   }
+  // PinholeCamera::backProject3: the ray of a pixel, z = 1 (distortion undone)
+  bool backProject3(const Eigen::Vector2d& keypoint, Eigen::Vector3d* ray) const {
+    double rx = (keypoint(0) - c_.cu) / c_.fu;
+    double ry = (keypoint(1) - c_.cv) / c_.fv;
+    amo::undistort_normalized(c_, &rx, &ry);
+    *ray = Eigen::Vector3d(rx, ry, 1.0);
+    return true;
+  }
   uint32_t imageWidth() const { return static_cast<uint32_t>(c_.width); }
   uint32_t imageHeight() const { return static_cast<uint32_t>(c_.height); }
+  const amo_camera& parameters() const { return c_; }
 
  private:
   amo_camera c_;
@@ -78,12 +97,14 @@ class Camera {
 class NCamera {
  public:
   typedef std::shared_ptr<NCamera> Ptr;
-  NCamera(const amo_camera& camera, const Transformation& T_C_B) : camera_(camera), T_C_B_(T_C_B) {}
-  const Camera& getCamera(size_t) const { return camera_; }
+  NCamera(const amo_camera& camera, const Transformation& T_C_B)
+      : camera_(new Camera(camera)), T_C_B_(T_C_B) {}
+  const Camera& getCamera(size_t) const { return *camera_; }
+  std::shared_ptr<const Camera> getCameraShared(size_t) const { return camera_; }
   const Transformation& get_T_C_B(size_t) const { return T_C_B_; }
 
  private:
-  Camera camera_;
+  std::shared_ptr<Camera> camera_;
   Transformation T_C_B_;
 };
 

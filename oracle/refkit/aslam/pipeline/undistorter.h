@@ -1,2 +1,2 @@
-// oracle/refkit: the three reference files include this header but use nothing from it on
-// the hot path (see refkit.h).  TEST INFRASTRUCTURE ONLY.
+// oracle/refkit: see aslam/pipeline/undistorter-mapped.h.  TEST INFRASTRUCTURE ONLY.
+#include <aslam/pipeline/undistorter-mapped.h>

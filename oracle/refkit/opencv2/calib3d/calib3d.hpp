@@ -8,9 +8,6 @@
 
 namespace cv {
 
-template <typename T>
-using Ptr = std::shared_ptr<T>;
-
 struct StereoBM {
   static Ptr<StereoBM> create(int, int) { return Ptr<StereoBM>(new StereoBM()); }
   void setMinDisparity(int) {}

@@ -4,7 +4,8 @@
  * Build kit for compiling the reference's OWN translation units of the hot path --
  * aerial_mapper_dsm/src/dsm.cc, aerial_mapper_ortho/src/ortho-backward-grid.cc,
  * aerial_mapper_ortho/src/ortho-from-pcl.cc, aerial_mapper_grid_map/src/aerial-mapper-grid-map.cc,
- * aerial_mapper_dense_pcl/src/densifier.cpp (+ aerial_mapper_utils/src/utils-common.cc) --
+ * aerial_mapper_dense_pcl/src/densifier.cpp, aerial_mapper_ortho/src/ortho-forward-homography.cc
+ * (+ aerial_mapper_utils/src/utils-common.cc) --
  * UNCHANGED, from where they lie under /root/reference, into oracle/_ref/ (oracle/Makefile,
  * target `loops`).  Those files need Eigen, glog, ROS, grid_map, aslam_cv2, minkindr and
  * OpenCV, none of which is in /root/reference or in this image; this directory holds
@@ -21,7 +22,10 @@
  *               initial values -- compiled from the reference's source.
  *   NOT pinned  the arithmetic INSIDE the externals' calls (GridMap::getPosition,
  *               QuatTransformation::inverse/transform/operator*, Camera::project3,
- *               colorVectorToValue, Eigen's 3x3 * 3x1 product in the densifier): the
+ *               colorVectorToValue, Eigen's 3x3 * 3x1 product in the densifier, and every
+ *               OpenCV / aslam operation of the forward mosaic -- getPerspectiveTransform,
+ *               warpPerspective, cvtColor, the feather blender, the mapped undistorter,
+ *               backProject3, see amo_cvlike.h): the
  *               stand-ins forward to / repeat the same formulas the restated oracle adopts
  *               (amo_compat.h).
  * The stand-ins are written for this purpose only; nothing is copied from the

@@ -5,6 +5,8 @@
 #define ORACLE_REFKIT_ROS_ROS_H_
 
 #include <chrono>
+#include <iomanip>  // (the reference's files rely on ROS / OpenCV bringing these in)
+#include <sstream>
 #include <cstdint>
 #include <ostream>
 #include <string>

@@ -126,7 +126,7 @@ def have_ref():
 # ---- the reference's OWN loops (oracle/_ref/libref_loops_*.so: dsm.cc, ortho-backward-grid.cc,
 # ortho-from-pcl.cc compiled unchanged against oracle/refkit/; `which="loops"` below) ----------
 LOOPS_SO = {name: os.path.join(ORACLE_DIR, "_ref", "libref_loops_%s.so" % name)
-            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map", "densify")}
+            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map", "densify", "forward")}
 _loops_libs = {}
 
 
@@ -150,6 +150,17 @@ def _loops(name):
                 C.POINTER(Grid), C.POINTER(Camera), f64p, f64p, C.POINTER(C.c_void_p),
                 C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_int, C.c_int,
                 f32p, f32p, f32p, f32p, f32p, f32p, f64p]
+        elif name == "forward":
+            so.amr_fwd_create.restype = C.c_void_p
+            so.amr_fwd_create.argtypes = [C.POINTER(Camera), C.POINTER(MosaicDesc), f64p]
+            so.amr_fwd_destroy.restype = None
+            so.amr_fwd_destroy.argtypes = [C.c_void_p]
+            so.amr_fwd_batch.restype = C.c_int
+            so.amr_fwd_batch.argtypes = [C.c_void_p, f64p, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_size_t), C.c_int, C.c_size_t, C.c_void_p]
+            so.amr_fwd_update.restype = C.c_int
+            so.amr_fwd_update.argtypes = [C.c_void_p, f64p, C.c_void_p, C.c_size_t, C.c_int,
+                                          C.c_void_p]
         elif name == "densify":
             so.amr_densify.restype = C.c_long
             so.amr_densify.argtypes = [f32p, C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_int,
@@ -409,6 +420,45 @@ class ForwardMosaic(object):
                                        C.c_void_p(image.ctypes.data), image.strides[0], ch,
                                        C.c_void_p(self.result.ctypes.data),
                                        C.c_void_p(self.mask.ctypes.data))
+
+
+class ReferenceForwardMosaic(object):
+    """The reference's own ortho::OrthoForwardHomography (ortho-forward-homography.cc compiled
+    unchanged against oracle/refkit/).  The class keeps its mosaic private: `result` is what
+    it hands to cv::imwrite (no mask)."""
+
+    def __init__(self, cam, desc, T_C_B=(0, 0, 0, 1, 0, 0, 0)):
+        self.lib = _loops("forward")
+        T = np.ascontiguousarray(T_C_B, np.float64).reshape(7)
+        self.h = self.lib.amr_fwd_create(C.byref(cam), C.byref(desc), _f64(T))
+        assert self.h
+        self.result = np.zeros((desc.height_mosaic_pixels, desc.width_mosaic_pixels, 3), np.int16)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.amr_fwd_destroy(self.h)
+            self.h = None
+
+    def batch(self, T_G_B, images):
+        T_G_B = np.ascontiguousarray(T_G_B, np.float64).reshape(-1, 7)
+        F = T_G_B.shape[0]
+        assert len(images) == F
+        ch = 3 if (F and images[0].ndim == 3) else 1
+        ptrs = (C.c_void_p * max(F, 1))()
+        steps = (C.c_size_t * max(F, 1))()
+        for k, im in enumerate(images):
+            assert im.dtype == np.uint8 and im.strides[-1] == 1
+            ptrs[k] = im.ctypes.data
+            steps[k] = im.strides[0]
+        return self.lib.amr_fwd_batch(self.h, _f64(T_G_B), ptrs, steps, ch, F,
+                                      C.c_void_p(self.result.ctypes.data))
+
+    def update(self, T_G_B7, image):
+        T = np.ascontiguousarray(T_G_B7, np.float64).reshape(7)
+        ch = 3 if image.ndim == 3 else 1
+        assert image.dtype == np.uint8 and image.strides[-1] == 1
+        return self.lib.amr_fwd_update(self.h, _f64(T), C.c_void_p(image.ctypes.data),
+                                       image.strides[0], ch, C.c_void_p(self.result.ctypes.data))
 
 
 def io_load_point_cloud(text, with_intensities=True, which="port"):

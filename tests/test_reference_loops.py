@@ -208,3 +208,53 @@ def test_densifier_restatement_equals_the_reference_loop(h, w, seed):
     assert a_p.shape == b_p.shape and a_p.shape[0] > 0.5 * h * w
     assert np.array_equal(a_p.view(np.uint64), b_p.view(np.uint64))
     assert np.array_equal(a_i, b_i)
+
+
+# ---------------------------------------------------------------------------
+# ortho::OrthoForwardHomography: the reference's own ortho-forward-homography.cc over the
+# oracle's restatements of the OpenCV / aslam operations it calls
+# ---------------------------------------------------------------------------
+def _mosaic_of(d):
+    m = d["mosaic"]
+    return O.mosaic_desc(int(m[0]), int(m[1]), float(m[2]), [float(v) for v in m[3:6]])
+
+
+@pytest.mark.parametrize("name", G.names("fwd"))
+def test_reference_forward_mosaic_reproduces_golden(name):
+    d = G.load(name)
+    fm = O.ReferenceForwardMosaic(G.camera_of(d), _mosaic_of(d), d["T_C_B"])
+    frames = d["frames"]
+    if bool(d["incremental"]):
+        sums = []
+        for k in range(frames.shape[0]):
+            assert fm.update(d["T_G_B"][k], frames[k]) == O.OK
+            sums.append(int(fm.result.astype(np.int64).sum()))
+        assert sums == [int(v) for v in d["step_checksums"]]
+    else:
+        assert fm.batch(d["T_G_B"], [f for f in frames]) == O.OK
+    assert np.array_equal(fm.result, d["result"])
+
+
+@pytest.mark.parametrize("colored", [False, True])
+@pytest.mark.parametrize("incremental", [False, True])
+def test_forward_restatement_equals_the_reference_flow(incremental, colored):
+    rng = np.random.default_rng(21 + 2 * int(incremental) + int(colored))
+    cam = S.camera(96, 54, 70.0)
+    desc = O.mosaic_desc(180, 140, 400.0, (2.0, -3.0, 0.0))      # width != height: batch()'s offset quirk
+    T_C_B = np.array([0.2, -0.1, 0.05, 0.9987502603949663, 0.0, 0.049979169270678331, 0.0])
+    poses = synth.make_lawnmower_poses(7, 30.0, 470.0, 5, tilt_deg=8.0)
+    shape = (54, 96, 3) if colored else (54, 96)
+    frames = [rng.integers(0, 256, shape, dtype=np.uint8) for _ in range(7)]
+    frames[2][10:20, 30:50] = 0                                  # zero pixels are "unobserved"
+    a = O.ForwardMosaic(cam, desc, T_C_B)
+    b = O.ReferenceForwardMosaic(cam, desc, T_C_B)
+    if incremental:
+        for k in range(7):
+            assert a.update(poses[k], frames[k]) == O.OK
+            assert b.update(poses[k], frames[k]) == O.OK
+            assert np.array_equal(a.result, b.result), k
+    else:
+        assert a.batch(poses, frames) == O.OK
+        assert b.batch(poses, frames) == O.OK
+        assert np.array_equal(a.result, b.result)
+    assert (a.result != 0).mean() > 0.05
