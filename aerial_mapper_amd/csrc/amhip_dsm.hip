@@ -814,6 +814,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             bool fill_untouched, float init_value, unsigned long long* zrange,
             const SortSplit* split) {
   const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value};
+  // any other sort on this context overwrites the histogram rows a pending
+  // amhip_dsm_tiled_begin_dev left behind: its finish call then fails instead of mis-binning
+  if (!split) c->tiled_pending = false;
   {
     const int rc = dsm_sort(c, dev_xyz, dev_values, n, p, zrange, split);
     if (rc) return rc;

@@ -258,8 +258,8 @@ int amhip_halo_select_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
  *      Dsm::process on all n_total rows; the ELEVATION layer is as after
  *      amhip_dsm_process_dev(dev_xyz, n_total).
  * Both asynchronous on the context's stream; dev_xyz must stay valid and rows [0, n_owned)
- * unchanged in between; any other DSM call on the context in between is an error the
- * library does not detect. */
+ * unchanged in between.  Any other DSM / OrthoFromPcl call on the context in between cancels
+ * the pending call: amhip_dsm_tiled_finish_dev then returns AMHIP_ERR_ARG. */
 int amhip_dsm_tiled_begin_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n_owned,
                               size_t n_total, int radius_sq, double center_easting,
                               double center_northing, const int32_t* dest_windows, int nd,

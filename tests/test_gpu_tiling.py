@@ -271,5 +271,17 @@ def test_tiled_dsm_reports_halo_overflow():
         t = tiling.TiledDsm(A.DsmSettings(), m, layout, 0, cap, comm=_Alone())
         with pytest.raises(RuntimeError, match="halo rows"):
             t.process(buf, n)
-        with pytest.raises(A.AmhipError):
+        with pytest.raises(A.AmhipError):            # finish without begin
             A.hip_lib.check(A.hip_lib.load().amhip_dsm_tiled_finish_dev(m.handle))
+
+        # another DSM call between begin and finish cancels the pending one
+        class _Intruder(object):
+            def exchange_equal(self, out_rows, in_rows):
+                out_rows.fill_(float("nan"))
+                A.Dsm(A.DsmSettings(), m).process(buf[:n], m)
+
+        t = tiling.TiledDsm(A.DsmSettings(), m, layout, 0, 4096, comm=_Intruder())
+        big = torch.empty((n + 2 * 4096, 3), dtype=torch.float64, device="cuda")
+        big[:n] = buf[:n]
+        with pytest.raises(A.AmhipError):
+            t.process(big, n)
