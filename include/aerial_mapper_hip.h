@@ -245,7 +245,7 @@ int amhip_halo_select_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
                           double* dev_out, size_t cap_per_dest,
                           int64_t* dev_counts);
 
-/* The same selection folded into dsm::Dsm::process (dsm.cc:182-217) of a window, around the
+/* The same selection folded into dsm::Dsm::process (dsm.cc:186-201) of a window, around the
  * caller's exchange -- the DSM's binning pass reads every point anyway:
  *   1. amhip_dsm_tiled_begin_dev: bins the rank's own points dev_xyz[0, n_owned) and, in the
  *      same pass, copies the ones the `nd` windows in dest_windows need into dev_out /
