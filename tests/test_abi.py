@@ -126,3 +126,25 @@ def test_argument_errors_are_reported_without_a_gpu(L):
     odesc = O.mosaic_desc(200, 120, 400.0)
     rc, want = O.fwd_homography(cam, odesc, T, True)
     assert rc == O.OK and np.array_equal(M.reshape(3, 3).view(np.uint64), want.view(np.uint64))
+
+
+def test_every_entry_point_is_mapped_in_integration_md():
+    """INTEGRATION.md says for every exported function which reference lines it replaces."""
+    import re
+    from aerial_mapper_amd import hip_lib
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    # rows abbreviate families: `amhip_layer_upload/_download/_device_ptr`, `amhip_x` / `_dev`
+    missing = []
+    for name in hip_lib.EXPORTS:
+        if name in doc:
+            continue
+        parts = name.split("_")
+        found = False
+        for cut in range(2, len(parts)):
+            stem, tail = "_".join(parts[:cut]), "_" + "_".join(parts[cut:])
+            if re.search(re.escape(stem) + r"[a-z_]*`?[^|\n]*" + re.escape(tail) + r"\b", doc):
+                found = True
+                break
+        if not found:
+            missing.append(name)
+    assert not missing, missing
