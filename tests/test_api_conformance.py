@@ -1,0 +1,34 @@
+"""The drop-in's public C++ surface IS the reference's: one source full of
+static_asserts about namespaces, Settings fields, constructor and member signatures
+(tests/cpp/api_conformance.cc) is compiled against the reference's own headers (externals from
+oracle/refkit/) and against include/ of this repository.  CPU only, syntax only."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+SRC = os.path.join(ROOT, "tests", "cpp", "api_conformance.cc")
+APIS = ["API_DSM", "API_BACKWARD", "API_FROM_PCL", "API_FORWARD"]
+
+
+def _compile(includes, api):
+    cmd = ["g++", "-std=c++11", "-fsyntax-only", "-D" + api] + ["-I" + i for i in includes] + [SRC]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("api", APIS)
+def test_drop_in_headers_satisfy_the_api_statements(api):
+    _compile([os.path.join(ROOT, "include")], api)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="needs /root/reference")
+@pytest.mark.parametrize("api", APIS)
+def test_reference_headers_satisfy_the_same_statements(api):
+    inc = [os.path.join(ROOT, "oracle", "refkit"), os.path.join(ROOT, "oracle")]
+    inc += [os.path.join(REF, d, "include") for d in
+            ("aerial_mapper_utils", "aerial_mapper_thirdparty", "aerial_mapper_dsm", "aerial_mapper_ortho",
+             "aerial_mapper_io", "aerial_mapper_grid_map")]
+    _compile(inc, api)
