@@ -3,9 +3,11 @@
 
 The reference has no tests or fixtures of its own, so
 these are produced HERE by the strongest checker available in the build
-container: oracle/_ref/liboracle_ref.so = the reference's VENDORED nanoflann
-(kd-tree build + radius search, compiled from /root/reference where it lies)
-driven by the restated dsm.cc / ortho-backward-grid.cc loops.  The fixtures
+container: the reference's OWN translation units compiled unchanged from
+/root/reference against oracle/refkit/ (oracle/_ref/libref_loops_*.so), falling
+back to oracle/_ref/liboracle_ref.so = the reference's VENDORED nanoflann
+driven by the restated dsm.cc / ortho-backward-grid.cc loops (the two agree bit
+for bit, tests/test_reference_loops.py).  The fixtures
 travel to the GPU box, where /root/reference does not exist.
 tests/test_reference_loops.py checks that the reference's OWN loops (dsm.cc,
 ortho-backward-grid.cc, ortho-from-pcl.cc compiled unchanged against
@@ -30,7 +32,11 @@ import oracle_ffi as O  # noqa: E402
 import scenarios as S  # noqa: E402
 from aerial_mapper_amd import synth  # noqa: E402
 
-WHICH = "ref"
+# the checker that writes the fixtures: the reference's OWN loops (dsm.cc, ortho-backward-grid.cc,
+# ortho-from-pcl.cc, densifier.cpp, ortho-forward-homography.cc compiled unchanged against
+# oracle/refkit/) where they are built, else the vendored-nanoflann build of the restated loops
+WHICH = "loops" if O.have_loops() else "ref"
+GRID = "ref" if O.have_ref() else "port"     # (geometry helpers live in the oracle libraries)
 
 
 def grid_tuple(g):
@@ -44,7 +50,7 @@ def cam_tuple(c):
 
 def dsm_case(name, length_x, length_y, res, n, seed, radius=1, ce=0.0, cn=0.0,
              center=(0.0, 0.0), keep=None, extent=None, init=None):
-    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=WHICH)
+    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=GRID)
     half = (max(length_x, length_y) / 2.0 + 4.0) if extent is None else extent
     pts = synth.make_points(n, half, seed, center=center)
     if keep is not None:
@@ -93,12 +99,12 @@ def ortho_case(name, length_x, length_y, res, n, seed, num_frames, altitude, col
 
 def pcl_case(name, length_x, length_y, res, n, seed, radius, adaptive, extent=None,
              center=(0.0, 0.0), exact_at=None):
-    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=WHICH)
+    g = O.make_grid(length_x, length_y, res, center[0], center[1], which=GRID)
     half = (max(length_x, length_y) / 2.0 + 4.0) if extent is None else extent
     pts = synth.make_points(n, half, seed, center=center)
     inten = ((np.arange(n) * 37 + seed) % 256).astype(np.int32)
     if exact_at is not None:
-        x, y = O.cell_position(g, exact_at[0], exact_at[1], which=WHICH)
+        x, y = O.cell_position(g, exact_at[0], exact_at[1], which=GRID)
         pts[3, :2] = (x, y)
         inten[3] = 249
     rc, ortho = O.ortho_from_pcl(pts, inten, g, radius, adaptive, which=WHICH)
@@ -122,14 +128,23 @@ def fwd_case(name, cam, mosaic_wh, ground, origin, num_frames, half_extent, alti
     # smooth the hash frames a little so that zero pixels (mask holes) exist but are rare
     frames = np.ascontiguousarray(np.where(frames < 6, 0, frames).astype(np.uint8))
     T_C_B = np.array([0.02, -0.01, 0.03, 1.0, 0.0, 0.0, 0.0])
-    fm = O.ForwardMosaic(cam, desc, T_C_B, which=WHICH)
+    fm = O.ForwardMosaic(cam, desc, T_C_B, which=GRID)
+    # the reference's own flow keeps its mask private: the mosaic comes from it, the mask from
+    # the restated flow (the mosaics of the two are required to agree)
+    rf = O.ReferenceForwardMosaic(cam, desc, T_C_B) if WHICH == "loops" else None
     steps = []
     if incremental:
         for k in range(num_frames):
             assert fm.update(poses[k], frames[k]) == O.OK
+            if rf is not None:
+                assert rf.update(poses[k], frames[k]) == O.OK
+                assert np.array_equal(rf.result, fm.result)
             steps.append(fm.result.copy())
     else:
         assert fm.batch(poses, [f for f in frames]) == O.OK
+        if rf is not None:
+            assert rf.batch(poses, [f for f in frames]) == O.OK
+            assert np.array_equal(rf.result, fm.result)
     np.savez_compressed(
         os.path.join(HERE, name + ".npz"), kind="fwd", camera=cam_tuple(cam),
         mosaic=np.array([mosaic_wh[0], mosaic_wh[1], ground] + list(origin), np.float64),
@@ -138,6 +153,27 @@ def fwd_case(name, cam, mosaic_wh, ground, origin, num_frames, half_extent, alti
         step_checksums=np.array([int(s.astype(np.int64).sum()) for s in steps], np.int64))
     print("%-28s %4dx%-4d F=%d covered=%.3f" % (name, mosaic_wh[0], mosaic_wh[1], num_frames,
                                                 float((fm.mask > 0).mean())))
+
+
+def densify_case(name, h, w, seed):
+    """stereo::Densifier::computePointCloud: disparity map -> world points, raster order."""
+    rng = np.random.default_rng(seed)
+    disp = rng.uniform(0.0, 80.0, (h, w)).astype(np.float32)
+    disp[rng.random((h, w)) < 0.2] = rng.choice(np.array([0.0, 1.0, -1.0, 0.5], np.float32))
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    K = np.array([[260.0, 0, (w - 1) / 2.0], [0, 265.5, (h - 1) / 2.0], [0, 0, 1]])
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    qw, qx, qy, qz = q
+    R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                  [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                  [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+    t = np.array([12.5, -40.0, 430.0])
+    pts, inten = O.densify(disp, img, K, 0.83, R, t, which=WHICH if WHICH == "loops" else GRID)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), kind="densify", disparity=disp,
+                        image_left=img, K=K, baseline=0.83, R_G_C=R, t_G_C1=t, points=pts,
+                        intensities=inten)
+    print("%-28s %4dx%-4d points=%d" % (name, w, h, pts.shape[0]))
 
 
 def main():
@@ -171,6 +207,7 @@ def main():
     pcl_case("pcl_dense_half_metre", 30.0, 22.0, 0.5, 5000, 302, 1, False, center=(2.0, 1.0))
     pcl_case("pcl_adaptive_corner", 40.0, 30.0, 1.0, 250, 303, 2, True, extent=8.0,
              center=(-10.0, -6.0))
+    densify_case("densify_small", 60, 88, 501)
     main_fwd()
 
 

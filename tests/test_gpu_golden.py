@@ -1,5 +1,6 @@
-"""GPU: the HIP path against the committed golden fixtures (generated by the
-vendored-nanoflann oracle build in the CPU container)."""
+"""GPU: the HIP path against the committed golden fixtures (written in the CPU container by
+the reference's own translation units compiled against oracle/refkit/ -- tests/golden/
+make_golden.py)."""
 import numpy as np
 import pytest
 
@@ -57,3 +58,18 @@ def test_hip_from_pcl_matches_golden(name):
         got = m.get("ortho")
     err = np.abs(got.astype(np.float64) - d["ortho"].astype(np.float64)).max()
     assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("name", G.names("densify"))
+def test_hip_densify_matches_golden(name):
+    """The fixture was written by the reference's own densifier.cpp (tests/golden/make_golden.py)."""
+    import torch
+    import aerial_mapper_amd as A
+    d = G.load(name)
+    with A.AerialGridMap(A.GridMapSettings(0, 0, 8, 8, 1.0)) as m:
+        pts, inten = A.densify(m, torch.from_numpy(d["disparity"]).cuda(),
+                               torch.from_numpy(d["image_left"]).cuda(), d["K"], float(d["baseline"]),
+                               d["R_G_C"], d["t_G_C1"])
+        pts, inten = pts.cpu().numpy(), inten.cpu().numpy()
+    assert np.array_equal(pts.view(np.uint64), d["points"].view(np.uint64))
+    assert np.array_equal(inten, d["intensities"])

@@ -347,3 +347,12 @@ def test_kat_densify_reprojection():
         exp.append([(u - cx) * b / d + 10.0, (fx / fy * v - cy * fx / fy) * b / d + 20.0,
                     fx * b / d + 30.0])
     assert np.allclose(pts, np.array(exp), rtol=1e-15, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", G.names("densify"))
+def test_port_reproduces_golden_densify_bitwise(name):
+    d = G.load(name)
+    pts, inten = O.densify(d["disparity"], d["image_left"], d["K"], float(d["baseline"]),
+                           d["R_G_C"], d["t_G_C1"])
+    assert np.array_equal(pts.view(np.uint64), d["points"].view(np.uint64))
+    assert np.array_equal(inten, d["intensities"])

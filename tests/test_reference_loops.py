@@ -258,3 +258,12 @@ def test_forward_restatement_equals_the_reference_flow(incremental, colored):
         assert b.batch(poses, frames) == O.OK
         assert np.array_equal(a.result, b.result)
     assert (a.result != 0).mean() > 0.05
+
+
+@pytest.mark.parametrize("name", G.names("densify"))
+def test_reference_loops_reproduce_golden_densify_bitwise(name):
+    d = G.load(name)
+    pts, inten = O.densify(d["disparity"], d["image_left"], d["K"], float(d["baseline"]),
+                           d["R_G_C"], d["t_G_C1"], which="loops")
+    assert np.array_equal(pts.view(np.uint64), d["points"].view(np.uint64))
+    assert np.array_equal(inten, d["intensities"])
