@@ -337,9 +337,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     }
     if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
       kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
-      cap = kTileJ == 16 ? 1024 : 2048;
-        if (p.p3_cap > 2048) p.p3_cap = 2048;  // kP3PlaceMaxCap
-        if (p.p3_cap < 64) p.p3_cap = 64;
+      cap = (kTileJ == 16 && need(16) <= 1024.0) ? 1024 : 2048;  // (the density still picks the capacity)
     }
   }
   p.tile_j = kTileJ;
@@ -374,6 +372,31 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
                          (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;
     p.lds_bytes = static_cast<unsigned>((bytes + 15) & ~size_t(15));
     if (p.lds_bytes > 150 * 1024) p.lds_ok = 0;
+  }
+  // ---- single-precision gather with exact guards (amhip_dsm.hip: k_dsm_gather_f32) ----
+  // Only for dsm::Dsm (heights): OrthoFromPcl interpolates 8-bit intensities whose spread
+  // (up to 255) leaves no room under the error bound.
+  p.fx_ok = 0;
+  if (p.lds_ok && mode == 0 && !c.dsm_exact) {
+    int S = 28;
+    while (((long long)(w0 + 2) << S) >= (1LL << 31)) --S;
+    const double scale2 = std::ldexp(1.0, 2 * S);
+    const double tc = p.T[0] / (g.resolution * g.resolution) * scale2;
+    // |d2_f32 - d2_reference| <= 3e-7 relative at the search radius; anything
+    // inside +-2e-6 is decided by the FP64 routine
+    const double margin = 2e-6;
+    double theta = 0.02;  // cells
+    if (std::getenv("AMHIP_FX_THETA")) theta = std::atof(std::getenv("AMHIP_FX_THETA"));
+    const double q = std::ldexp(1.0, -(S + 1));
+    p.fx_S = S;
+    p.fx_thi = static_cast<float>(tc * (1.0 + margin));
+    p.fx_tlo = static_cast<float>(tc * (1.0 - margin));
+    p.fx_denmax = static_cast<float>(1.0 / (theta * theta * scale2));
+    p.fx_epsw = static_cast<float>(2.0 * std::sqrt(2.0) * q / theta + 4e-7);
+    const size_t bytes = ((size_t)p.lds_cap + 2) * 16 + ((size_t)p.lds_cells + 1) * 4 +
+                         (96 + 97 + 24 + 8 + 4 * kMaxW0 + 4) * 4 + 64 + (size_t)kTileI * kTileJ * 2 + 64;
+    p.lds_bytes_f32 = static_cast<unsigned>((bytes + 15) & ~size_t(15));
+    p.fx_ok = 1;
   }
   *out = p;
   return AMHIP_OK;
@@ -741,6 +764,7 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
   c->win_rows = rows;
   c->win_cols = cols;
   c->cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
+  c->dsm_exact = std::getenv("AMHIP_DSM_EXACT") ? 1 : 0;
   int rc = AMHIP_OK;
   do {
     if ((rc = use_device(c))) break;
@@ -793,6 +817,13 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   if (c->host_err) (void)hipHostFree(c->host_err);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
+}
+
+int amhip_ctx_set_dsm_precision(amhip_ctx* h, int mode) {
+  if (!h) return arg_fail("null context");
+  if (mode != AMHIP_DSM_FAST && mode != AMHIP_DSM_EXACT) return arg_fail("unknown DSM precision mode");
+  h->impl.dsm_exact = mode == AMHIP_DSM_EXACT ? 1 : 0;
+  return AMHIP_OK;
 }
 
 int amhip_ctx_set_stream(amhip_ctx* h, void* hip_stream) {

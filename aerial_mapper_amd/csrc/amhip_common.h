@@ -71,6 +71,15 @@ struct DsmParams {
   int tile_j;                 // tile height in cells: 32, or 16 for dense clouds
   int tiles_i, tiles_j;
   unsigned lds_bytes;
+  // single-precision gather with exact guards (k_dsm_gather_f32): point
+  // positions as 32-bit fixed point in units of 2^-fx_S cells (wrapping: only differences of
+  // at most w0 + 2 cells are ever formed), squared distances in f32 in (2^-fx_S cells)^2
+  int fx_ok;                  // 0 -> the FP64 gather only
+  int fx_S;
+  float fx_thi, fx_tlo;       // T[0] in those units, widened / narrowed by the decision margin
+  float fx_denmax;            // a hit nearer than fx_theta cells makes the weight sum exceed this
+  float fx_epsw;              // bound on the relative error of one weight
+  unsigned lds_bytes_f32;
 };
 
 // FramePose / FrameFast (per-frame inverse pose T_C_G = T_G_C^-1): amhip_ortho_fold.h
@@ -155,6 +164,7 @@ struct Ctx {
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   size_t cells = 0;
+  int dsm_exact = 0;          // amhip_ctx_set_dsm_precision
 
   float* layers[AMHIP_NUM_LAYERS] = {nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr};

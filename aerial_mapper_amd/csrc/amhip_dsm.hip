@@ -152,8 +152,10 @@ __device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& 
   if (acc.exact) {
     if (p.pcl_mode)
       emit_value(p, o, i, j, acc.exact_z);  // ortho-from-pcl.cc:91-96 perfect match
-    else
+    else {
       atomicOr(o.dev_err, kDevErrExactHit);  // dsm.cc:165 CHECK(distances[i] > 0.0)
+      leave_untouched(p, o, i, j);           // (the reference aborts; never uninitialised memory)
+    }
     return true;
   }
   if (acc.cnt > 0) {
@@ -339,6 +341,8 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 // in LDS and finished by the fallback path on the global bins.
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
+constexpr int kListHdr = 8;         // counters in front of the tile lists
+constexpr int kNumLists = 5;
 // s_setreg operand: HW_REG_MODE (id 1), offset 6, width 2 = FP_DENORM for f64 / f16
 constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 
@@ -351,9 +355,11 @@ constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 // Clouds are not uniform (overlapping strips, partial coverage): the capacity of
 // the main launch follows the MEAN density, denser tiles go to launches with more
 // LDS per workgroup instead of falling back to the global-memory path.
-//   lists (may be null): [4 counters] then four arrays of ntiles ids:
+//   lists (may be null): [kListHdr counters] then arrays of ntiles ids:
 //     list 0  occupied class-0 tiles (only filled when `list0` -- sparse calls)
-//     list k  class-k tiles
+//     list k  class-k tiles (k = 1, 2, 3)
+//     list 4  class-0 tiles the single-precision gather hands to the FP64 kernel
+//             (filled by k_dsm_gather_f32, not here)
 __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
@@ -390,7 +396,7 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
   occ[tile] = (uint8_t)(1 + cls);
   if (lists && (cls > 0 || list0)) {
     unsigned* cnt = reinterpret_cast<unsigned*>(lists);
-    lists[4 + (size_t)cls * ntiles + atomicAdd(&cnt[cls], 1u)] = tile;  // (order is irrelevant)
+    lists[kListHdr + (size_t)cls * ntiles + atomicAdd(&cnt[cls], 1u)] = tile;  // (order is irrelevant)
   }
 }
 
@@ -734,6 +740,470 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   }
 }
 
+// ---------------------------------------------------------------------------
+// LDS-tiled gather in single precision with exact guards (dsm::Dsm only)
+// ---------------------------------------------------------------------------
+// The FP64 gather above is bound by FP64 VALU issue (5 + 4 FP64 instructions per
+// candidate test + hit).  The contract asks for the reference's neighbour SETS and
+// heights within 1e-4 m, not for its doubles, so this variant does the per-pair work
+// at the f32 rate:
+//   * staging converts a point to 32-bit fixed point in units of 2^-S cells relative
+//     to the tile region (S = 28 for a 4-cell radius; the integers wrap, only
+//     differences of <= w0 + 2 cells are formed and those are exact) and its height to
+//     an f32 offset from the middle z0 of the region's height range;
+//   * a test is  dx = cvt(Ui - U), dy = cvt(Vj - V), d2 = dx*dx + dy*dy  in f32: within
+//     3e-7 (relative) of the reference's double at the search radius.  d2 < T(1 + 2e-6)
+//     counts as a hit; a hit with d2 >= T(1 - 2e-6) marks the cell AMBIGUOUS;
+//   * a hit adds  w = v_rcp_f32(d2)  to the weight sum and  w * (z - z0)  to the
+//     numerator; the cell's height is z0 + N / D.
+// Guards (any of them sends the CELL to the FP64 routine, which decides with the
+// reference's own doubles): an ambiguous hit; a weight sum that a hit nearer than
+// fx_theta cells would produce (the fixed-point quantum 2^-(S+1) cells is then no
+// longer small against the distance; also catches exact hits: rcp(0) = inf); more
+// hits than the error bound allows for the tile's height range.  A TILE whose height
+// range leaves no room under the bound (|dh| <= 2 (eps_w + (n + 2) 2^-24) (zmax - zmin)/2
+// must stay below 1e-4 m minus one float spacing of the stored height) is appended to
+// a list and done by the FP64 kernel afterwards.  Empty first searches take the FP64
+// ladder as before, so the NaN pattern is the reference's by construction.
+__device__ __forceinline__ void wave_minmax_d(double* lo, double* hi) {
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    *lo = fmin(*lo, __shfl_xor(*lo, d, 64));
+    *hi = fmax(*hi, __shfl_xor(*hi, d, 64));
+  }
+}
+
+// One cell by a whole WAVE on the global bins, the lanes over the candidates of the
+// first-level window (FP64, reciprocal weights): the guard path of the f32 gather.
+// Same decisions as cell_global(); all 64 lanes must call it with the same cell.
+__device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32_t* __restrict__ start,
+                                                const double* __restrict__ sorted, int i, int j,
+                                                const CellOut& o) {
+  const int lane = threadIdx.x & 63;
+  const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
+  const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
+  const int w = p.w[0];
+  const double T = p.T[0];
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
+  double num = 0.0, den = 0.0;
+  unsigned exact = 0;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    for (uint32_t k = s0 + lane; k < e0; k += 64) {
+      const double dx = qx - sorted[3 * (size_t)k + 0];
+      const double dy = qy - sorted[3 * (size_t)k + 1];
+      double d2 = dx * dx;
+      d2 = d2 + dy * dy;       // L2_Adaptor (nanoflann.hpp:319-322)
+      if (d2 < T) {            // strict (nanoflann.hpp:157)
+        if (d2 > 0.0) idw_add(d2, sorted[3 * (size_t)k + 2], &num, &den);
+        else exact = 1;
+      }
+    }
+  }
+  num = wave_sum_d(num);
+  den = wave_sum_d(den);
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) exact |= __shfl_xor(exact, d, 64);
+  if (lane != 0) return;
+  if (exact || !(den > 0.0)) {
+    // exact hit (dsm.cc:165 CHECK) or an empty first search (the ladder): scalar routine
+    cell_global(p, start, sorted, i, j, o);
+    return;
+  }
+  emit_value(p, o, i, j, num / den);
+}
+
+// kVar: 0 = the product kernel; 1..3 = TIMING PROBES / A-B variants selected with
+// AMHIP_F32_VARIANT (1: candidate loop without the hit updates, 2: no candidate loop -- both
+// give wrong heights; 3: the next record is read one iteration ahead)
+template <int NT, int kTileJ, int kCap, int kVar = 0>
+__device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32_t* __restrict__ start,
+                                                const double* __restrict__ sorted,
+                                                const uint8_t* __restrict__ tile_occ, const CellOut& o,
+                                                const int tile, unsigned char* smem, int my_class,
+                                                int* __restrict__ exact_list,
+                                                unsigned* __restrict__ exact_count) {
+  constexpr int kWaves = NT / 64;
+  constexpr int kCellsPerLane = kTileJ / kWaves;
+  // [rec: cap+1 uint4 (U, V, dz, -)][cell offsets][rows][scan][ctl][z range][flags]
+  uint4* s_rec = reinterpret_cast<uint4*>(smem);
+  uint32_t* s_off = reinterpret_cast<uint32_t*>(smem + (size_t)(p.lds_cap + 2) * 16);
+  uint32_t* s_rowg = s_off + p.lds_cells + 1;
+  uint32_t* s_rowp = s_rowg + kMaxRegionRows;
+  uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;
+  uint32_t* s_ctl = s_scan + 24;  // [0] np, [1] nflag, [2..3] pad, [4..7] zmin / zmax keys
+  unsigned long long* s_zr = reinterpret_cast<unsigned long long*>(
+      (reinterpret_cast<uintptr_t>(s_ctl + 4) + 7) & ~uintptr_t(7));
+  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_zr + 2);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = tid >> 6;
+  const int ti = tile % p.tiles_i;
+  const int tj = tile / p.tiles_i;
+  const int i0 = ti * kTileI;
+  const int j0 = tj * kTileJ;
+  const int i_hi = min(i0 + kTileI, p.rows) - 1;
+  const int j_hi = min(j0 + kTileJ, p.cols) - 1;
+  const int w0 = p.w[0];
+
+  const int occ = tile_occ[tile];
+  if (my_class >= 0 && occ != 0 && occ - 1 != my_class) return;
+  if (occ == 0) {
+    if (o.unfilled && tid == 0)
+      atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
+    if (o.fill_untouched) {
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
+        if (i <= i_hi && j <= j_hi) leave_untouched(p, o, i, j);
+      }
+    }
+    return;
+  }
+
+  const int rbx0 = (i0 - w0 + p.M) / p.B;
+  const int rbx1 = (i_hi + w0 + p.M) / p.B;
+  const int rby0 = (j0 - w0 + p.M) / p.B;
+  const int rby1 = (j_hi + w0 + p.M) / p.B;
+  const int nrb = rby1 - rby0 + 1;
+  const int RW = (rbx1 - rbx0 + 1) * p.B;
+  const int RH = nrb * p.B;
+  const int sh = (j0 - w0 + p.M - (rby0 * p.B)) & 1;
+  const int RW2 = 2 * RW;
+  const int ncell = (RH / 2 + 2) * RW2;
+  const int ox = rbx0 * p.B;
+  const int oy = rby0 * p.B;
+
+  const bool geom_ok = nrb <= kMaxRegionRows && ncell <= p.lds_cells;
+  if (geom_ok && tid < nrb) {
+    const uint32_t* row = start + (size_t)(rby0 + tid) * p.nbx;
+    const uint32_t gs = row[rbx0];
+    s_rowg[tid] = gs;
+    s_rowp[tid + 1] = row[rbx1 + 1] - gs;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    s_rowp[0] = 0;
+    if (geom_ok) {
+      for (int r = 0; r < nrb; ++r) {
+        run += s_rowp[r + 1];
+        s_rowp[r + 1] = run;
+      }
+    }
+    s_ctl[0] = run;
+    s_ctl[1] = 0;
+    s_zr[0] = kOrderedPlusInf;   // running min (ordered keys)
+    s_zr[1] = kOrderedMinusInf;  // running max
+  }
+  __syncthreads();
+  const int np = (int)s_ctl[0];
+  if (!(geom_ok && np <= p.lds_cap)) {
+    // (cannot happen for the class this launch serves; kept for safety) FP64 global path
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
+      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
+    }
+    return;
+  }
+
+  // ---- stage: load, count per cell, height range -------------------------------
+  for (int k = tid; k <= ncell; k += NT) s_off[k] = 0;
+  __syncthreads();
+  static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
+  constexpr int kMaxK = (kCap + NT - 1) / NT;
+  uint32_t pslot[kMaxK];
+  uint32_t pU[kMaxK], pV[kMaxK];
+  double ppz[kMaxK];
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
+  const double fx_scale = (double)(1u << p.fx_S);
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    const int idx = tid + k * NT;
+    pslot[k] = 0xFFFFFFFFu;
+    if (idx < np) {
+      int r = 0;
+      while (idx >= (int)s_rowp[r + 1]) ++r;
+      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
+      const double px = sorted[3 * g + 0];
+      const double py = sorted[3 * g + 1];
+      const double pz = sorted[3 * g + 2];
+      ppz[k] = pz;
+      zlo = fmin(zlo, pz);
+      zhi = fmax(zhi, pz);
+      // the point's cell (same arithmetic as point_bin()) and its offset from that
+      // cell's centre, in cells
+      const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+      const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+      int ix = (int)floor(cx + 0.5) + p.M;
+      int iy = (int)floor(cy + 0.5) + p.M;
+      ix = min(max(ix, 0), p.rows + 2 * p.M - 1) - ox;
+      iy = min(max(iy, 0), p.cols + 2 * p.M - 1) - oy;
+      ix = min(max(ix, 0), RW - 1);
+      iy = min(max(iy, 0), RH - 1);
+      const double fx = (cx + (double)(p.M - ox)) - (double)ix;  // in [-0.5, 0.5]
+      const double fy = (cy + (double)(p.M - oy)) - (double)iy;
+      pU[k] = ((uint32_t)ix << p.fx_S) + (uint32_t)(int)rint(fx * fx_scale);
+      pV[k] = ((uint32_t)iy << p.fx_S) + (uint32_t)(int)rint(fy * fx_scale);
+      iy += sh;
+      const uint32_t cell = (uint32_t)((iy >> 1) * RW2 + 2 * ix + (iy & 1));
+      pslot[k] = (cell << 13) | atomicAdd(&s_off[cell], 1u);
+    }
+  }
+  if (kVar == 6) return;
+  wave_minmax_d(&zlo, &zhi);
+  if (lane == 0 && zlo <= zhi) {
+    atomicMin(&s_zr[0], ordered_key(zlo));
+    atomicMax(&s_zr[1], ordered_key(zhi));
+  }
+  __syncthreads();
+  {
+    const int per = (ncell + NT - 1) / NT;
+    const int lo = tid * per;
+    const int hi = min(lo + per, ncell);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_off[k];
+    unsigned total;
+    unsigned run = block_excl_scan<NT>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_off[k];
+      s_off[k] = run;
+      run += t;
+    }
+    if (tid == 0) s_off[ncell] = total;
+  }
+  __syncthreads();
+  // ---- the tile's error budget ------------------------------------------------------
+  //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24, n = hits
+  //   accumulated between two flushes of the running sums (a trip's, plus one add per trip)
+  const double zmin = np ? from_ordered_key(s_zr[0]) : 0.0;
+  const double zmax = np ? from_ordered_key(s_zr[1]) : 0.0;
+  const double z0 = 0.5 * zmin + 0.5 * zmax;
+  const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f;
+  int n_allowed;
+  {
+    const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
+    // spacing of the stored floats at that height
+    const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+    // north_star: 1e-4 m; above 1024 m one float spacing is already more than that:
+    // there "1 LSB" is the bar, and a quarter of a spacing the budget
+    const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
+    if (!(S_half <= 3.0e38f)) n_allowed = -1;
+    else if (S_half == 0.0f) n_allowed = 1 << 20;
+    else {
+      const float room = (0.5f * allowed / S_half - p.fx_epsw) * 16777216.0f - 2.0f;
+      n_allowed = room > 1.0e6f ? (1 << 20) : (int)room;
+    }
+  }
+  // (a trip of a dense tile brings up to ~20 candidates: below that the FP64 kernel takes
+  // the whole tile -- staging it twice is cheaper than redoing most of its cells)
+  if (n_allowed < 48) {
+    if (tid == 0) exact_list[atomicAdd(exact_count, 1u)] = tile;
+    return;
+  }
+  // pass 2: drop the points into their sorted slot
+#pragma unroll
+  for (int k = 0; k < kMaxK; ++k) {
+    if (pslot[k] != 0xFFFFFFFFu) {
+      const uint32_t pos = s_off[pslot[k] >> 13] + (pslot[k] & 0x1FFFu);
+      s_rec[pos] = make_uint4(pU[k], pV[k], __float_as_uint((float)(ppz[k] - z0)), 0u);
+    }
+  }
+  __syncthreads();
+
+  if (kVar == 5) return;
+  // ---- gather -------------------------------------------------------------------
+  const int i = i0 + lane;
+  const float thi = p.fx_thi, tlo = p.fx_tlo;
+  const float one_cell = (float)(1u << p.fx_S);
+  if (i <= i_hi) {
+    const int ci = i + p.M - ox;
+    const uint32_t Ui = (uint32_t)ci << p.fx_S;
+    for (int c = 0; c < kCellsPerLane; c += 2) {
+      const int jA = j0 + wid * kCellsPerLane + c;
+      if (jA > j_hi) break;
+      const bool haveB = (jA + 1 <= j_hi) && (c + 1 < kCellsPerLane);
+      const float thiB = haveB ? thi : -1.0f;
+      const int cj = jA + p.M - oy;
+      const uint32_t VjA = (uint32_t)cj << p.fx_S;
+      float NA = 0.f, DA = 0.f, NB = 0.f, DB = 0.f;      // totals
+      float mA = 0.f, mB = 0.f;                          // largest d2 among the hits
+      int nmax = 0;                                      // most candidates of one trip
+      const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * RW2 + 2 * ci;
+      for (int r = 0; r <= w0; ++r) {
+        const int w = p.wrp[r];
+        const uint32_t kb = orow[-2 * w];
+        const uint32_t ke = orow[2 * w + 2];
+        orow += RW2;
+        nmax = max(nmax, (int)(ke - kb));
+        float nA = 0.f, dA = 0.f, nB = 0.f, dB = 0.f;  // this trip's sums
+        // One candidate = 18 f32-rate VALU instructions for the two cells: exact integer
+        // differences, conversions, d2 for A and B, and per cell the hit update under the
+        // EXEC mask of the test (v_cmpx): w = rcp(d2); m = max(m, d2); d += w; n += w dz.
+        // (Left to the compiler the two hits become 8 selects + 2 canonicalising max.)
+        // v_max sits between v_rcp and the first use of its result: gfx950 needs one
+        // wait state after a transcendental.
+        const uint4* pr = s_rec + kb;
+        const uint4* const pe = s_rec + (kVar == 2 ? kb : ke);
+        auto cand = [&](const uint4 rec) __attribute__((always_inline)) {
+          if (kVar == 1) {
+            float t0, t1, t3;
+            asm volatile(
+                "v_sub_u32 %[t0], %[Ui], %[x]\n\t"
+                "v_sub_u32 %[t1], %[Vj], %[y]\n\t"
+                "v_cvt_f32_i32 %[t0], %[t0]\n\t"
+                "v_cvt_f32_i32 %[t1], %[t1]\n\t"
+                "v_mul_f32 %[t0], %[t0], %[t0]\n\t"
+                "v_add_f32 %[t3], %[one], %[t1]\n\t"
+                "v_fma_f32 %[t1], %[t1], %[t1], %[t0]\n\t"
+                "v_fma_f32 %[t3], %[t3], %[t3], %[t0]\n\t"
+                "v_max_f32 %[mA], %[mA], %[t1]\n\t"
+                "v_max_f32 %[mB], %[mB], %[t3]"
+                : [t0] "=&v"(t0), [t1] "=&v"(t1), [t3] "=&v"(t3), [mA] "+v"(nA), [mB] "+v"(nB)
+                : [Ui] "v"(Ui), [Vj] "v"(VjA), [x] "v"(rec.x), [y] "v"(rec.y), [z] "v"(rec.z),
+                  [pad] "v"(rec.w), [one] "v"(one_cell));
+            dA = 1.f;
+            dB = 1.f;
+            return;
+          }
+          float t0, t1, t3;
+          unsigned long long sv;
+          asm volatile(
+              "v_sub_u32 %[t0], %[Ui], %[x]\n\t"
+              "v_sub_u32 %[t1], %[Vj], %[y]\n\t"
+              "v_cvt_f32_i32 %[t0], %[t0]\n\t"
+              "v_cvt_f32_i32 %[t1], %[t1]\n\t"
+              "v_mul_f32 %[t0], %[t0], %[t0]\n\t"
+              "v_add_f32 %[t3], %[one], %[t1]\n\t"
+              "v_fma_f32 %[t1], %[t1], %[t1], %[t0]\n\t"
+              "v_fma_f32 %[t3], %[t3], %[t3], %[t0]\n\t"
+              "s_mov_b64 %[sv], exec\n\t"
+              "v_cmpx_gt_f32 %[thi], %[t1]\n\t"
+              "v_rcp_f32 %[t0], %[t1]\n\t"
+              "v_max_f32 %[mA], %[mA], %[t1]\n\t"
+              "v_add_f32 %[dA], %[dA], %[t0]\n\t"
+              "v_fmac_f32 %[nA], %[t0], %[z]\n\t"
+              "s_mov_b64 exec, %[sv]\n\t"
+              "v_cmpx_gt_f32 %[thiB], %[t3]\n\t"
+              "v_rcp_f32 %[t0], %[t3]\n\t"
+              "v_max_f32 %[mB], %[mB], %[t3]\n\t"
+              "v_add_f32 %[dB], %[dB], %[t0]\n\t"
+              "v_fmac_f32 %[nB], %[t0], %[z]\n\t"
+              "s_mov_b64 exec, %[sv]"
+              : [t0] "=&v"(t0), [t1] "=&v"(t1), [t3] "=&v"(t3), [sv] "=&s"(sv), [mA] "+v"(mA),
+                [mB] "+v"(mB), [nA] "+v"(nA), [dA] "+v"(dA), [nB] "+v"(nB), [dB] "+v"(dB)
+              : [Ui] "v"(Ui), [Vj] "v"(VjA), [x] "v"(rec.x), [y] "v"(rec.y), [z] "v"(rec.z),
+                [pad] "v"(rec.w), [one] "v"(one_cell), [thi] "v"(thi), [thiB] "v"(thiB)
+              : "vcc");
+        };
+        if (kVar == 3) {
+          uint4 nxt = *pr;  // (s_rec[ke] exists: the array has cap + 2 entries)
+          for (; pr < pe;) {
+            const uint4 rec = nxt;
+            ++pr;
+            nxt = *pr;
+            cand(rec);
+          }
+        } else if (kVar == 4) {
+          for (; pr + 1 < pe; pr += 2) {
+            const uint4 r0 = pr[0], r1 = pr[1];
+            cand(r0);
+            cand(r1);
+          }
+          if (pr < pe) cand(*pr);
+        } else {
+          for (; pr < pe; ++pr) cand(*pr);
+        }
+        if (kVar == 2) dA = dB = 1.f;
+        NA += nA;
+        DA += dA;
+        NB += nB;
+        DB += dB;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1 && !haveB) break;
+        const float Nn = h ? NB : NA, Dd = h ? DB : DA, mm = h ? mB : mA;
+        const int jj = jA + h;
+        int queue = 0;  // 1: no first-level neighbour (ladder), 2: redo the cell in FP64
+        if (Dd > 0.0f) {
+          // (NaN / inf sums fail the first comparison)
+          if (kVar != 1 && kVar != 2 &&
+              (!(Dd < p.fx_denmax) || mm >= tlo || nmax + w0 + 1 > n_allowed)) queue = 2;
+          else emit_value(p, o, i, jj, z0 + (double)(Nn * __builtin_amdgcn_rcpf(Dd)));
+        } else if (Dd == 0.0f) {
+          queue = 1;
+        } else {
+          queue = 2;
+        }
+        if (queue) {
+          const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
+          s_flag[slot] = (uint16_t)(((wid * kCellsPerLane + c + h) * kTileI + lane) |
+                                    (queue == 2 ? 0x8000 : 0));
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- queued cells: the ladder lane-parallel, the FP64 redos wave by wave ----------
+  const int nflag = (int)s_ctl[1];
+  for (int f = tid; f < nflag; f += NT) {
+    if (s_flag[f] & 0x8000) continue;
+    const int code = s_flag[f] & 0x7FFF;
+    const int fi = i0 + (code % kTileI);
+    const int fj = j0 + (code / kTileI);
+    const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
+    const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
+    const bool done = cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, o);
+    if (!done) {
+      leave_untouched(p, o, fi, fj);
+      if (o.unfilled) atomicAdd(o.unfilled, 1u);
+    }
+  }
+  for (int f = wid; f < nflag; f += kWaves) {
+    if (!(s_flag[f] & 0x8000)) continue;
+    const int code = s_flag[f] & 0x7FFF;
+    cell_wave_exact(p, start, sorted, i0 + (code % kTileI), j0 + (code / kTileI), o);
+  }
+}
+
+#ifndef AMHIP_F32_WAVES
+#define AMHIP_F32_WAVES 8
+#endif
+template <int NT, int kTileJ, int kCap, int kVar = 0>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(AMHIP_F32_WAVES, AMHIP_F32_WAVES)))
+k_dsm_gather_f32(DsmParams p, const uint32_t* __restrict__ start,
+                 const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                 CellOut o, int* __restrict__ exact_list, unsigned* __restrict__ exact_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntiles = p.tiles_i * p.tiles_j;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, k = b >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  gather_tile_f32<NT, kTileJ, kCap, kVar>(p, start, sorted, tile_occ, o, tile, smem, 0, exact_list,
+                                          exact_count);
+}
+
+template <int NT, int kTileJ, int kCap>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
+                      const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                      const int* __restrict__ tile_list, const unsigned* __restrict__ tile_count,
+                      CellOut o, int* __restrict__ exact_list,
+                      unsigned* __restrict__ exact_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned count = *tile_count;
+  for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+    gather_tile_f32<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem, -1,
+                                      exact_list, exact_count);
+    __syncthreads();
+  }
+}
+
 // Dense launch: one workgroup per tile.  XCD-aware tile order: consecutive tiles
 // (which share halo points) go to the same XCD's L2.  Blocks are dealt
 // round-robin to the 8 XCDs, so XCD x gets the x-th contiguous chunk of the tile
@@ -851,11 +1321,13 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const int cap2 = std::max(cap1, std::min(p.tile_j == 16 ? 5600 : 5200, cap_fit(150 * 1024)));
       {
         int rc;
-        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, 4 * (size_t)ntiles + 4))) return rc;
+        if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap,
+                                  kNumLists * (size_t)ntiles + kListHdr)))
+          return rc;
       }
       unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
       int* const lists = c->tile_list;
-      AMHIP_TRY(hipMemsetAsync(tile_count, 0, 4 * sizeof(unsigned), c->stream));
+      AMHIP_TRY(hipMemsetAsync(tile_count, 0, kListHdr * sizeof(unsigned), c->stream));
       int ccap0 = cap0, ccap1 = cap1, ccap2 = cap2;  // classification thresholds
       if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
         sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
@@ -878,32 +1350,86 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                        p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,       \
                        cell_out);                                                             \
   } while (0)
-#define AMHIP_LAUNCH_LIST(NT_, TJ_, CAP_, CLS_, GRID_)                                        \
+      // FP64 list launch: list LIST_ with an LDS image of CAPV_ points (CAP_ sizes the
+      // instance's registers; the LDS image holds what fits)
+#define AMHIP_LAUNCH_LIST_EX(NT_, TJ_, CAP_, CAPV_, LIST_, GRID_)                             \
   do {                                                                                        \
-    /* CAP_ sizes the instance's registers; the LDS image holds what fits */                  \
-    const DsmParams q = with_cap((CLS_) == 0 ? cap0 : std::min((int)(CAP_), (CLS_) == 1 ? cap1 : cap2)); \
+    const DsmParams q = with_cap(CAPV_);                                                      \
     AMHIP_TRY(hipFuncSetAttribute(                                                            \
         reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),             \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>), dim3(GRID_), dim3(NT_),   \
                        q.lds_bytes, c->stream, q, c->bin_start, c->sorted, c->tile_occ,       \
-                       lists + 4 + (size_t)(CLS_) * ntiles, tile_count + (CLS_), cell_out);   \
+                       lists + kListHdr + (size_t)(LIST_) * ntiles, tile_count + (LIST_),     \
+                       cell_out);                                                             \
+  } while (0)
+#define AMHIP_LAUNCH_LIST(NT_, TJ_, CAP_, CLS_, GRID_)                                        \
+  AMHIP_LAUNCH_LIST_EX(NT_, TJ_, CAP_,                                                        \
+                       ((CLS_) == 0 ? cap0 : std::min((int)(CAP_), (CLS_) == 1 ? cap1 : cap2)), \
+                       CLS_, GRID_)
+      // class-0 tiles in single precision (dense or list 0), then the tiles it handed back
+      // (list 4) through the FP64 kernel
+#define AMHIP_LAUNCH_F32(TJ_, CAP_)                                                           \
+  do {                                                                                        \
+    int* const xl = lists + kListHdr + (size_t)4 * ntiles;                                    \
+    if (sparse) {                                                                             \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),               \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
+      hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(8192), dim3(512),      \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         lists + kListHdr, tile_count, cell_out, xl, tile_count + 4);         \
+    } else if (f32_variant && (TJ_) == 16 && (CAP_) == 1024) {                                \
+      AMHIP_F32_DENSE(16, 1024, f32_variant);                                                 \
+    } else {                                                                                  \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_f32<512, TJ_, CAP_>),                    \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
+      hipLaunchKernelGGL((k_dsm_gather_f32<512, TJ_, CAP_>), dim3(ntiles), dim3(512),         \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         cell_out, xl, tile_count + 4);                                       \
+    }                                                                                         \
+    AMHIP_LAUNCH_LIST_EX(512, TJ_, CAP_, cap0, 4, 4096);                                      \
+  } while (0)
+      const bool f32 = p.fx_ok && !p.pcl_mode && !p.only_unfilled && !mask && !unfilled;
+      static const int f32_variant = getenv("AMHIP_F32_VARIANT") ? atoi(getenv("AMHIP_F32_VARIANT")) : 0;
+      // (A-B variants / timing probes of the 64 x 16 / 1024-point instance)
+#define AMHIP_F32_DENSE_V(V_)                                                                 \
+  do {                                                                                        \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_f32<512, 16, 1024, V_>),                   \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                   \
+    hipLaunchKernelGGL((k_dsm_gather_f32<512, 16, 1024, V_>), dim3(ntiles), dim3(512),        \
+                       p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ,   \
+                       cell_out, lists + kListHdr + (size_t)4 * ntiles, tile_count + 4);      \
+  } while (0)
+#define AMHIP_F32_DENSE(TJ_, CAP_, VAR_)                                                      \
+  do {                                                                                        \
+    if ((VAR_) == 1) AMHIP_F32_DENSE_V(1);                                                    \
+    else if ((VAR_) == 2) AMHIP_F32_DENSE_V(2);                                               \
+    else if ((VAR_) == 4) AMHIP_F32_DENSE_V(4);                                               \
+    else if ((VAR_) == 5) AMHIP_F32_DENSE_V(5);                                               \
+    else if ((VAR_) == 6) AMHIP_F32_DENSE_V(6);                                               \
+    else AMHIP_F32_DENSE_V(3);                                                                \
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
       if (p.tile_j == 16 && cap0 == 1024) {
-        if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
+        if (f32) AMHIP_LAUNCH_F32(16, 1024);
+        else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 16, 1024);
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else if (p.tile_j == 16) {
-        if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
+        if (f32) AMHIP_LAUNCH_F32(16, 2048);
+        else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
         else AMHIP_LAUNCH_DENSE(512, 16, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
         AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else {
-        if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
+        if (f32) AMHIP_LAUNCH_F32(32, 2048);
+        else if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
         else if (nt == 1024) AMHIP_LAUNCH_DENSE(1024, 32, 2048);
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
@@ -912,8 +1438,12 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       }
 #undef AMHIP_LAUNCH_DENSE
 #undef AMHIP_LAUNCH_LIST
+#undef AMHIP_LAUNCH_LIST_EX
+#undef AMHIP_LAUNCH_F32
+#undef AMHIP_F32_DENSE
+#undef AMHIP_F32_DENSE_V
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
-                         c->bin_start, c->sorted, lists + 4 + (size_t)3 * ntiles, tile_count + 3,
+                         c->bin_start, c->sorted, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
                          cell_out);
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));

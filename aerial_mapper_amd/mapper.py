@@ -192,6 +192,11 @@ class AerialGridMap(object):
         """Waits for the GPU and raises if a device-side CHECK fired."""
         L.check(self._lib.amhip_ctx_synchronize(self._h))
 
+    def set_dsm_precision(self, exact):
+        """AMHIP_DSM_EXACT (True): the FP64 gather everywhere; AMHIP_DSM_FAST (False, default):
+        single-precision arithmetic under exact guards (include/aerial_mapper_hip.h)."""
+        L.check(self._lib.amhip_ctx_set_dsm_precision(self._h, 1 if exact else 0))
+
     def enable_timing(self, on=True):
         L.check(self._lib.amhip_ctx_enable_timing(self._h, int(bool(on))))
 

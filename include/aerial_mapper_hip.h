@@ -142,6 +142,18 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
  * void*; NULL = back to the context's own stream). */
 int amhip_ctx_set_stream(amhip_ctx* ctx, void* hip_stream);
 
+/* Arithmetic of the DSM gather (dsm::Dsm::process, dsm.cc:160-172).
+ *   AMHIP_DSM_FAST  (default) single-precision distances and weights under exact guards:
+ *                   the reference's neighbour sets (any decision within 2e-6 of the radius is
+ *                   taken in its own doubles), identical NaN pattern, heights within the
+ *                   contract's 1e-4 m (1 float spacing above 1024 m) by a per-tile error
+ *                   bound; tiles / cells without room under the bound take the FP64 path;
+ *   AMHIP_DSM_EXACT the FP64 gather everywhere (bit-identical floats in every test so far).
+ * The environment variable AMHIP_DSM_EXACT=1 makes EXACT the default of new contexts. */
+#define AMHIP_DSM_FAST 0
+#define AMHIP_DSM_EXACT 1
+int amhip_ctx_set_dsm_precision(amhip_ctx* ctx, int mode);
+
 /* Wait for everything enqueued on the context and return the sticky status
  * of the device-side CHECKs (EXACT_HIT / ALPHA_NONPOS) or HIP errors since
  * the last synchronize; the status is then cleared. */

@@ -46,6 +46,33 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters, double see
       a0 += a1; a1 += a2; a2 += a3; a3 += a4; a4 += a5; a5 += a6; a6 += a7; a7 += a0;
     } else if (MODE == 5) {  // 8 cvt f64->f32->f64
       a0 = (double)(float)a0 + 1; a1 = (double)(float)a1 + 1; a2 = (double)(float)a2 + 1; a3 = (double)(float)a3 + 1;
+    } else if (MODE == 6) {  // 8 v_fma_f32 (two dependent rounds over 4 registers)
+      f0 = fmaf(f0, 1.0000001f, 0.5f); f1 = fmaf(f1, 1.0000001f, 0.5f); f2 = fmaf(f2, 1.0000001f, 0.5f); f3 = fmaf(f3, 1.0000001f, 0.5f);
+      f0 = fmaf(f0, 0.9999999f, 0.25f); f1 = fmaf(f1, 0.9999999f, 0.25f); f2 = fmaf(f2, 0.9999999f, 0.25f); f3 = fmaf(f3, 0.9999999f, 0.25f);
+    } else if (MODE == 7) {  // 8 v_pk_fma_f32 (16 f32 fma)
+      typedef float fpair __attribute__((ext_vector_type(2)));
+      fpair p0 = {f0, f1}, p1 = {f2, f3}, c = {1.0000001f, 0.9999999f}, d = {0.5f, 0.25f};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        asm volatile("v_pk_fma_f32 %0, %0, %2, %3\n\tv_pk_fma_f32 %1, %1, %2, %3" : "+v"(p0), "+v"(p1) : "v"(c), "v"(d));
+      }
+      f0 = p0.x; f1 = p0.y; f2 = p1.x; f3 = p1.y;
+    } else if (MODE == 8) {  // 8 x (v_sub_u32 + v_cvt_f32_i32): counted as 16 instructions
+      int i0 = __float_as_int(f0), i1 = __float_as_int(f1), i2 = __float_as_int(f2), i3 = __float_as_int(f3);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f0 = (float)(i0 - i1); f1 = (float)(i1 - i2); f2 = (float)(i2 - i3); f3 = (float)(i3 - i0);
+        i0 = __float_as_int(f0) ^ it; i1 = __float_as_int(f1); i2 = __float_as_int(f2); i3 = __float_as_int(f3);
+      }
+    } else if (MODE == 9) {  // the gather's masked hit block, twice: 2 x (cmpx + rcp + max + add + fmac)
+      unsigned long long sv;
+      asm volatile(
+          "s_mov_b64 %4, exec\n\t"
+          "v_cmpx_gt_f32 %5, %0\n\tv_rcp_f32 %1, %0\n\tv_max_f32 %2, %2, %0\n\tv_add_f32 %3, %3, %1\n\tv_fmac_f32 %0, %1, %5\n\t"
+          "s_mov_b64 exec, %4\n\t"
+          "v_cmpx_gt_f32 %5, %3\n\tv_rcp_f32 %1, %3\n\tv_max_f32 %2, %2, %3\n\tv_add_f32 %0, %0, %1\n\tv_fmac_f32 %3, %1, %5\n\t"
+          "s_mov_b64 exec, %4"
+          : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "=&s"(sv) : "v"(1.5f) : "vcc");
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + f0 + f1 + f2 + f3;
@@ -102,8 +129,9 @@ int main() {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   double* rout; CK(hipMalloc(&rout, 256 * 8 * 256 * 8 * 2));
   const int blocks = 256 * 8, iters = 4096;
-  const char* names[] = {"v_fma_f64", "v_rcp_f64", "v_rcp_f32", "cmp+select f64", "v_add_f64", "cvt f64<->f32 (+add)"};
-  for (int mode = 0; mode < 6; ++mode) {
+  const char* names[] = {"v_fma_f64", "v_rcp_f64", "v_rcp_f32", "cmp+select f64", "v_add_f64", "cvt f64<->f32 (+add)",
+                         "v_fma_f32", "v_pk_fma_f32", "v_sub_u32+v_cvt_f32_i32", "masked hit block (10 VALU)"};
+  for (int mode = 0; mode < 10; ++mode) {
     float ms = 0;
     for (int rep = 0; rep < 2; ++rep) {
       CK(hipEventRecord(e0));
@@ -114,10 +142,14 @@ int main() {
         case 3: k_rate<3><<<blocks, 256>>>(rout, iters, 1.0); break;
         case 4: k_rate<4><<<blocks, 256>>>(rout, iters, 1.0); break;
         case 5: k_rate<5><<<blocks, 256>>>(rout, iters, 1.0); break;
+        case 6: k_rate<6><<<blocks, 256>>>(rout, iters, 1.0); break;
+        case 7: k_rate<7><<<blocks, 256>>>(rout, iters, 1.0); break;
+        case 8: k_rate<8><<<blocks, 256>>>(rout, iters, 1.0); break;
+        case 9: k_rate<9><<<blocks, 256>>>(rout, iters, 1.0); break;
       }
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
     }
-    const double ops = (double)blocks * 256 * iters * (mode == 5 ? 4 : 8);
+    const double ops = (double)blocks * 256 * iters * (mode == 5 ? 4 : (mode == 8 ? 16 : (mode == 9 ? 10 : 8)));
     // 8 blocks of 4 waves per CU = 8 waves/SIMD; cycles per wave-instruction per SIMD
     const double wave_instr_per_simd = ops / 64.0 / 1024.0;
     printf("%-22s %8.3f ms  %7.2f Gop/s/lane-total  ~%.2f cycles per wave-instr per SIMD @2.4GHz\n", names[mode], ms,
