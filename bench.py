@@ -292,23 +292,32 @@ def main():
         b_dsm = 24.0 * N + 4.0 * cells
         b_ortho = (20.0 * cells + F * wl["W"] * wl["H"] * ch + 56.0 * F) if F else 0.0
         alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho}
-        traffic = {}
-        try:  # PMC-measured HBM bytes per launch (committed; same workload only)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        # PMC evidence of the same command, collected by tools/collect_profiles.sh and committed
+        # under profiles/ (newest round first); never measured inside this run -- the line says so
+        import glob
+        import re
+
+        def newest(pattern):
+            fs = glob.glob(os.path.join(ROOT, "profiles", pattern))
+            def key(f):
+                m = re.search(r"r(\d+)_(?:v(\d+)_)?", os.path.basename(f))
+                return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+            return sorted(fs, key=key)[-1] if fs else None
+
+        traffic, traffic_src = {}, None
+        try:
+            f = newest("r*_pmc_traffic.json")
+            tj = json.load(open(f))
             if tj.get("workload") == args.workload and not args.colored:
                 traffic = {k: v["bytes"] for k, v in tj["kernels"].items()}
+                traffic_src = "profiles/" + os.path.basename(f)
         except Exception:
             pass
-        # what actually bounds the dominant kernel when it is not HBM: the SQ counters of the
-        # committed PMC pass (same workload only) -- share of VALU issue slots used, lanes active
         valu = None
         try:
-            import glob
-            import re
-            sq = sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_v*_cfg3_pmc_sq.json")),
-                        key=lambda f: int(re.search(r"_v(\d+)_", f).group(1)))
-            if sq and args.workload in ("cfg3", "cfg2") and not args.colored:
-                valu = (os.path.basename(sq[-1]), json.load(open(sq[-1]))["kernels"])
+            f = newest("r*_cfg3_pmc_sq.json")
+            if f and args.workload in ("cfg3", "cfg2") and not args.colored:
+                valu = (os.path.basename(f), json.load(open(f))["kernels"])
         except Exception:
             pass
         kern = {}
@@ -327,7 +336,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic" if not one_gpu else
+            "dtype": "f64 (decisions, staging, mosaic) + f32 (DSM pair arithmetic under exact guards)"
+            if not os.environ.get("AMHIP_DSM_EXACT") else "f64", "data": "synthetic" if not one_gpu else
             "synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a measurement" % world,
             "config": {"workload": args.workload + ": " + wl["desc"],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
@@ -336,10 +346,13 @@ def main():
                                "%sDsm::process + OrthoBackwardGrid::process, inputs resident in HBM" %
                                ("halo exchange (RCCL all_to_all) + " if world > 1 else ""),
                        "parallelism": "one map, %d x 1 windows, one per GPU" % world},
+            # the contract's HBM roofline of the dominant kernel (algorithmic bytes / live
+            # HIP-event time / 8 TB/s) -- and, because nothing on this path is HBM bound, what
+            # does bound it (below: "bound", "valu")
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic.get(dom),
+                         "traffic": traffic.get(dom), "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes[dom],
                          "kernel_ms": round(dom_ms, 4)},
             "whole_step_hbm": {"algorithmic_bytes": total_alg,
@@ -349,17 +362,39 @@ def main():
             "dsm_stats": m.dsm_stats(),
         }
         if valu is not None:
-            prefix = {"k_dsm_gather": "k_dsm_gather_tiled<", "k_ortho_backward": "k_ortho_backward"}[dom]
-            rows = [v for k, v in valu[1].items() if k.startswith(prefix) and v.get("GRBM_GUI_ACTIVE")]
+            prefixes = {"k_dsm_gather": ("k_dsm_gather_f32<", "k_dsm_gather_tiled<"),
+                        "k_ortho_backward": ("k_ortho_backward",)}[dom]
+            rows = [v for k, v in valu[1].items() if k.startswith(prefixes) and v.get("GRBM_GUI_ACTIVE")]
             if rows:
                 v = max(rows, key=lambda r: r.get("SQ_INSTS_VALU", 0))
                 busy = v["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
+                lanes = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(v["SQ_INSTS_VALU"], 1.0) / 64.0
+                # VALU roofline: lane-instructions the kernel issues per launch (committed SQ
+                # counters of the same command) over the LIVE kernel time, against 256 CUs x 4
+                # SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s (one f32 op per lane
+                # and cycle; FP64 ops issue at half that)
+                peak_valu = 256 * 4 * 32 * 2.4e9
+                lane_ops = v["SQ_INSTS_VALU"] * 64.0 * lanes
+                out["roofline"]["bound"] = "valu"
                 out["roofline"]["valu"] = {
-                    "note": "FP64 VALU-issue bound, not HBM bound (no MFMA-shaped work on this path)",
+                    "note": "VALU-issue bound (f32 pair arithmetic + FP64 staging / decisions), not "
+                            "HBM bound; no MFMA-shaped work on this path",
+                    "frac": round(lane_ops / (dom_ms * 1e-3) / peak_valu, 4),
+                    "lane_instructions_per_launch": lane_ops, "peak_lane_instructions_per_s": peak_valu,
                     "issue_slot_frac": round(v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / busy, 3),
-                    "lanes_active_frac": round(v.get("SQ_THREAD_CYCLES_VALU", 0.0) /
-                                               max(v["SQ_INSTS_VALU"], 1.0) / 64.0, 3),
-                    "source": "profiles/" + valu[0]}
+                    "lanes_active_frac": round(lanes, 3),
+                    "source": "profiles/" + valu[0] + " (counters); kernel_ms live"}
+        parity_done = False
+        if world == 1 and not args.no_cpu_baseline:
+            # (before anything else runs: the layers still hold the result of the TIMED steps)
+            try:
+                cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
+                parity["pass"] = "timed"
+                out["cpu_baseline"] = cb
+                out["parity_sample"] = parity
+            except Exception as e:  # the GPU number stands on its own
+                out["cpu_baseline"] = {"error": repr(e)}
+            parity_done = True
         if world == 1 and args.host_path:
             # the reference-shaped call: cloud, frames and layers in host memory
             h_pts = pts.cpu().numpy()
@@ -384,13 +419,6 @@ def main():
                 "Mcells_per_s": round(cells / (t2h - t0h) / 1e6, 1),
                 "note": "one pass, pageable host buffers: cloud H2D + elevation up/down, frames "
                         "H2D, output layers D2H"}
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
-                out["cpu_baseline"] = cb
-                out["parity_sample"] = parity
-            except Exception as e:  # the GPU number stands on its own
-                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

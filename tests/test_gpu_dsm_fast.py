@@ -1,0 +1,146 @@
+"""GPU tests of the DSM gather's single-precision mode (amhip_ctx_set_dsm_precision,
+AMHIP_DSM_FAST, the default): its guards -- error budget per tile, near-centre points, decisions
+within 2e-6 of the search radius -- must hand exactly the right work to the FP64 routines, so
+that the contract holds everywhere: the reference's NaN pattern, heights within 1e-4 m (one
+float spacing of the stored height where that is larger, i.e. above 1024 m).
+Oracle: dsm.cc:113-184 restated (oracle/amo_dsm.cc), checked against the reference's own code
+in tests/test_reference_loops.py."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(scene, exact, radius=1):
+    import aerial_mapper_amd as A
+    g = scene.grid
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    with A.AerialGridMap(st) as m:
+        m.set_dsm_precision(exact)
+        A.Dsm(A.DsmSettings(radius), m).process(scene.points, m)
+        return m.get("elevation")
+
+
+def _oracle(scene, radius=1):
+    rc, want, _ = O.dsm_process(scene.points, scene.grid, radius, 0.0, 0.0)
+    assert rc == O.OK
+    return want
+
+
+def _spacing(z):
+    """spacing of the float32 grid at |z|"""
+    return np.spacing(np.abs(z).astype(np.float32)).astype(np.float64)
+
+
+def _check(got, want, lsb=False):
+    gn, wn = np.isnan(got), np.isnan(want)
+    assert np.array_equal(gn, wn), "NaN pattern differs in %d cells" % int((gn != wn).sum())
+    ok = ~wn
+    err = np.abs(got[ok].astype(np.float64) - want[ok].astype(np.float64))
+    tol = np.maximum(1e-4, _spacing(want[ok])) if lsb else 1e-4
+    assert (err <= tol).all(), "max |dh| = %g m" % err.max()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (gn & wn)
+    return float(same.mean()), float(err.max()) if ok.any() else 0.0
+
+
+def test_rough_heights_send_every_tile_to_the_fp64_kernel():
+    # +-30 m of height noise: no tile has room under the f32 error bound
+    sc = S.Scene(100.0, 80.0, 0.25, int(8 * 108 * 88), seed=301)
+    rng = np.random.default_rng(5)
+    sc.points[:, 2] += rng.uniform(-30.0, 30.0, sc.points.shape[0])
+    want = _oracle(sc)
+    fast, exact = _run(sc, False), _run(sc, True)
+    frac_f, _ = _check(fast, want)
+    frac_e, _ = _check(exact, want)
+    assert frac_f > 0.999 and frac_e > 0.999    # both are the FP64 arithmetic
+
+
+def test_a_step_in_the_terrain_mixes_both_kernels():
+    # flat ground with a 25 m "building" in the middle: the tiles along its walls go to the
+    # FP64 kernel, the rest stay in single precision
+    sc = S.Scene(120.0, 100.0, 0.25, int(8 * 128 * 108), seed=302)
+    x, y = sc.points[:, 0], sc.points[:, 1]
+    sc.points[:, 2] += np.where((np.abs(x) < 20.0) & (np.abs(y) < 15.0), 25.0, 0.0)
+    want = _oracle(sc)
+    frac, err = _check(_run(sc, False), want)
+    assert 0.3 < frac < 1.0
+
+
+def test_slopes_and_canopy_noise_stay_inside_the_budget():
+    # 30 % slope plus +-1.5 m of noise: height range of a tile region ~8 m, near the budget
+    sc = S.Scene(100.0, 90.0, 0.25, int(8 * 108 * 98), seed=303)
+    rng = np.random.default_rng(6)
+    sc.points[:, 2] += 0.3 * sc.points[:, 0] + rng.uniform(-1.5, 1.5, sc.points.shape[0])
+    want = _oracle(sc)
+    _check(_run(sc, False), want)
+
+
+def test_above_1024_m_the_bar_is_one_float_spacing():
+    sc = S.Scene(80.0, 70.0, 0.25, int(8 * 88 * 78), seed=304)
+    sc.points[:, 2] += 2600.0     # ~3000 m: one float spacing = 2.4e-4 m > 1e-4 m
+    want = _oracle(sc)
+    frac, err = _check(_run(sc, False), want, lsb=True)
+    assert frac > 0.9             # the budget there is a quarter of a spacing
+    frac_e, err_e = _check(_run(sc, True), want, lsb=True)
+    assert frac_e > 0.999
+
+
+def test_points_next_to_cell_centres():
+    # returns a hair away from cell centres with heights metres apart (ground + canopy): the
+    # weights 1/d2 are huge and differ by orders of magnitude
+    sc = S.Scene(60.0, 50.0, 0.25, int(8 * 68 * 58), seed=305)
+    g = sc.grid
+    rng = np.random.default_rng(7)
+    extra = []
+    for k in range(400):
+        i, j = int(rng.integers(5, g.rows - 5)), int(rng.integers(5, g.cols - 5))
+        cx, cy = O.cell_position(g, i, j)
+        for d, dz in ((10.0 ** -rng.uniform(1.5, 9.0), 0.0), (10.0 ** -rng.uniform(1.5, 9.0), 3.0)):
+            a = rng.uniform(0, 2 * np.pi)
+            extra.append((cx + d * np.cos(a), cy + d * np.sin(a), 400.0 + dz))
+    sc.points = np.ascontiguousarray(np.vstack([sc.points, np.array(extra)]))
+    want = _oracle(sc)
+    _check(_run(sc, False), want)
+
+
+def test_decisions_at_the_search_radius_are_the_references():
+    # points at sqrt(T) (1 +- k 1e-9 .. 1e-6) from cell centres, 1000 m above the rest: one wrong
+    # inclusion moves the cell by metres
+    sc = S.Scene(60.0, 50.0, 0.25, int(8 * 68 * 58), seed=306)
+    g = sc.grid
+    rng = np.random.default_rng(8)
+    extra = []
+    for k in range(600):
+        i, j = int(rng.integers(8, g.rows - 8)), int(rng.integers(8, g.cols - 8))
+        cx, cy = O.cell_position(g, i, j)
+        rel = rng.choice([0.0, 1e-15, 1e-12, 1e-9, 1e-8, 1e-7, 5e-7, 1e-6, 3e-6]) * rng.choice([-1.0, 1.0])
+        d = 1.0 * (1.0 + rel)
+        if k % 3:
+            ca, sa = np.cos(rng.uniform(0, 2 * np.pi)), 0.0
+            sa = np.sqrt(1.0 - ca * ca) * rng.choice([-1.0, 1.0])
+        else:  # 3-4-5 directions: dx*dx + dy*dy lands on (or one ulp off) the radius itself
+            ca, sa = rng.choice([0.6, -0.6]), rng.choice([0.8, -0.8])
+            if k % 2:
+                ca, sa = sa, ca
+        extra.append((cx + d * ca, cy + d * sa, 1400.0))
+    sc.points = np.ascontiguousarray(np.vstack([sc.points, np.array(extra)]))
+    want = _oracle(sc)
+    # (the outliers push their tiles over the height budget: those go to the FP64 kernel,
+    # the decisions of the others are taken by the per-cell guard)
+    _check(_run(sc, False), want, lsb=True)
+    sc.points[-len(extra):, 2] = 404.0     # now inside the budget: the f32 kernel keeps the tiles
+    want = _oracle(sc)
+    _check(_run(sc, False), want)
+
+
+@pytest.mark.parametrize("res,radius", [(0.3, 1), (0.1, 1), (0.7, 3)])
+def test_utm_magnitudes_and_non_dyadic_resolutions(res, radius):
+    ce, cn = 464980.3, 5272690.7
+    sc = S.Scene(90.0 * res / 0.3, 70.0 * res / 0.3, res, 60000, seed=307, center=(ce, cn),
+                 point_extent=50.0 * res / 0.3)
+    want = _oracle(sc, radius)
+    _check(_run(sc, False, radius), want)
+    _check(_run(sc, True, radius), want)

@@ -2,27 +2,28 @@
 # Collect the round's rocprofv3 evidence ON the GPU box and leave only the small
 # summaries in gpurun_out/profiles_out/ (the rocpd databases exceed what gpurun
 # copies back).  Usage (from the repo root, through gpurun):
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh v6'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh v1 r02'
 set -u
 TAG=${1:-vX}
+RND=${2:-r02}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=/tmp/amhip_prof_$$
 OUT=$R/gpurun_out/profiles_out
 rm -rf "$O" "$OUT"; mkdir -p "$O" "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 900 python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/r01_bench_cfg3_n1.json" 2> "$O/bench.err"
+timeout 900 python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/${RND}_bench_cfg3_n1.json" 2> "$O/bench.err"
 B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path"
-timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o t -- $B > "$OUT/r01_${TAG}_cfg3_bench_under_rocprof.json" 2> "$O/trace.err"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o t -- $B > "$OUT/${RND}_${TAG}_cfg3_bench_under_rocprof.json" 2> "$O/trace.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/fetch" -o f -- $B > /dev/null 2> "$O/fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/write" -o w -- $B > /dev/null 2> "$O/write.err"
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --kernel-trace -d "$O/sq1" -o s -- $B > /dev/null 2> "$O/sq1.err"
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d "$O/sq2" -o s -- $B > /dev/null 2> "$O/sq2.err"
 python "$R/tools/rocprof_summary.py" --trace "$O/trace/t_results.db" --fetch "$O/fetch/f_results.db" \
   --write "$O/write/w_results.db" \
-  --title "r01 $TAG: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path under rocprofv3, cfg3" \
-  -o "$OUT/r01_${TAG}_cfg3_rocprofv3.md" --traffic-json "$OUT/r01_pmc_traffic.json" \
-  --note "Round 1 $TAG kernels; see profiles/r01_${TAG}_cfg3_rocprofv3.md." > /dev/null
+  --title "$RND $TAG: python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path under rocprofv3, cfg3" \
+  -o "$OUT/${RND}_${TAG}_cfg3_rocprofv3.md" --traffic-json "$OUT/${RND}_pmc_traffic.json" \
+  --note "$RND $TAG kernels; see profiles/${RND}_${TAG}_cfg3_rocprofv3.md." > /dev/null
 python "$R/tools/rocprof_summary.py" --sq "$O/sq1/s_results.db" "$O/sq2/s_results.db" \
-  --sq-json "$OUT/r01_${TAG}_cfg3_pmc_sq.json" --tag "$TAG"
+  --sq-json "$OUT/${RND}_${TAG}_cfg3_pmc_sq.json" --tag "$TAG"
 rm -rf "$O"
 ls -la "$OUT"
