@@ -695,7 +695,20 @@ static int fetch_status(Ctx* c) {
         "CHECK(alpha > 0.0))");
     return AMHIP_ERR_ALPHA_NONPOS;
   }
+  if (e & kDevErrHaloOverflow) {
+    set_last_error(
+        "tiled DSM: more halo points for a neighbouring window than send rows were reserved "
+        "(cap_per_dest): the elevation near that edge is incomplete");
+    return AMHIP_ERR_HALO_OVERFLOW;
+  }
   return AMHIP_OK;
+}
+
+// tiled DSM: a selection that did not fit its send rows must fail the step (the points beyond
+// the capacity were not shipped), without a host round trip inside the step
+__global__ void k_halo_overflow_check(const unsigned long long* __restrict__ counts, int nd,
+                                      unsigned long long cap, unsigned* __restrict__ dev_err) {
+  if ((int)threadIdx.x < nd && counts[threadIdx.x] > cap) atomicOr(dev_err, kDevErrHaloOverflow);
 }
 
 static bool valid_layer(int l) { return l >= 0 && l < AMHIP_NUM_LAYERS; }
@@ -1214,6 +1227,8 @@ int amhip_dsm_tiled_finish_dev(amhip_ctx* h) {
     return rc;
   SortSplit sp = c->tiled_split;
   sp.phase = 2;
+  hipLaunchKernelGGL(k_halo_overflow_check, dim3(1), dim3(64), 0, c->stream, sp.halo_counts,
+                     sp.hp.nd, sp.hp.cap, c->dev_err);
   const bool fused_fill = c->layer_state[AMHIP_LAYER_ELEVATION] == 3;
   if (fused_fill)
     c->layer_state[AMHIP_LAYER_ELEVATION] = 1;

@@ -124,7 +124,7 @@ struct OrthoParams {
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
-enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u };
+enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u, kDevErrHaloOverflow = 4u };
 
 // ---------------------------------------------------------------------------
 // context

@@ -13,10 +13,11 @@ LIB_PATH = os.path.join(PKG, "lib", "libaerial_mapper_hip.so")
 ABI_VERSION = 1
 
 # amhip_status
-OK, ERR_ARG, ERR_EXACT_HIT, ERR_ALPHA_NONPOS, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM = range(7)
+OK, ERR_ARG, ERR_EXACT_HIT, ERR_ALPHA_NONPOS, ERR_HIP, ERR_NO_DEVICE, ERR_NOMEM, ERR_HALO_OVERFLOW = range(8)
 STATUS_NAMES = {OK: "AMHIP_OK", ERR_ARG: "AMHIP_ERR_ARG", ERR_EXACT_HIT: "AMHIP_ERR_EXACT_HIT",
                 ERR_ALPHA_NONPOS: "AMHIP_ERR_ALPHA_NONPOS", ERR_HIP: "AMHIP_ERR_HIP",
-                ERR_NO_DEVICE: "AMHIP_ERR_NO_DEVICE", ERR_NOMEM: "AMHIP_ERR_NOMEM"}
+                ERR_NO_DEVICE: "AMHIP_ERR_NO_DEVICE", ERR_NOMEM: "AMHIP_ERR_NOMEM",
+                ERR_HALO_OVERFLOW: "AMHIP_ERR_HALO_OVERFLOW"}
 
 # amhip_layer
 (LAYER_ORTHO, LAYER_ELEVATION, LAYER_ELEVATION_ANGLE, LAYER_NUM_OBSERVATIONS,

@@ -261,62 +261,87 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
     return out
 
 
+def neighbours(layout, rank, margin_cells):
+    """Ranks whose window, grown by the halo margin, reaches into `rank`'s window (and vice
+    versa: the relation is symmetric).  Host geometry -- at most 8 in a 2-D tiling."""
+    i0, j0, r, c = layout.window(rank)
+    out = []
+    for q in range(layout.world):
+        if q == rank:
+            continue
+        a0, b0, ar, ac = layout.window(q)
+        if a0 - margin_cells <= i0 + r and a0 + ar + margin_cells >= i0 and \
+                b0 - margin_cells <= j0 + c and b0 + ac + margin_cells >= j0:
+            out.append(q)
+    return out
+
+
 class TiledDsm(object):
     """dsm::Dsm::process of one window of a tiled map, the halo exchange folded in
     (amhip_dsm_tiled_begin_dev / _finish_dev): the DSM's binning pass selects the
-    points the other windows need on the way, ONE all_to_all of equal splits ships
-    them (unused rows are NaN and dropped by the receiver's binning), and nothing
-    synchronises with the host -- the counts stay on the device until
-    `check_overflow()` is asked, e.g. once after a run of steps.
+    points the NEIGHBOURING windows need on the way, ONE all_to_all ships them --
+    `cap` rows to / from every geometric neighbour, nothing to anyone else (split
+    sizes are host geometry: no count exchange; unused rows are NaN and dropped by the
+    receiver's binning) -- and nothing synchronises with the host.  This replaces the
+    halo all-reduce of BASELINE.json's wording by the exact option SURVEY 8e (i): halo
+    POINTS travel, every window then runs the single-GPU kernels unchanged.  A
+    selection that does not fit its `cap` rows raises AMHIP_ERR_HALO_OVERFLOW at the
+    next synchronize (device-side check in the finish call: the step fails, not a
+    later audit).
 
-    workspace  (n_owned + world * cap, 3) float64 CUDA tensor whose first n_owned
-               rows are this rank's own points; the received rows land behind them
+    workspace  (n_owned + len(neighbours) * cap, 3) float64 CUDA tensor whose first
+               n_owned rows are this rank's own points; the received rows land behind
     cap        rows per (source, destination) pair: a few times edge x margin x
                density (halo_strip_rows())
     """
 
     def __init__(self, settings, map_, layout, rank, cap, comm=None):
         import torch
-        if layout.world > MAX_DESTS:
-            raise ValueError("at most %d windows per exchange" % MAX_DESTS)
         self.settings, self.map, self.layout, self.rank = settings, map_, layout, rank
         self.cap = int(cap)
         self.comm = comm or TorchComm()
         dev = torch.device("cuda", map_.device)
-        world = layout.world
-        self.send = torch.empty((world * self.cap, 3), dtype=torch.float64, device=dev)
-        self.counts = torch.zeros(world, dtype=torch.int64, device=dev)
-        wins = layout.windows()
-        wins[rank] = (-(1 << 28), -(1 << 28), 1, 1)   # placeholder: nothing travels to oneself
-        self._wins = (C.c_int32 * (4 * world))(*[int(v) for w in wins for v in w])
         self._margin = halo_margin(settings.interpolation_radius, map_.grid.resolution)
+        self.nbrs = neighbours(layout, rank, self._margin / map_.grid.resolution + 1.0)
+        nn = len(self.nbrs)
+        if nn > MAX_DESTS:
+            raise ValueError("more than %d neighbouring windows" % MAX_DESTS)
+        self.recv_rows = nn * self.cap
+        self.send = torch.empty((max(nn, 1) * self.cap, 3), dtype=torch.float64, device=dev)
+        self.counts = torch.zeros(max(nn, 1), dtype=torch.int64, device=dev)
+        wins = [layout.window(q) for q in self.nbrs]   # ascending rank = the all_to_all's order
+        self._wins = (C.c_int32 * (4 * max(nn, 1)))(*[int(v) for w in wins for v in w])
+        self.splits = [self.cap if q in self.nbrs else 0 for q in range(layout.world)]
 
     def process(self, workspace, n_owned, sync=True):
         import torch
         from . import hip_lib as L
         lib = L.load()
-        world, cap, m, s = self.layout.world, self.cap, self.map, self.settings
-        n_total = n_owned + world * cap
+        cap, m, s = self.cap, self.map, self.settings
+        nn = len(self.nbrs)
+        n_total = n_owned + nn * cap
         assert workspace.is_cuda and workspace.dtype == torch.float64 and workspace.is_contiguous()
         assert workspace.shape[0] >= n_total and workspace.shape[1] == 3
+        if nn == 0:
+            from .mapper import Dsm
+            Dsm(s, m).process(workspace[:n_owned], m, sync=sync)
+            return
         self.send.fill_(float("nan"))
         m.wait_for_torch(workspace)
         m._touched("elevation")
         L.check(lib.amhip_dsm_tiled_begin_dev(
             m.handle, C.c_void_p(workspace.data_ptr()), n_owned, n_total, s.interpolation_radius,
-            s.center_easting, s.center_northing, self._wins, world, float(self._margin),
+            s.center_easting, s.center_northing, self._wins, nn, float(self._margin),
             C.c_void_p(self.send.data_ptr()), cap, C.c_void_p(self.counts.data_ptr())))
         m.torch_waits()
-        self.comm.exchange_equal(workspace[n_owned:n_total], self.send)
+        self.comm.exchange_rows(workspace[n_owned:n_total], self.send, self.splits, self.splits)
         m.wait_for_torch(workspace)
         L.check(lib.amhip_dsm_tiled_finish_dev(m.handle))
         if sync:
-            m.synchronize()
-            self.check_overflow()
+            m.synchronize()   # raises AMHIP_ERR_HALO_OVERFLOW if a selection did not fit
 
     def check_overflow(self):
-        """Raises if the last process() had more halo points for some window than `cap`
-        rows (the excess was not shipped: the result near that edge is incomplete)."""
+        """(kept for callers that run unsynchronised steps) the same check from the counts."""
         worst = int(self.counts.max().item())
         if worst > self.cap:
             raise RuntimeError("halo rows: %d points for one window, capacity %d" % (worst, self.cap))

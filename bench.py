@@ -46,6 +46,20 @@ WORKLOADS = {
     "small": dict(side=2000, res=0.25, points=2_000_000, frames=24, W=1920, H=1080,
                   f=1400.0, altitude=700.0,
                   desc="2M pts -> 2000x2000 @0.25m DSM + ortho, 24 frames (smoke-size)"),
+    # BASELINE.json configs[3] / configs[4]: ONE fixed survey cut over the ranks (strong scaling;
+    # 2 x 4 windows of 20000 x 10000 cells on 8 GPUs; the whole map on one GPU at N = 1)
+    "cfg4": dict(side=40000, res=0.25, points=400_000_000, frames=0, W=1920, H=1080,
+                 f=1400.0, altitude=700.0, fixed_map=True,
+                 desc="400M pts -> 40000x40000 @0.25m DSM (radius_sq=1), tiled over the GPUs, halo "
+                      "points exchanged with the neighbouring windows over RCCL"),
+    "cfg5": dict(side=40000, res=0.25, points=400_000_000, frames=2000, batch=64, W=1920, H=1080,
+                 f=1400.0, altitude=700.0, fixed_map=True,
+                 desc="incremental mosaic: 2000 frames of a 10 km lawn-mower flight appended in "
+                      "64-frame batches onto the resident layers of the 40000x40000 @0.25m map "
+                      "(DSM of the 400M-point cloud built once, untimed); a step = one batch"),
+    "small4": dict(side=4096, res=0.25, points=4_000_000, frames=0, W=1920, H=1080,
+                   f=1400.0, altitude=700.0, fixed_map=True,
+                   desc="4M pts -> 4096x4096 @0.25m DSM, tiled like cfg4 (test size)"),
 }
 
 
@@ -64,6 +78,9 @@ def parse():
                          "entry points, PCIe transfers included (reported as pcie_inclusive, never "
                          "as value)")
     ap.add_argument("--no-host-path", dest="host_path", action="store_false")
+    ap.add_argument("--verify", action="store_true",
+                    help="N > 1, small workloads: after the timed steps gather the cloud and every "
+                         "window's elevation on rank 0 and compare with ONE full-map DSM there")
     ap.add_argument("--map-origin", default="0,0",
                     help="easting,northing of the map centre (default 0,0; e.g. 464980.25,5272690.5 "
                          "puts the same workload at UTM magnitudes)")
@@ -155,6 +172,36 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
             "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}, parity
 
 
+def verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, m, pts, settings):
+    """Every window of the tiled run against ONE full-map DSM of the gathered cloud on rank 0
+    (small workloads only).  Returns the comparison on rank 0, None elsewhere."""
+    import numpy as np
+    import torch
+    elev = torch.from_numpy(m.get("elevation"))
+    mine = (pts.cpu().contiguous(), elev)
+    gathered = [None] * world
+    dist.gather_object(mine, gathered if rank == 0 else None, dst=0)
+    if rank != 0:
+        return None
+    cloud = torch.cat([g[0] for g in gathered], 0).to(dev)
+    with A.AerialGridMap(st, device=dev.index) as full:
+        A.Dsm(settings, full).process(cloud, full)
+        want = full.get("elevation")
+    worst, nan_equal, cells = 0.0, True, 0
+    for r in range(world):
+        i0, j0, nr, nc = layout.window(r)
+        got = gathered[r][1].numpy()
+        ref = want[j0:j0 + nc, i0:i0 + nr]
+        gn, wn = np.isnan(got), np.isnan(ref)
+        nan_equal = nan_equal and bool(np.array_equal(gn, wn))
+        ok = ~(gn | wn)
+        if ok.any():
+            worst = max(worst, float(np.abs(got[ok].astype(np.float64) - ref[ok]).max()))
+        cells += int(got.size)
+    return {"windows": world, "cells": cells, "nan_pattern_equal": nan_equal,
+            "max_abs_err_m_vs_single_gpu": worst, "pass": bool(nan_equal and worst <= 1e-4)}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -195,29 +242,47 @@ def main():
     wl = WORKLOADS[args.workload]
     side, res = wl["side"], wl["res"]
     L = side * res
-    # ONE survey map of world x 1 tiles (weak scaling: every rank owns a
-    # side x side window of it, cell positions are those of the full map)
     ox, oy = (float(v) for v in args.map_origin.split(","))
-    st = A.GridMapSettings(ox, oy, world * L, L, res)
-    layout = tiling.TileLayout(world * side, side, world, 1)
+    fixed = bool(wl.get("fixed_map"))
+    if fixed:
+        # ONE fixed survey (strong scaling): the map is cut into windows, 2 x 4 on a node's 8 GPUs
+        Lx = Ly = L
+        rows_all = cols_all = side
+        layout = (tiling.TileLayout(side, side, 2, 4) if world == 8
+                  else tiling.TileLayout.for_world(side, side, world))
+        pts_per_rank = wl["points"] // world
+    else:
+        # ONE survey map of world x 1 tiles (weak scaling: every rank owns a side x side window
+        # of it, cell positions are those of the full map)
+        Lx, Ly = world * L, L
+        rows_all, cols_all = world * side, side
+        layout = tiling.TileLayout(rows_all, cols_all, world, 1)
+        pts_per_rank = wl["points"]
+    st = A.GridMapSettings(ox, oy, Lx, Ly, res)
     win = layout.window(rank)
     m = A.AerialGridMap(st, device=local_rank, window=win)
     m.set_stream(stream.cuda_stream)
-    # centre of this rank's window in map coordinates (x decreases with i)
-    tile_center = (ox + world * L / 2.0 - (win[0] + win[2] / 2.0) * res, oy)
+    # centre of this rank's window in map coordinates (x decreases with i, y with j)
+    tile_center = (ox + Lx / 2.0 - (win[0] + win[2] / 2.0) * res,
+                   oy + Ly / 2.0 - (win[1] + win[3] / 2.0) * res)
+    win_lx, win_ly = win[2] * res, win[3] * res
 
-    # inputs, generated in HBM (synthetic, seeded).  N = 1: the tile's points
-    # plus a 4 m apron.  N > 1: each rank holds exactly the points of ITS
-    # window; the halo strips are exchanged over RCCL inside every step (tiling.TiledDsm).
+    # inputs, generated in HBM (synthetic, seeded).  N = 1: the map's points plus a 4 m apron.
+    # N > 1: each rank holds exactly the points of ITS window; the halo strips are exchanged
+    # with the neighbouring windows over RCCL inside every step (tiling.TiledDsm).
     apron = 4.0 if world == 1 else 0.0
-    n_pts = wl["points"]
+    n_pts = pts_per_rank
     halo_cap = 0       # rows per (source, destination) pair of the halo exchange
     if world > 1:
-        halo_cap = tiling.halo_strip_rows(n_pts / (L * L), L, 1, res)
-    pts_buf = torch.empty((n_pts + world * halo_cap, 3), dtype=torch.float64, device=dev)
+        # (the same on every rank -- it is a split size of the all_to_all: densest window, longest edge)
+        wins_all = layout.windows()
+        dens = max(pts_per_rank / (w[2] * res * w[3] * res) for w in wins_all)
+        edge = max(max(w[2], w[3]) * res for w in wins_all)
+        halo_cap = tiling.halo_strip_rows(dens, edge, 1, res)
+    pts_buf = torch.empty((n_pts + tiling.MAX_DESTS * halo_cap, 3), dtype=torch.float64, device=dev)
     # (N > 1: window edges are multiples of 64 cells, so a window is not exactly L wide;
     # its points cover exactly its own extent, no strip of the map is left without points)
-    half = L / 2.0 + apron if world == 1 else (win[2] * res / 2.0, L / 2.0)
+    half = (win_lx / 2.0 + apron, win_ly / 2.0 + apron)
     pts_buf[:n_pts] = synth.make_points_torch(n_pts, half, 43 + rank, dev, center=tile_center)
     if world > 1:
         # keep only points whose cell is inside the window (a point exactly on
@@ -230,12 +295,15 @@ def main():
         del cxx, cyy, own, kept
     pts = pts_buf[:n_pts]
     F = wl["frames"]
+    batch = wl.get("batch", 0)
     ch = 3 if args.colored else 1
     frames = poses = ncam = mosaic = None
     if F:
-        frames = synth.make_frames_torch(F, wl["H"], wl["W"], ch, 44 + rank, dev)
-        poses = synth.make_lawnmower_poses(F, L / 2.0, wl["altitude"], 44 + rank,
-                                           tilt_deg=5.0, center=tile_center)
+        # (cfg5: the frames of the WHOLE flight over the whole map, replicated on every rank)
+        fl_center = (ox, oy) if fixed else tile_center
+        frames = synth.make_frames_torch(F, wl["H"], wl["W"], ch, 44 + (0 if fixed else rank), dev)
+        poses = synth.make_lawnmower_poses(F, L / 2.0, wl["altitude"], 44 + (0 if fixed else rank),
+                                           tilt_deg=5.0, center=fl_center)
         ncam = A.NCamera(wl["f"], wl["f"], (wl["W"] - 1) / 2.0, (wl["H"] - 1) / 2.0,
                          wl["W"], wl["H"])
         mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(colored_ortho=args.colored), m)
@@ -243,19 +311,36 @@ def main():
 
     tiled = None
     if world > 1:
-        # the DSM's binning pass selects the halo points on its way, one all_to_all of equal
-        # splits ships them, nothing synchronises with the host inside a step
+        # the DSM's binning pass selects the halo points on its way, one all_to_all (rows only
+        # between geometric neighbours) ships them, nothing synchronises with the host in a step
         tiled = tiling.TiledDsm(dsm.settings, m, layout, rank, halo_cap,
                                 comm=tiling.TorchComm(via_host=True) if one_gpu else None)
 
-    def step():
-        m.reset()
+    def run_dsm():
         if tiled is not None:
             tiled.process(pts_buf, n_pts, sync=False)
         else:
             dsm.process(pts, m, sync=False)
-        if F:
-            mosaic.process(poses, frames, m, sync=False)
+
+    if batch:
+        # incremental mapping: layers stay resident, every step appends the next batch
+        m.reset()
+        run_dsm()
+        m.synchronize()
+        nb = (F + batch - 1) // batch
+        state = {"b": 0}
+
+        def step():
+            b = state["b"] % nb
+            state["b"] += 1
+            lo, hi = b * batch, min((b + 1) * batch, F)
+            mosaic.process(poses[lo:hi], frames[lo:hi], m, sync=False)
+    else:
+        def step():
+            m.reset()
+            run_dsm()
+            if F:
+                mosaic.process(poses, frames, m, sync=False)
 
     def fence():
         torch.cuda.synchronize()
@@ -283,14 +368,24 @@ def main():
     m.enable_timing(False)
     if tiled is not None:
         tiled.check_overflow()
+    verify = None
+    if args.verify and world > 1:
+        verify = verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, m, pts,
+                                dsm.settings)
 
-    cells = side * side
-    value = world * cells * args.steps / dt / 1e6
+    cells = win[2] * win[3] if not fixed else side * side // world   # per rank (reported)
+    cells_all = rows_all * cols_all
+    value = cells_all * args.steps / dt / 1e6
 
     if rank == 0:
-        N = wl["points"]
-        b_dsm = 24.0 * N + 4.0 * cells
-        b_ortho = (20.0 * cells + F * wl["W"] * wl["H"] * ch + 56.0 * F) if F else 0.0
+        N = pts_per_rank
+        if batch:
+            F_step = batch
+            b_dsm = 0.0
+        else:
+            F_step = F
+            b_dsm = 24.0 * N + 4.0 * cells
+        b_ortho = (20.0 * cells + F_step * wl["W"] * wl["H"] * ch + 56.0 * F_step) if F else 0.0
         alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho}
         # PMC evidence of the same command, collected by tools/collect_profiles.sh and committed
         # under profiles/ (newest round first); never measured inside this run -- the line says so
@@ -335,17 +430,17 @@ def main():
             "value": round(value, 2), "unit": "Mcells/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if fixed else "weak", "vs_baseline": None,
             "dtype": "f64 (decisions, staging, mosaic) + f32 (DSM pair arithmetic under exact guards)"
             if not os.environ.get("AMHIP_DSM_EXACT") else "f64", "data": "synthetic" if not one_gpu else
             "synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a measurement" % world,
             "config": {"workload": args.workload + ": " + wl["desc"],
-                       "cells_per_gpu": cells, "points_per_gpu": N, "frames": F,
+                       "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
                                "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
                                "%sDsm::process + OrthoBackwardGrid::process, inputs resident in HBM" %
                                ("halo exchange (RCCL all_to_all) + " if world > 1 else ""),
-                       "parallelism": "one map, %d x 1 windows, one per GPU" % world},
+                       "parallelism": "one map, %d x %d windows, one per GPU" % (layout.tiles_i, layout.tiles_j)},
             # the contract's HBM roofline of the dominant kernel (algorithmic bytes / live
             # HIP-event time / 8 TB/s) -- and, because nothing on this path is HBM bound, what
             # does bound it (below: "bound", "valu")
@@ -361,6 +456,11 @@ def main():
             "kernels": kern,
             "dsm_stats": m.dsm_stats(),
         }
+        if batch:
+            out["config"]["step"] = ("OrthoBackwardGrid::process of one %d-frame batch onto the resident "
+                                     "layers (the DSM was built once before the timed steps)" % batch)
+        if verify is not None:
+            out["verify"] = verify
         if valu is not None:
             prefixes = {"k_dsm_gather": ("k_dsm_gather_f32<", "k_dsm_gather_tiled<"),
                         "k_ortho_backward": ("k_ortho_backward",)}[dom]
@@ -385,7 +485,7 @@ def main():
                     "lanes_active_frac": round(lanes, 3),
                     "source": "profiles/" + valu[0] + " (counters); kernel_ms live"}
         parity_done = False
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not fixed:
             # (before anything else runs: the layers still hold the result of the TIMED steps)
             try:
                 cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
@@ -395,7 +495,7 @@ def main():
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"error": repr(e)}
             parity_done = True
-        if world == 1 and args.host_path:
+        if world == 1 and args.host_path and not fixed:
             # the reference-shaped call: cloud, frames and layers in host memory
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None

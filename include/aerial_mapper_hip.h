@@ -58,7 +58,9 @@ typedef enum amhip_status {
   AMHIP_ERR_ALPHA_NONPOS = 3, /* ortho-backward-grid.cc:178 CHECK(alpha > 0) */
   AMHIP_ERR_HIP = 4,          /* HIP runtime failure, see amhip_last_error() */
   AMHIP_ERR_NO_DEVICE = 5,    /* no usable gfx950 device                     */
-  AMHIP_ERR_NOMEM = 6
+  AMHIP_ERR_NOMEM = 6,
+  AMHIP_ERR_HALO_OVERFLOW = 7 /* tiled DSM: a window had more halo points for a neighbour than
+                                 the send rows reserved: the step's result is incomplete   */
 } amhip_status;
 
 /* Geometry of the grid_map::GridMap the layers belong to

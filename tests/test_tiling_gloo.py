@@ -118,3 +118,89 @@ def test_halo_margin_is_last_ladder_radius():
     from aerial_mapper_amd import tiling
     assert abs(tiling.halo_margin(1, 0.25) - (np.sqrt(1.1 ** 20) + 0.25)) < 1e-9
     assert abs(tiling.halo_margin(9, 1.0) - (3.0 + 1.0)) < 1e-12
+
+
+def _worker_neighbours(rank, world, port, tiles, ret):
+    """The exchange protocol of tiling.TiledDsm without the GPU: every rank fills `cap` rows per
+    GEOMETRIC neighbour (what k_dsm_p3_count<true> / k_halo_select do on the device, here by
+    masking), NaN-pads them, and ONE all_to_all with split sizes cap / 0 ships them; the NaN
+    rows are dropped like the receiver's binning drops them."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from aerial_mapper_amd import synth, tiling
+    import oracle_ffi as OO
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = OO.make_grid(192.0, 160.0, 0.5)
+        layout = tiling.TileLayout(g.rows, g.cols, tiles[0], tiles[1])
+        cloud = synth.make_points(70000, 100.0, 78)
+        cx, cy = tiling.cell_coords(cloud, g)
+        inside_any = np.zeros(len(cloud), bool)
+        for r in range(world):
+            inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
+        own_mask = tiling.owner_mask(cx, cy, layout.window(rank))
+        margin = tiling.halo_margin(1, g.resolution)
+        mc = margin / g.resolution
+        nbrs = tiling.neighbours(layout, rank, mc + 1.0)
+        cap = 6000
+        send = np.full((max(len(nbrs), 1) * cap, 3), np.nan)
+        for k, q in enumerate(nbrs):
+            sel = cloud[own_mask & tiling.in_window(cx, cy, layout.window(q), mc)]
+            assert sel.shape[0] <= cap
+            send[k * cap:k * cap + sel.shape[0]] = sel
+        splits = [cap if q in nbrs else 0 for q in range(world)]
+        recv = torch.empty((len(nbrs) * cap, 3), dtype=torch.float64)
+        tiling.TorchComm().exchange_rows(recv, torch.from_numpy(send[:len(nbrs) * cap]), splits, splits)
+        got = recv.numpy()
+        got = got[~np.isnan(got[:, 0])]
+        want = cloud[tiling.in_window(cx, cy, layout.window(rank), mc) & inside_any & ~own_mask]
+        key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        # a rank that is NOT a neighbour holds nothing this window needs
+        for q in range(world):
+            if q != rank and q not in nbrs:
+                stray = tiling.owner_mask(cx, cy, layout.window(q)) & \
+                    tiling.in_window(cx, cy, layout.window(rank), mc)
+                assert not stray.any()
+        ret[rank] = (got.shape == want.shape and np.array_equal(key(got), key(want)), len(nbrs),
+                     int(got.shape[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tiles,max_nbrs", [(2, (2, 1), 1), (4, (2, 2), 3), (6, (3, 2), 5),
+                                                  (4, (4, 1), 2)])
+def test_neighbour_only_exchange_gloo(world, tiles, max_nbrs):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_neighbours, args=(r, world, port, tiles, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    for r in range(world):
+        ok, nn, n = ret[r]
+        assert ok, "rank %d received the wrong halo set" % r
+        assert 1 <= nn <= max_nbrs and n > 0
+
+
+def test_neighbours_of_a_node_sized_layout():
+    from aerial_mapper_amd import tiling
+    lay = tiling.TileLayout(40000, 40000, 2, 4)           # configs[3]: 2 x 4 windows
+    mc = tiling.halo_margin(1, 0.25) / 0.25 + 1.0
+    for r in range(8):
+        nb = tiling.neighbours(lay, r, mc)
+        ti, tj = r % 2, r // 2
+        want = sorted(q for q in range(8) if q != r and abs(q % 2 - ti) <= 1 and abs(q // 2 - tj) <= 1)
+        assert nb == want and len(nb) <= tiling.MAX_DESTS
+        for q in nb:                                       # symmetric
+            assert r in tiling.neighbours(lay, q, mc)
+    strip = tiling.TileLayout(80000, 10000, 8, 1)          # the weak-scaling strip of bench.py
+    assert [len(tiling.neighbours(strip, r, mc)) for r in range(8)] == [1, 2, 2, 2, 2, 2, 2, 1]
