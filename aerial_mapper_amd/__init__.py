@@ -7,11 +7,11 @@ class API.  See DESIGN.md / INTEGRATION.md.
 """
 from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,  # noqa: F401
                       DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
-from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, NCamera,  # noqa: F401
+from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, HostSession, NCamera,  # noqa: F401
                      OrthoBackwardGrid, OrthoForwardHomography, OrthoForwardHomographySettings,
                      OrthoFromPcl, OrthoFromPclSettings, OrthoSettings, compose_T_G_C, densify)
 
-__all__ = ["AerialGridMap", "GridMapSettings", "Dsm", "DsmSettings", "OrthoBackwardGrid",
+__all__ = ["AerialGridMap", "GridMapSettings", "HostSession", "Dsm", "DsmSettings", "OrthoBackwardGrid",
            "OrthoSettings", "OrthoForwardHomography", "OrthoForwardHomographySettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "AmhipError", "Camera", "GridDesc",
            "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
            "DIST_EQUIDISTANT"]

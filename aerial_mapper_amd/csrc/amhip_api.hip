@@ -912,6 +912,36 @@ static void overwrite(Ctx* c, int layer) {
   if (layer == AMHIP_LAYER_ELEVATION) c->zrange_valid = false;  // heights from outside
 }
 
+}  // extern "C"
+
+namespace amhip {
+int ctx_use_device(Ctx* c) { return use_device(c); }
+int ctx_materialize(Ctx* c, int layer) { return materialize(c, layer); }
+void ctx_overwrite(Ctx* c, int layer) { overwrite(c, layer); }
+int ctx_fetch_status(Ctx* c) { return fetch_status(c); }
+float ctx_layer_init_value(int layer) { return layer_init_value(layer); }
+bool ctx_layer_is_initial(const Ctx* c, int layer) {
+  return c->layer_state[layer] == 0 || c->layer_state[layer] == 3;
+}
+int arg_failure(const char* msg) { return arg_fail(msg); }
+int ctx_layer_set_initial(Ctx* c, int layer) {
+  unsigned char& st = c->layer_state[layer];
+  if (layer == AMHIP_LAYER_ELEVATION) {  // every elevation is NaN again: empty height range
+    static const unsigned long long empty[2] = {0xFFF0000000000000ull, 0x000FFFFFFFFFFFFFull};
+    AMHIP_TRY(hipMemcpyAsync(c->dev_zrange, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
+    c->zrange_valid = true;
+  }
+  if (st == 0 || st == 3) return AMHIP_OK;
+  if (st == 1) {
+    st = 3;
+    return AMHIP_OK;
+  }
+  return launch_fill(c, c->layers[layer], c->cells, layer_init_value(layer));  // (handed out: eager)
+}
+}  // namespace amhip
+
+extern "C" {
+
 int amhip_layer_upload(amhip_ctx* h, int layer, const float* host) {
   if (!h || !host || !valid_layer(layer)) return arg_fail("amhip_layer_upload: bad argument");
   Ctx* c = &h->impl;

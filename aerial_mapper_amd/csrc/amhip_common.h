@@ -289,6 +289,16 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
               const uint8_t* dev_frames);
 
+// context internals shared with amhip_session.hip (defined in amhip_api.hip)
+int ctx_use_device(Ctx* c);
+int ctx_materialize(Ctx* c, int layer);      // lazy-initial -> filled
+void ctx_overwrite(Ctx* c, int layer);       // about to be fully overwritten from outside
+int ctx_layer_set_initial(Ctx* c, int layer);  // one layer back to its (lazy) initial state
+int ctx_fetch_status(Ctx* c);                // synchronize + sticky device status
+float ctx_layer_init_value(int layer);
+bool ctx_layer_is_initial(const Ctx* c, int layer);
+int arg_failure(const char* msg);
+
 // host-side restatements of the external pose math (minkindr), used to build
 // T_G_C and T_C_G; kept in one place so the composition and the per-cell
 // transform agree operation for operation.

@@ -1,0 +1,567 @@
+// amhip_session.hip -- one map served through HOST matrices by one or several GPUs.
+//
+// The reference's host is ONE C++ process whose state is the GridMap's float matrices
+// (main-dsm.cc:103-107, main-ortho-backward-grid.cc:128-141): Dsm::process and
+// OrthoBackwardGrid::process read and write them.  A session is what the drop-in classes
+// (aerial_mapper_amd/cpp/*.cc) share per map:
+//   * windows    the map cut into tiles_i x tiles_j windows, window k on devices[k] (one
+//                context each; a device may serve several windows).  A DSM call uploads a
+//                slice of the cloud to every device, each selects what every window needs
+//                (its cells + the halo margin, k_halo_select) and the selections travel
+//                device to device (hipMemcpyPeerAsync: xGMI) -- SURVEY 8e option (i), halo
+//                POINTS, inside one process; every window then runs the single-GPU kernels.
+//                Frames and poses are replicated; the mosaic needs no exchange.
+//   * residency  the layers stay on the devices between calls.  Whether a host matrix still
+//                holds what the device holds is decided by CONTENT: a 64-bit position-weighted
+//                sum over the matrix (any single changed cell changes it), computed with host
+//                threads on the way in and by a kernel on the way out.  Equal -> no transfer;
+//                a matrix that holds its initial constant -> a lazy device-side reset instead
+//                of an upload; anything else is uploaded.  Outputs the kernels did not change
+//                (num_observations: `+= itself`, ortho-backward-grid.cc:183) are not downloaded.
+//                AMHIP_SESSION_ALWAYS_COPY=1: every matrix up and down, like round 1.
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "amhip_common.h"
+
+namespace amhip {
+
+struct Win {
+  int i0, j0, rows, cols;
+};
+
+struct LayerSync {
+  bool valid = false;          // the device layer equals a host matrix with this hash
+  unsigned long long hash = 0;
+};
+
+struct Session {
+  amhip_grid_desc grid;
+  int ti = 1, tj = 1;
+  std::vector<int> edges_i, edges_j;
+  std::vector<amhip_ctx*> ctx;
+  std::vector<Win> win;
+  std::vector<int> dev;
+  std::vector<LayerSync> sync;                 // [window][layer]
+  std::vector<unsigned long long> const_hash;  // [window][layer]: hash of the initial constant
+  bool always_copy = false;
+  // DSM routing (W > 1)
+  std::vector<double*> route_out;
+  std::vector<size_t> route_cap;               // doubles
+  std::vector<long long*> route_counts;        // device, W per window
+  std::vector<double*> cloud;
+  std::vector<size_t> cloud_cap;               // doubles
+  std::vector<unsigned long long*> dev_hash;   // device scratch: one u64 per layer
+  int W() const { return (int)ctx.size(); }
+};
+
+// ---- content hash ---------------------------------------------------------------
+// h = sum over the cells of (bits(v) + C) * (2 g + 1)  mod 2^64,  g = i + j * map rows.
+// A change of one cell by d bits moves h by d * odd != 0; the sum is order-free, so host
+// threads and GPU lanes can each take any part.
+constexpr unsigned long long kHashC = 0x9E3779B97F4A7C15ull;
+
+__host__ __device__ inline unsigned long long cell_hash(unsigned bits, unsigned long long g) {
+  return ((unsigned long long)bits + kHashC) * ((g << 1) | 1ull);
+}
+
+__global__ void __launch_bounds__(256)
+k_layer_hash(const float* __restrict__ layer, int rows, int cols, int i0, int j0, int map_rows,
+             unsigned long long* __restrict__ out) {
+  unsigned long long h = 0;
+  const size_t n = (size_t)rows * (size_t)cols;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
+    const int i = (int)(k % (size_t)rows), j = (int)(k / (size_t)rows);
+    const unsigned long long g = (unsigned long long)(i0 + i) +
+                                 (unsigned long long)(j0 + j) * (unsigned long long)map_rows;
+    h += cell_hash(__float_as_uint(layer[k]), g);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
+  if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
+}
+
+static unsigned long long window_const_hash(const Session& s, const Win& w, float value) {
+  unsigned bits;
+  std::memcpy(&bits, &value, 4);
+  unsigned long long sum_odd = 0;  // sum of (2 g + 1) over the window
+  for (int j = 0; j < w.cols; ++j) {
+    const unsigned long long g0 = (unsigned long long)w.i0 +
+                                  (unsigned long long)(w.j0 + j) * (unsigned long long)s.grid.rows;
+    // sum_{i < rows} (2 (g0 + i) + 1) = rows (2 g0 + 1) + rows (rows - 1)
+    sum_odd += (unsigned long long)w.rows * ((g0 << 1) | 1ull) +
+               (unsigned long long)w.rows * (unsigned long long)(w.rows - 1);
+  }
+  return ((unsigned long long)bits + kHashC) * sum_odd;
+}
+
+// per-window hashes of `nl` host matrices (column-major, the map's size) with host threads
+static void host_hashes(const Session& s, const float* const* mats, int nl,
+                        std::vector<unsigned long long>* out /* [nl][W] */) {
+  const int W = s.W(), R = s.grid.rows, Cc = s.grid.cols;
+  out->assign((size_t)nl * W, 0ull);
+  unsigned hw = std::thread::hardware_concurrency();
+  int T = (int)std::min<unsigned>(hw ? hw : 8u, 64u);
+  if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) T = std::max(1, std::atoi(e));
+  T = std::max(1, std::min(T, Cc));
+  std::vector<std::vector<unsigned long long>> part(T, std::vector<unsigned long long>((size_t)nl * W, 0ull));
+  auto work = [&](int t) {
+    const int c0 = (int)((long long)Cc * t / T), c1 = (int)((long long)Cc * (t + 1) / T);
+    std::vector<unsigned long long>& acc = part[t];
+    int b = 0;
+    for (int j = c0; j < c1; ++j) {
+      while (j >= s.edges_j[b + 1]) ++b;
+      for (int a = 0; a < s.ti; ++a) {
+        const int k = a + b * s.ti;
+        const int ia = s.edges_i[a], ib = s.edges_i[a + 1];
+        const unsigned long long g0 = (unsigned long long)j * (unsigned long long)R;
+        for (int l = 0; l < nl; ++l) {
+          if (!mats[l]) continue;
+          const unsigned* col = reinterpret_cast<const unsigned*>(mats[l]) + (size_t)j * R;
+          unsigned long long h = 0;
+          for (int i = ia; i < ib; ++i) h += cell_hash(col[i], g0 + (unsigned long long)i);
+          acc[(size_t)l * W + k] += h;
+        }
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+  for (int t = 0; t < T; ++t)
+    for (size_t q = 0; q < out->size(); ++q) (*out)[q] += part[t][q];
+}
+
+static inline float* map_at(float* base, const Session& s, const Win& w) {
+  return base + (size_t)w.i0 + (size_t)w.j0 * (size_t)s.grid.rows;
+}
+static inline const float* map_at(const float* base, const Session& s, const Win& w) {
+  return base + (size_t)w.i0 + (size_t)w.j0 * (size_t)s.grid.rows;
+}
+
+// host matrix -> window layer, as far as needed (asynchronous on the context's stream)
+static int sync_in(Session& s, int k, int layer, const float* host, unsigned long long host_hash) {
+  Ctx* c = &s.ctx[k]->impl;
+  LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layer];
+  int rc = ctx_use_device(c);
+  if (rc) return rc;
+  if (!s.always_copy) {
+    if (st.valid && st.hash == host_hash) return AMHIP_OK;  // the device holds exactly this
+    if (host_hash == s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + layer]) {
+      // (any matrix with this hash is taken for the initial constant: 2^-64)
+      if ((rc = ctx_layer_set_initial(c, layer))) return rc;
+      st.valid = true;
+      st.hash = host_hash;
+      return AMHIP_OK;
+    }
+  }
+  const Win& w = s.win[k];
+  ctx_overwrite(c, layer);
+  AMHIP_TRY(hipMemcpy2DAsync(c->layers[layer], (size_t)w.rows * 4, map_at(host, s, w),
+                             (size_t)s.grid.rows * 4, (size_t)w.rows * 4, (size_t)w.cols,
+                             hipMemcpyHostToDevice, c->stream));
+  st.valid = true;
+  st.hash = host_hash;
+  return AMHIP_OK;
+}
+
+// window layers -> host matrices where the device content differs from what the host holds
+static int sync_out(Session& s, int k, const int* layers, float* const* hosts, int nl) {
+  Ctx* c = &s.ctx[k]->impl;
+  int rc = ctx_use_device(c);
+  if (rc) return rc;
+  const Win& w = s.win[k];
+  unsigned long long h[AMHIP_NUM_LAYERS] = {};
+  bool run[AMHIP_NUM_LAYERS] = {};
+  if (!s.always_copy) {
+    AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * AMHIP_NUM_LAYERS, c->stream));
+    for (int q = 0; q < nl; ++q) {
+      if (!hosts[q]) continue;
+      const int l = layers[q];
+      if (ctx_layer_is_initial(c, l)) {  // nothing wrote it since its (lazy) reset
+        h[q] = s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + l];
+        continue;
+      }
+      run[q] = true;
+      hipLaunchKernelGGL(k_layer_hash, dim3(2048), dim3(256), 0, c->stream, c->layers[l], w.rows,
+                         w.cols, w.i0, w.j0, s.grid.rows, s.dev_hash[k] + q);
+    }
+    unsigned long long got[AMHIP_NUM_LAYERS];
+    AMHIP_TRY(hipMemcpyAsync(got, s.dev_hash[k], sizeof(got), hipMemcpyDeviceToHost, c->stream));
+    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    for (int q = 0; q < nl; ++q)
+      if (run[q]) h[q] = got[q];
+  }
+  for (int q = 0; q < nl; ++q) {
+    if (!hosts[q]) continue;
+    const int l = layers[q];
+    LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + l];
+    if (!s.always_copy && st.valid && st.hash == h[q]) continue;  // the host already holds it
+    if ((rc = ctx_materialize(c, l))) return rc;
+    AMHIP_TRY(hipMemcpy2DAsync(map_at(hosts[q], s, w), (size_t)s.grid.rows * 4, c->layers[l],
+                               (size_t)w.rows * 4, (size_t)w.rows * 4, (size_t)w.cols,
+                               hipMemcpyDeviceToHost, c->stream));
+    st.valid = !s.always_copy;
+    st.hash = h[q];
+  }
+  return AMHIP_OK;
+}
+
+// dsm.cc:127-144: the largest squared radius of the ladder -> metres a window grows by
+static double halo_margin_m(int radius_sq, double res) {
+  double tmax = (double)radius_sq, lambda = 1.0;
+  for (;;) {
+    tmax = std::max(tmax, lambda * radius_sq);
+    lambda *= 1.1;
+    if (lambda * radius_sq > 7.0) break;
+  }
+  return std::sqrt(tmax) + res;
+}
+
+template <typename F>
+static int for_windows(Session& s, F fn) {
+  const int W = s.W();
+  std::vector<int> rcs(W, AMHIP_OK);
+  std::vector<std::string> msgs(W);
+  if (W == 1) return fn(0);
+  std::vector<std::thread> th;
+  for (int k = 0; k < W; ++k)
+    th.emplace_back([&, k]() {
+      rcs[k] = fn(k);
+      if (rcs[k]) msgs[k] = amhip_last_error();  // (thread-local message)
+    });
+  for (auto& x : th) x.join();
+  for (int k = 0; k < W; ++k)
+    if (rcs[k]) {
+      set_last_error(msgs[k]);
+      return rcs[k];
+    }
+  return AMHIP_OK;
+}
+
+}  // namespace amhip
+
+using namespace amhip;
+
+struct amhip_session {
+  amhip::Session impl;
+};
+
+extern "C" {
+
+int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
+                         const int32_t* devices, amhip_session** out) {
+  if (!grid || !out || tiles_i < 1 || tiles_j < 1)
+    return arg_failure("amhip_session_create: bad argument");
+  if (tiles_i > grid->rows || tiles_j > grid->cols || (long long)tiles_i * tiles_j > 64)
+    return arg_failure("amhip_session_create: more windows than the map can be cut into (<= 64)");
+  *out = nullptr;
+  amhip_session* h = new (std::nothrow) amhip_session();
+  if (!h) return AMHIP_ERR_NOMEM;
+  Session& s = h->impl;
+  s.grid = *grid;
+  s.ti = tiles_i;
+  s.tj = tiles_j;
+  s.always_copy = std::getenv("AMHIP_SESSION_ALWAYS_COPY") != nullptr;
+  // window edges on multiples of the gather tile (64 x 32 cells) except at the map border
+  auto edges = [](int n, int parts, int align, std::vector<int>* e) {
+    e->assign(1, 0);
+    for (int k = 1; k < parts; ++k) {
+      int v = (int)std::llround((double)n * k / parts / align) * align;
+      v = std::min(std::max(v, e->back() + 1), n - (parts - k));
+      e->push_back(v);
+    }
+    e->push_back(n);
+  };
+  edges(grid->rows, tiles_i, 64, &s.edges_i);
+  edges(grid->cols, tiles_j, 32, &s.edges_j);
+  const int W = tiles_i * tiles_j;
+  int rc = AMHIP_OK;
+  for (int k = 0; k < W && rc == AMHIP_OK; ++k) {
+    const int a = k % tiles_i, b = k / tiles_i;
+    Win w = {s.edges_i[a], s.edges_j[b], s.edges_i[a + 1] - s.edges_i[a],
+             s.edges_j[b + 1] - s.edges_j[b]};
+    amhip_ctx* c = nullptr;
+    const int d = devices ? devices[k] : 0;
+    rc = amhip_ctx_create_window(grid, w.i0, w.j0, w.rows, w.cols, d, &c);
+    if (rc) break;
+    s.ctx.push_back(c);
+    s.win.push_back(w);
+    s.dev.push_back(d);
+    unsigned long long* dh = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&dh), sizeof(unsigned long long) * AMHIP_NUM_LAYERS) !=
+        hipSuccess) {
+      rc = hip_fail(hipGetLastError(), "hipMalloc(session scratch)", __FILE__, __LINE__);
+      break;
+    }
+    s.dev_hash.push_back(dh);
+  }
+  if (rc) {
+    amhip_session_destroy(h);
+    return rc;
+  }
+  s.sync.assign((size_t)W * AMHIP_NUM_LAYERS, LayerSync());
+  s.const_hash.resize((size_t)W * AMHIP_NUM_LAYERS);
+  for (int k = 0; k < W; ++k)
+    for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+      s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + l] =
+          window_const_hash(s, s.win[k], ctx_layer_init_value(l));
+  s.route_out.assign(W, nullptr);
+  s.route_cap.assign(W, 0);
+  s.route_counts.assign(W, nullptr);
+  s.cloud.assign(W, nullptr);
+  s.cloud_cap.assign(W, 0);
+  // direct device-to-device copies where the hardware allows them (xGMI)
+  for (int a = 0; a < W; ++a)
+    for (int b = 0; b < W; ++b)
+      if (s.dev[a] != s.dev[b]) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, s.dev[a], s.dev[b]) == hipSuccess && can &&
+            hipSetDevice(s.dev[a]) == hipSuccess)
+          (void)hipDeviceEnablePeerAccess(s.dev[b], 0);
+        (void)hipGetLastError();  // (already enabled is fine)
+      }
+  *out = h;
+  return AMHIP_OK;
+}
+
+void amhip_session_destroy(amhip_session* h) {
+  if (!h) return;
+  Session& s = h->impl;
+  for (size_t k = 0; k < s.ctx.size(); ++k) {
+    if (s.ctx[k]) {
+      (void)ctx_use_device(&s.ctx[k]->impl);
+      (void)hipStreamSynchronize(s.ctx[k]->impl.stream);
+      if (k < s.route_out.size() && s.route_out[k]) (void)hipFree(s.route_out[k]);
+      if (k < s.route_counts.size() && s.route_counts[k]) (void)hipFree(s.route_counts[k]);
+      if (k < s.cloud.size() && s.cloud[k]) (void)hipFree(s.cloud[k]);
+      if (k < s.dev_hash.size() && s.dev_hash[k]) (void)hipFree(s.dev_hash[k]);
+      amhip_ctx_destroy(s.ctx[k]);
+    }
+  }
+  delete h;
+}
+
+int amhip_session_num_windows(const amhip_session* h) { return h ? h->impl.W() : 0; }
+
+amhip_ctx* amhip_session_context(amhip_session* h, int k) {
+  if (!h || k < 0 || k >= h->impl.W()) return nullptr;
+  return h->impl.ctx[k];
+}
+
+int amhip_session_window(const amhip_session* h, int k, int32_t* i0_j0_rows_cols) {
+  if (!h || k < 0 || k >= h->impl.W() || !i0_j0_rows_cols)
+    return arg_failure("amhip_session_window: bad argument");
+  const Win& w = h->impl.win[k];
+  i0_j0_rows_cols[0] = w.i0;
+  i0_j0_rows_cols[1] = w.j0;
+  i0_j0_rows_cols[2] = w.rows;
+  i0_j0_rows_cols[3] = w.cols;
+  return AMHIP_OK;
+}
+
+int amhip_session_set_always_copy(amhip_session* h, int on) {
+  if (!h) return arg_failure("null session");
+  h->impl.always_copy = on != 0;
+  for (auto& st : h->impl.sync) st.valid = false;
+  return AMHIP_OK;
+}
+
+// dsm::Dsm::process (dsm.cc:186-201) on host buffers: `elevation` is the GridMap's matrix
+// (map rows x cols, column-major), read and written like the reference does.
+int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n, int radius_sq,
+                              double center_easting, double center_northing, float* elevation) {
+  if (!h) return arg_failure("null session");
+  if (n == 0) return AMHIP_OK;  // "Passed empty point cloud to DSM module" (dsm.cc:189-192)
+  if (!host_xyz || !elevation) return arg_failure("amhip_session_dsm_process: null buffer");
+  if (radius_sq <= 0) return arg_failure("interpolation_radius must be >= 1");
+  Session& s = h->impl;
+  const int W = s.W();
+  // (1) what do the devices already hold of `elevation`?  (host threads; the cloud's upload
+  // is enqueued first where there is a single window, so that both overlap)
+  std::vector<unsigned long long> hh;
+  const float* mats[1] = {elevation};
+  int rc;
+  if (W == 1) {
+    Ctx* c = &s.ctx[0]->impl;
+    if ((rc = ctx_use_device(c))) return rc;
+    if (n >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points");
+    if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
+    // (a pageable source makes this call return only once the data is staged; the hash runs
+    // in a second thread meanwhile)
+    std::thread hasher([&]() {
+      if (!s.always_copy) host_hashes(s, mats, 1, &hh);
+      else hh.assign(1, 0ull);
+    });
+    hipError_t e = hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
+                                  hipMemcpyHostToDevice, c->stream);
+    hasher.join();
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cloud)", __FILE__, __LINE__);
+    if ((rc = sync_in(s, 0, AMHIP_LAYER_ELEVATION, elevation, hh[0]))) return rc;
+    if ((rc = amhip_dsm_process_dev(s.ctx[0], c->stage_points, n, radius_sq, center_easting,
+                                    center_northing)))
+      return rc;
+    const int lay[1] = {AMHIP_LAYER_ELEVATION};
+    float* outs[1] = {elevation};
+    if ((rc = sync_out(s, 0, lay, outs, 1))) return rc;
+    return ctx_fetch_status(c);
+  }
+
+  if (!s.always_copy) host_hashes(s, mats, 1, &hh);
+  else hh.assign(W, 0ull);
+  // (2) slice k of the cloud goes to window k's device, which selects what EVERY window
+  // needs of it (its cells grown by the halo margin)
+  const double margin = halo_margin_m(radius_sq, s.grid.resolution);
+  std::vector<int32_t> wins(4 * (size_t)W);
+  for (int d = 0; d < W; ++d) {
+    wins[4 * d + 0] = s.win[d].i0;
+    wins[4 * d + 1] = s.win[d].j0;
+    wins[4 * d + 2] = s.win[d].rows;
+    wins[4 * d + 3] = s.win[d].cols;
+  }
+  std::vector<size_t> lo(W + 1);
+  for (int k = 0; k <= W; ++k) lo[k] = n * (size_t)k / (size_t)W;
+  std::vector<long long> counts((size_t)W * W, 0);
+  rc = for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    const size_t nk = lo[k + 1] - lo[k];
+    if ((r = sync_in(s, k, AMHIP_LAYER_ELEVATION, elevation, hh[k]))) return r;
+    if (nk == 0) return AMHIP_OK;
+    if ((r = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * nk))) return r;
+    AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz + 3 * lo[k], 3 * nk * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+    if ((r = ensure_capacity(&s.route_out[k], &s.route_cap[k], 3 * nk * (size_t)W))) return r;
+    if (!s.route_counts[k])
+      AMHIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.route_counts[k]), sizeof(long long) * W));
+    for (int d0 = 0; d0 < W; d0 += kMaxHaloDests) {
+      const int nd = std::min(kMaxHaloDests, W - d0);
+      if ((r = amhip_halo_select_dev(s.ctx[k], c->stage_points, nk, center_easting, center_northing,
+                                     &wins[4 * (size_t)d0], nd, margin,
+                                     s.route_out[k] + 3 * nk * (size_t)d0, nk,
+                                     reinterpret_cast<int64_t*>(s.route_counts[k] + d0))))
+        return r;
+    }
+    AMHIP_TRY(hipMemcpyAsync(&counts[(size_t)k * W], s.route_counts[k], sizeof(long long) * W,
+                             hipMemcpyDeviceToHost, c->stream));
+    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    return AMHIP_OK;
+  });
+  if (rc) return rc;
+  // (3) every window collects its points from all slices, device to device, and runs
+  // Dsm::process on them
+  rc = for_windows(s, [&](int d) -> int {
+    Ctx* c = &s.ctx[d]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    size_t total = 0;
+    for (int k = 0; k < W; ++k) total += (size_t)counts[(size_t)k * W + d];
+    if (total >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points in one window");
+    if (total) {
+      if ((r = ensure_capacity(&s.cloud[d], &s.cloud_cap[d], 3 * total))) return r;
+      size_t off = 0;
+      for (int k = 0; k < W; ++k) {
+        const size_t cnt = (size_t)counts[(size_t)k * W + d];
+        if (!cnt) continue;
+        const size_t nk = lo[k + 1] - lo[k];
+        const double* src = s.route_out[k] + 3 * nk * (size_t)d;
+        if (s.dev[k] == s.dev[d])
+          AMHIP_TRY(hipMemcpyAsync(s.cloud[d] + 3 * off, src, cnt * 24, hipMemcpyDeviceToDevice,
+                                   c->stream));
+        else
+          AMHIP_TRY(hipMemcpyPeerAsync(s.cloud[d] + 3 * off, s.dev[d], src, s.dev[k], cnt * 24,
+                                       c->stream));
+        off += cnt;
+      }
+      if ((r = amhip_dsm_process_dev(s.ctx[d], s.cloud[d], total, radius_sq, center_easting,
+                                     center_northing)))
+        return r;
+    }
+    const int lay[1] = {AMHIP_LAYER_ELEVATION};
+    float* outs[1] = {elevation};
+    if ((r = sync_out(s, d, lay, outs, 1))) return r;
+    return ctx_fetch_status(c);
+  });
+  return rc;
+}
+
+// ortho::OrthoBackwardGrid::process (ortho-backward-grid.cc:223-239) on host buffers.
+int amhip_session_ortho_backward_process(
+    amhip_session* h, const amhip_camera* cam, const double* host_T_G_C, size_t F,
+    const uint8_t* const* images, const size_t* steps, int channels, int colored,
+    const float* elevation, float* elevation_angle, float* observation_index,
+    float* num_observations, float* ortho, float* colored_ortho) {
+  if (!h || !cam) return arg_failure("null session / camera");
+  if (F == 0 || !host_T_G_C || !images || !steps)
+    return arg_failure("empty pose / image list (CHECK(!T_G_Bs.empty()))");
+  if (cam->width <= 0 || cam->height <= 0) return arg_failure("bad image size");
+  if (!elevation || !elevation_angle || !observation_index || !num_observations ||
+      !(colored ? colored_ortho : ortho))
+    return arg_failure("amhip_session_ortho_backward_process: null layer");
+  Session& s = h->impl;
+  const int W = s.W();
+  const size_t row = (size_t)cam->width * (size_t)channels;
+  const size_t frame = row * (size_t)cam->height;
+  for (size_t f = 0; f < F; ++f) {
+    if (!images[f]) return arg_failure("null image");
+    if (steps[f] < row) return arg_failure("image step smaller than a row");
+  }
+  // layer order of the context: ORTHO, ELEVATION, ELEVATION_ANGLE, NUM_OBSERVATIONS,
+  // OBSERVATION_INDEX, COLORED_ORTHO
+  const float* ins[AMHIP_NUM_LAYERS] = {ortho, elevation, elevation_angle, num_observations,
+                                        observation_index, colored_ortho};
+  std::vector<unsigned long long> hh;
+  auto upload_frames = [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    if ((r = ensure_capacity(&c->stage_frames, &c->stage_frames_cap, frame * F))) return r;
+    for (size_t f = 0; f < F; ++f) {
+      if (steps[f] == row)
+        AMHIP_TRY(hipMemcpyAsync(c->stage_frames + f * frame, images[f], frame,
+                                 hipMemcpyHostToDevice, c->stream));
+      else
+        AMHIP_TRY(hipMemcpy2DAsync(c->stage_frames + f * frame, row, images[f], steps[f], row,
+                                   (size_t)cam->height, hipMemcpyHostToDevice, c->stream));
+    }
+    return AMHIP_OK;
+  };
+  // the frames go up while host threads hash the six matrices
+  int rc_up = AMHIP_OK;
+  std::string up_msg;
+  std::thread uploader([&]() {
+    rc_up = for_windows(s, upload_frames);
+    if (rc_up) up_msg = amhip_last_error();
+  });
+  if (!s.always_copy) host_hashes(s, ins, AMHIP_NUM_LAYERS, &hh);
+  else hh.assign((size_t)AMHIP_NUM_LAYERS * W, 0ull);
+  uploader.join();
+  if (rc_up) {
+    set_last_error(up_msg);
+    return rc_up;
+  }
+  return for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
+      if (ins[l] && (r = sync_in(s, k, l, ins[l], hh[(size_t)l * W + k]))) return r;
+    if ((r = amhip_ortho_backward_process_dev(s.ctx[k], cam, host_T_G_C, F, c->stage_frames, frame,
+                                              row, channels, colored)))
+      return r;
+    const int lay[5] = {AMHIP_LAYER_ORTHO, AMHIP_LAYER_ELEVATION_ANGLE, AMHIP_LAYER_NUM_OBSERVATIONS,
+                        AMHIP_LAYER_OBSERVATION_INDEX, AMHIP_LAYER_COLORED_ORTHO};
+    float* outs[5] = {ortho, elevation_angle, num_observations, observation_index, colored_ortho};
+    if ((r = sync_out(s, k, lay, outs, 5))) return r;
+    return ctx_fetch_status(c);
+  });
+}
+
+}  // extern "C"

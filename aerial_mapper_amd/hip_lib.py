@@ -49,6 +49,9 @@ EXPORTS = [
     "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
     "amhip_mosaic_download", "amhip_mosaic_device_ptr", "amhip_mosaic_homography",
     "amhip_camera_view_bounds",
+    "amhip_session_create", "amhip_session_destroy", "amhip_session_num_windows",
+    "amhip_session_context", "amhip_session_window", "amhip_session_set_always_copy",
+    "amhip_session_dsm_process", "amhip_session_ortho_backward_process",
     "amhip_io_parse_point_cloud_text", "amhip_io_download_point_cloud", "amhip_io_free",
 ]
 
@@ -143,6 +146,18 @@ def load():
     lib.amhip_ortho_backward_process_dev.argtypes = [
         vp, cp, f64p, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_int]
     lib.amhip_ortho_backward_process.argtypes = [
+        vp, cp, f64p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int,
+        vp, vp, vp, vp, vp, vp]
+    lib.amhip_session_create.argtypes = [gp, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(vp)]
+    lib.amhip_session_destroy.restype = None
+    lib.amhip_session_destroy.argtypes = [vp]
+    lib.amhip_session_num_windows.argtypes = [vp]
+    lib.amhip_session_context.restype = vp
+    lib.amhip_session_context.argtypes = [vp, C.c_int]
+    lib.amhip_session_window.argtypes = [vp, C.c_int, C.POINTER(C.c_int32)]
+    lib.amhip_session_set_always_copy.argtypes = [vp, C.c_int]
+    lib.amhip_session_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
+    lib.amhip_session_ortho_backward_process.argtypes = [
         vp, cp, f64p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int,
         vp, vp, vp, vp, vp, vp]
     lib.amhip_ctx_enable_timing.argtypes = [vp, C.c_int]

@@ -388,6 +388,103 @@ class OrthoBackwardGrid(object):
             int(colored), None, None, None, None, None, None))
 
 
+LAYER_INIT = {"ortho": 255.0, "elevation": float("nan"), "elevation_angle": 0.0,
+              "num_observations": 0.0, "observation_index": float("nan"),
+              "colored_ortho": float("nan")}
+
+
+class HostSession(object):
+    """amhip_session: the entry points the C++ drop-in classes use, on HOST matrices.
+
+    `layers[name]` are numpy float32 arrays of shape (cols, rows) -- the memory of the GridMap's
+    column-major Eigen matrices -- initialised like AerialGridMap::initialize()
+    (aerial-mapper-grid-map.cc:40-48).  dsm_process / ortho_process read and write them like
+    dsm::Dsm::process / ortho::OrthoBackwardGrid::process do; between calls the caller may
+    change them freely (the session notices by content).  tiles = (tiles_i, tiles_j) windows on
+    `devices` (one entry per window; default: all on device 0)."""
+
+    def __init__(self, settings, tiles=(1, 1), devices=None):
+        lib = L.load()
+        self._lib = lib
+        self.settings = settings
+        self.grid = L.make_grid(settings.delta_easting, settings.delta_northing,
+                                settings.resolution, settings.center_easting,
+                                settings.center_northing)
+        nw = int(tiles[0]) * int(tiles[1])
+        devs = (C.c_int32 * nw)(*([0] * nw if devices is None else [int(d) for d in devices]))
+        h = C.c_void_p()
+        L.check(lib.amhip_session_create(C.byref(self.grid), int(tiles[0]), int(tiles[1]), devs,
+                                         C.byref(h)))
+        self._h = h
+        shape = (self.grid.cols, self.grid.rows)
+        self.layers = {n: np.full(shape, v, np.float32) for n, v in LAYER_INIT.items()}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.amhip_session_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def num_windows(self):
+        return int(self._lib.amhip_session_num_windows(self._h))
+
+    def window(self, k):
+        w = (C.c_int32 * 4)()
+        L.check(self._lib.amhip_session_window(self._h, int(k), w))
+        return tuple(int(v) for v in w)
+
+    def set_always_copy(self, on):
+        L.check(self._lib.amhip_session_set_always_copy(self._h, int(bool(on))))
+
+    def set_dsm_precision(self, exact):
+        for k in range(self.num_windows):
+            L.check(self._lib.amhip_ctx_set_dsm_precision(
+                C.c_void_p(self._lib.amhip_session_context(self._h, k)), 1 if exact else 0))
+
+    def dsm_process(self, dsm_settings, points):
+        pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        s = dsm_settings
+        L.check(self._lib.amhip_session_dsm_process(
+            self._h, pts.ctypes.data, pts.shape[0], s.interpolation_radius, s.center_easting,
+            s.center_northing, self.layers["elevation"].ctypes.data))
+
+    def ortho_process(self, ncameras, ortho_settings, T_G_Bs, images):
+        T_G_Bs = np.ascontiguousarray(T_G_Bs, np.float64).reshape(-1, 7)
+        F = T_G_Bs.shape[0]
+        colored = bool(ortho_settings.colored_ortho)
+        T_G_C = compose_T_G_C(T_G_Bs, ncameras.T_C_B)
+        ptrs = (C.c_void_p * F)()
+        steps = (C.c_size_t * F)()
+        keep = []
+        for k, im in enumerate(images):
+            im = np.asarray(im)
+            if im.dtype != np.uint8 or im.strides[-1] != 1 or \
+                    (im.ndim == 3 and (im.shape[2] != 3 or im.strides[1] != 3)):
+                im = np.ascontiguousarray(im, np.uint8)
+            keep.append(im)
+            ptrs[k] = im.ctypes.data
+            steps[k] = im.strides[0]
+        lay = self.layers
+        L.check(self._lib.amhip_session_ortho_backward_process(
+            self._h, C.byref(ncameras.camera), T_G_C.ctypes.data_as(C.POINTER(C.c_double)), F, ptrs,
+            steps, 3 if colored else 1, int(colored), lay["elevation"].ctypes.data,
+            lay["elevation_angle"].ctypes.data, lay["observation_index"].ctypes.data,
+            lay["num_observations"].ctypes.data, lay["ortho"].ctypes.data,
+            lay["colored_ortho"].ctypes.data))
+
+
 class OrthoFromPclSettings(object):
     """ortho::Settings of ortho-from-pcl.h:28-35."""
 

@@ -496,29 +496,42 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
             parity_done = True
         if world == 1 and args.host_path and not fixed:
-            # the reference-shaped call: cloud, frames and layers in host memory
+            # the reference-shaped call, as the C++ drop-in classes make it: cloud, frames and
+            # the GridMap's six matrices in (pageable) host memory, one amhip_session per map
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None
-            out_names = ["elevation"] + (["elevation_angle", "observation_index", "ortho"] if F else [])
-            # the caller's layer matrices exist (and are touched) before the call,
-            # like the GridMap's in the C++ shim
-            h_layers = {n: np.full((m.cols, m.rows), -1.0, np.float32) for n in out_names}
-            dsm.process(h_pts[:1024], m)  # (allocates the host mirror of the elevation layer)
-            m.reset()
-            m.synchronize()
-            t0h = time.perf_counter()
-            dsm.process(h_pts, m)
-            t1h = time.perf_counter()
-            if F:
-                mosaic.process(poses, h_frames, m)
-            for name in out_names:
-                m.get(name, out=h_layers[name])
-            t2h = time.perf_counter()
+            with A.HostSession(st) as hs:
+                warm = A.HostSession(A.GridMapSettings(ox, oy, 64 * res, 32 * res, res))
+                warm.dsm_process(dsm.settings, h_pts[:4096])   # (loads the code objects)
+                warm.close()
+                torch.cuda.synchronize()
+                t0h = time.perf_counter()
+                hs.dsm_process(dsm.settings, h_pts)
+                t1h = time.perf_counter()
+                if F:
+                    hs.ortho_process(ncam, mosaic.settings, poses, h_frames)
+                t2h = time.perf_counter()
+                # a second pass over the SAME map (incremental mapping: the layers are resident,
+                # the matrices unchanged since the session wrote them)
+                hs.dsm_process(dsm.settings, h_pts)
+                t3h = time.perf_counter()
+                if F:
+                    hs.ortho_process(ncam, mosaic.settings, poses, h_frames)
+                t4h = time.perf_counter()
+            bytes_up = h_pts.nbytes + (sum(f.nbytes for f in h_frames) if F else 0)
+            bytes_down = 4.0 * cells * (4 if F else 1)
             out["pcie_inclusive"] = {
                 "ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
                 "Mcells_per_s": round(cells / (t2h - t0h) / 1e6, 1),
-                "note": "one pass, pageable host buffers: cloud H2D + elevation up/down, frames "
-                        "H2D, output layers D2H"}
+                "second_pass_ms": round((t4h - t2h) * 1e3, 1),
+                "bytes_up": bytes_up, "bytes_down": bytes_down,
+                "link_floor_ms": round((bytes_up + bytes_down) / 56e9 * 1e3, 1),
+                "note": "amhip_session_dsm_process + amhip_session_ortho_backward_process on pageable "
+                        "host buffers (the drop-in classes' route): cloud + frames up, the matrices "
+                        "that changed down (elevation, elevation_angle, observation_index, ortho); "
+                        "initial-state matrices are recognised by content and not uploaded; "
+                        "link_floor_ms = those bytes at the 56 GB/s this host moves one way at a time "
+                        "(H2D and D2H of one synchronous call cannot overlap)"}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:

@@ -414,6 +414,41 @@ typedef enum amhip_kernel {
   AMHIP_NUM_KERNELS = 7
 } amhip_kernel;
 
+/* ---- session: one map served through HOST matrices by one or several GPUs ---------------
+ *
+ * What the drop-in classes share per grid_map::GridMap (the .cc files under aerial_mapper_amd/cpp): the map
+ * is cut into tiles_i x tiles_j windows, window k = (k % tiles_i, k / tiles_i) lives on
+ * devices[k] (NULL = all on device 0; a device may serve several windows), everything inside ONE
+ * host process like the reference's demos (main-dsm.cc:103-107, main-ortho-backward-grid.cc:
+ * 128-141).  A DSM call uploads one slice of the cloud per window, every device selects what
+ * every window needs of its slice (cells + halo margin) and the selections travel device to
+ * device (hipMemcpyPeerAsync over xGMI); frames and poses are replicated.
+ * The layers stay resident between calls: whether a host matrix still holds what the devices
+ * hold is decided by a 64-bit content sum (host threads on the way in, a kernel on the way out)
+ * -- equal: no transfer; the layer's initial constant: a lazy device-side reset; anything
+ * else: uploaded.  Outputs the kernels left unchanged are not downloaded.  Results are those
+ * of the single-context calls (same kernels; windows reproduce the full map).
+ * AMHIP_SESSION_ALWAYS_COPY=1 / amhip_session_set_always_copy: every matrix up and down. */
+typedef struct amhip_session amhip_session;
+int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
+                         const int32_t* devices, amhip_session** out);
+void amhip_session_destroy(amhip_session* s);
+int amhip_session_num_windows(const amhip_session* s);
+amhip_ctx* amhip_session_context(amhip_session* s, int window);
+int amhip_session_window(const amhip_session* s, int window, int32_t* i0_j0_rows_cols);
+int amhip_session_set_always_copy(amhip_session* s, int on);
+/* dsm::Dsm::process (dsm.cc:186-201): `elevation` = the GridMap's matrix (map rows x cols,
+ * column-major), read and written like the reference does. */
+int amhip_session_dsm_process(amhip_session* s, const double* host_xyz, size_t n, int radius_sq,
+                              double center_easting, double center_northing, float* elevation);
+/* ortho::OrthoBackwardGrid::process (ortho-backward-grid.cc:223-239): the six matrices of the
+ * map (all required except the one of ortho / colored_ortho the mode does not write). */
+int amhip_session_ortho_backward_process(
+    amhip_session* s, const amhip_camera* cam, const double* host_T_G_C, size_t F,
+    const uint8_t* const* images, const size_t* steps, int channels, int colored,
+    const float* elevation, float* elevation_angle, float* observation_index,
+    float* num_observations, float* ortho, float* colored_ortho);
+
 /* With timing enabled every launch is bracketed by hipEvents on the
  * context's stream.  amhip_ctx_kernel_time() synchronises, then reports the
  * accumulated milliseconds and launch count of one slot since the last

@@ -1,0 +1,116 @@
+"""amhip_session (include/aerial_mapper_hip.h): the GridMap-matrix-shaped entry points the C++
+drop-in classes share per map -- residency by content, and ONE host process driving several
+windows (here: several windows on the one GPU of the test box; on a node they sit on different
+devices and the halo points travel over xGMI).  Oracle: dsm.cc / ortho-backward-grid.cc
+restated (oracle/amo_*.cc, pinned in tests/test_reference_loops.py)."""
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import scenarios as S
+
+pytestmark = pytest.mark.gpu
+
+ORTHO_LAYERS = ["elevation_angle", "observation_index", "num_observations", "ortho",
+                "colored_ortho"]
+
+
+def _settings(A, g):
+    return A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+
+
+def _oracle(sc, colored=False, layers=None):
+    lay = layers or O.new_layers(sc.grid)
+    rc, elev, _ = O.dsm_process(sc.points, sc.grid, 1, 0.0, 0.0, elevation=lay["elevation"].copy())
+    assert rc == O.OK
+    lay["elevation"] = elev
+    rc = O.ortho_process(sc.grid, sc.cam, sc.poses, sc.T_C_B, sc.frames, lay, colored=colored)
+    assert rc == O.OK
+    return lay
+
+
+def _ncam(A, sc):
+    c = sc.cam
+    n = A.NCamera(c.fu, c.fv, c.cu, c.cv, c.width, c.height)
+    return n
+
+
+@pytest.mark.parametrize("tiles", [(1, 1), (2, 1), (2, 2), (3, 2)])
+@pytest.mark.parametrize("colored", [False, True])
+def test_session_reproduces_the_reference_through_host_matrices(tiles, colored):
+    import aerial_mapper_amd as A
+    sc = S.Scene(160.0, 128.0, 0.5, 120000, seed=401, num_frames=10, colored=colored)
+    want = _oracle(sc, colored)
+    with A.HostSession(_settings(A, sc.grid), tiles=tiles) as hs:
+        assert hs.num_windows == tiles[0] * tiles[1]
+        hs.set_dsm_precision(True)     # (windows vs one map: the FP64 gather, see test_gpu_tiling)
+        hs.dsm_process(A.DsmSettings(1), sc.points)
+        S.assert_dsm_close(hs.layers["elevation"], want["elevation"], tol=1e-6)
+        hs.ortho_process(_ncam(A, sc), A.OrthoSettings(colored_ortho=colored), sc.poses, sc.frames)
+        # the mosaic reads the float elevation: identical floats in, identical layers out
+        if np.array_equal(hs.layers["elevation"].view(np.uint32), want["elevation"].view(np.uint32)):
+            S.assert_layers_equal(hs.layers, want, ORTHO_LAYERS)
+        cover = np.zeros((sc.grid.rows, sc.grid.cols), np.int32)
+        for k in range(hs.num_windows):
+            i0, j0, r, c = hs.window(k)
+            cover[i0:i0 + r, j0:j0 + c] += 1
+        assert (cover == 1).all()
+
+
+def test_session_fast_mode_two_windows_within_the_contract():
+    import aerial_mapper_amd as A
+    sc = S.Scene(160.0, 128.0, 0.25, 400000, seed=402, num_frames=6)
+    want = _oracle(sc)
+    with A.HostSession(_settings(A, sc.grid), tiles=(2, 1)) as hs:
+        hs.dsm_process(A.DsmSettings(1), sc.points)
+        S.assert_dsm_close(hs.layers["elevation"], want["elevation"], tol=1e-4)
+
+
+def test_session_notices_host_side_changes_by_content():
+    """Residency: nothing is uploaded while the host matrices hold what the devices hold; any
+    host-side edit (one cell, a refill, a fresh map) is noticed and honoured, exactly like the
+    reference, which only ever sees the host matrices."""
+    import aerial_mapper_amd as A
+    sc = S.Scene(120.0, 96.0, 0.5, 70000, seed=403, num_frames=8)
+    sc2 = S.Scene(120.0, 96.0, 0.5, 9000, seed=404, num_frames=8)
+    sc2.points = np.ascontiguousarray(sc2.points[sc2.points[:, 1] > 5.0])
+    sc2.points[:, 2] += 3.0
+    ncam = None
+    for always_copy in (False, True):
+        with A.HostSession(_settings(A, sc.grid), tiles=(2, 1)) as hs:
+            hs.set_dsm_precision(True)
+            hs.set_always_copy(always_copy)
+            ncam = _ncam(A, sc)
+            ref = O.new_layers(sc.grid)
+            # 1. first cloud + first batch
+            hs.dsm_process(A.DsmSettings(1), sc.points)
+            hs.ortho_process(ncam, A.OrthoSettings(), sc.poses, sc.frames)
+            ref = _oracle(sc, layers=ref)
+            # 2. the host edits ONE elevation cell and wipes a block of the angle layer
+            for lay in (hs.layers, ref):
+                lay["elevation"][40, 50] = 123.25
+                lay["elevation_angle"][10:30, 20:60] = 0.0
+                lay["observation_index"][10:30, 20:60] = np.nan
+            # 3. incremental: a second, partial cloud (untouched cells keep their values, incl.
+            # the edited one) and the same frames again
+            hs.dsm_process(A.DsmSettings(1), sc2.points)
+            rc, elev, _ = O.dsm_process(sc2.points, sc.grid, 1, 0.0, 0.0, elevation=ref["elevation"].copy())
+            assert rc == O.OK
+            ref["elevation"] = elev
+            S.assert_dsm_close(hs.layers["elevation"], ref["elevation"], tol=1e-6)
+            assert hs.layers["elevation"][40, 50] == np.float32(123.25) or \
+                not np.isnan(elev[40, 50])
+            hs.ortho_process(ncam, A.OrthoSettings(), sc.poses, sc.frames)
+            rc = O.ortho_process(sc.grid, sc.cam, sc.poses, sc.T_C_B, sc.frames, ref)
+            assert rc == O.OK
+            if np.array_equal(hs.layers["elevation"].view(np.uint32), ref["elevation"].view(np.uint32)):
+                S.assert_layers_equal(hs.layers, ref, ORTHO_LAYERS)
+            # 4. a fresh map in the same matrices (AerialGridMap::initialize again)
+            for name, v in A.mapper.LAYER_INIT.items():
+                hs.layers[name].fill(v)
+            hs.dsm_process(A.DsmSettings(1), sc.points)
+            hs.ortho_process(ncam, A.OrthoSettings(), sc.poses, sc.frames)
+            fresh = _oracle(sc)
+            S.assert_dsm_close(hs.layers["elevation"], fresh["elevation"], tol=1e-6)
+            if np.array_equal(hs.layers["elevation"].view(np.uint32), fresh["elevation"].view(np.uint32)):
+                S.assert_layers_equal(hs.layers, fresh, ORTHO_LAYERS)
