@@ -8,20 +8,18 @@
 namespace dsm {
 
 Dsm::Dsm(const Settings& settings, grid_map::GridMap* map)
-    : settings_(settings), ctx_(nullptr), ctx_rows_(0), ctx_cols_(0) {
+    : settings_(settings), session_(nullptr) {
   if (!map) amhip_shim::fatal("Dsm::Dsm", "CHECK(map)");
   printParams();
   // The reference builds a sample->cell-index table for every cell here
   // (dsm.cc:24-33); the GPU path needs the geometry only.
-  ensureContext(*map);
+  ensureSession(*map);
 }
 
-Dsm::~Dsm() {
-  if (ctx_) amhip_ctx_destroy(ctx_);
-}
+Dsm::~Dsm() { amhip_shim::release_session(session_); }
 
-void Dsm::ensureContext(const grid_map::GridMap& map) {
-  amhip_shim::ensure_context(&ctx_, &ctx_rows_, &ctx_cols_, ctx_geom_, map, "Dsm");
+void Dsm::ensureSession(const grid_map::GridMap& map) {
+  session_ = amhip_shim::acquire_session(map, session_, "Dsm");
 }
 
 void Dsm::process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_cloud,
@@ -31,14 +29,15 @@ void Dsm::process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_c
     return;
   }
   if (!map) amhip_shim::fatal("Dsm::process", "CHECK(map)");
-  ensureContext(*map);
+  ensureSession(*map);
   static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double),
                 "point cloud must be contiguous x,y,z doubles");
   const double* xyz = reinterpret_cast<const double*>(point_cloud.data());
   grid_map::Matrix& elevation = (*map)["elevation"];
   amhip_shim::check_status(
-      amhip_dsm_process(ctx_, xyz, point_cloud.size(), settings_.interpolation_radius,
-                        settings_.center_easting, settings_.center_northing, elevation.data()),
+      amhip_session_dsm_process(session_, xyz, point_cloud.size(), settings_.interpolation_radius,
+                                settings_.center_easting, settings_.center_northing,
+                                elevation.data()),
       "Dsm::process");
 }
 

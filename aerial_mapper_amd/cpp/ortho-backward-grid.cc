@@ -14,20 +14,18 @@ using amhip_shim::pose_to7;
 
 OrthoBackwardGrid::OrthoBackwardGrid(const std::shared_ptr<aslam::NCamera> ncameras,
                                      const Settings& settings, grid_map::GridMap* map)
-    : ncameras_(ncameras), settings_(settings), ctx_(nullptr), ctx_rows_(0), ctx_cols_(0) {
+    : ncameras_(ncameras), settings_(settings), session_(nullptr) {
   if (!ncameras_) amhip_shim::fatal("OrthoBackwardGrid", "CHECK(ncameras_)");
   printParams();
   // The reference dereferences `map` here when use_multi_threads is set
   // (ortho-backward-grid.cc:30-39); a null map is simply deferred to process().
-  if (map) ensureContext(*map);
+  if (map) ensureSession(*map);
 }
 
-OrthoBackwardGrid::~OrthoBackwardGrid() {
-  if (ctx_) amhip_ctx_destroy(ctx_);
-}
+OrthoBackwardGrid::~OrthoBackwardGrid() { amhip_shim::release_session(session_); }
 
-void OrthoBackwardGrid::ensureContext(const grid_map::GridMap& map) const {
-  amhip_shim::ensure_context(&ctx_, &ctx_rows_, &ctx_cols_, ctx_geom_, map, "OrthoBackwardGrid");
+void OrthoBackwardGrid::ensureSession(const grid_map::GridMap& map) const {
+  session_ = amhip_shim::acquire_session(map, session_, "OrthoBackwardGrid");
 }
 
 void OrthoBackwardGrid::process(const Poses& T_G_Bs, const Images& images,
@@ -37,7 +35,7 @@ void OrthoBackwardGrid::process(const Poses& T_G_Bs, const Images& images,
     amhip_shim::fatal("OrthoBackwardGrid::process", "CHECK(T_G_Bs.size() == images.size())");
   if (!map) amhip_shim::fatal("OrthoBackwardGrid::process", "CHECK(map)");
   std::fprintf(stderr, "[aerial_mapper_hip] Num. images = %zu\n", images.size());
-  ensureContext(*map);
+  ensureSession(*map);
 
   const size_t F = T_G_Bs.size();
   std::vector<double> T_G_B(7 * F), T_G_C(7 * F);
@@ -60,8 +58,8 @@ void OrthoBackwardGrid::process(const Poses& T_G_Bs, const Images& images,
     steps[f] = static_cast<size_t>(images[f].step);
   }
   amhip_shim::check_status(
-      amhip_ortho_backward_process(
-          ctx_, &cam, T_G_C.data(), F, data.data(), steps.data(), channels,
+      amhip_session_ortho_backward_process(
+          session_, &cam, T_G_C.data(), F, data.data(), steps.data(), channels,
           settings_.colored_ortho ? 1 : 0, (*map)["elevation"].data(),
           (*map)["elevation_angle"].data(), (*map)["observation_index"].data(),
           (*map)["num_observations"].data(), (*map)["ortho"].data(),

@@ -22,6 +22,10 @@ inline void check_status(int status, const char* where) {
 }
 
 inline amhip_grid_desc describe(const grid_map::GridMap& map) {
+  // the raw matrices are addressed from (0, 0): a map that was move()d (circular buffer start
+  // index != 0) would be mis-addressed -- the hot path never moves the map, refuse if it was
+  if (map.getStartIndex()(0) != 0 || map.getStartIndex()(1) != 0)
+    fatal("describe(GridMap)", "map.getStartIndex() != (0, 0): moved maps are not supported");
   amhip_grid_desc g;
   g.rows = map.getSize()(0);
   g.cols = map.getSize()(1);
@@ -33,7 +37,8 @@ inline amhip_grid_desc describe(const grid_map::GridMap& map) {
   return g;
 }
 
-// (Re)create the context when the map's geometry is not the one it was made for.
+// (Re)create the context when the map's geometry is not the one it was made for
+// (classes that keep a context of their own: OrthoFromPcl).
 inline void ensure_context(amhip_ctx** ctx, int* rows, int* cols, double* geom,
                            const grid_map::GridMap& map, const char* where) {
   const amhip_grid_desc g = describe(map);
@@ -53,6 +58,15 @@ inline void ensure_context(amhip_ctx** ctx, int* rows, int* cols, double* geom,
   geom[3] = g.length_x;
 }
 
+// One amhip_session per grid_map::GridMap (keyed by the map's address and geometry), shared
+// by every dsm::Dsm / ortho::OrthoBackwardGrid working on that map: the layers stay on the
+// device(s) between Dsm::process and OrthoBackwardGrid::process, and with
+// AERIAL_MAPPER_HIP_DEVICES=0,1,... the map is cut into one window per listed device.
+// acquire() returns the session of `map` (creating or re-creating it when the geometry
+// changed) and releases `*held`; release() drops a reference (the last one destroys it).
+amhip_session* acquire_session(const grid_map::GridMap& map, amhip_session* held, const char* where);
+void release_session(amhip_session* held);
+
 // kindr::minimal::QuatTransformation -> tx,ty,tz,qw,qx,qy,qz
 inline void pose_to7(const kindr::minimal::QuatTransformation& T, double* o) {
   const Eigen::Vector3d& t = T.getPosition();
@@ -67,8 +81,16 @@ inline void pose_to7(const kindr::minimal::QuatTransformation& T, double* o) {
 }
 
 inline amhip_camera describe_camera(const aslam::Camera& camera) {
+  // The reference calls the virtual camera.project3() (ortho-backward-grid.cc:160-161), so it
+  // works with every aslam camera; the kernels implement the pinhole projection with no /
+  // radial-tangential / equidistant distortion.  Anything else must fail loudly -- treated as
+  // an undistorted pinhole it would give a silently wrong mosaic.
+  if (camera.getType() != aslam::Camera::Type::kPinhole)
+    fatal("describe_camera", "only aslam::PinholeCamera is implemented on the GPU "
+                             "(parameters fu, fv, cu, cv); UnifiedProjection and others are not");
   amhip_camera c;
   const Eigen::VectorXd& p = camera.getParameters();  // fu, fv, cu, cv
+  if (p.size() != 4) fatal("describe_camera", "pinhole camera with other than 4 parameters");
   c.fu = p(0);
   c.fv = p(1);
   c.cu = p(2);
@@ -79,6 +101,9 @@ inline amhip_camera describe_camera(const aslam::Camera& camera) {
   for (int k = 0; k < 4; ++k) c.dist[k] = 0.0;
   const aslam::Distortion& d = camera.getDistortion();
   switch (d.getType()) {
+    case aslam::Distortion::Type::kNoDistortion:
+      c.distortion = AMHIP_DIST_NONE;
+      break;
     case aslam::Distortion::Type::kRadTan:
       c.distortion = AMHIP_DIST_RADTAN;
       break;
@@ -86,16 +111,16 @@ inline amhip_camera describe_camera(const aslam::Camera& camera) {
       c.distortion = AMHIP_DIST_EQUIDISTANT;
       break;
     default:
-      c.distortion = AMHIP_DIST_NONE;
-      break;
+      fatal("describe_camera", "distortion model not implemented on the GPU (none, radtan and "
+                               "equidistant are; e.g. fisheye / FOV is not)");
   }
   if (c.distortion != AMHIP_DIST_NONE) {
     const Eigen::VectorXd& dp = d.getParameters();
-    for (int k = 0; k < 4 && k < static_cast<int>(dp.size()); ++k) c.dist[k] = dp(k);
+    if (dp.size() != 4) fatal("describe_camera", "distortion with other than 4 parameters");
+    for (int k = 0; k < 4; ++k) c.dist[k] = dp(k);
   }
   return c;
 }
-
 
 }  // namespace amhip_shim
 

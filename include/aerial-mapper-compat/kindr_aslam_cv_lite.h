@@ -52,7 +52,9 @@ typedef kindr::minimal::QuatTransformation Transformation;
 
 class Distortion {
  public:
-  enum class Type { kNoDistortion = 0, kRadTan = 1, kEquidistant = 2 };
+  // (aslam_cv2 also has kFisheye: one such value here, so that the drop-in's refusal of models
+  // it does not implement can be tested)
+  enum class Type { kNoDistortion = 0, kRadTan = 1, kEquidistant = 2, kFisheye = 3 };
   Distortion() : type_(Type::kNoDistortion), params_(4) {}
   Distortion(Type type, double a, double b, double c, double d) : type_(type), params_(4) {
     params_(0) = a;
@@ -71,9 +73,10 @@ class Distortion {
 // aslam::PinholeCamera: parameters = (fu, fv, cu, cv)
 class Camera {
  public:
+  enum class Type { kPinhole = 0, kUnifiedProjection = 1 };
   Camera(double fu, double fv, double cu, double cv, uint32_t width, uint32_t height,
-         const Distortion& distortion = Distortion())
-      : params_(4), width_(width), height_(height), distortion_(distortion) {
+         const Distortion& distortion = Distortion(), Type type = Type::kPinhole)
+      : params_(4), width_(width), height_(height), distortion_(distortion), type_(type) {
     params_(0) = fu;
     params_(1) = fv;
     params_(2) = cu;
@@ -83,11 +86,13 @@ class Camera {
   uint32_t imageHeight() const { return height_; }
   const Eigen::VectorXd& getParameters() const { return params_; }
   const Distortion& getDistortion() const { return distortion_; }
+  Type getType() const { return type_; }
 
  private:
   Eigen::VectorXd params_;
   uint32_t width_, height_;
   Distortion distortion_;
+  Type type_;
 };
 
 class NCamera {

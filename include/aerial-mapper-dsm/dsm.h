@@ -12,7 +12,7 @@
 #include "aerial-mapper-deps.h"
 #include "aerial-mapper-utils/utils-nearest-neighbor.h"
 
-struct amhip_ctx;
+struct amhip_session;
 
 namespace dsm {
 
@@ -42,13 +42,13 @@ class Dsm {
                grid_map::GridMap* map);
 
  private:
-  void ensureContext(const grid_map::GridMap& map);
+  void ensureSession(const grid_map::GridMap& map);
   void printParams();
 
   Settings settings_;
-  amhip_ctx* ctx_;
-  int ctx_rows_, ctx_cols_;
-  double ctx_geom_[4];  // resolution, pos x, pos y, length x
+  // the map's session (device windows + resident layers), shared with the other drop-in
+  // objects working on the same grid_map::GridMap (aerial_mapper_amd/cpp/shim_common.cc)
+  amhip_session* session_;
 };
 
 }  // namespace dsm

@@ -14,7 +14,7 @@
 #include "aerial-mapper-deps.h"
 #include "aerial-mapper-io/aerial-mapper-io.h"
 
-struct amhip_ctx;
+struct amhip_session;
 
 namespace ortho {
 
@@ -44,15 +44,14 @@ class OrthoBackwardGrid {
   void process(const Poses& T_G_Bs, const Images& images, grid_map::GridMap* map) const;
 
  private:
-  void ensureContext(const grid_map::GridMap& map) const;
+  void ensureSession(const grid_map::GridMap& map) const;
   void printParams() const;
 
   std::shared_ptr<aslam::NCamera> ncameras_;
   static constexpr size_t kFrameIdx = 0u;
   Settings settings_;
-  mutable amhip_ctx* ctx_;
-  mutable int ctx_rows_, ctx_cols_;
-  mutable double ctx_geom_[4];
+  // the map's session, shared with dsm::Dsm on the same grid_map::GridMap
+  mutable amhip_session* session_;
 };
 
 }  // namespace ortho

@@ -32,3 +32,23 @@ def test_reference_headers_satisfy_the_same_statements(api):
             ("aerial_mapper_utils", "aerial_mapper_thirdparty", "aerial_mapper_dsm", "aerial_mapper_ortho",
              "aerial_mapper_io", "aerial_mapper_grid_map")]
     _compile(inc, api)
+
+
+@pytest.mark.parametrize("camera,refused", [("ok", False), ("fisheye", True), ("unified", True)])
+def test_dropin_refuses_camera_models_it_does_not_implement(tmp_path, camera, refused):
+    """ADVICE r1 / VERDICT r1 #9: describe_camera() used to map every unknown distortion to
+    'none' and never looked at the camera type."""
+    from aerial_mapper_amd import build
+    build.build_all()
+    exe = str(tmp_path / "refusal")
+    lib = os.path.join(ROOT, "aerial_mapper_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_camera_refusal.cc"), "-o", exe,
+                           "-L" + lib, "-laerial_mapper_hip", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe, camera], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=60)
+    if refused:
+        assert r.returncode != 0 and "NOT REFUSED" not in r.stdout
+        assert "FATAL describe_camera" in r.stderr
+    else:
+        assert r.returncode == 0, r.stdout + r.stderr

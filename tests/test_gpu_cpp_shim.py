@@ -39,8 +39,17 @@ def exe_forward(tmp_path_factory):
 
 
 @pytest.mark.parametrize("mode", ["gray", "colored"])
-def test_cpp_dropin_classes_match_oracle(exe, mode):
-    r = subprocess.run([exe, mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+@pytest.mark.parametrize("devices", [None, "0,0", "0,0,0,0,0,0"])
+def test_cpp_dropin_classes_match_oracle(exe, mode, devices):
+    """devices: AERIAL_MAPPER_HIP_DEVICES -- ONE host process, the map cut into one window per
+    listed device (here all on device 0; on a node: different GPUs, halo points over xGMI).
+    Dsm and OrthoBackwardGrid share the map's session: the layers stay on the device(s)."""
+    env = dict(os.environ)
+    env.pop("AERIAL_MAPPER_HIP_DEVICES", None)
+    if devices:
+        env["AERIAL_MAPPER_HIP_DEVICES"] = devices
+    r = subprocess.run([exe, mode], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300,
+                       env=env)
     print(r.stdout.decode())
     assert r.returncode == 0, r.stdout.decode()[-2000:]
 
