@@ -13,9 +13,19 @@
 #include <glog/logging.h>  // (the real aslam headers bring glog in; the reference relies on it)
 
 #include "../../../amo_cvlike.h"
+#include "distortion.h"
 
 namespace kindr {
 namespace minimal {
+
+class RotationQuaternion {
+ public:
+  RotationQuaternion(double w, double x, double y, double z) : q_(w, x, y, z) {}
+  const Eigen::Quaterniond& toImplementation() const { return q_; }
+
+ private:
+  Eigen::Quaterniond q_;
+};
 
 class QuatTransformation {
  public:
@@ -43,6 +53,16 @@ class QuatTransformation {
     return m;
   }
   const amo::Pose& pose() const { return p_; }
+  // (minkindr: a RotationQuaternion(w, x, y, z) + a position; getRotation().toImplementation()
+  // is the Eigen quaternion)
+  QuatTransformation(const RotationQuaternion& q, const Eigen::Vector3d& t) {
+    const double p[7] = {t(0), t(1), t(2), q.toImplementation().w(), q.toImplementation().x(),
+                         q.toImplementation().y(), q.toImplementation().z()};
+    p_ = amo::pose_from7(p);
+  }
+  RotationQuaternion getRotation() const {
+    return RotationQuaternion(p_.q.w, p_.q.x, p_.q.y, p_.q.z);
+  }
 
  private:
   amo::Pose p_;
@@ -85,6 +105,25 @@ class Camera {
     amo::undistort_normalized(c_, &rx, &ry);
     *ray = Eigen::Vector3d(rx, ry, 1.0);
     return true;
+  }
+  // aslam::Camera::getType / getParameters / getDistortion (pinhole: fu, fv, cu, cv)
+  enum class Type { kPinhole = 0, kUnifiedProjection = 1 };
+  Type getType() const { return Type::kPinhole; }
+  Eigen::VectorXd getParameters() const {
+    Eigen::VectorXd p(4);
+    p(0) = c_.fu;
+    p(1) = c_.fv;
+    p(2) = c_.cu;
+    p(3) = c_.cv;
+    return p;
+  }
+  Distortion getDistortion() const {
+    Eigen::VectorXd d(4);
+    for (int k = 0; k < 4; ++k) d(k) = c_.dist[k];
+    return Distortion(c_.distortion == 1   ? Distortion::Type::kRadTan
+                      : c_.distortion == 2 ? Distortion::Type::kEquidistant
+                                           : Distortion::Type::kNoDistortion,
+                      d);
   }
   uint32_t imageWidth() const { return static_cast<uint32_t>(c_.width); }
   uint32_t imageHeight() const { return static_cast<uint32_t>(c_.height); }

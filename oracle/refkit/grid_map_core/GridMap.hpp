@@ -41,6 +41,8 @@ class GridMap {
     for (auto& kv : data_) kv.second.resize(g_.rows, g_.cols);
   }
   const Size& getSize() const { return size_; }
+  double getResolution() const { return g_.resolution; }
+  Index getStartIndex() const { return Index(0, 0); }  // (never moved)
   const amo_grid& geometry() const { return g_; }
   Matrix& operator[](const std::string& layer) { return get(layer); }
   const Matrix& operator[](const std::string& layer) const { return get(layer); }

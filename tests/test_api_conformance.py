@@ -52,3 +52,27 @@ def test_dropin_refuses_camera_models_it_does_not_implement(tmp_path, camera, re
         assert "FATAL describe_camera" in r.stderr
     else:
         assert r.returncode == 0, r.stdout + r.stderr
+
+
+SHIM_SOURCES = ["dsm.cc", "ortho-backward-grid.cc", "ortho-from-pcl.cc", "ortho-forward-homography.cc",
+                "aerial-mapper-io.cc", "shim_common.cc"]
+
+
+@pytest.mark.parametrize("source", SHIM_SOURCES)
+def test_shim_compiles_in_its_real_dependencies_branch(source):
+    """include/aerial-mapper-deps.h picks the REAL grid_map_core / aslam_cv2 / minkindr / Eigen /
+    OpenCV headers when they are on the include path (a catkin workspace).  None of them exists
+    in this image; oracle/refkit/ holds stand-ins under the externals' own include paths with
+    the member names the real classes have, so the AERIAL_MAPPER_REAL_DEPS=1 branch of every
+    shim source is at least compiled (syntax only; VERDICT r1 #10)."""
+    src = os.path.join(ROOT, "aerial_mapper_amd", "cpp", source)
+    probe = ('#include "aerial-mapper-deps.h"\n#if !AERIAL_MAPPER_REAL_DEPS\n'
+             '#error compat branch taken\n#endif\n')
+    inc = ["-I" + os.path.join(ROOT, "oracle", "refkit"), "-I" + os.path.join(ROOT, "oracle"),
+           "-I" + os.path.join(ROOT, "include")]
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-x", "c++", "-"] + inc,
+                       input=probe.encode(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only"] + inc + [src], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
