@@ -376,6 +376,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   // ---- single-precision gather with exact guards (amhip_dsm.hip: k_dsm_gather_f32) ----
   // Only for dsm::Dsm (heights): OrthoFromPcl interpolates 8-bit intensities whose spread
   // (up to 255) leaves no room under the error bound.
+  p.knn_k = mode == 0 ? c.dsm_knn : 0;
+  if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
   p.fx_ok = 0;
   if (p.lds_ok && mode == 0 && !c.dsm_exact) {
     int S = 28;
@@ -836,6 +838,13 @@ int amhip_ctx_set_dsm_precision(amhip_ctx* h, int mode) {
   if (!h) return arg_fail("null context");
   if (mode != AMHIP_DSM_FAST && mode != AMHIP_DSM_EXACT) return arg_fail("unknown DSM precision mode");
   h->impl.dsm_exact = mode == AMHIP_DSM_EXACT ? 1 : 0;
+  return AMHIP_OK;
+}
+
+int amhip_ctx_set_dsm_knn(amhip_ctx* h, int k) {
+  if (!h) return arg_fail("null context");
+  if (k < 0 || k > 8) return arg_fail("amhip_ctx_set_dsm_knn: k must be 0 (off) .. 8");
+  h->impl.dsm_knn = k;
   return AMHIP_OK;
 }
 

@@ -74,6 +74,9 @@ struct DsmParams {
   // single-precision gather with exact guards (k_dsm_gather_f32): point
   // positions as 32-bit fixed point in units of 2^-fx_S cells (wrapping: only differences of
   // at most w0 + 2 cells are ever formed), squared distances in f32 in (2^-fx_S cells)^2
+  // OPTIONAL capped mode (not a reference code path): only the knn_k nearest points of a
+  // cell's search result take part (0 = off = the reference's behaviour)
+  int knn_k;
   int fx_ok;                  // 0 -> the FP64 gather only
   int fx_S;
   float fx_thi, fx_tlo;       // T[0] in those units, widened / narrowed by the decision margin
@@ -165,6 +168,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   size_t cells = 0;
   int dsm_exact = 0;          // amhip_ctx_set_dsm_precision
+  int dsm_knn = 0;            // amhip_ctx_set_dsm_knn
 
   float* layers[AMHIP_NUM_LAYERS] = {nullptr, nullptr, nullptr,
                                      nullptr, nullptr, nullptr};

@@ -192,12 +192,110 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
   return finish_accum(p, o, i, j, acc);
 }
 
+// ---- OPTIONAL capped mode (amhip_ctx_set_dsm_knn; not a reference code path) ----------
+// The k nearest points of the search result, kept sorted by ascending d2 in registers
+// (nanoflann::KNNResultSet::addPoint, nanoflann.hpp:100-125: a later arrival never
+// displaces an equal distance).
+constexpr int kMaxKnn = 8;
+struct KnnSet {
+  double d2[kMaxKnn], z[kMaxKnn];
+  int n;
+};
+
+__device__ __forceinline__ void knn_add(KnnSet* s, int k, double d2, double z) {
+  if (s->n == k && !(d2 < s->d2[k - 1])) return;
+  // shift the strictly greater entries up (static indices only: the set lives in registers)
+  double cd = d2, cz = z;
+  bool inserted = false;  // from the insertion point on every entry moves up by one
+#pragma unroll
+  for (int q = 0; q < kMaxKnn; ++q) {
+    if (q < k) {
+      const bool here = inserted || q >= s->n || cd < s->d2[q];
+      const double od = s->d2[q], oz = s->z[q];
+      if (here) {
+        s->d2[q] = cd;
+        s->z[q] = cz;
+        cd = od;
+        cz = oz;
+        inserted = true;
+      }
+    }
+  }
+  if (s->n < k) ++s->n;
+}
+
+__device__ __forceinline__ void knn_scan(const DsmParams& p, const uint32_t* __restrict__ start,
+                                         const double* __restrict__ sorted, double qx, double qy,
+                                         int i, int j, int w, double T, KnnSet* s) {
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t e = row[bx1 + 1];
+    for (uint32_t k = row[bx0]; k < e; ++k) {
+      const double dx = qx - sorted[3 * (size_t)k + 0];
+      const double dy = qy - sorted[3 * (size_t)k + 1];
+      double d2 = dx * dx;
+      d2 = d2 + dy * dy;
+      if (d2 < T) knn_add(s, p.knn_k, d2, sorted[3 * (size_t)k + 2]);
+    }
+  }
+}
+
+__device__ __forceinline__ void cell_global_knn(const DsmParams& p,
+                                                const uint32_t* __restrict__ start,
+                                                const double* __restrict__ sorted, int i, int j,
+                                                const CellOut& o) {
+  const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
+  const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
+  KnnSet s;
+  s.n = 0;
+#pragma unroll
+  for (int q = 0; q < kMaxKnn; ++q) s.d2[q] = s.z[q] = 0.0;
+  knn_scan(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &s);
+  if (s.n == 0 && p.nlevels > 1) {  // the ladder of dsm.cc:133-144, as in cell_fallback_global
+    Accum acc = {0.0, 0.0, 0u, false, 0.0};
+    const int last = p.nlevels - 1;
+    double dmin = __builtin_huge_val();
+    scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
+    for (int k = 1; k <= last; ++k)
+      if (dmin < p.T[k]) {
+        knn_scan(p, start, sorted, qx, qy, i, j, p.w[k], p.T[k], &s);
+        break;
+      }
+  }
+  if (s.n == 0) {
+    leave_untouched(p, o, i, j);
+    return;
+  }
+  // the oracle's arithmetic: true divisions, ascending distance
+  double num = 0.0, den = 0.0;
+  bool exact = false;
+#pragma unroll
+  for (int q = 0; q < kMaxKnn; ++q)
+    if (q < s.n) {
+      if (!(s.d2[q] > 0.0)) exact = true;
+      num += s.z[q] / s.d2[q];
+      den += 1.0 / s.d2[q];
+    }
+  if (exact) {
+    atomicOr(o.dev_err, kDevErrExactHit);  // dsm.cc:165 CHECK(distances[i] > 0.0)
+    leave_untouched(p, o, i, j);
+    return;
+  }
+  emit_value(p, o, i, j, num / den);
+}
+
 // Whole cell through the global bins (first level + fallback).
 __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
                                             const double* __restrict__ sorted, int i, int j,
                                             const CellOut& o) {
   if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  if (p.knn_k > 0) {
+    cell_global_knn(p, start, sorted, i, j, o);
+    return;
+  }
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));

@@ -36,7 +36,7 @@ DIST_NONE, DIST_RADTAN, DIST_EQUIDISTANT = 0, 1, 2
 # every symbol include/aerial_mapper_hip.h declares
 EXPORTS = [
     "amhip_abi_version", "amhip_last_error", "amhip_make_grid", "amhip_cell_position",
-    "amhip_ctx_create", "amhip_ctx_create_window", "amhip_ctx_destroy", "amhip_ctx_set_dsm_precision", "amhip_ctx_set_stream", "amhip_ctx_synchronize",
+    "amhip_ctx_create", "amhip_ctx_create_window", "amhip_ctx_destroy", "amhip_ctx_set_dsm_precision", "amhip_ctx_set_dsm_knn", "amhip_ctx_set_stream", "amhip_ctx_synchronize",
     "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
     "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
     "amhip_ortho_from_pcl_process_dev", "amhip_ortho_from_pcl_process",
@@ -122,6 +122,7 @@ def load():
     lib.amhip_ctx_destroy.argtypes = [vp]
     lib.amhip_ctx_set_stream.argtypes = [vp, vp]
     lib.amhip_ctx_set_dsm_precision.argtypes = [vp, C.c_int]
+    lib.amhip_ctx_set_dsm_knn.argtypes = [vp, C.c_int]
     lib.amhip_ctx_synchronize.argtypes = [vp]
     lib.amhip_layers_reset.argtypes = [vp]
     lib.amhip_layer_upload.argtypes = [vp, C.c_int, vp]

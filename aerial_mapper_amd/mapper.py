@@ -197,6 +197,11 @@ class AerialGridMap(object):
         single-precision arithmetic under exact guards (include/aerial_mapper_hip.h)."""
         L.check(self._lib.amhip_ctx_set_dsm_precision(self._h, 1 if exact else 0))
 
+    def set_dsm_knn(self, k):
+        """OPTIONAL capped mode: only the k nearest points of a cell's search take part (0 = off,
+        the reference's behaviour; include/aerial_mapper_hip.h)."""
+        L.check(self._lib.amhip_ctx_set_dsm_knn(self._h, int(k)))
+
     def enable_timing(self, on=True):
         L.check(self._lib.amhip_ctx_enable_timing(self._h, int(bool(on))))
 

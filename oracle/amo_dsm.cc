@@ -27,6 +27,7 @@
  * is grid_map_core's arithmetic behind setGeometry / getPosition
  * (amo_compat.h) -- PARITY UNPINNED for that.
  */
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -76,11 +77,12 @@ typedef nanoflann::KDTreeSingleIndexAdaptor<
 
 class DsmOracle {
  public:
-  DsmOracle(const amo_grid& g, int radius_sq, double center_e, double center_n)
+  DsmOracle(const amo_grid& g, int radius_sq, double center_e, double center_n, int knn_k = 0)
       : grid_(g),
         radius_(radius_sq),
         center_e_(center_e),
         center_n_(center_n),
+        knn_k_(knn_k),
         error_(AMO_OK) {}
 
   // dsm.cc:36-52 -- note x uses center_NORTHING and y center_EASTING.
@@ -145,6 +147,39 @@ class DsmOracle {
 #endif
     if (hits.empty()) return;  // cell left untouched
 
+    // OPTIONAL capped mode (BASELINE.json "IDW k=4"; NOT a reference code path -- the
+    // reference weights ALL points of the radius search): only the k
+    // nearest of the search's result take part, in nanoflann::KNNResultSet's order
+    // (nanoflann.hpp:80-131: ascending distance, a later arrival never displaces an equal
+    // distance).  Vendored build: KNNResultSet itself on the same tree (the k nearest of the
+    // whole cloud are the k nearest of the search result as soon as that holds more than k
+    // points); port: a stable sort of the search result.  Parity of this mode is UNPINNED
+    // by the reference; it is reported separately and never graded.
+    if (knn_k_ > 0) {
+      if (static_cast<int>(hits.size()) > knn_k_) {
+#ifdef AMO_USE_VENDORED_NANOFLANN
+        std::vector<int> idx(knn_k_);
+        std::vector<double> d2s(knn_k_);
+        nanoflann::KNNResultSet<double, int> knn(knn_k_);
+        knn.init(idx.data(), d2s.data());
+        tree_->findNeighbors(knn, query_pt, nanoflann::SearchParams());
+        hits.clear();
+        for (int k = 0; k < knn_k_; ++k) hits.push_back(std::make_pair(idx[k], d2s[k]));
+#else
+        std::stable_sort(hits.begin(), hits.end(),
+                         [](const std::pair<int, double>& a, const std::pair<int, double>& b) {
+                           return a.second < b.second;
+                         });
+        hits.resize(knn_k_);
+#endif
+      } else {
+        std::stable_sort(hits.begin(), hits.end(),
+                         [](const std::pair<int, double>& a, const std::pair<int, double>& b) {
+                           return a.second < b.second;
+                         });
+      }
+    }
+
     double num = 0.0, den = 0.0;
     for (size_t k = 0; k < hits.size(); ++k) {
       const double d2 = hits[k].second;
@@ -177,6 +212,7 @@ class DsmOracle {
   amo_grid grid_;
   int radius_;  // dsm::Settings::interpolation_radius is an int (dsm.h:27)
   double center_e_, center_n_;
+  int knn_k_;  // 0: the reference's behaviour (every point of the radius search)
   volatile int error_;
 #ifdef AMO_USE_VENDORED_NANOFLANN
   RefCloud cloud_;
@@ -238,15 +274,15 @@ int amo_uses_vendored_nanoflann(void) {
  *   timing       optional double[2]: kd-tree fill+build seconds, cell loop s
  * Empty cloud is the reference's soft no-op (dsm.cc:189-192).
  */
-int amo_dsm_process(const double* xyz, size_t n, const amo_grid* grid,
+static int dsm_process_impl(const double* xyz, size_t n, const amo_grid* grid,
                     int radius_sq, double center_easting,
                     double center_northing, int multi_thread, int num_threads,
-                    float* elevation, double* timing) {
+                    float* elevation, double* timing, int knn_k) {
   if (!grid || !elevation || (n && !xyz)) return AMO_ERR_ARG;
   if (timing) timing[0] = timing[1] = 0.0;
   if (n == 0) return AMO_OK;
 
-  amo::DsmOracle dsm(*grid, radius_sq, center_easting, center_northing);
+  amo::DsmOracle dsm(*grid, radius_sq, center_easting, center_northing, knn_k);
   const double t0 = now_s();
   dsm.fill_and_build(xyz, n);
   const double t1 = now_s();
@@ -273,6 +309,24 @@ int amo_dsm_process(const double* xyz, size_t n, const amo_grid* grid,
     timing[1] = t2 - t1;
   }
   return dsm.error();
+}
+
+int amo_dsm_process(const double* xyz, size_t n, const amo_grid* grid,
+                    int radius_sq, double center_easting,
+                    double center_northing, int multi_thread, int num_threads,
+                    float* elevation, double* timing) {
+  return dsm_process_impl(xyz, n, grid, radius_sq, center_easting, center_northing, multi_thread,
+                          num_threads, elevation, timing, 0);
+}
+
+/* The OPTIONAL capped mode: as amo_dsm_process, with only the knn_k nearest points of every
+ * cell's search result (see DsmOracle::cell).  Not a reference code path. */
+int amo_dsm_process_knn(const double* xyz, size_t n, const amo_grid* grid, int radius_sq,
+                        double center_easting, double center_northing, int knn_k,
+                        int multi_thread, int num_threads, float* elevation) {
+  if (knn_k < 1) return AMO_ERR_ARG;
+  return dsm_process_impl(xyz, n, grid, radius_sq, center_easting, center_northing, multi_thread,
+                          num_threads, elevation, nullptr, knn_k);
 }
 
 /* Neighbour probe used by the known-answer tests: radius search around one

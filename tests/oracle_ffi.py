@@ -58,6 +58,10 @@ def _bind(lib):
     lib.amo_dsm_process.argtypes = [
         f64p, C.c_size_t, C.POINTER(Grid), C.c_int, C.c_double, C.c_double,
         C.c_int, C.c_int, f32p, f64p]
+    lib.amo_dsm_process_knn.restype = C.c_int
+    lib.amo_dsm_process_knn.argtypes = [
+        f64p, C.c_size_t, C.POINTER(Grid), C.c_int, C.c_double, C.c_double, C.c_int,
+        C.c_int, C.c_int, f32p]
     lib.amo_dsm_radius_probe.restype = C.c_int
     lib.amo_dsm_radius_probe.argtypes = [
         f64p, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_int,
@@ -250,6 +254,19 @@ def dsm_process(xyz, g, radius_sq=1, center_easting=0.0, center_northing=0.0,
         center_easting, center_northing, int(bool(multi_thread)),
         int(num_threads), _f32(elevation), _f64(t))
     return rc, elevation, (t[0], t[1])
+
+
+def dsm_process_knn(xyz, g, k, radius_sq=1, center_easting=0.0, center_northing=0.0,
+                    elevation=None, multi_thread=True, which="port"):
+    """The OPTIONAL capped mode (only the k nearest points of a cell's search result take part;
+    not a reference code path).  Returns (rc, elevation)."""
+    xyz = np.ascontiguousarray(xyz, np.float64).reshape(-1, 3)
+    if elevation is None:
+        elevation = np.full((g.cols, g.rows), np.nan, np.float32)
+    rc = lib(which).amo_dsm_process_knn(_f64(xyz), xyz.shape[0], C.byref(g), int(radius_sq),
+                                        center_easting, center_northing, int(k),
+                                        int(bool(multi_thread)), 0, _f32(elevation))
+    return rc, elevation
 
 
 def ortho_from_pcl(xyz, intensities, g, radius_sq=2, adaptive=False, ortho=None, which="port"):
