@@ -9,9 +9,10 @@ from .hip_lib import (AmhipError, Camera, GridDesc, DIST_EQUIDISTANT, DIST_NONE,
                       DIST_RADTAN, LAYER_NAMES, make_grid, cell_position)
 from .mapper import (AerialGridMap, Dsm, DsmSettings, GridMapSettings, HostSession, NCamera,  # noqa: F401
                      OrthoBackwardGrid, OrthoForwardHomography, OrthoForwardHomographySettings,
-                     OrthoFromPcl, OrthoFromPclSettings, OrthoSettings, compose_T_G_C, densify)
+                     OrthoFromPcl, OrthoFromPclSettings, OrthoSettings, compose_T_G_C, densify,
+                     rectify_stereo_pair)
 
 __all__ = ["AerialGridMap", "GridMapSettings", "HostSession", "Dsm", "DsmSettings", "OrthoBackwardGrid",
-           "OrthoSettings", "OrthoForwardHomography", "OrthoForwardHomographySettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "AmhipError", "Camera", "GridDesc",
+           "OrthoSettings", "OrthoForwardHomography", "OrthoForwardHomographySettings", "OrthoFromPcl", "OrthoFromPclSettings", "NCamera", "compose_T_G_C", "densify", "rectify_stereo_pair", "AmhipError", "Camera", "GridDesc",
            "make_grid", "cell_position", "LAYER_NAMES", "DIST_NONE", "DIST_RADTAN",
            "DIST_EQUIDISTANT"]

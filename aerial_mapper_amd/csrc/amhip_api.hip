@@ -697,6 +697,10 @@ static int fetch_status(Ctx* c) {
         "CHECK(alpha > 0.0))");
     return AMHIP_ERR_ALPHA_NONPOS;
   }
+  if (e & kDevErrRectifyZeroW) {
+    set_last_error("rectification: w == 0 (reference: rectifier.cpp:93,99 CHECK_NE(xyw(2), 0.0))");
+    return AMHIP_ERR_ARG;
+  }
   if (e & kDevErrHaloOverflow) {
     set_last_error(
         "tiled DSM: more halo points for a neighbouring window than send rows were reserved "

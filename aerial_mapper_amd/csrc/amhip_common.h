@@ -127,7 +127,8 @@ struct OrthoParams {
 };
 
 // Device error word bits (sticky until amhip_ctx_synchronize).
-enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u, kDevErrHaloOverflow = 4u };
+enum : unsigned { kDevErrExactHit = 1u, kDevErrAlphaNonPos = 2u, kDevErrHaloOverflow = 4u,
+                  kDevErrRectifyZeroW = 8u };
 
 // ---------------------------------------------------------------------------
 // context

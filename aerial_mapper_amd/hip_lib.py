@@ -40,7 +40,7 @@ EXPORTS = [
     "amhip_layers_reset", "amhip_layer_upload", "amhip_layer_download",
     "amhip_layer_device_ptr", "amhip_dsm_process_dev", "amhip_dsm_process",
     "amhip_ortho_from_pcl_process_dev", "amhip_ortho_from_pcl_process",
-    "amhip_densify_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
+    "amhip_densify_dev", "amhip_rectify_stereo_pair_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
     "amhip_dsm_tiled_finish_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
     "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
@@ -161,6 +161,8 @@ def load():
     lib.amhip_session_ortho_backward_process.argtypes = [
         vp, cp, f64p, C.c_size_t, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_int, C.c_int,
         vp, vp, vp, vp, vp, vp]
+    lib.amhip_rectify_stereo_pair_dev.argtypes = [vp, f64p, f64p, f64p, f64p, f64p, C.c_int, C.c_int,
+                                                  vp, C.c_size_t, vp, C.c_size_t, f64p, f64p, vp, vp, vp, vp]
     lib.amhip_ctx_enable_timing.argtypes = [vp, C.c_int]
     lib.amhip_ctx_timing_reset.argtypes = [vp]
     lib.amhip_ctx_kernel_time.argtypes = [vp, C.c_int, f64p, C.POINTER(C.c_int64)]

@@ -573,6 +573,40 @@ def densify(map, disparity, image_left, K, baseline, R_G_C, t_G_C1):
     return xyz[:n], inten[:n]
 
 
+def rectify_stereo_pair(map, K, R_G_C1, R_G_C2, t_G_C1, t_G_C2, image_left, image_right,
+                        want_maps=False):
+    """stereo::Rectifier::rectifyStereoPair + computeMask (rectifier.cpp:34-128) on the GPU of
+    `map`: image_left / image_right CUDA torch uint8 tensors (H, W).  Returns a dict: R_G_C
+    (3,3) and baseline (host), image_left, image_right, mask (CUDA uint8 (H, W)) and, with
+    want_maps, maps (4, H, W) float32 -- the inputs of the block matcher and of densify()."""
+    import torch
+    assert image_left.is_cuda and image_left.dtype == torch.uint8 and image_left.stride(1) == 1
+    assert image_right.is_cuda and image_right.dtype == torch.uint8 and image_right.stride(1) == 1
+    H, W = image_left.shape
+    assert tuple(image_right.shape) == (H, W)
+    f64p = C.POINTER(C.c_double)
+    arr = lambda a, n: np.ascontiguousarray(a, np.float64).reshape(n)
+    Kc, R1, R2, t1, t2 = arr(K, 9), arr(R_G_C1, 9), arr(R_G_C2, 9), arr(t_G_C1, 3), arr(t_G_C2, 3)
+    dev = image_left.device
+    out_l = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    out_r = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    mask = torch.empty((H, W), dtype=torch.uint8, device=dev)
+    maps = torch.empty((4, H, W), dtype=torch.float32, device=dev) if want_maps else None
+    R = np.zeros(9)
+    b = C.c_double()
+    map.wait_for_torch(image_left)
+    L.check(L.load().amhip_rectify_stereo_pair_dev(
+        map.handle, Kc.ctypes.data_as(f64p), R1.ctypes.data_as(f64p), R2.ctypes.data_as(f64p),
+        t1.ctypes.data_as(f64p), t2.ctypes.data_as(f64p), W, H,
+        C.c_void_p(image_left.data_ptr()), image_left.stride(0),
+        C.c_void_p(image_right.data_ptr()), image_right.stride(0), R.ctypes.data_as(f64p),
+        C.byref(b), C.c_void_p(maps.data_ptr()) if want_maps else None,
+        C.c_void_p(out_l.data_ptr()), C.c_void_p(out_r.data_ptr()), C.c_void_p(mask.data_ptr())))
+    map.synchronize()
+    return {"R_G_C": R.reshape(3, 3), "baseline": b.value, "image_left": out_l,
+            "image_right": out_r, "mask": mask, "maps": maps}
+
+
 # ---------------------------------------------------------------------------
 # ortho::OrthoForwardHomography
 # ---------------------------------------------------------------------------

@@ -424,6 +424,24 @@ typedef enum amhip_kernel {
   AMHIP_NUM_KERNELS = 7
 } amhip_kernel;
 
+/* ---- stereo::Rectifier::rectifyStereoPair (+ computeMask)
+ *      aerial_mapper_dense_pcl/src/rectifier.cpp:34-128 -- the step in front of the block
+ *      matcher of the dense-point-cloud pipeline (its other half is amhip_densify_dev) --------
+ * K, R_G_C1, R_G_C2: row-major 3x3 on the HOST (intrinsics; orientation of the left / right
+ * camera in the world), t_G_C1, t_G_C2 their positions.  dev_left / dev_right: 8UC1 rasters on
+ * the GPU, rows `*_step` bytes apart.  Outputs, any may be NULL: R_G_C_out (host, 3x3 rectified
+ * rotation, RectifiedStereoPair::R_G_C), baseline_out (host), dev_maps (4 planes of
+ * width*height floats: map_rectify_1_x, _1_y, _2_x, _2_y), the rectified images and the mask
+ * (dense width*height bytes on the GPU).  Asynchronous on the context's stream.  A zero w of
+ * the inverse rectifying transformation (CHECK_NE(xyw(2), 0.0)) is reported by
+ * amhip_ctx_synchronize as AMHIP_ERR_ARG. */
+int amhip_rectify_stereo_pair_dev(amhip_ctx* ctx, const double* K, const double* R_G_C1,
+                                  const double* R_G_C2, const double* t_G_C1, const double* t_G_C2,
+                                  int width, int height, const uint8_t* dev_left, size_t left_step,
+                                  const uint8_t* dev_right, size_t right_step, double* R_G_C_out,
+                                  double* baseline_out, float* dev_maps, uint8_t* dev_rect_left,
+                                  uint8_t* dev_rect_right, uint8_t* dev_mask);
+
 /* ---- session: one map served through HOST matrices by one or several GPUs ---------------
  *
  * What the drop-in classes share per grid_map::GridMap (the .cc files under aerial_mapper_amd/cpp): the map

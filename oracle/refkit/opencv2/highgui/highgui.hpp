@@ -17,6 +17,7 @@
 
 #include "../../refkit.h"
 #include "../../../amo_cvlike.h"
+#include "../../../amo_rectify.h"
 
 typedef unsigned char uchar;
 
@@ -28,6 +29,9 @@ typedef unsigned char uchar;
 #define CV_8UC1 CV_MAKETYPE(CV_8U, 1)
 #define CV_8UC3 CV_MAKETYPE(CV_8U, 3)
 #define CV_16SC3 CV_MAKETYPE(CV_16S, 3)
+#define CV_32FC1 CV_MAKETYPE(CV_32F, 1)
+#define CV_INTER_LINEAR 1
+#define CV_FILLED (-1)
 #define CV_RGB2GRAY 7
 #define CV_GRAY2RGB 8
 
@@ -79,6 +83,7 @@ struct Rect {
 struct Scalar {
   double val[4];
   Scalar(double v0 = 0.0) : val{v0, 0.0, 0.0, 0.0} {}
+  Scalar(double v0, double v1, double v2) : val{v0, v1, v2, 0.0} {}
 };
 
 // rows x cols elements of `type`, rows `step` bytes apart: either a view of the caller's
@@ -93,6 +98,12 @@ class Mat {
     own_.reset(new std::vector<uint8_t>(static_cast<size_t>(r) * step, 0));
     data = own_->data();
   }
+  Mat(int r, int c, int type, const Scalar& fill) : rows(r), cols(c), type_(type) {
+    step = static_cast<size_t>(c) * elemSize();
+    own_.reset(new std::vector<uint8_t>(static_cast<size_t>(r) * step, static_cast<uint8_t>(fill.val[0])));
+    data = own_->data();
+  }
+  void create(int r, int c, int type) { *this = Mat(r, c, type); }
   int type() const { return type_; }
   int depth() const { return type_ & 7; }
   int channels() const { return (type_ >> 3) + 1; }
@@ -246,6 +257,30 @@ inline Mat& last_written() {
   static Mat m;
   return m;
 }
+// cv::remap(8UC1, CV_32FC1 maps, INTER_LINEAR, BORDER_CONSTANT) and cv::drawContours(filled) as
+// the rectifier calls them: the oracle's adopted definitions (../../../amo_rectify.h).
+inline void remap(const Mat& src, Mat& dst, const Mat& map_x, const Mat& map_y, int /*interp*/,
+                  int /*border*/, const Scalar& /*value*/) {
+  dst = Mat(map_x.rows, map_x.cols, CV_8UC1);
+  for (int v = 0; v < dst.rows; ++v)
+    for (int u = 0; u < dst.cols; ++u)
+      dst.at<uchar>(v, u) = amo::rect::remap_bilinear(src.data, src.step, src.cols, src.rows,
+                                                      map_x.at<float>(v, u), map_y.at<float>(v, u));
+}
+inline void drawContours(Mat& image, const std::vector<std::vector<Point> >& contours, int index,
+                         const Scalar& color, int /*thickness: CV_FILLED*/, int /*line type*/) {
+  const std::vector<Point>& c = contours[static_cast<size_t>(index)];
+  if (c.size() != 4) return;
+  int cx[4], cy[4];
+  for (int k = 0; k < 4; ++k) {
+    cx[k] = c[k].x;
+    cy[k] = c[k].y;
+  }
+  for (int v = 0; v < image.rows; ++v)
+    for (int u = 0; u < image.cols; ++u)
+      if (amo::rect::in_quad(cx, cy, u, v)) image.at<uchar>(v, u) = static_cast<uchar>(color.val[0]);
+}
+
 inline bool imwrite(const std::string&, const Mat& image) {
   last_written() = image.clone();
   return true;

@@ -130,7 +130,7 @@ def have_ref():
 # ---- the reference's OWN loops (oracle/_ref/libref_loops_*.so: dsm.cc, ortho-backward-grid.cc,
 # ortho-from-pcl.cc compiled unchanged against oracle/refkit/; `which="loops"` below) ----------
 LOOPS_SO = {name: os.path.join(ORACLE_DIR, "_ref", "libref_loops_%s.so" % name)
-            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map", "densify", "forward")}
+            for name in ("dsm", "ortho_backward", "ortho_from_pcl", "grid_map", "densify", "forward", "rectify")}
 _loops_libs = {}
 
 
@@ -174,6 +174,8 @@ def _loops(name):
             so.amr_grid_map_initialize.restype = C.c_int
             so.amr_grid_map_initialize.argtypes = [C.c_double] * 5 + [C.POINTER(Grid),
                                                                       C.POINTER(C.c_void_p)]
+        elif name == "rectify":
+            pass  # (bound by rectify_stereo_pair)
         else:
             so.amr_ortho_from_pcl_process.restype = C.c_int
             so.amr_ortho_from_pcl_process.argtypes = [f64p, C.POINTER(C.c_int32), C.c_size_t,
@@ -267,6 +269,34 @@ def dsm_process_knn(xyz, g, k, radius_sq=1, center_easting=0.0, center_northing=
                                         center_easting, center_northing, int(k),
                                         int(bool(multi_thread)), 0, _f32(elevation))
     return rc, elevation
+
+
+def rectify_stereo_pair(K, R1, R2, t1, t2, left, right, which="port"):
+    """stereo::Rectifier::rectifyStereoPair.  left / right: (H, W) uint8.  Returns (rc, dict with
+    R_G_C (3,3), baseline, maps (4,H,W) float32, left, right, mask (H,W) uint8)."""
+    f64 = lambda a, n: np.ascontiguousarray(a, np.float64).reshape(n)
+    K, R1, R2, t1, t2 = f64(K, 9), f64(R1, 9), f64(R2, 9), f64(t1, 3), f64(t2, 3)
+    left = np.ascontiguousarray(left, np.uint8)
+    right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    R = np.zeros(9)
+    b = C.c_double()
+    maps = np.zeros((4, H, W), np.float32)
+    ol, orr, mask = (np.zeros((H, W), np.uint8) for _ in range(3))
+    u8 = lambda a: a.ctypes.data_as(C.c_void_p)
+    if which == "loops":
+        fn = _loops("rectify").amr_rectify_stereo_pair
+    else:
+        fn = lib(which).amo_rectify_stereo_pair
+    fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.c_double)] * 5 + [C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                 C.c_size_t, C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_double), C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
+    rc = fn(_f64(K), _f64(R1), _f64(R2), _f64(t1), _f64(t2), W, H, u8(left), left.strides[0],
+            u8(right), right.strides[0], _f64(R), C.byref(b), u8(maps), u8(ol), u8(orr), u8(mask))
+    return rc, {"R_G_C": R.reshape(3, 3), "baseline": b.value, "maps": maps, "left": ol,
+                "right": orr, "mask": mask}
 
 
 def ortho_from_pcl(xyz, intensities, g, radius_sq=2, adaptive=False, ortho=None, which="port"):
