@@ -932,9 +932,8 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   uint32_t* s_rowp = s_rowg + kMaxRegionRows;
   uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;
   uint32_t* s_ctl = s_scan + 24;  // [0] np, [1] nflag, [2..3] pad, [4..7] zmin / zmax keys
-  unsigned long long* s_zr = reinterpret_cast<unsigned long long*>(
-      (reinterpret_cast<uintptr_t>(s_ctl + 4) + 7) & ~uintptr_t(7));
-  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_zr + 2);
+  uint32_t* s_zkey = s_ctl + 4;  // [0] min, [1] max of the region's heights (ordered f32 keys)
+  uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_ctl + 8);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -993,8 +992,8 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     }
     s_ctl[0] = run;
     s_ctl[1] = 0;
-    s_zr[0] = kOrderedPlusInf;   // running min (ordered keys)
-    s_zr[1] = kOrderedMinusInf;  // running max
+    s_zkey[0] = 0xFFFFFFFFu;  // running min of the heights (ordered float keys)
+    s_zkey[1] = 0u;           // running max
   }
   __syncthreads();
   const int np = (int)s_ctl[0];
@@ -1051,10 +1050,22 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     }
   }
   if (kVar == 6) return;
-  wave_minmax_d(&zlo, &zhi);
-  if (lane == 0 && zlo <= zhi) {
-    atomicMin(&s_zr[0], ordered_key(zlo));
-    atomicMax(&s_zr[1], ordered_key(zhi));
+  // height range of the region, in f32 (the budget below widens it by the conversion's error):
+  // a wave reduction of floats (12 ds_bpermute + 12 f32 min / max instead of 24 + 34 FP64), one
+  // LDS atomic pair per wave on order-preserving keys.  (An atomic pair per THREAD on the one
+  // address serialises: measured +0.5 ms.)
+  {
+    float flo = (float)zlo, fhi = (float)zhi;   // (+-inf where the thread had no point)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      flo = fminf(flo, __shfl_xor(flo, d, 64));
+      fhi = fmaxf(fhi, __shfl_xor(fhi, d, 64));
+    }
+    if (lane == 0 && flo <= fhi) {
+      const uint32_t klo = __float_as_uint(flo), khi = __float_as_uint(fhi);
+      atomicMin(&s_zkey[0], (klo >> 31) ? ~klo : (klo | 0x80000000u));
+      atomicMax(&s_zkey[1], (khi >> 31) ? ~khi : (khi | 0x80000000u));
+    }
   }
   __syncthreads();
   {
@@ -1076,10 +1087,17 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   // ---- the tile's error budget ------------------------------------------------------
   //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24, n = hits
   //   accumulated between two flushes of the running sums (a trip's, plus one add per trip)
-  const double zmin = np ? from_ordered_key(s_zr[0]) : 0.0;
-  const double zmax = np ? from_ordered_key(s_zr[1]) : 0.0;
+  float zmin_f = 0.f, zmax_f = 0.f;
+  if (np) {
+    const uint32_t a = s_zkey[0], b = s_zkey[1];
+    zmin_f = __uint_as_float((a >> 31) ? (a & 0x7FFFFFFFu) : ~a);
+    zmax_f = __uint_as_float((b >> 31) ? (b & 0x7FFFFFFFu) : ~b);
+  }
+  const double zmin = (double)zmin_f, zmax = (double)zmax_f;
   const double z0 = 0.5 * zmin + 0.5 * zmax;
-  const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f;
+  // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
+  const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
+                       (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
   int n_allowed;
   {
     const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
@@ -1508,6 +1526,14 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     else if ((VAR_) == 4) AMHIP_F32_DENSE_V(4);                                               \
     else if ((VAR_) == 5) AMHIP_F32_DENSE_V(5);                                               \
     else if ((VAR_) == 6) AMHIP_F32_DENSE_V(6);                                               \
+    else if ((VAR_) == 7) { /* 256-thread workgroups: 8 per CU, two cell pairs per lane */      \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_f32<256, 16, 1024, 0>),                  \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
+      hipLaunchKernelGGL((k_dsm_gather_f32<256, 16, 1024, 0>), dim3(ntiles), dim3(256),       \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         cell_out, lists + kListHdr + (size_t)4 * ntiles, tile_count + 4);    \
+    }                                                                                         \
     else AMHIP_F32_DENSE_V(3);                                                                \
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the

@@ -583,6 +583,9 @@ def _lazy_reset_scenario():
              "colored_ortho"]
     out = []
     with _map_for(sc, A) as m:
+        # (two RUNS are compared layer by layer: the FP64 gather, whose heights do not move by a
+        # float spacing with the order of the points inside a bin)
+        m.set_dsm_precision(True)
         for rnd in range(2):
             A.Dsm(A.DsmSettings(), m).process(pts if rnd == 0 else pts[::3], m)
             A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m).process(sc.poses, sc.frames, m)
