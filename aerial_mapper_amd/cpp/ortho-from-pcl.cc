@@ -17,21 +17,19 @@ void OrthoFromPcl::process(const AlignedType<std::vector, Eigen::Vector3d>::type
   if (intensities.size() < pointcloud.size())
     amhip_shim::fatal("OrthoFromPcl::process", "CHECK(i < intensities.size())");
   std::fprintf(stderr, "[aerial_mapper_hip] Number of points: %zu\n", pointcloud.size());
-  // the reference keeps no state between calls either: a context per call
-  amhip_ctx* ctx = nullptr;
-  int rows = 0, cols = 0;
-  double geom[4];
-  amhip_shim::ensure_context(&ctx, &rows, &cols, geom, *map, "OrthoFromPcl");
+  // the reference keeps no state between calls either; the map's session is shared with the
+  // other drop-in objects working on this GridMap (created for the call if there is none)
+  amhip_session* session = amhip_shim::acquire_session(*map, nullptr, "OrthoFromPcl");
   static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double),
                 "point cloud must be contiguous x,y,z doubles");
   static_assert(sizeof(int) == sizeof(int32_t), "intensities are 32-bit ints");
-  const int status = amhip_ortho_from_pcl_process(
-      ctx, reinterpret_cast<const double*>(pointcloud.data()),
+  const int status = amhip_session_ortho_from_pcl_process(
+      session, reinterpret_cast<const double*>(pointcloud.data()),
       reinterpret_cast<const int32_t*>(intensities.data()), pointcloud.size(),
       settings_.interpolation_radius, settings_.use_adaptive_interpolation ? 1 : 0,
       (*map)["ortho"].data());
   if (status != AMHIP_OK) amhip_shim::fatal("OrthoFromPcl::process", amhip_last_error());
-  amhip_ctx_destroy(ctx);
+  amhip_shim::release_session(session);
 }
 
 void OrthoFromPcl::printParams() const {

@@ -564,4 +564,41 @@ int amhip_session_ortho_backward_process(
   });
 }
 
+// ortho::OrthoFromPcl::process (ortho-from-pcl.cc:20-113) on host buffers: `ortho` = the
+// GridMap's matrix.  Every window gets the whole cloud (its binning drops what lies outside the
+// window + margin): intensities travel with their points, and this rank-1 "next" path is not
+// worth a routing pass of its own.
+int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xyz,
+                                         const int32_t* host_intensities, size_t n, int radius_sq,
+                                         int adaptive, float* ortho) {
+  if (!h) return arg_failure("null session");
+  if (n == 0 || !host_xyz || !host_intensities || !ortho)
+    return arg_failure("empty point cloud / null buffer (CHECK(!pointcloud.empty()))");
+  if (n >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points");
+  Session& s = h->impl;
+  std::vector<unsigned long long> hh;
+  const float* mats[1] = {ortho};
+  if (!s.always_copy) host_hashes(s, mats, 1, &hh);
+  else hh.assign(s.W(), 0ull);
+  return for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    if ((r = sync_in(s, k, AMHIP_LAYER_ORTHO, ortho, hh[k]))) return r;
+    if ((r = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return r;
+    if ((r = ensure_capacity(&c->stage_values, &c->stage_values_cap, n))) return r;
+    AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
+                             hipMemcpyHostToDevice, c->stream));
+    AMHIP_TRY(hipMemcpyAsync(c->stage_values, host_intensities, n * sizeof(int32_t),
+                             hipMemcpyHostToDevice, c->stream));
+    if ((r = amhip_ortho_from_pcl_process_dev(s.ctx[k], c->stage_points, c->stage_values, n,
+                                              radius_sq, adaptive)))
+      return r;
+    const int lay[1] = {AMHIP_LAYER_ORTHO};
+    float* outs[1] = {ortho};
+    if ((r = sync_out(s, k, lay, outs, 1))) return r;
+    return ctx_fetch_status(c);
+  });
+}
+
 }  // extern "C"

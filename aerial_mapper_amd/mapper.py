@@ -465,6 +465,14 @@ class HostSession(object):
             self._h, pts.ctypes.data, pts.shape[0], s.interpolation_radius, s.center_easting,
             s.center_northing, self.layers["elevation"].ctypes.data))
 
+    def ortho_from_pcl_process(self, settings, points, intensities):
+        pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
+        inten = np.ascontiguousarray(intensities, np.int32).reshape(-1)
+        assert inten.shape[0] == pts.shape[0]
+        L.check(self._lib.amhip_session_ortho_from_pcl_process(
+            self._h, pts.ctypes.data, inten.ctypes.data, pts.shape[0], settings.interpolation_radius,
+            int(bool(settings.use_adaptive_interpolation)), self.layers["ortho"].ctypes.data))
+
     def ortho_process(self, ncameras, ortho_settings, T_G_Bs, images):
         T_G_Bs = np.ascontiguousarray(T_G_Bs, np.float64).reshape(-1, 7)
         F = T_G_Bs.shape[0]

@@ -469,6 +469,10 @@ int amhip_session_set_always_copy(amhip_session* s, int on);
  * column-major), read and written like the reference does. */
 int amhip_session_dsm_process(amhip_session* s, const double* host_xyz, size_t n, int radius_sq,
                               double center_easting, double center_northing, float* elevation);
+/* ortho::OrthoFromPcl::process (ortho-from-pcl.cc:20-113): `ortho` = the GridMap's matrix. */
+int amhip_session_ortho_from_pcl_process(amhip_session* s, const double* host_xyz,
+                                         const int32_t* host_intensities, size_t n, int radius_sq,
+                                         int adaptive, float* ortho);
 /* ortho::OrthoBackwardGrid::process (ortho-backward-grid.cc:223-239): the six matrices of the
  * map (all required except the one of ortho / colored_ortho the mode does not write). */
 int amhip_session_ortho_backward_process(

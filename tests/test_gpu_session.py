@@ -114,3 +114,28 @@ def test_session_notices_host_side_changes_by_content():
             S.assert_dsm_close(hs.layers["elevation"], fresh["elevation"], tol=1e-6)
             if np.array_equal(hs.layers["elevation"].view(np.uint32), fresh["elevation"].view(np.uint32)):
                 S.assert_layers_equal(hs.layers, fresh, ORTHO_LAYERS)
+
+
+@pytest.mark.parametrize("tiles", [(1, 1), (2, 2)])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_session_ortho_from_pcl(tiles, adaptive):
+    import aerial_mapper_amd as A
+    sc = S.Scene(120.0, 90.0, 0.5, 30000, seed=405)
+    if adaptive:   # a strip without points: the x10, x100 retries
+        sc.points = np.ascontiguousarray(sc.points[np.abs(sc.points[:, 0]) > 6.0])
+    inten = (np.arange(sc.points.shape[0]) * 7 % 251).astype(np.int32)
+    st = A.OrthoFromPclSettings(interpolation_radius=2, use_adaptive_interpolation=adaptive)
+    rc, want = O.ortho_from_pcl(sc.points, inten, sc.grid, 2, adaptive)
+    assert rc == O.OK
+    with A.HostSession(_settings(A, sc.grid), tiles=tiles) as hs:
+        hs.ortho_from_pcl_process(st, sc.points, inten)
+        got = hs.layers["ortho"]
+        assert np.abs(got.astype(np.float64) - want).max() <= 1e-3      # intensities 0..250
+        assert ((got == 255.0) == (want == 255.0)).all()
+        # a second cloud onto the same matrix: untouched cells keep what the first call left
+        pts2 = np.ascontiguousarray(sc.points[sc.points[:, 1] > 10.0] + np.array([0.1, 0.1, 0.0]))
+        inten2 = np.full(pts2.shape[0], 17, np.int32)
+        hs.ortho_from_pcl_process(A.OrthoFromPclSettings(interpolation_radius=2), pts2, inten2)
+        rc, want2 = O.ortho_from_pcl(pts2, inten2, sc.grid, 2, False, ortho=want.copy())
+        assert rc == O.OK
+        assert np.abs(hs.layers["ortho"].astype(np.float64) - want2).max() <= 1e-3
