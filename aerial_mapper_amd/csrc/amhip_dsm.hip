@@ -292,10 +292,6 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const double* __restrict__ sorted, int i, int j,
                                             const CellOut& o) {
   if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
-  if (p.knn_k > 0) {
-    cell_global_knn(p, start, sorted, i, j, o);
-    return;
-  }
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
@@ -425,6 +421,19 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
   cell_global(p, start, sorted, i, j, o);
+}
+
+// The optional capped mode has a kernel of its own: its register-resident result set
+// would otherwise set the register budget (and with it the occupancy) of every
+// kernel that can reach cell_global.
+__global__ void __launch_bounds__(256)
+k_dsm_gather_knn(DsmParams p, const uint32_t* __restrict__ start,
+                 const double* __restrict__ sorted, CellOut o) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= p.rows || j >= p.cols) return;
+  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  cell_global_knn(p, start, sorted, i, j, o);
 }
 
 // ---------------------------------------------------------------------------
@@ -1571,8 +1580,12 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          cell_out);
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
-      hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,
-                         c->sorted, cell_out);
+      if (p.knn_k > 0)
+        hipLaunchKernelGGL(k_dsm_gather_knn, grid, dim3(256), 0, c->stream, p, c->bin_start,
+                           c->sorted, cell_out);
+      else
+        hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,
+                           c->sorted, cell_out);
     }
     AMHIP_TRY(hipGetLastError());
   }
