@@ -17,6 +17,7 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libaerial_mapper_hip.so")
 SHIM_PATH = os.path.join(LIB_DIR, "libaerial_mapper_shim.so")
+RESOURCES_PATH = os.path.join(LIB_DIR, "kernel_resources.txt")
 
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
                "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip"]
@@ -50,11 +51,23 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB_PATH, deps):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage",
+                                      "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                                       "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # the compiler's per-kernel register / spill / occupancy remarks are kept next to the
+    # library (tests/test_kernel_resources.py holds the hot kernels to their budgets)
+    res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    remarks, other = [], []
+    for line in res.stderr.splitlines():
+        (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
+    if res.returncode != 0:
+        raise subprocess.CalledProcessError(res.returncode, cmd)
+    with open(RESOURCES_PATH, "w") as fh:
+        fh.write("\n".join(remarks) + "\n")
     return LIB_PATH
 
 

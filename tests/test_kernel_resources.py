@@ -1,0 +1,52 @@
+"""The register / occupancy budgets of the hot kernels, from the compiler's own remarks
+(aerial_mapper_amd/lib/kernel_resources.txt, written by every build): code added to a cold
+path of a kernel raises the register allocation of the WHOLE kernel, silently (round 2: an
+optional mode hooked into cell_global took the FP64 gather from 7 to 4 waves per SIMD)."""
+import os
+import re
+
+import pytest
+
+from aerial_mapper_amd import build
+
+
+def _kernels():
+    build.build_hip()
+    if not os.path.exists(build.RESOURCES_PATH):
+        build.build_hip(force=True)
+    out, cur = {}, None
+    for line in open(build.RESOURCES_PATH):
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def _one(kernels, needle):
+    hits = {k: v for k, v in kernels.items() if needle in k}
+    assert len(hits) == 1, (needle, sorted(hits))
+    return next(iter(hits.values()))
+
+
+BUDGETS = [
+    # (mangled-name fragment, min waves/SIMD, max spilled VGPRs)
+    ("k_dsm_gather_f32ILi512ELi16ELi1024ELi0E", 8, 0),   # the default DSM gather
+    ("k_dsm_gather_f32ILi512ELi16ELi2048ELi0E", 8, 0),
+    ("k_dsm_gather_tiledILi512ELi16ELi1024E", 7, 0),      # FP64 mode
+    ("k_dsm_p3_countILb0E", 8, 0),
+    ("k_dsm_p3_scatterILb0E", 8, 0),
+    ("k_dsm_p3_scatterILb1E", 8, 0),
+    ("14k_dsm_p3_placeE", 4, 0),
+    ("21k_ortho_backward_fastE", 3, 0),
+]
+
+
+@pytest.mark.parametrize("needle,min_waves,max_spill", BUDGETS)
+def test_hot_kernel_budget(needle, min_waves, max_spill):
+    k = _one(_kernels(), needle)
+    assert k["Occupancy"] >= min_waves, k
+    assert k["VGPRs Spill"] <= max_spill, k
