@@ -292,14 +292,27 @@ __device__ __forceinline__ int cull_chunk(const OrthoParams& p, const FramePose*
   return kept;
 }
 
+// The sampled pixel of a cell's winning view as the output layer stores it
+// (ortho-backward-grid.cc:186-208).
+__device__ __forceinline__ float read_pixel(const OrthoParams& p, const uint8_t* __restrict__ frames,
+                                            int frame, int kp_x, int kp_y) {
+  const uint8_t* px = frames + (size_t)frame * p.frame_stride + (size_t)kp_y * p.row_step;
+  if (p.colored) {
+    // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B
+    px += (size_t)kp_x * 3u;
+    const unsigned bits = ((unsigned)px[2] << 16) | ((unsigned)px[1] << 8) | (unsigned)px[0];
+    return __uint_as_float(bits);
+  }
+  return (float)px[kp_x];
+}
+
 // One cell's results (ortho-backward-grid.cc:181-208): angle, frame index, the
 // `num_observations += itself` updates and the sampled pixel.
-__device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* __restrict__ frames,
-                                           float* __restrict__ elevation_angle,
+__device__ __forceinline__ void store_cell(const OrthoParams& p, float* __restrict__ elevation_angle,
                                            float* __restrict__ observation_index,
                                            float* __restrict__ num_observations,
                                            float* __restrict__ out_layer, int i, int j, float angle,
-                                           int frame, int accepted, int kp_x, int kp_y) {
+                                           int frame, int accepted, float pixel) {
   const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
   elevation_angle[at] = angle;
   observation_index[at] = (float)frame;
@@ -312,15 +325,17 @@ __device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* 
       num_observations[at] = nobs;
     }
   }
-  const uint8_t* px = frames + (size_t)frame * p.frame_stride + (size_t)kp_y * p.row_step;
-  if (p.colored) {
-    // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B
-    px += (size_t)kp_x * 3u;
-    const unsigned bits = ((unsigned)px[2] << 16) | ((unsigned)px[1] << 8) | (unsigned)px[0];
-    out_layer[at] = __uint_as_float(bits);
-  } else {
-    out_layer[at] = (float)px[kp_x];
-  }
+  out_layer[at] = pixel;
+}
+
+__device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* __restrict__ frames,
+                                           float* __restrict__ elevation_angle,
+                                           float* __restrict__ observation_index,
+                                           float* __restrict__ num_observations,
+                                           float* __restrict__ out_layer, int i, int j, float angle,
+                                           int frame, int accepted, int kp_x, int kp_y) {
+  store_cell(p, elevation_angle, observation_index, num_observations, out_layer, i, j, angle, frame,
+             accepted, read_pixel(p, frames, frame, kp_x, kp_y));
 }
 
 // One slab (64 x kSlabJ cells, kCellsPerLane per lane) of the block's tile: fold
@@ -340,8 +355,8 @@ __device__ __forceinline__ void ortho_slab(
     const float* __restrict__ elevation, float* __restrict__ elevation_angle,
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err, int* s_cand, int* s_wave_cnt,
-    double* s_best, const V3& centre, double radius, double slack, int i, bool i_ok, int js,
-    bool single, int ncand0) {
+    double* s_best, const double* s_atan, const V3& centre, double radius, double slack, int i,
+    bool i_ok, int js, bool single, int ncand0) {
   const int wid = threadIdx.x >> 6;
   const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
   float elev[kCellsPerLane];
@@ -413,22 +428,36 @@ __device__ __forceinline__ void ortho_slab(
 
     // ---- write back, pass 1: the winner's keypoint and stored angle from the
     // approximate point wherever that is provably the reference's result --------
+    // The four cells of the lane side by side: first all the arithmetic (no branch between
+    // the cells, so their dependent FP64 chains overlap), then the four pixel reads, then
+    // the stores.
     int pending = 0;  // 2 bits per cell: kFoldFinish / kFoldRedo
+    int what[kCellsPerLane], ku[kCellsPerLane], kv[kCellsPerLane];
+    float angle[kCellsPerLane], pix[kCellsPerLane];
 #pragma unroll
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int j = js + wid + c * (kOrthoThreads / 64);
-      if (!(i_ok && j < p.cols)) continue;
-      int ku = 0, kv = 0;
-      float angle = 0.0f;
-      const int what = fold_finish(&st[c], p.fold, cam_tab + 8, epsL, p.width, p.height, &ku, &kv,
-                                   &angle);
-      if (what == kFoldNone) {
+      ku[c] = kv[c] = 0;
+      angle[c] = 0.0f;
+      what[c] = fold_finish(&st[c], p.fold, s_atan, epsL, p.width, p.height, &ku[c], &kv[c],
+                            &angle[c]);
+      if (!(i_ok && j < p.cols)) what[c] = -1;  // no such cell
+    }
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      pix[c] = 0.0f;
+      if (what[c] == kFoldDone) pix[c] = read_pixel(p, frames, st[c].best_f, ku[c], kv[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < kCellsPerLane; ++c) {
+      const int j = js + wid + c * (kOrthoThreads / 64);
+      if (what[c] == kFoldNone) {
         if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
-      } else if (what == kFoldDone) {
-        write_cell(p, frames, elevation_angle, observation_index, num_observations, out_layer, i, j,
-                   angle, st[c].best_f, st[c].accepted, ku, kv);
-      } else {
-        pending |= what << (2 * c);
+      } else if (what[c] == kFoldDone) {
+        store_cell(p, elevation_angle, observation_index, num_observations, out_layer, i, j,
+                   angle[c], st[c].best_f, st[c].accepted, pix[c]);
+      } else if (what[c] > 0) {
+        pending |= what[c] << (2 * c);
         // (what slow_finish needs survives in two registers per cell)
       }
     }
@@ -596,12 +625,19 @@ __device__ __forceinline__ void ortho_backward_tile(
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
     const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt,
-    double* s_best) {
+    double* s_best, double* s_atan) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int i = blockIdx.x * kTileI + lane;
   const int j0 = blockIdx.y * kTileJ;
   const bool i_ok = i < p.rows;
+  if constexpr (kFast) {
+    // fold_angle()'s table (doubles 8 .. 24 behind the frame table) next to the lanes: a
+    // global read in the middle of the write-back's dependent chain costs a cache round trip
+    // per cell (the barriers of the frame cull below order it before its first use)
+    const double* cam_tab = reinterpret_cast<const double*>(fast_tab + p.num_frames);
+    if (threadIdx.x < kAtanTabSize) s_atan[threadIdx.x] = cam_tab[8 + threadIdx.x];
+  }
 
   // tile extents (cell centres)
   const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
@@ -689,14 +725,14 @@ __device__ __forceinline__ void ortho_backward_tile(
   if (!single) ncand0 = 0;
   if constexpr (kTileJ == kSlabJ) {
     ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
-                      num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,
-                      uradius, uslack, i, i_ok, j0, single, ncand0);
+                      num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
+                      ucentre, uradius, uslack, i, i_ok, j0, single, ncand0);
   } else {
 #pragma unroll 1
     for (int js = j0; js <= j_hi; js += kSlabJ)
       ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
-                        num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, ucentre,
-                        uradius, uslack, i, i_ok, js, single, ncand0);
+                        num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
+                        ucentre, uradius, uslack, i, i_ok, js, single, ncand0);
   }
 }
 
@@ -711,9 +747,10 @@ __device__ __forceinline__ void ortho_backward_tile(
   __shared__ int s_cand[kChunk];                                                             \
   __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
   __shared__ double s_best[kOrthoThreads / 64];                                              \
+  __shared__ double s_atan[kAtanTabSize];                                                    \
   ortho_backward_tile<FAST>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
                             observation_index, num_observations, out_layer, dev_err, zrange, \
-                            s_red, s_cand, s_wave_cnt, s_best);
+                            s_red, s_cand, s_wave_cnt, s_best, s_atan);
 
 // every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))

@@ -304,8 +304,11 @@ inline void make_atan_table(double* tab) {
 
 // pi/2 - atan(r) for r in [1e-3, 2], absolute error < 1e-15 (table + 6 terms
 // on |y| <= 1/16: truncation y^13 / 13 < 2e-17).  false: r out of range.
-AMHIP_HD bool fold_angle(const double* atan_tab, double r, double* alpha) {
-  if (!(r >= 1e-3 && r <= 2.0)) return false;
+AMHIP_HD bool fold_angle(const double* atan_tab, double r_in, double* alpha) {
+  // (no early exit: the four cells of a lane are finished side by side, and a branch per cell
+  // would keep their dependent chains from overlapping; out of range = arithmetic on 1.0)
+  const bool in_range = r_in >= 1e-3 && r_in <= 2.0;
+  const double r = in_range ? r_in : 1.0;
   const double fi = rint(r * 8.0);
   const double c = fi * 0.125;
   const double y = (r - c) * fold_rcp(fma(r, c, 1.0));
@@ -317,7 +320,7 @@ AMHIP_HD bool fold_angle(const double* atan_tab, double r, double* alpha) {
   const double at = fma(y * y2, q, y);
   const double theta = atan_tab[(int)fi] + at;
   *alpha = (1.5707963267948966 - theta) + 6.123233995736766e-17;
-  return true;
+  return in_range;
 }
 
 // Fold state of one cell.
@@ -422,14 +425,16 @@ enum { kFoldNone = 0, kFoldDone = 1, kFoldFinish = 2, kFoldRedo = 3 };
 AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan_tab,
                          double epsL, int width, int height, int* kp_x, int* kp_y,
                          float* angle) {
-  if (s->redo) return kFoldRedo;
-  if (s->accepted == 0) return kFoldNone;
-  const double rcz = fold_rcp(s->bz);
-  const double kx = s->bx * rcz;
-  const double ky = s->by * rcz;
+  // Written without early exits (see fold_angle): a cell that is to be replayed or that no
+  // view was accepted for runs the arithmetic on the point (1, 0, 1) and drops the result.
+  const bool live = !s->redo && s->accepted != 0;
+  const double bx = live ? s->bx : 1.0, by = live ? s->by : 0.0, bz = live ? s->bz : 1.0;
+  const double rcz = fold_rcp(bz);
+  const double kx = bx * rcz;
+  const double ky = by * rcz;
   const double u = fma(k.fu, kx, k.cu);
   const double v = fma(k.fv, ky, k.cv);
-  const double eps = fma(0x1p-49, fabs(s->bx) + fabs(s->by) + fabs(s->bz), epsL);
+  const double eps = fma(0x1p-49, fabs(bx) + fabs(by) + fabs(bz), epsL);
   const double ez = eps * rcz;  // the direction of the ray is known to within this
   const double duv = fma(k.kround * ez, 1.0 + fabs(kx) + fabs(ky), k.uv_abs);
   // std::round of a non-negative number = floor(x + 1/2) away from the ties
@@ -452,7 +457,7 @@ AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan
   // (just below a power of two the spacing halves: stay clear of those floats)
   ok = ok & (fabs(e) < half - da) & (fl != 1.0f) & (fl != 0.5f) & (fl > 0.26f);
   *angle = fl;
-  return ok ? kFoldDone : kFoldFinish;
+  return s->redo ? kFoldRedo : (s->accepted == 0 ? kFoldNone : (ok ? kFoldDone : kFoldFinish));
 }
 
 // ---- the reference's arithmetic, for the cells the margins could not settle ----
