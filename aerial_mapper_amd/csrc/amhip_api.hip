@@ -366,7 +366,9 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     const int rh = kTileJ + 2 * w0 + 2 * (B - 1);
     for (int k = 0; k <= w0; ++k)
       p.wrp[k] = p.wr2[2 * k] > p.wr2[2 * k + 1] ? p.wr2[2 * k] : p.wr2[2 * k + 1];
-    p.lds_cells = rw * (rh + 4);  // row pairs, +1 pair for the parity shift, +1 spill
+    // row pairs, +1 pair for the parity shift, +1 spill; (lds_cells + 1) entries, a multiple of
+    // four with three to spare: the single-precision gather clears / scans the table in quads
+    p.lds_cells = ((rw * (rh + 4) + 4 + 3) & ~3) - 1;
     p.lds_cap = cap;  // == kCap of the kernel instance
     const size_t bytes = ((size_t)p.lds_cap + 2) * 24 + ((size_t)p.lds_cells + 1) * 4 +
                          (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;

@@ -982,27 +982,34 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   const int ox = rbx0 * p.B;
   const int oy = rby0 * p.B;
 
-  const bool geom_ok = nrb <= kMaxRegionRows && ncell <= p.lds_cells;
-  if (geom_ok && tid < nrb) {
-    const uint32_t* row = start + (size_t)(rby0 + tid) * p.nbx;
-    const uint32_t gs = row[rbx0];
-    s_rowg[tid] = gs;
-    s_rowp[tid + 1] = row[rbx1 + 1] - gs;
+  // (the cell table is cleared, scanned and rewritten in whole quads: entries 0 .. ncell + 3)
+  const bool geom_ok = nrb <= 64 && ncell + 3 <= p.lds_cells;
+  // ONE phase: the cell table is cleared (16 bytes per lane) while wave 0 reads the region's bin
+  // rows and prefixes their lengths across its lanes (no serial pass, no barrier in between)
+  {
+    uint4* q = reinterpret_cast<uint4*>(s_off);
+    const int nq = geom_ok ? (ncell + 4) >> 2 : 0;
+    for (int k = tid; k < nq; k += NT) q[k] = make_uint4(0u, 0u, 0u, 0u);
   }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    s_rowp[0] = 0;
-    if (geom_ok) {
-      for (int r = 0; r < nrb; ++r) {
-        run += s_rowp[r + 1];
-        s_rowp[r + 1] = run;
-      }
+  if (wid == 0) {
+    uint32_t gs = 0, cnt = 0;
+    if (geom_ok && lane < nrb) {
+      const uint32_t* row = start + (size_t)(rby0 + lane) * p.nbx;
+      gs = row[rbx0];
+      cnt = row[rbx1 + 1] - gs;
     }
-    s_ctl[0] = run;
-    s_ctl[1] = 0;
-    s_zkey[0] = 0xFFFFFFFFu;  // running min of the heights (ordered float keys)
-    s_zkey[1] = 0u;           // running max
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    if (lane < nrb && geom_ok) {
+      s_rowg[lane] = gs;
+      s_rowp[lane + 1] = incl;
+    }
+    if (lane == 63) s_ctl[0] = incl;
+    if (lane == 0) {
+      s_rowp[0] = 0;
+      s_ctl[1] = 0;
+      s_zkey[0] = 0xFFFFFFFFu;  // running min of the heights (ordered float keys)
+      s_zkey[1] = 0u;           // running max
+    }
   }
   __syncthreads();
   const int np = (int)s_ctl[0];
@@ -1016,8 +1023,6 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   }
 
   // ---- stage: load, count per cell, height range -------------------------------
-  for (int k = tid; k <= ncell; k += NT) s_off[k] = 0;
-  __syncthreads();
   static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
   constexpr int kMaxK = (kCap + NT - 1) / NT;
   uint32_t pslot[kMaxK];
@@ -1077,57 +1082,82 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     }
   }
   __syncthreads();
-  {
-    const int per = (ncell + NT - 1) / NT;
-    const int lo = tid * per;
-    const int hi = min(lo + per, ncell);
-    unsigned sum = 0;
-    for (int k = lo; k < hi; ++k) sum += s_off[k];
-    unsigned total;
-    unsigned run = block_excl_scan<NT>(sum, &total, s_scan);
-    for (int k = lo; k < hi; ++k) {
-      const unsigned t = s_off[k];
-      s_off[k] = run;
-      run += t;
+  // ---- cell-table scan: a thread owns consecutive whole quads (one at the usual sizes), a wave
+  // their prefix; the last wave works out the tile's error budget while the others wait ----
+  const int nq = (ncell + 4) >> 2;  // quads that cover entries 0 .. ncell
+  const int qper = (nq + NT - 1) / NT;
+  const int q0 = tid * qper, q1 = min(q0 + qper, nq);
+  uint4* const qoff = reinterpret_cast<uint4*>(s_off);
+  unsigned qsum = 0;
+  for (int k = q0; k < q1; ++k) {
+    const uint4 v = qoff[k];
+    qsum += (v.x + v.y) + (v.z + v.w);
+  }
+  const unsigned qincl = wave_incl_scan(qsum, lane);
+  if (lane == 63) s_scan[wid] = qincl;
+  if (wid == kWaves - 1) {
+    // ---- the tile's error budget ----------------------------------------------------
+    //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24, n = hits
+    //   accumulated between two flushes of the running sums (a trip's, plus one add per trip)
+    float zmin_f = 0.f, zmax_f = 0.f;
+    if (np) {
+      const uint32_t a = s_zkey[0], b = s_zkey[1];
+      zmin_f = __uint_as_float((a >> 31) ? (a & 0x7FFFFFFFu) : ~a);
+      zmax_f = __uint_as_float((b >> 31) ? (b & 0x7FFFFFFFu) : ~b);
     }
-    if (tid == 0) s_off[ncell] = total;
+    const double zmin = (double)zmin_f, zmax = (double)zmax_f;
+    const double z0w = 0.5 * zmin + 0.5 * zmax;
+    // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
+    const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
+                         (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
+    int na;
+    {
+      const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
+      // spacing of the stored floats at that height
+      const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+      // north_star: 1e-4 m; above 1024 m one float spacing is already more than that:
+      // there "1 LSB" is the bar, and a quarter of a spacing the budget
+      const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
+      if (!(S_half <= 3.0e38f)) na = -1;
+      else if (S_half == 0.0f) na = 1 << 20;
+      else {
+        const float room = (0.5f * allowed / S_half - p.fx_epsw) * 16777216.0f - 2.0f;
+        na = room > 1.0e6f ? (1 << 20) : (int)room;
+      }
+    }
+    if (lane == 0) {
+      s_ctl[2] = (uint32_t)na;
+      s_zkey[2] = (uint32_t)__double2loint(z0w);
+      s_zkey[3] = (uint32_t)__double2hiint(z0w);
+    }
   }
   __syncthreads();
-  // ---- the tile's error budget ------------------------------------------------------
-  //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24, n = hits
-  //   accumulated between two flushes of the running sums (a trip's, plus one add per trip)
-  float zmin_f = 0.f, zmax_f = 0.f;
-  if (np) {
-    const uint32_t a = s_zkey[0], b = s_zkey[1];
-    zmin_f = __uint_as_float((a >> 31) ? (a & 0x7FFFFFFFu) : ~a);
-    zmax_f = __uint_as_float((b >> 31) ? (b & 0x7FFFFFFFu) : ~b);
-  }
-  const double zmin = (double)zmin_f, zmax = (double)zmax_f;
-  const double z0 = 0.5 * zmin + 0.5 * zmax;
-  // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
-  const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
-                       (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
-  int n_allowed;
   {
-    const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
-    // spacing of the stored floats at that height
-    const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
-    // north_star: 1e-4 m; above 1024 m one float spacing is already more than that:
-    // there "1 LSB" is the bar, and a quarter of a spacing the budget
-    const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
-    if (!(S_half <= 3.0e38f)) n_allowed = -1;
-    else if (S_half == 0.0f) n_allowed = 1 << 20;
-    else {
-      const float room = (0.5f * allowed / S_half - p.fx_epsw) * 16777216.0f - 2.0f;
-      n_allowed = room > 1.0e6f ? (1 << 20) : (int)room;
+    const int mywave = __builtin_amdgcn_readfirstlane(wid);
+    unsigned run = qincl - qsum;
+#pragma unroll
+    for (int w = 0; w < kWaves - 1; ++w)
+      if (w < mywave) run += s_scan[w];
+    for (int k = q0; k < q1; ++k) {
+      const uint4 v = qoff[k];
+      uint4 e;
+      e.x = run;
+      e.y = run + v.x;
+      e.z = e.y + v.y;
+      e.w = e.z + v.z;
+      run = e.w + v.w;
+      qoff[k] = e;  // (entry ncell, an empty count, receives the total)
     }
   }
+  const int n_allowed = (int)s_ctl[2];
+  const double z0 = __hiloint2double((int)s_zkey[3], (int)s_zkey[2]);
   // (a trip of a dense tile brings up to ~20 candidates: below that the FP64 kernel takes
   // the whole tile -- staging it twice is cheaper than redoing most of its cells)
   if (n_allowed < 48) {
     if (tid == 0) exact_list[atomicAdd(exact_count, 1u)] = tile;
     return;
   }
+  __syncthreads();
   // pass 2: drop the points into their sorted slot
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
