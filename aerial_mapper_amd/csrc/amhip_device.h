@@ -9,12 +9,46 @@ namespace amhip {
 // ---------------------------------------------------------------------------
 // wave / workgroup scans
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
-  }
+// Inclusive prefix sum across the 64 lanes of a wave (EVERY lane of the wave must be active:
+// callers sit in wave-uniform control flow).  Six DPP adds: a Kogge-Stone scan inside each row
+// of 16 lanes (row_shr:1/2/4/8; a lane without a source adds the `old` operand, 0), then the
+// row totals travel on (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned v, int /*lane*/) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+  return v;
+}
+
+// min / max of a float across the wave, delivered in LANE 63 (other lanes hold partial results).
+// Same six DPP steps; a lane without a source combines with itself.
+__device__ __forceinline__ float wave_min_to_lane63(float v) {
+#define AMHIP_DPP_MIN(CTRL, ROWS)                                                              \
+  v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), \
+                                                          CTRL, ROWS, 0xf, false)))
+  AMHIP_DPP_MIN(0x111, 0xf);
+  AMHIP_DPP_MIN(0x112, 0xf);
+  AMHIP_DPP_MIN(0x114, 0xf);
+  AMHIP_DPP_MIN(0x118, 0xf);
+  AMHIP_DPP_MIN(0x142, 0xa);
+  AMHIP_DPP_MIN(0x143, 0xc);
+#undef AMHIP_DPP_MIN
+  return v;
+}
+__device__ __forceinline__ float wave_max_to_lane63(float v) {
+#define AMHIP_DPP_MAX(CTRL, ROWS)                                                              \
+  v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), \
+                                                          CTRL, ROWS, 0xf, false)))
+  AMHIP_DPP_MAX(0x111, 0xf);
+  AMHIP_DPP_MAX(0x112, 0xf);
+  AMHIP_DPP_MAX(0x114, 0xf);
+  AMHIP_DPP_MAX(0x118, 0xf);
+  AMHIP_DPP_MAX(0x142, 0xa);
+  AMHIP_DPP_MAX(0x143, 0xc);
+#undef AMHIP_DPP_MAX
   return v;
 }
 

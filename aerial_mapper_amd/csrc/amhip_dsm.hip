@@ -1065,17 +1065,13 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   }
   if (kVar == 6) return;
   // height range of the region, in f32 (the budget below widens it by the conversion's error):
-  // a wave reduction of floats (12 ds_bpermute + 12 f32 min / max instead of 24 + 34 FP64), one
+  // a wave reduction of floats (6 + 6 DPP min / max instead of 24 ds_bpermute + 34 FP64 ops), one
   // LDS atomic pair per wave on order-preserving keys.  (An atomic pair per THREAD on the one
   // address serialises: measured +0.5 ms.)
   {
-    float flo = (float)zlo, fhi = (float)zhi;   // (+-inf where the thread had no point)
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      flo = fminf(flo, __shfl_xor(flo, d, 64));
-      fhi = fmaxf(fhi, __shfl_xor(fhi, d, 64));
-    }
-    if (lane == 0 && flo <= fhi) {
+    // (+-inf where the thread had no point; six DPP steps each, result in lane 63)
+    const float flo = wave_min_to_lane63((float)zlo), fhi = wave_max_to_lane63((float)zhi);
+    if (lane == 63 && flo <= fhi) {
       const uint32_t klo = __float_as_uint(flo), khi = __float_as_uint(fhi);
       atomicMin(&s_zkey[0], (klo >> 31) ? ~klo : (klo | 0x80000000u));
       atomicMax(&s_zkey[1], (khi >> 31) ? ~khi : (khi | 0x80000000u));

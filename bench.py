@@ -153,6 +153,25 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
             b = layers[name]
             eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
             parity[name + "_mismatch_cells"] = int((~eq).sum())
+        if any(parity[k] for k in parity if k.endswith("_mismatch_cells")):
+            # The reference's mosaic above stands on the REFERENCE's heights, the GPU's on its own
+            # (default single-precision gather: within 1e-4 m, not bit-identical).  A height that
+            # moved by one float spacing can carry a keypoint across a pixel boundary; whether the
+            # mosaic kernel itself is exact is decided on equal inputs: the reference's loop once
+            # more, on the GPU's heights.
+            layers2 = O.new_layers(g)
+            layers2["elevation"] = np.ascontiguousarray(gpu_elev)
+            rc = O.ortho_process(g, cam, poses, ncam.T_C_B, frames_host, layers2,
+                                 colored=args.colored, which=which)
+            assert rc == 0
+            for name in ("observation_index", "colored_ortho" if args.colored else "ortho"):
+                a = map_.get(name)[:s, :s]
+                b = layers2[name]
+                eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+                parity[name + "_mismatch_cells_on_equal_heights"] = int((~eq).sum())
+            parity["note"] = ("*_mismatch_cells: GPU DSM + mosaic against reference DSM + mosaic (the "
+                              "heights differ by <= dsm_max_abs_err_m); *_on_equal_heights: the "
+                              "reference's mosaic loop fed the GPU's heights")
     cores = os.cpu_count() or 1
     if which == "loops":
         # the two process() calls alone; the constructors' one-sample-per-cell tables
@@ -491,7 +510,10 @@ def main():
                             "HBM bound; no MFMA-shaped work on this path",
                     "frac": round(lane_ops / (dom_ms * 1e-3) / peak_valu, 4),
                     "lane_instructions_per_launch": lane_ops, "peak_lane_instructions_per_s": peak_valu,
-                    "issue_slot_frac": round(v["SQ_INSTS_VALU"] / 1024.0 * 4.0 / busy, 3),
+                    # wave-instructions per SIMD and clock; the guide's 2 clocks per wave64 f32
+                    # instruction would make 0.5 the ceiling, tools/ubench/ubench2.hip measures 3.3
+                    # (v_fma_f32) to 4.7 (v_cmp / v_cvt / v_cndmask) clocks on this part: 0.21 - 0.30
+                    "wave_instructions_per_simd_clock": round(v["SQ_INSTS_VALU"] / 1024.0 / busy, 3),
                     "lanes_active_frac": round(lanes, 3),
                     "source": "profiles/" + valu[0] + " (counters); kernel_ms live"}
         parity_done = False
