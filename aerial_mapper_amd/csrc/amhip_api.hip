@@ -1339,7 +1339,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   if (rc) return rc;
   // one buffer, one upload: FramePose[F], then FrameFast[F + 2] (two FramePose
   // slots each; the two extra entries carry the camera for exact_view(),
-  // doubles 0..5, and the atan table of fold_angle(), doubles 8..24)
+  // doubles 0..5, and the atan table of fold_finish(), doubles 8..24)
   const size_t slots = F + 2 * (F + 2);
   if ((rc = ensure_capacity(&c->frame_poses, &c->frame_pose_cap, slots))) return rc;
 

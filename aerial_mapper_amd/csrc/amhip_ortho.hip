@@ -632,7 +632,7 @@ __device__ __forceinline__ void ortho_backward_tile(
   const int j0 = blockIdx.y * kTileJ;
   const bool i_ok = i < p.rows;
   if constexpr (kFast) {
-    // fold_angle()'s table (doubles 8 .. 24 behind the frame table) next to the lanes: a
+    // fold_finish()'s atan table (doubles 8 .. 24 behind the frame table) next to the lanes: a
     // global read in the middle of the write-back's dependent chain costs a cache round trip
     // per cell (the barriers of the frame cull below order it before its first use)
     const double* cam_tab = reinterpret_cast<const double*>(fast_tab + p.num_frames);

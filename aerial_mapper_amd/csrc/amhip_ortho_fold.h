@@ -35,6 +35,7 @@
 #define AMHIP_ORTHO_FOLD_H_
 
 #include <cmath>
+#include <cstring>
 #include <limits>
 
 #if defined(__HIPCC__)
@@ -268,30 +269,43 @@ AMHIP_HD ExactView exact_view_inline(const double* cam, const FramePose& T, doub
 // (their relative error is <= 7e-7 in the worst admissible geometry).
 constexpr double kSineBand = 4e-6;
 
-// ---- small numeric helpers (device: hardware seed + Newton; host: libm) -------
-AMHIP_HD double fold_rcp(double x) {
+// ---- small numeric helpers (device: hardware seed + one refinement step; host: libm) -------
+// tools/ubench/precision.hip on gfx950: v_rcp_f64 / v_rsq_f64 are good to 2^-24.4 / 2^-24.2, ONE
+// refinement step brings the reciprocal to 2.3e-15 and the square root to 4.2e-15 (relative), a
+// second one to 1.1e-16 / 2.3e-16.  fold_finish's error bounds carry slack in the 1e-14 .. 1e-12
+// range (uv_abs, da): one step is enough there.
+AMHIP_HD double fold_rcp1(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  double r = __builtin_amdgcn_rcp(x);
-  r = fma(fma(-x, r, 1.0), r, r);
-  r = fma(fma(-x, r, 1.0), r, r);
-  return r;  // ~1 ulp
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
 #else
   return 1.0 / x;
 #endif
 }
 
-AMHIP_HD double fold_sqrt(double x) {  // x > 0, normal
+AMHIP_HD double fold_sqrt1(double x) {  // x > 0, normal
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
-  double r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  h = fma(h, r, h);
-  r = fma(-h, g, 0.5);
-  g = fma(g, r, g);
-  return g;  // ~1 ulp
+  const double g = x * y, h = 0.5 * y;
+  return fma(g, fma(-h, g, 0.5), g);
 #else
   return std::sqrt(x);
+#endif
+}
+
+AMHIP_HD float fold_rcpf(float x) {  // ~1 ulp (only picks a table entry)
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
+AMHIP_HD double fold_fract(double x) {  // x - floor(x), x >= 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fract(x);
+#else
+  return x - std::floor(x);
 #endif
 }
 
@@ -300,27 +314,6 @@ AMHIP_HD double fold_sqrt(double x) {  // x > 0, normal
 constexpr int kAtanTabSize = 17;
 inline void make_atan_table(double* tab) {
   for (int i = 0; i < kAtanTabSize; ++i) tab[i] = std::atan((double)i / 8.0);
-}
-
-// pi/2 - atan(r) for r in [1e-3, 2], absolute error < 1e-15 (table + 6 terms
-// on |y| <= 1/16: truncation y^13 / 13 < 2e-17).  false: r out of range.
-AMHIP_HD bool fold_angle(const double* atan_tab, double r_in, double* alpha) {
-  // (no early exit: the four cells of a lane are finished side by side, and a branch per cell
-  // would keep their dependent chains from overlapping; out of range = arithmetic on 1.0)
-  const bool in_range = r_in >= 1e-3 && r_in <= 2.0;
-  const double r = in_range ? r_in : 1.0;
-  const double fi = rint(r * 8.0);
-  const double c = fi * 0.125;
-  const double y = (r - c) * fold_rcp(fma(r, c, 1.0));
-  const double y2 = y * y;
-  double q = fma(y2, -1.0 / 11.0, 1.0 / 9.0);
-  q = fma(y2, q, -1.0 / 7.0);
-  q = fma(y2, q, 1.0 / 5.0);
-  q = fma(y2, q, -1.0 / 3.0);
-  const double at = fma(y * y2, q, y);
-  const double theta = atan_tab[(int)fi] + at;
-  *alpha = (1.5707963267948966 - theta) + 6.123233995736766e-17;
-  return in_range;
 }
 
 // Fold state of one cell.
@@ -425,37 +418,72 @@ enum { kFoldNone = 0, kFoldDone = 1, kFoldFinish = 2, kFoldRedo = 3 };
 AMHIP_HD int fold_finish(const CellFold* s, const FoldCam& k, const double* atan_tab,
                          double epsL, int width, int height, int* kp_x, int* kp_y,
                          float* angle) {
-  // Written without early exits (see fold_angle): a cell that is to be replayed or that no
-  // view was accepted for runs the arithmetic on the point (1, 0, 1) and drops the result.
+  // Written without early exits: the four cells of a lane are finished side by side, and a
+  // branch per cell would keep their dependent chains from overlapping; a cell that is to be
+  // replayed or that no view was accepted for runs the arithmetic on the point (1, 0, 1) and
+  // drops the result.
   const bool live = !s->redo && s->accepted != 0;
   const double bx = live ? s->bx : 1.0, by = live ? s->by : 0.0, bz = live ? s->bz : 1.0;
-  const double rcz = fold_rcp(bz);
+  // tan(theta) = rho / z, theta = angle between the optical axis and the ray; the stored angle is
+  // pi/2 - atan(tan theta) with atan from the table of atan(i / 8) plus a 6-term series in
+  //   y = (r - c) / (1 + r c) = (rho - c z) / (z + rho c),   c = i / 8 nearest to r,
+  // so that ONE reciprocal, of z (z + rho c), serves the series AND the keypoint's 1 / z.
+  // (rho = 0, a view exactly along the axis: NaN from here on, `in_range` false.)
+  const double rho = fold_sqrt1(fma(bx, bx, by * by));
+  // which table entry: single precision is plenty (|y| <= 1/16 + 1e-6 either way)
+  const float rf = (float)rho * fold_rcpf((float)bz);
+  const bool in_range = rf >= 1.001e-3f && rf <= 1.999f;
+  const float fi = in_range ? rintf(rf * 8.0f) : 8.0f;
+  const double c = (double)(fi * 0.125f);
+  const double num = fma(-c, bz, rho);
+  const double den = fma(c, rho, bz);
+  const double rc = fold_rcp1(bz * den);
+  const double rcz = den * rc;  // 1 / z to within 2.6e-15 (relative)
+  const double y = num * (bz * rc);
   const double kx = bx * rcz;
   const double ky = by * rcz;
   const double u = fma(k.fu, kx, k.cu);
   const double v = fma(k.fv, ky, k.cv);
   const double eps = fma(0x1p-49, fabs(bx) + fabs(by) + fabs(bz), epsL);
   const double ez = eps * rcz;  // the direction of the ray is known to within this
+  // (uv_abs = 128 u (|fu| + ... + W + H) also covers the 24 u |fu kx| of the one-step reciprocal)
   const double duv = fma(k.kround * ez, 1.0 + fabs(kx) + fabs(ky), k.uv_abs);
-  // std::round of a non-negative number = floor(x + 1/2) away from the ties
+  // std::round of a non-negative number = floor(x + 1/2) away from the ties; a winner is inside
+  // the image box, so x + 1/2 > 0 and the conversion's truncation is the floor
   const double tu = u + 0.5, tv = v + 0.5;
-  const double fu_ = floor(tu), fv_ = floor(tv);
-  const double ru = tu - fu_, rv = tv - fv_;
-  bool ok = (ru > duv) & (ru < 1.0 - duv) & (rv > duv) & (rv < 1.0 - duv);
-  const int kx_i = (int)fu_, ky_i = (int)fv_;
+  const double ru = fold_fract(tu), rv = fold_fract(tv);
+  const double hi = 1.0 - duv;
+  bool ok = in_range & (ru > duv) & (ru < hi) & (rv > duv) & (rv < hi);
+  const int kx_i = (int)tu, ky_i = (int)tv;
   *kp_y = ky_i < height - 1 ? ky_i : height - 1;
   *kp_x = kx_i < width - 1 ? kx_i : width - 1;
-  const double r = fold_sqrt(fma(kx, kx, ky * ky));
-  double alpha = 0.0;
-  ok = ok & fold_angle(atan_tab, r, &alpha);
-  // (2u / tan(theta) <= 2^-49 / r; r >= 1e-3 in fold_angle's range)
+  // atan(r) - atan(c) = atan(y): truncation y^13 / 13 < 2e-17; what the one-step square root and
+  // reciprocal leave in y is < 3e-15 (absolute), the table entry is correctly rounded
+  const double y2 = y * y;
+  double q = fma(y2, -1.0 / 11.0, 1.0 / 9.0);
+  q = fma(y2, q, -1.0 / 7.0);
+  q = fma(y2, q, 1.0 / 5.0);
+  q = fma(y2, q, -1.0 / 3.0);
+  const double theta = atan_tab[(int)fi] + fma(y * y2, q, y);
+  const double alpha = (1.5707963267948966 - theta) + 6.123233995736766e-17;
+  // |alpha - alpha_ref| <= 2 eps / z (direction of the ray) + 2u / tan(theta) (the rounding of
+  // |z| / ||p|| under the reference's asin: <= 2^-49 / r, r >= 1e-3) + 2e-12 (everything else,
+  // the 5e-15 of this routine's own arithmetic included)
   const double da = 2.0 * ez + 2e-12;
   const float fl = (float)alpha;
   const double e = alpha - (double)fl;
-  // alpha in [0.46, 1.57]: float spacing 2^-23 (>= 1), 2^-24 ([0.5, 1)), 2^-25
-  const double half = fl >= 1.0f ? 0x1p-24 : (fl >= 0.5f ? 0x1p-25 : 0x1p-26);
-  // (just below a power of two the spacing halves: stay clear of those floats)
-  ok = ok & (fabs(e) < half - da) & (fl != 1.0f) & (fl != 0.5f) & (fl > 0.26f);
+  // half the spacing of the floats around fl: 2^(exponent - 24), straight from fl's bits
+  // (alpha in [0.46, 1.57]: 2^-24 in [1, 2), 2^-25 in [0.5, 1), 2^-26 below)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned flb = __float_as_uint(fl);
+  const double half = __hiloint2double((int)(((flb >> 23) + 872u) << 20), 0);
+#else
+  unsigned flb;
+  std::memcpy(&flb, &fl, 4);
+  const double half = std::ldexp(1.0, (int)(flb >> 23) - 127 - 24);
+#endif
+  // (a float with an all-zero mantissa sits where the spacing halves below it: stay clear)
+  ok = ok & (fabs(e) < half - da) & ((flb & 0x7FFFFFu) != 0u) & (fl > 0.26f);
   *angle = fl;
   return s->redo ? kFoldRedo : (s->accepted == 0 ? kFoldNone : (ok ? kFoldDone : kFoldFinish));
 }

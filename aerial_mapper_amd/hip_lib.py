@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "lib", "libaerial_mapper_hip.so")
+# (AMHIP_LIB_PATH: another build of the same library -- A-B timing of two builds on one box,
+# tools/gpu_ab.sh; never a different implementation)
+LIB_PATH = os.environ.get("AMHIP_LIB_PATH") or os.path.join(PKG, "lib", "libaerial_mapper_hip.so")
 
 ABI_VERSION = 1
 
