@@ -20,7 +20,7 @@ SHIM_PATH = os.path.join(LIB_DIR, "libaerial_mapper_shim.so")
 RESOURCES_PATH = os.path.join(LIB_DIR, "kernel_resources.txt")
 
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
-               "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip"]
+               "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip"]
 HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box

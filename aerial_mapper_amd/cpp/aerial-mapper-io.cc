@@ -122,4 +122,71 @@ void AerialMapperIO::subtractOriginFromPoses(const Eigen::Vector3d& origin, Pose
   }
 }
 
+// aerial-mapper-io.cc:349-431: one byte band; the geotransform is the constant the reference
+// hard-codes (`xy` is not used there either), UTM 32 north on WGS 84.
+void AerialMapperIO::toGeoTiff(const cv::Mat& orthomosaic, const Eigen::Vector2d& /*xy*/,
+                               const std::string& geotiff_filename) {
+  if (orthomosaic.empty() || orthomosaic.channels() != 1)
+    amhip_shim::fatal("toGeoTiff", "an 8UC1 image is expected (orthomosaic.at<uchar>)");
+  const double gt[6] = {464499.00, 1.0, 0.0, 5.2727e+06, 0.0, -1.0};
+  amhip_shim::check_status(
+      amhip_geotiff_write_u8(geotiff_filename.c_str(), orthomosaic.data, orthomosaic.cols,
+                             orthomosaic.rows, orthomosaic.step, 1, gt, 32, 1),
+      "toGeoTiff");
+}
+
+// aerial-mapper-io.cc:433-509: three byte bands, band 1 / 2 / 3 = channel 2 / 0 / 1 of the
+// cv::Vec3b pixel (the reference's "TODO: Fix color bands"), unit pixels anchored at xy.
+void AerialMapperIO::writeDataToDEMGeoTiffColor(const cv::Mat& ortho_image,
+                                                const Eigen::Vector2d& xy,
+                                                const std::string& geotiff_filename) {
+  if (ortho_image.empty() || ortho_image.channels() != 3)
+    amhip_shim::fatal("writeDataToDEMGeoTiffColor", "an 8UC3 image is expected (at<cv::Vec3b>)");
+  const int w = ortho_image.cols, h = ortho_image.rows;
+  std::vector<uint8_t> bands(static_cast<size_t>(w) * h * 3);
+  for (int y = 0; y < h; ++y) {
+    const uint8_t* src = ortho_image.data + static_cast<size_t>(y) * ortho_image.step;
+    uint8_t* dst = bands.data() + static_cast<size_t>(y) * w * 3;
+    for (int x = 0; x < w; ++x) {
+      dst[3 * x + 0] = src[3 * x + 2];
+      dst[3 * x + 1] = src[3 * x + 0];
+      dst[3 * x + 2] = src[3 * x + 1];
+    }
+  }
+  const double gt[6] = {xy(0), 1.0, 0.0, xy(1), 0.0, -1.0};
+  amhip_shim::check_status(
+      amhip_geotiff_write_u8(geotiff_filename.c_str(), bands.data(), w, h,
+                             static_cast<size_t>(w) * 3, 3, gt, 32, 1),
+      "writeDataToDEMGeoTiffColor");
+}
+
+void AerialMapperIO::savePointCloudToBinaryFile(
+    const std::string& filename,
+    const AlignedType<std::vector, Eigen::Vector3d>::type& point_cloud_xyz,
+    const std::vector<int>& point_cloud_intensities) {
+  static_assert(sizeof(Eigen::Vector3d) == 3 * sizeof(double), "Vector3d must be 3 packed doubles");
+  if (!point_cloud_intensities.empty() && point_cloud_intensities.size() != point_cloud_xyz.size())
+    amhip_shim::fatal("savePointCloudToBinaryFile", "CHECK(xyz.size() == intensities.size())");
+  amhip_shim::check_status(
+      amhip_io_write_point_cloud_binary(
+          filename.c_str(), reinterpret_cast<const double*>(point_cloud_xyz.data()),
+          point_cloud_intensities.empty()
+              ? nullptr
+              : reinterpret_cast<const int32_t*>(point_cloud_intensities.data()),
+          point_cloud_xyz.size()),
+      "savePointCloudToBinaryFile");
+}
+
+void AerialMapperIO::loadPointCloudFromBinaryFileToDevice(const std::string& filename,
+                                                          double** dev_xyz,
+                                                          int32_t** dev_intensities,
+                                                          size_t* num_points) {
+  amhip_shim::check_status(
+      amhip_io_load_point_cloud_binary(device_index(), filename.c_str(), dev_xyz, dev_intensities,
+                                       num_points),
+      "loadPointCloudFromBinaryFileToDevice");
+  if (*num_points == 0)
+    amhip_shim::fatal("loadPointCloudFromBinaryFileToDevice", "CHECK(point_cloud_xyz->size() > 0)");
+}
+
 }  // namespace io

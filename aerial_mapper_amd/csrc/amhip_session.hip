@@ -601,4 +601,94 @@ int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xy
   });
 }
 
+// ---- what leaves the map (formats: amhip_export.hip) ---------------
+
+// grid_map_msgs/GridMap in ROS 1 wire format (AerialGridMap::publishOnce,
+// aerial-mapper-grid-map.cc:66-72: setTimestamp + GridMapRosConverter::toMessage + publish):
+// the resident layers travel from the devices STRAIGHT into the message buffer -- no host matrix
+// in between.  layer_ids[l] = the amhip layer behind message layer l, or -1: then host_layers[l]
+// (a rows x cols column-major matrix) is copied, or, if that is null, the layer is NaN (the three
+// layers of AerialGridMap the path never touches).
+int amhip_session_grid_map_msg(amhip_session* h, uint64_t stamp_ns, const char* frame_id,
+                               int num_layers, const char* const* layer_names,
+                               const int32_t* layer_ids, const float* const* host_layers,
+                               uint8_t* out, size_t cap, size_t* written) {
+  if (!h || !frame_id || num_layers < 1 || num_layers > 64 || !layer_names || !layer_ids || !out)
+    return arg_failure("amhip_session_grid_map_msg: bad argument");
+  Session& s = h->impl;
+  for (int l = 0; l < num_layers; ++l)
+    if (layer_ids[l] >= AMHIP_NUM_LAYERS) return arg_failure("amhip_session_grid_map_msg: bad layer id");
+  std::vector<size_t> at(num_layers);
+  int rc = amhip_grid_map_msg_layout(&s.grid, stamp_ns, frame_id, num_layers, layer_names, out, cap,
+                                     at.data());
+  if (rc) return rc;
+  const size_t cells = (size_t)s.grid.rows * (size_t)s.grid.cols;
+  for (int l = 0; l < num_layers; ++l) {
+    if (layer_ids[l] >= 0) continue;
+    float* dst = reinterpret_cast<float*>(out + at[l]);  // (unaligned: bytes only)
+    if (host_layers && host_layers[l]) {
+      std::memcpy(dst, host_layers[l], cells * 4);
+    } else {
+      const float nanv = std::nanf("");
+      unsigned bits;
+      std::memcpy(&bits, &nanv, 4);
+      uint8_t* p = out + at[l];
+      for (size_t k = 0; k < cells; ++k) std::memcpy(p + 4 * k, &bits, 4);
+    }
+  }
+  rc = for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    const Win& w = s.win[k];
+    for (int l = 0; l < num_layers; ++l) {
+      const int id = layer_ids[l];
+      if (id < 0) continue;
+      if ((r = ctx_materialize(c, id))) return r;
+      uint8_t* dst = out + at[l] + 4 * ((size_t)w.i0 + (size_t)w.j0 * (size_t)s.grid.rows);
+      AMHIP_TRY(hipMemcpy2DAsync(dst, (size_t)s.grid.rows * 4, c->layers[id], (size_t)w.rows * 4,
+                                 (size_t)w.rows * 4, (size_t)w.cols, hipMemcpyDeviceToHost,
+                                 c->stream));
+    }
+    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    return AMHIP_OK;
+  });
+  if (rc) return rc;
+  if (written) *written = amhip_grid_map_msg_bytes(&s.grid, frame_id, num_layers, layer_names);
+  return AMHIP_OK;
+}
+
+// The whole map's layer as an image (grid_map_cv's toImage orientation: image row = index 0):
+// every window is turned on its own device (k_layer_to_image) and lands in its block of the
+// host image.
+int amhip_session_layer_to_image(amhip_session* h, int layer, int bgr, float lower, float upper,
+                                 uint8_t* host_image, size_t step) {
+  if (!h || !host_image || layer < 0 || layer >= AMHIP_NUM_LAYERS)
+    return arg_failure("amhip_session_layer_to_image: bad argument");
+  Session& s = h->impl;
+  const size_t bpp = bgr ? 3u : 1u;
+  if (step < (size_t)s.grid.cols * bpp)
+    return arg_failure("amhip_session_layer_to_image: step smaller than an image row");
+  if (!bgr && !(upper > lower)) return arg_failure("amhip_session_layer_to_image: upper <= lower");
+  return for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    const Win& w = s.win[k];
+    const size_t row = (size_t)w.cols * bpp;
+    uint8_t* dev = nullptr;
+    AMHIP_TRY(hipMalloc(reinterpret_cast<void**>(&dev), row * (size_t)w.rows));
+    r = amhip_layer_to_image_dev(s.ctx[k], layer, bgr, lower, upper, dev, row);
+    if (r == AMHIP_OK) {
+      hipError_t e = hipMemcpy2DAsync(host_image + (size_t)w.i0 * step + (size_t)w.j0 * bpp, step,
+                                      dev, row, row, (size_t)w.rows, hipMemcpyDeviceToHost,
+                                      c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      if (e != hipSuccess) r = hip_fail(e, "image download", __FILE__, __LINE__);
+    }
+    (void)hipFree(dev);
+    return r;
+  });
+}
+
 }  // extern "C"

@@ -56,6 +56,9 @@ EXPORTS = [
     "amhip_session_dsm_process", "amhip_session_ortho_backward_process",
     "amhip_session_ortho_from_pcl_process",
     "amhip_io_parse_point_cloud_text", "amhip_io_download_point_cloud", "amhip_io_free",
+    "amhip_layer_to_image_dev", "amhip_layer_to_image", "amhip_geotiff_write_u8",
+    "amhip_grid_map_msg_bytes", "amhip_grid_map_msg_layout", "amhip_io_write_point_cloud_binary",
+    "amhip_io_load_point_cloud_binary", "amhip_session_grid_map_msg", "amhip_session_layer_to_image",
 ]
 
 
@@ -195,6 +198,26 @@ def load():
                                                     C.POINTER(C.c_size_t)]
     lib.amhip_io_download_point_cloud.argtypes = [vp, vp, C.c_size_t, vp, vp]
     lib.amhip_io_free.argtypes = [vp]
+    u8p = C.POINTER(C.c_uint8)
+    lib.amhip_layer_to_image_dev.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_size_t]
+    lib.amhip_layer_to_image.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_size_t]
+    lib.amhip_geotiff_write_u8.argtypes = [C.c_char_p, vp, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                           f64p, C.c_int, C.c_int]
+    lib.amhip_grid_map_msg_bytes.restype = C.c_size_t
+    lib.amhip_grid_map_msg_bytes.argtypes = [gp, C.c_char_p, C.c_int, C.POINTER(C.c_char_p)]
+    lib.amhip_grid_map_msg_layout.argtypes = [gp, C.c_uint64, C.c_char_p, C.c_int,
+                                              C.POINTER(C.c_char_p), vp, C.c_size_t,
+                                              C.POINTER(C.c_size_t)]
+    lib.amhip_io_write_point_cloud_binary.argtypes = [C.c_char_p, vp, vp, C.c_size_t]
+    lib.amhip_io_load_point_cloud_binary.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp),
+                                                     C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.amhip_session_grid_map_msg.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_int,
+                                               C.POINTER(C.c_char_p), C.POINTER(C.c_int32),
+                                               C.POINTER(vp), vp, C.c_size_t,
+                                               C.POINTER(C.c_size_t)]
+    lib.amhip_session_layer_to_image.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, vp,
+                                                 C.c_size_t]
+    del u8p
     missing = [name for name in EXPORTS if not hasattr(lib, name)]
     if missing:
         raise ImportError("libaerial_mapper_hip.so lacks %s (stale build?)" % missing)

@@ -41,15 +41,16 @@ class DeviceCloud(object):
 
     @property
     def intensities(self):
-        return self._view(self._inten_ptr, (self.n,), "<i4") if self.n else None
+        return self._view(self._inten_ptr, (self.n,), "<i4") if self.n and self._inten_ptr else None
 
     def to_host(self):
         xyz = np.empty((self.n, 3), np.float64)
-        inten = np.empty(self.n, np.int32)
+        inten = np.empty(self.n, np.int32) if (self._inten_ptr or not self.n) else None
         if self.n:
             L.check(L.load().amhip_io_download_point_cloud(
                 C.c_void_p(self._xyz_ptr), C.c_void_p(self._inten_ptr), self.n,
-                C.c_void_p(xyz.ctypes.data), C.c_void_p(inten.ctypes.data)))
+                C.c_void_p(xyz.ctypes.data),
+                C.c_void_p(inten.ctypes.data) if inten is not None else None))
         return xyz, inten
 
     def close(self):

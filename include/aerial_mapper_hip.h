@@ -410,6 +410,56 @@ int amhip_io_download_point_cloud(const double* dev_xyz, const int32_t* dev_inte
                                   size_t n, double* host_xyz, int32_t* host_intensities);
 int amhip_io_free(void* dev_ptr);
 
+/* ---- what leaves the map: images, GeoTiff, grid_map_msgs, binary clouds
+ *      (the formats either side of the path) ------------------
+ * grid_map_cv, grid_map_ros, GDAL and roscpp are not part of the reference tree; the adopted
+ * definitions are restated in oracle/amo_export.py (parity unpinned). */
+
+/* A layer as an 8-bit image in grid_map_cv::GridMapCvConverter::toImage's orientation (image row
+ * = grid index 0, image column = grid index 1; aerial-mapper-grid-map.cc:10 includes it).
+ * bgr == 0: toImage<unsigned char, 1>(map, layer, CV_8UC1, lower, upper, image): the layer clamped
+ * to [lower, upper], finite cells -> (uchar)(((v - lower) / (upper - lower)) * 255.0f), others 0.
+ * bgr != 0: the layer holds grid_map's packed colours (colored_ortho: the float's bits are
+ * R << 16 | G << 8 | B, ortho-backward-grid.cc:203-207): an 8UC3 image in OpenCV's B, G, R order,
+ * NaN -> 0, 0, 0 (lower / upper unused).  step = bytes per image row.  A transposition through
+ * LDS on the device; the _dev form leaves the image in HBM. */
+int amhip_layer_to_image_dev(amhip_ctx* ctx, int layer, int bgr, float lower, float upper,
+                             uint8_t* dev_image, size_t step);
+int amhip_layer_to_image(amhip_ctx* ctx, int layer, int bgr, float lower, float upper,
+                         uint8_t* host_image, size_t step);
+
+/* The GeoTiff container io::AerialMapperIO::toGeoTiff / writeDataToDEMGeoTiffColor produce with
+ * GDAL (aerial_mapper_io/src/aerial-mapper-io.cc:349-509), without GDAL: classic little-endian
+ * TIFF, 8 bits per sample, bands = 1 (BlackIsZero) or 3 (pixel interleaved, as GDAL's GTiff
+ * driver lays out Create(.., 3, GDT_Byte, NULL)), uncompressed strips, ModelPixelScale /
+ * ModelTiepoint from the north-up geotransform {x0, dx, 0, y0, 0, -dy}, GeoKeys of
+ * "WGS 84 / UTM zone <utm_zone><N|S>" with the reference's citation.  pixels = height rows of
+ * `step` bytes.  Host code only (no device is touched). */
+int amhip_geotiff_write_u8(const char* filename, const uint8_t* pixels, int width, int height,
+                           size_t step, int bands, const double* geotransform, int utm_zone,
+                           int northern);
+
+/* grid_map_msgs/GridMap in ROS 1 wire format, as GridMapRosConverter::toMessage fills it for
+ * AerialGridMap::publishOnce / publishUntilShutdown (aerial-mapper-grid-map.cc:51-72).
+ * _bytes: size of the message; _layout: writes everything except the layers' float payloads and
+ * reports where each payload (rows * cols floats, column-major) belongs.  Host code only. */
+size_t amhip_grid_map_msg_bytes(const amhip_grid_desc* grid, const char* frame_id, int num_layers,
+                                const char* const* layer_names);
+int amhip_grid_map_msg_layout(const amhip_grid_desc* grid, uint64_t stamp_ns, const char* frame_id,
+                              int num_layers, const char* const* layer_names, uint8_t* out,
+                              size_t cap, size_t* payload_offsets);
+
+/* A binary point-cloud file ("AMPCLD01", n, flags, n x 3 float64, n x int32 intensities: what
+ * loadPointCloudFromFile, aerial-mapper-io.cc:309-347, leaves in its vectors).  The loader
+ * stages the file through two pinned buffers (read() of one chunk overlaps the link transfer of
+ * the previous one) and leaves the cloud in HBM in the layout of amhip_dsm_process_dev /
+ * amhip_ortho_from_pcl_process_dev; release with amhip_io_free().  *dev_intensities = NULL for a
+ * file without intensities. */
+int amhip_io_write_point_cloud_binary(const char* filename, const double* host_xyz,
+                                      const int32_t* host_intensities, size_t n);
+int amhip_io_load_point_cloud_binary(int device, const char* filename, double** dev_xyz,
+                                     int32_t** dev_intensities, size_t* num_points);
+
 /* ---- measurement ----------------------------------------------------------*/
 
 /* Kernel slots for amhip_ctx_kernel_time(). */
@@ -495,6 +545,18 @@ const char* amhip_kernel_name(int kernel);
  * filter, number of bins, bin edge in cells. */
 int amhip_ctx_dsm_stats(amhip_ctx* ctx, int64_t* points_binned,
                         int64_t* num_bins, int32_t* bin_cells);
+
+/* The session's map as a grid_map_msgs/GridMap message (ROS 1 wire format): the resident layers
+ * travel from the devices straight into `out`.  layer_ids[l] = the amhip layer behind message
+ * layer l, or -1: host_layers[l] (rows x cols floats, column-major) is copied, NaN-filled when
+ * null.  cap >= amhip_grid_map_msg_bytes(..); *written = the message size. */
+int amhip_session_grid_map_msg(amhip_session* s, uint64_t stamp_ns, const char* frame_id,
+                               int num_layers, const char* const* layer_names,
+                               const int32_t* layer_ids, const float* const* host_layers,
+                               uint8_t* out, size_t cap, size_t* written);
+/* amhip_layer_to_image for the whole map of a session (every window on its own device). */
+int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float lower, float upper,
+                                 uint8_t* host_image, size_t step);
 
 #ifdef __cplusplus
 }
