@@ -39,9 +39,11 @@ namespace amhip {
 
 constexpr int kTileI = 64;
 constexpr int kTileJ = 64;   // a workgroup's tile ...
-constexpr int kSlabJ = 16;   // ... is folded in slabs of this many cell columns
+// ... is folded in slabs of kSlab cell columns (template parameter of the kernels): 16 = four
+// cells per lane for the kernel that folds every pair in the reference's arithmetic, 8 = two for
+// the margin-guarded one (it then fits 128 VGPRs = 4 waves per SIMD almost without spills:
+// 1.36 -> 1.27 ms; with four cells per lane the 128-VGPR build spills 26 registers: 1.69 ms)
 constexpr int kOrthoThreads = 256;
-constexpr int kCellsPerLane = kSlabJ / (kOrthoThreads / 64);  // 4 per slab
 constexpr int kChunk = 1024;  // frames culled per pass
 
 // V3, cross3, transform_point, exact_view_inline, fold_init / fold_pair / fold_finish: amhip_ortho_fold.h
@@ -338,7 +340,7 @@ __device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* 
              accepted, read_pixel(p, frames, frame, kp_x, kp_y));
 }
 
-// One slab (64 x kSlabJ cells, kCellsPerLane per lane) of the block's tile: fold
+// One slab (64 x kSlab cells, kSlab / 4 per lane) of the block's tile: fold
 // the tile's frame list into the slab's cells and write them back.
 //
 // kFast: the margin-guarded fold of amhip_ortho_fold.h (undistorted pinhole,
@@ -348,7 +350,7 @@ __device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* 
 //
 // single: the whole frame list fits one cull chunk and is already in s_cand
 // (ncand0 entries); otherwise the chunks are culled here, per slab.
-template <bool kFast>
+template <bool kFast, int kSlab>
 __device__ __forceinline__ void ortho_slab(
     const OrthoParams& p, const FramePose* __restrict__ poses,
     const FrameFast* __restrict__ fast_tab, const uint8_t* __restrict__ frames,
@@ -357,6 +359,7 @@ __device__ __forceinline__ void ortho_slab(
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err, int* s_cand, int* s_wave_cnt,
     double* s_best, const double* s_atan, const V3& centre, double radius, double slack, int i,
     bool i_ok, int js, bool single, int ncand0) {
+  constexpr int kCellsPerLane = kSlab / (kOrthoThreads / 64);
   const int wid = threadIdx.x >> 6;
   const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
   float elev[kCellsPerLane];
@@ -613,11 +616,11 @@ __device__ __forceinline__ void ortho_slab(
   }
 }
 
-// One workgroup owns a tile of 64 x kTileJ cells = kTileJ / kSlabJ slabs.  The
+// One workgroup owns a tile of 64 x kTileJ cells = kTileJ / kSlab slabs.  The
 // frame list is built ONCE per tile (elevation range -> bounding sphere -> cull
 // + dominance pruning, one thread per frame: that is 250 transforms, a sqrt and
 // two divisions per tile, as much work as folding a slab) and every slab folds it.
-template <bool kFast>
+template <bool kFast, int kSlab>
 __device__ __forceinline__ void ortho_backward_tile(
     const OrthoParams& p, const FramePose* __restrict__ poses,
     const FrameFast* __restrict__ fast_tab, const uint8_t* __restrict__ frames,
@@ -723,14 +726,14 @@ __device__ __forceinline__ void ortho_backward_tile(
                                  s_cand, s_wave_cnt, s_best);
   const bool single = ncand0 >= 0;
   if (!single) ncand0 = 0;
-  if constexpr (kTileJ == kSlabJ) {
-    ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
+  if constexpr (kTileJ == kSlab) {
+    ortho_slab<kFast, kSlab>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
                       num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
                       ucentre, uradius, uslack, i, i_ok, j0, single, ncand0);
   } else {
 #pragma unroll 1
-    for (int js = j0; js <= j_hi; js += kSlabJ)
-      ortho_slab<kFast>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
+    for (int js = j0; js <= j_hi; js += kSlab)
+      ortho_slab<kFast, kSlab>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
                         num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
                         ucentre, uradius, uslack, i, i_ok, js, single, ncand0);
   }
@@ -742,30 +745,31 @@ __device__ __forceinline__ void ortho_backward_tile(
       float *__restrict__ elevation_angle, float *__restrict__ observation_index,            \
       float *__restrict__ num_observations, float *__restrict__ out_layer,                   \
       unsigned *__restrict__ dev_err, const unsigned long long *__restrict__ zrange
-#define AMHIP_ORTHO_KERNEL_BODY(FAST)                                                        \
+#define AMHIP_ORTHO_KERNEL_BODY(FAST, SLAB)                                                      \
   __shared__ float s_red[2 * (kOrthoThreads / 64)];                                          \
   __shared__ int s_cand[kChunk];                                                             \
   __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
   __shared__ double s_best[kOrthoThreads / 64];                                              \
   __shared__ double s_atan[kAtanTabSize];                                                    \
-  ortho_backward_tile<FAST>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
+  ortho_backward_tile<FAST, SLAB>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
                             observation_index, num_observations, out_layer, dev_err, zrange, \
                             s_red, s_cand, s_wave_cnt, s_best, s_atan);
 
 // every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
 k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
-  AMHIP_ORTHO_KERNEL_BODY(false)
+  AMHIP_ORTHO_KERNEL_BODY(false, 16)
 }
-// margin-guarded fold, registers as they come (3 waves per SIMD)
+// margin-guarded fold, four cells per lane, registers as they come (3 waves per SIMD):
+// AMHIP_ORTHO_FAST_WAVES=3 (A-B knob)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
 k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
-  AMHIP_ORTHO_KERNEL_BODY(true)
+  AMHIP_ORTHO_KERNEL_BODY(true, 16)
 }
-// the same held to 128 VGPRs (4 waves per SIMD); AMHIP_ORTHO_FAST_WAVES picks
+// margin-guarded fold, two cells per lane, held to 128 VGPRs (4 waves per SIMD): the default
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_ortho_backward_fast4(AMHIP_ORTHO_KERNEL_ARGS) {
-  AMHIP_ORTHO_KERNEL_BODY(true)
+  AMHIP_ORTHO_KERNEL_BODY(true, 8)
 }
 
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
@@ -776,7 +780,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
   const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 8
-  const int fast_waves = fw ? std::atoi(fw) : 3;
+  const int fast_waves = fw ? std::atoi(fw) : 4;
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
   hipLaunchKernelGGL(kernel, grid, dim3(kOrthoThreads), 0, c->stream,

@@ -42,6 +42,7 @@ BUDGETS = [
     ("k_dsm_p3_scatterILb1E", 8, 0),
     ("14k_dsm_p3_placeE", 4, 0),
     ("21k_ortho_backward_fastE", 3, 0),
+    ("22k_ortho_backward_fast4E", 4, 12),                 # the default mosaic kernel (two cells per lane)
 ]
 
 
