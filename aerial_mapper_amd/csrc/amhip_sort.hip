@@ -290,8 +290,14 @@ k_dsm_stripe_sort(const double* __restrict__ tmp, DsmParams p,
 // Sub-partitions are ordered (bin row, column block), so the result is the
 // same row-major-by-bin order the gather kernels expect.
 constexpr int kP3CountThreads = 1024;
-constexpr int kP3Threads = 512;
-constexpr int kP3Chunk = 2560;  // points staged per scatter workgroup (70 KB of LDS: 2 per CU)
+#ifndef AMHIP_P3_THREADS
+#define AMHIP_P3_THREADS 512
+#endif
+#ifndef AMHIP_P3_PER
+#define AMHIP_P3_PER 5
+#endif
+constexpr int kP3Threads = AMHIP_P3_THREADS;
+constexpr int kP3Chunk = AMHIP_P3_THREADS * AMHIP_P3_PER;  // points staged per scatter workgroup (2560: 70 KB of LDS, 2 per CU)
 constexpr int kP3PerThread = kP3Chunk / kP3Threads;
 constexpr int kP3MaxKeys = 256;
 constexpr int kP3PlaceThreads = 256;
