@@ -256,23 +256,6 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       (unsigned long long)p.nbx * (unsigned long long)p.nby;
   if (nbins + 1 >= 0xFFFFFFFFull) return arg_fail("grid too large for 32-bit bin ids");
 
-  // ---- two-level stripe sort plan (amhip_dsm.hip) -----------------------------
-  p.stripe_rows = 0;
-  p.nstripes = 0;
-  if (p.nbx <= 8192) {
-    int rps = 8192 / p.nbx;          // bins of a stripe must fit the LDS histogram
-    const int want = p.nby / 1024;   // ~1000 stripes keep every CU busy
-    if (want >= 1 && rps > want) rps = want;
-    if (std::getenv("AMHIP_STRIPE_ROWS")) rps = std::atoi(std::getenv("AMHIP_STRIPE_ROWS"));
-    if (rps < 1) rps = 1;
-    if (rps > 8192 / p.nbx && 8192 / p.nbx >= 1) rps = 8192 / p.nbx;
-    const int ns = (p.nby + rps - 1) / rps;
-    if (ns <= 8192) {
-      p.stripe_rows = rps;
-      p.nstripes = ns;
-    }
-  }
-
   // ---- three-pass partition sort plan (amhip_dsm.hip) ---------------------------
   // Worth it once the cloud is large enough that the sort is bandwidth bound;
   // sub-partitions are sized for ~1.5 K points (a pass-3 workgroup sorts up to
@@ -1507,8 +1490,8 @@ int amhip_ctx_kernel_time(amhip_ctx* h, int kernel, double* total_ms,
 const char* amhip_kernel_name(int kernel) {
   switch (kernel) {
     // sort slots: named after the kernels of the default path for large clouds
-    // (three-pass partition sort); the stripe sort / one-level sort fallbacks
-    // report their count / scatter / placement launches in the same slots
+    // (three-pass partition sort); the one-level sort of small clouds reports its
+    // count / scan / scatter launches in the same slots
     case AMHIP_K_DSM_BIN_COUNT:
       return "k_dsm_p3_count";    // + k_dsm_p3_reduce, k_dsm_p3_scan
     case AMHIP_K_DSM_SCATTER:

@@ -49,8 +49,6 @@ struct DsmParams {
   // binning: bins of B x B cells, grid extended by M cells on every side
   double inv_res;
   int B, M, nbx, nby;
-  // two-level stripe sort: a stripe = stripe_rows consecutive bin rows (0 = off)
-  int stripe_rows, nstripes;
   // radius ladder (squared radii, exactly the doubles dsm.cc:127-144 uses)
   int nlevels;
   double T[kMaxLevels];

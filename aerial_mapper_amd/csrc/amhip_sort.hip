@@ -4,13 +4,13 @@
 // instead of a kd-tree the points are sorted into a uniform grid of bins of
 // B x B cells (B = first search radius in cells), bins row-major, with
 // bin_start[] = exclusive offsets; dsm.cc:42-43's centre offsets are applied on
-// the way.  Three implementations produce the same order:
-//   k_dsm_p3_*      three-pass partition sort (default for >= 1 M points):
+// the way.  Two implementations produce the same order:
+//   k_dsm_p3_*      three-pass partition sort (>= 1 M points):
 //                   count -> two LDS-staged scatter passes -> in-LDS placement
-//   k_dsm_stripe_*  two-level stripe sort (smaller clouds)
 //   k_dsm_bin_count / k_scan_* / k_dsm_scatter
-//                   one-level counting sort with global atomics (very wide
-//                   grids; fallback)
+//                   one-level counting sort with global atomics (smaller clouds: fewer
+//                   launches; measured equal or faster there than the two-level stripe
+//                   sort that round 1 kept for them -- tools/small_cloud_probe.py)
 // plus k_halo_select, the multi-GPU halo compaction (same streaming shape).
 #include <algorithm>
 #include <cstdlib>
@@ -91,25 +91,7 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
   if (zpart) range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
-// ---------------------------------------------------------------------------
-// two-level stripe sort (clouds below the partition sort's threshold; AMHIP_SORT_TWO_LEVEL=1)
-// ---------------------------------------------------------------------------
-// The one-level counting sort above pays one device-scope atomic and two
-// random 24..64-byte HBM transactions per point.  The stripe sort replaces it:
-//   level 1  points -> STRIPES (a few consecutive bin rows, ~1000 stripes).
-//            Per-workgroup LDS histograms aggregate the global atomics (one
-//            per stripe per 16 K points) and every workgroup appends runs of
-//            consecutive points to each stripe -> near-streaming writes.
-//   level 2  one workgroup per stripe: LDS histogram over the stripe's bins,
-//            LDS scan -> bin_start[] for those bins, then the points are
-//            placed; a stripe is ~1 MB, so the second read and the random
-//            placement stay inside the XCD's L2.
-// Stripes are whole bin rows, so the final order is still row-major by bin.
-// (make_dsm_params keeps to <= 8192 stripes of <= 8192 bins: the LDS histograms' sizes)
-constexpr int kL1Threads = 256;
-constexpr int kL1Chunk = 65536;  // points per workgroup in the level-1 scatter (A/B: 16K..128K)
-constexpr int kL2Threads = 512;
-
+// bin (bx, by) of a (centre-shifted) point: point_bin() without the flattening
 __device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, double py,
                                              int* bx, int* by) {
   const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
@@ -127,154 +109,13 @@ __device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, doub
   return true;
 }
 
-__global__ void __launch_bounds__(kL1Threads)
-k_dsm_stripe_count(const double* __restrict__ xyz, size_t n, DsmParams p,
-                   uint32_t* __restrict__ stripe_cnt) {
-  extern __shared__ uint32_t s_hist[];
-  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_hist[k] = 0;
-  __syncthreads();
-  const size_t stride = (size_t)gridDim.x * kL1Threads;
-  for (size_t idx = (size_t)blockIdx.x * kL1Threads + threadIdx.x; idx < n; idx += stride) {
-    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
-    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
-    int bx, by;
-    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_hist[by / p.stripe_rows], 1u);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
-    const uint32_t c = s_hist[k];
-    if (c) atomicAdd(&stripe_cnt[k], c);
-  }
-}
-
-// One block: stripe_start = exclusive scan of stripe_cnt (+ total), and a copy
-// that the level-1 scatter uses as its append cursors.
-__global__ void __launch_bounds__(1024)
-k_dsm_stripe_scan(const uint32_t* __restrict__ stripe_cnt, int nstripes,
-                  uint32_t* __restrict__ stripe_start, uint32_t* __restrict__ cursor) {
-  __shared__ unsigned lds[1024 / 64 + 1];
-  unsigned carry = 0;
-  for (int base = 0; base < nstripes; base += 1024) {
-    const int i = base + threadIdx.x;
-    const unsigned v = (i < nstripes) ? stripe_cnt[i] : 0u;
-    unsigned total;
-    const unsigned ex = block_excl_scan<1024>(v, &total, lds);
-    if (i < nstripes) {
-      stripe_start[i] = carry + ex;
-      cursor[i] = carry + ex;
-    }
-    carry += total;
-  }
-  if (threadIdx.x == 0) stripe_start[nstripes] = carry;
-}
-
-__global__ void __launch_bounds__(kL1Threads)
-k_dsm_stripe_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values,
-                     size_t n, size_t chunk, DsmParams p, uint32_t* __restrict__ cursor,
-                     double* __restrict__ tmp, double* __restrict__ zpart) {
-  extern __shared__ uint32_t s_mem[];
-  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
-  uint32_t* s_cnt = s_mem;                // points of this chunk per stripe / local rank
-  uint32_t* s_base = s_mem + p.nstripes;  // where this chunk's run of a stripe starts
-  const size_t c0 = (size_t)blockIdx.x * chunk;
-  const size_t c1 = min(c0 + chunk, n);
-  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) s_cnt[k] = 0;
-  __syncthreads();
-  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {
-    const double px = xyz[3 * idx + 0] - p.sub_x;
-    const double py = xyz[3 * idx + 1] - p.sub_y;
-    int bx, by;
-    if (point_bin_xy(p, px, py, &bx, &by)) atomicAdd(&s_cnt[by / p.stripe_rows], 1u);
-  }
-  __syncthreads();
-  for (int k = threadIdx.x; k < p.nstripes; k += kL1Threads) {
-    const uint32_t c = s_cnt[k];
-    s_base[k] = c ? atomicAdd(&cursor[k], c) : 0u;
-    s_cnt[k] = 0;
-  }
-  __syncthreads();
-  for (size_t idx = c0 + threadIdx.x; idx < c1; idx += kL1Threads) {  // (L2 hits)
-    const double px = xyz[3 * idx + 0] - p.sub_x;
-    const double py = xyz[3 * idx + 1] - p.sub_y;
-    int bx, by;
-    if (point_bin_xy(p, px, py, &bx, &by)) {
-      const int st = by / p.stripe_rows;
-      const size_t slot = (size_t)s_base[st] + atomicAdd(&s_cnt[st], 1u);
-      const double z = values ? (double)values[idx] : xyz[3 * idx + 2];
-      tmp[3 * slot + 0] = px;
-      tmp[3 * slot + 1] = py;
-      tmp[3 * slot + 2] = z;
-      zlo = fmin(zlo, z);
-      zhi = fmax(zhi, z);
-    }
-  }
-  if (zpart)
-    range_commit_wave(zlo, zhi, zpart,
-                      (size_t)blockIdx.x * (kL1Threads / 64) + (threadIdx.x >> 6));
-}
-
-__global__ void __launch_bounds__(kL2Threads)
-k_dsm_stripe_sort(const double* __restrict__ tmp, DsmParams p,
-                  const uint32_t* __restrict__ stripe_start,
-                  uint32_t* __restrict__ bin_start, double* __restrict__ sorted) {
-  extern __shared__ uint32_t s_bins[];  // bins of this stripe (+ scan scratch behind)
-  const int st = blockIdx.x;
-  const int row0 = st * p.stripe_rows;
-  const int nrow = min(p.stripe_rows, p.nby - row0);
-  const int nb = nrow * p.nbx;
-  uint32_t* s_scan = s_bins + nb;
-  const uint32_t g0 = stripe_start[st];
-  const uint32_t g1 = stripe_start[st + 1];
-  for (int k = threadIdx.x; k < nb; k += kL2Threads) s_bins[k] = 0;
-  __syncthreads();
-  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {
-    const double px = tmp[3 * (size_t)idx + 0];
-    const double py = tmp[3 * (size_t)idx + 1];
-    int bx, by;
-    point_bin_xy(p, px, py, &bx, &by);  // same arithmetic as level 1: always inside
-    atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
-  }
-  __syncthreads();
-  {
-    const int per = (nb + kL2Threads - 1) / kL2Threads;
-    const int lo = threadIdx.x * per;
-    const int hi = min(lo + per, nb);
-    unsigned sum = 0;
-    for (int k = lo; k < hi; ++k) sum += s_bins[k];
-    unsigned total;
-    unsigned run = block_excl_scan<kL2Threads>(sum, &total, s_scan);
-    for (int k = lo; k < hi; ++k) {
-      const unsigned t = s_bins[k];
-      s_bins[k] = run;
-      run += t;
-    }
-  }
-  __syncthreads();
-  uint32_t* out_start = bin_start + (size_t)row0 * p.nbx;
-  for (int k = threadIdx.x; k < nb; k += kL2Threads) out_start[k] = g0 + s_bins[k];
-  if (st == p.nstripes - 1 && threadIdx.x == 0)
-    bin_start[(size_t)p.nbx * p.nby] = stripe_start[p.nstripes];
-  __syncthreads();
-  for (uint32_t idx = g0 + threadIdx.x; idx < g1; idx += kL2Threads) {  // (L2 hits)
-    const double px = tmp[3 * (size_t)idx + 0];
-    const double py = tmp[3 * (size_t)idx + 1];
-    const double pz = tmp[3 * (size_t)idx + 2];
-    int bx, by;
-    point_bin_xy(p, px, py, &bx, &by);
-    const size_t slot = (size_t)g0 + atomicAdd(&s_bins[(by - row0) * p.nbx + bx], 1u);
-    sorted[3 * slot + 0] = px;
-    sorted[3 * slot + 1] = py;
-    sorted[3 * slot + 2] = pz;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // three-pass partition sort (the default for clouds that are worth it)
 // ---------------------------------------------------------------------------
-// The stripe sort above appends 24-byte records to ~1000 open runs per
-// workgroup straight from registers; the partially written cache lines do not
-// survive in the L2 until their neighbours arrive, and the PMC counters show
-// 2-3x the algorithmic write traffic.  Here every pass sorts its chunk in LDS
+// (Round 1's two-level stripe sort appended 24-byte records to ~1000 open runs per
+// workgroup straight from registers; the partially written cache lines did not
+// survive in the L2 until their neighbours arrived, and the PMC counters showed
+// 2-3x the algorithmic write traffic.)  Here every pass sorts its chunk in LDS
 // first and then writes each run with consecutive lanes on consecutive
 // addresses, so whole lines leave the CU at once; the price is a third pass
 // (partition counts per pass are limited by run length = chunk / partitions):
@@ -935,8 +776,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   c->last_bin_cells = p.B;
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
-  static const bool force_two_level = getenv("AMHIP_SORT_TWO_LEVEL") != nullptr;
-  const bool three_pass = p.p3_n1 > 0 && !force_one_level && !force_two_level;
+  const bool three_pass = p.p3_n1 > 0 && !force_one_level;
   if (split && split->phase == 1 && !three_pass)  // small clouds: selection in a pass of its own
     return halo_select_run(c, dev_xyz, split->n_prefix, split->hp, split->halo_out,
                            split->halo_counts);
@@ -1031,51 +871,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          c->tmp_points, p, start2, c->bin_start, c->sorted, big_list);
       AMHIP_TRY(hipGetLastError());
     }
-  } else if (p.nstripes > 0 && !force_one_level) {
-    // ---- two-level stripe sort ------------------------------------------------
-    int rc;
-    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
-    if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, 3 * (size_t)p.nstripes + 8)))
-      return rc;
-    uint32_t* stripe_cnt = c->stripe_ws;
-    uint32_t* stripe_start = c->stripe_ws + p.nstripes;          // nstripes + 1
-    uint32_t* stripe_cursor = c->stripe_ws + 2 * p.nstripes + 1;  // nstripes
-    {
-      ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
-      AMHIP_TRY(hipMemsetAsync(stripe_cnt, 0, p.nstripes * sizeof(uint32_t), c->stream));
-      size_t grid = (n + kL1Threads - 1) / kL1Threads;
-      if (grid > 256 * 8) grid = 256 * 8;
-      hipLaunchKernelGGL(k_dsm_stripe_count, dim3((unsigned)grid), dim3(kL1Threads),
-                         p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, n, p, stripe_cnt);
-      hipLaunchKernelGGL(k_dsm_stripe_scan, dim3(1), dim3(1024), 0, c->stream, stripe_cnt,
-                         p.nstripes, stripe_start, stripe_cursor);
-      AMHIP_TRY(hipGetLastError());
-    }
-    {
-      ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
-      // 64 K points per workgroup for big clouds (long runs per stripe); small
-      // clouds (incremental mapping) are cut finer so that the chip is still filled
-      size_t chunk = (n / 1024 + 255) & ~size_t(255);
-      if (chunk < 2048) chunk = 2048;
-      if (chunk > (size_t)kL1Chunk) chunk = kL1Chunk;
-      const size_t grid = (n + chunk - 1) / chunk;
-      hipLaunchKernelGGL(k_dsm_stripe_scatter, dim3((unsigned)grid), dim3(kL1Threads),
-                         2 * p.nstripes * sizeof(uint32_t), c->stream, dev_xyz, dev_values, n,
-                         chunk, p, stripe_cursor, c->tmp_points, zpart);
-      if (zpart)
-        hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
-                           (size_t)grid * (kL1Threads / 64), zrange);
-      AMHIP_TRY(hipGetLastError());
-    }
-    {
-      ScopedTimer t(c, AMHIP_K_DSM_SCAN);
-      const size_t lds = ((size_t)p.stripe_rows * p.nbx + 32) * sizeof(uint32_t);
-      hipLaunchKernelGGL(k_dsm_stripe_sort, dim3((unsigned)p.nstripes), dim3(kL2Threads), lds,
-                         c->stream, c->tmp_points, p, stripe_start, c->bin_start, c->sorted);
-      AMHIP_TRY(hipGetLastError());
-    }
   } else {
-    // ---- one-level counting sort (fallback: very wide grids, or forced) --------
+    // ---- one-level counting sort (clouds below the partition sort's threshold) --------
     {
       int rc;
       if ((rc = ensure_capacity(&c->rank, &c->rank_cap, n))) return rc;

@@ -409,14 +409,13 @@ def test_dsm_dense_clouds_take_the_wave_per_cell_path(dens):
 
 @pytest.mark.parametrize("knobs", [
     {"AMHIP_SORT_ONE_LEVEL": "1"},
-    {"AMHIP_SORT_TWO_LEVEL": "1"},
     {"AMHIP_P3_MIN_POINTS": "0"},
     {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "48"},
-], ids=["one-level", "two-level", "three-pass", "three-pass-many-blocks"])
+], ids=["one-level", "three-pass", "three-pass-many-blocks"])
 def test_dsm_every_sort_path_matches(knobs):
-    # The binning sort has three implementations (one-level counting sort for
-    # very wide grids, two-level stripe sort, three-pass partition sort for
-    # large clouds); each is forced through its environment knob in a child
+    # The binning sort has two implementations (one-level counting sort for
+    # clouds below 2^20 points, three-pass partition sort for large clouds; round 1's
+    # two-level stripe sort is gone); each is forced through its environment knob in a child
     # process, on a uniform cloud, a clustered one (over-full LDS partitions)
     # and the intensity variant (OrthoFromPcl).
     import os

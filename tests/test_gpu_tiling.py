@@ -183,7 +183,7 @@ def test_route_points_cuda_path_two_ranks_one_gpu():
                                                 (150000, 768.0, 64.0, (8, 1))])   # a node's 8 GPUs
 def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
     """tiling.TiledDsm (amhip_dsm_tiled_begin_dev / _finish_dev): small clouds take a selection
-    pass of their own (two-level sort), the large one the three-pass sort whose count kernel
+    pass of their own (one-level sort), the large one the three-pass sort whose count kernel
     selects on the way; NaN padding rows are dropped; every window equals the full-map DSM."""
     import threading
     import torch
