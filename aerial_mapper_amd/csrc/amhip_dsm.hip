@@ -922,9 +922,9 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   emit_value(p, o, i, j, num / den);
 }
 
-// kVar: 0 = the product kernel; 1..3 = TIMING PROBES / A-B variants selected with
+// kVar: 0 = the product kernel; 1, 2, 5, 6 = TIMING PROBES selected with
 // AMHIP_F32_VARIANT (1: candidate loop without the hit updates, 2: no candidate loop -- both
-// give wrong heights; 3: the next record is read one iteration ahead)
+// give wrong heights; 5 / 6: leave after the staging / after the loads)
 template <int NT, int kTileJ, int kCap, int kVar = 0>
 __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32_t* __restrict__ start,
                                                 const double* __restrict__ sorted,
@@ -1249,24 +1249,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
                 [pad] "v"(rec.w), [one] "v"(one_cell), [thi] "v"(thi), [thiB] "v"(thiB)
               : "vcc");
         };
-        if (kVar == 3) {
-          uint4 nxt = *pr;  // (s_rec[ke] exists: the array has cap + 2 entries)
-          for (; pr < pe;) {
-            const uint4 rec = nxt;
-            ++pr;
-            nxt = *pr;
-            cand(rec);
-          }
-        } else if (kVar == 4) {
-          for (; pr + 1 < pe; pr += 2) {
-            const uint4 r0 = pr[0], r1 = pr[1];
-            cand(r0);
-            cand(r1);
-          }
-          if (pr < pe) cand(*pr);
-        } else {
-          for (; pr < pe; ++pr) cand(*pr);
-        }
+        for (; pr < pe; ++pr) cand(*pr);
         if (kVar == 2) dA = dB = 1.f;
         NA += nA;
         DA += dA;
@@ -1558,18 +1541,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   do {                                                                                        \
     if ((VAR_) == 1) AMHIP_F32_DENSE_V(1);                                                    \
     else if ((VAR_) == 2) AMHIP_F32_DENSE_V(2);                                               \
-    else if ((VAR_) == 4) AMHIP_F32_DENSE_V(4);                                               \
     else if ((VAR_) == 5) AMHIP_F32_DENSE_V(5);                                               \
-    else if ((VAR_) == 6) AMHIP_F32_DENSE_V(6);                                               \
-    else if ((VAR_) == 7) { /* 256-thread workgroups: 8 per CU, two cell pairs per lane */      \
-      AMHIP_TRY(hipFuncSetAttribute(                                                          \
-          reinterpret_cast<const void*>(k_dsm_gather_f32<256, 16, 1024, 0>),                  \
-          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
-      hipLaunchKernelGGL((k_dsm_gather_f32<256, 16, 1024, 0>), dim3(ntiles), dim3(256),       \
-                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
-                         cell_out, lists + kListHdr + (size_t)4 * ntiles, tile_count + 4);    \
-    }                                                                                         \
-    else AMHIP_F32_DENSE_V(3);                                                                \
+    else AMHIP_F32_DENSE_V(6);                                                                \
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
