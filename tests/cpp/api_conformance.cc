@@ -19,6 +19,8 @@
 #include <aerial-mapper-ortho/ortho-from-pcl.h>
 #elif defined(API_FORWARD)
 #include <aerial-mapper-ortho/ortho-forward-homography.h>
+#elif defined(API_IO)
+#include <aerial-mapper-io/aerial-mapper-io.h>
 #endif
 
 #define FIELD(S, name, T) \
@@ -114,3 +116,37 @@ static_assert(std::is_same<decltype(&ortho::OrthoForwardHomography::batch),
 #endif
 
 int main() { return 0; }
+
+#if defined(API_IO)
+// io::AerialMapperIO: the loaders in front of the path and the writers behind it
+// (aerial-mapper-io.h:32-64; callers main-dsm.cc:84-90, main-ortho-backward-grid.cc:86-101)
+static_assert(std::is_default_constructible<io::AerialMapperIO>::value, "AerialMapperIO()");
+static_assert(std::is_same<decltype(&io::AerialMapperIO::loadPosesFromFileStandard),
+                           void (io::AerialMapperIO::*)(const std::string&, Poses*)>::value,
+              "void loadPosesFromFileStandard(const std::string&, Poses*)");
+static_assert(std::is_same<decltype(static_cast<void (io::AerialMapperIO::*)(
+                               const std::string&, Cloud*, std::vector<int>*)>(
+                               &io::AerialMapperIO::loadPointCloudFromFile)),
+                           void (io::AerialMapperIO::*)(const std::string&, Cloud*,
+                                                        std::vector<int>*)>::value,
+              "void loadPointCloudFromFile(const std::string&, cloud*, std::vector<int>*)");
+static_assert(std::is_same<decltype(static_cast<void (io::AerialMapperIO::*)(
+                               const std::string&, Cloud*)>(
+                               &io::AerialMapperIO::loadPointCloudFromFile)),
+                           void (io::AerialMapperIO::*)(const std::string&, Cloud*)>::value,
+              "void loadPointCloudFromFile(const std::string&, cloud*)");
+static_assert(std::is_same<decltype(&io::AerialMapperIO::subtractOriginFromPoses),
+                           void (io::AerialMapperIO::*)(const Eigen::Vector3d&, Poses*)>::value,
+              "void subtractOriginFromPoses(const Eigen::Vector3d&, Poses*)");
+static_assert(std::is_same<decltype(&io::AerialMapperIO::toGeoTiff),
+                           void (io::AerialMapperIO::*)(const cv::Mat&, const Eigen::Vector2d&,
+                                                        const std::string&)>::value,
+              "void toGeoTiff(const cv::Mat&, const Eigen::Vector2d&, const std::string&)");
+static_assert(std::is_same<decltype(&io::AerialMapperIO::writeDataToDEMGeoTiffColor),
+                           void (io::AerialMapperIO::*)(const cv::Mat&, const Eigen::Vector2d&,
+                                                        const std::string&)>::value,
+              "void writeDataToDEMGeoTiffColor(const cv::Mat&, const Eigen::Vector2d&, "
+              "const std::string&)");
+static_assert(std::is_same<Image, cv::Mat>::value && std::is_same<Images, std::vector<cv::Mat> >::value,
+              "typedef cv::Mat Image; typedef std::vector<Image> Images");
+#endif

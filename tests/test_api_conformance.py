@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 SRC = os.path.join(ROOT, "tests", "cpp", "api_conformance.cc")
-APIS = ["API_DSM", "API_BACKWARD", "API_FROM_PCL", "API_FORWARD"]
+APIS = ["API_DSM", "API_BACKWARD", "API_FROM_PCL", "API_FORWARD", "API_IO"]
 
 
 def _compile(includes, api):
