@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -145,6 +146,21 @@ static inline const float* map_at(const float* base, const Session& s, const Win
   return base + (size_t)w.i0 + (size_t)w.j0 * (size_t)s.grid.rows;
 }
 
+// window block <-> map-shaped host matrix (bytes: the grid_map message's payloads are not
+// aligned).  A window that spans all rows of the map is ONE contiguous range of both: a plain
+// copy instead of a pitched one (the runtime stages pitched copies of pageable memory row by row).
+static hipError_t copy_window(void* dst_host_or_dev, const void* src, const Session& s, const Win& w,
+                              bool to_host, hipStream_t stream) {
+  const size_t col = (size_t)w.rows * 4;
+  if (w.rows == s.grid.rows)
+    return hipMemcpyAsync(dst_host_or_dev, src, col * (size_t)w.cols,
+                          to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice, stream);
+  return to_host ? hipMemcpy2DAsync(dst_host_or_dev, (size_t)s.grid.rows * 4, src, col, col,
+                                    (size_t)w.cols, hipMemcpyDeviceToHost, stream)
+                 : hipMemcpy2DAsync(dst_host_or_dev, col, src, (size_t)s.grid.rows * 4, col,
+                                    (size_t)w.cols, hipMemcpyHostToDevice, stream);
+}
+
 // host matrix -> window layer, as far as needed (asynchronous on the context's stream)
 static int sync_in(Session& s, int k, int layer, const float* host, unsigned long long host_hash) {
   Ctx* c = &s.ctx[k]->impl;
@@ -163,9 +179,7 @@ static int sync_in(Session& s, int k, int layer, const float* host, unsigned lon
   }
   const Win& w = s.win[k];
   ctx_overwrite(c, layer);
-  AMHIP_TRY(hipMemcpy2DAsync(c->layers[layer], (size_t)w.rows * 4, map_at(host, s, w),
-                             (size_t)s.grid.rows * 4, (size_t)w.rows * 4, (size_t)w.cols,
-                             hipMemcpyHostToDevice, c->stream));
+  AMHIP_TRY(copy_window(c->layers[layer], map_at(host, s, w), s, w, false, c->stream));
   st.valid = true;
   st.hash = host_hash;
   return AMHIP_OK;
@@ -204,9 +218,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + l];
     if (!s.always_copy && st.valid && st.hash == h[q]) continue;  // the host already holds it
     if ((rc = ctx_materialize(c, l))) return rc;
-    AMHIP_TRY(hipMemcpy2DAsync(map_at(hosts[q], s, w), (size_t)s.grid.rows * 4, c->layers[l],
-                               (size_t)w.rows * 4, (size_t)w.rows * 4, (size_t)w.cols,
-                               hipMemcpyDeviceToHost, c->stream));
+    AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
     st.valid = !s.always_copy;
     st.hash = h[q];
   }
@@ -623,17 +635,28 @@ int amhip_session_grid_map_msg(amhip_session* h, uint64_t stamp_ns, const char* 
                                      at.data());
   if (rc) return rc;
   const size_t cells = (size_t)s.grid.rows * (size_t)s.grid.cols;
-  for (int l = 0; l < num_layers; ++l) {
-    if (layer_ids[l] >= 0) continue;
-    float* dst = reinterpret_cast<float*>(out + at[l]);  // (unaligned: bytes only)
-    if (host_layers && host_layers[l]) {
-      std::memcpy(dst, host_layers[l], cells * 4);
-    } else {
-      const float nanv = std::nanf("");
-      unsigned bits;
-      std::memcpy(&bits, &nanv, 4);
-      uint8_t* p = out + at[l];
-      for (size_t k = 0; k < cells; ++k) std::memcpy(p + 4 * k, &bits, 4);
+  // the layers without a device copy are filled by host threads WHILE the others travel
+  std::vector<std::thread> fillers;
+  {
+    std::vector<float> nan_block(std::min<size_t>(cells, 1u << 16), std::nanf(""));
+    const size_t nb = nan_block.size();
+    auto fill = [&, nb](int l, size_t k0, size_t k1, const std::vector<float>* block) {
+      uint8_t* p = out + at[l];  // (not aligned: bytes only)
+      if (host_layers && host_layers[l]) {
+        std::memcpy(p + 4 * k0, host_layers[l] + k0, 4 * (k1 - k0));
+      } else {
+        for (size_t k = k0; k < k1; k += nb)
+          std::memcpy(p + 4 * k, block->data(), 4 * std::min(nb, k1 - k));
+      }
+    };
+    const auto shared = std::make_shared<std::vector<float>>(std::move(nan_block));
+    const int parts = cells >= (size_t(1) << 22) ? 4 : 1;
+    for (int l = 0; l < num_layers; ++l) {
+      if (layer_ids[l] >= 0) continue;
+      for (int q = 0; q < parts; ++q) {
+        const size_t k0 = cells * q / parts, k1 = cells * (q + 1) / parts;
+        fillers.emplace_back([=]() { fill(l, k0, k1, shared.get()); });
+      }
     }
   }
   rc = for_windows(s, [&](int k) -> int {
@@ -646,13 +669,12 @@ int amhip_session_grid_map_msg(amhip_session* h, uint64_t stamp_ns, const char* 
       if (id < 0) continue;
       if ((r = ctx_materialize(c, id))) return r;
       uint8_t* dst = out + at[l] + 4 * ((size_t)w.i0 + (size_t)w.j0 * (size_t)s.grid.rows);
-      AMHIP_TRY(hipMemcpy2DAsync(dst, (size_t)s.grid.rows * 4, c->layers[id], (size_t)w.rows * 4,
-                                 (size_t)w.rows * 4, (size_t)w.cols, hipMemcpyDeviceToHost,
-                                 c->stream));
+      AMHIP_TRY(copy_window(dst, c->layers[id], s, w, true, c->stream));
     }
     AMHIP_TRY(hipStreamSynchronize(c->stream));
     return AMHIP_OK;
   });
+  for (auto& t : fillers) t.join();
   if (rc) return rc;
   if (written) *written = amhip_grid_map_msg_bytes(&s.grid, frame_id, num_layers, layer_names);
   return AMHIP_OK;

@@ -86,9 +86,9 @@ def grid_map_msg_layout(grid, stamp_ns, frame_id="world", layers=GRID_MAP_LAYERS
 
 
 def session_grid_map_msg(session, stamp_ns, frame_id="world", layers=GRID_MAP_LAYERS,
-                         host_layers=None):
+                         host_layers=None, out=None):
     """amhip_session_grid_map_msg: the serialized grid_map_msgs/GridMap of a HostSession's map,
-    resident layers straight from the devices."""
+    resident layers straight from the devices.  out: a uint8 buffer to reuse (a publisher's)."""
     lib = L.load()
     names = (C.c_char_p * len(layers))(*[n.encode() for n in layers])
     ids = (C.c_int32 * len(layers))(*[_layer_id(n) for n in layers])
@@ -100,7 +100,8 @@ def session_grid_map_msg(session, stamp_ns, frame_id="world", layers=GRID_MAP_LA
             keep.append(a)
             hosts[k] = a.ctypes.data
     n = lib.amhip_grid_map_msg_bytes(C.byref(session.grid), frame_id.encode(), len(layers), names)
-    buf = np.zeros(n, np.uint8)
+    buf = np.empty(n, np.uint8) if out is None else out[:n]
+    assert buf.dtype == np.uint8 and buf.shape[0] == n and buf.flags.c_contiguous
     written = C.c_size_t()
     L.check(lib.amhip_session_grid_map_msg(session._h, int(stamp_ns), frame_id.encode(),
                                            len(layers), names, ids, hosts,

@@ -54,6 +54,8 @@ class DeviceCloud(object):
         return xyz, inten
 
     def close(self):
+        if L is None or not (getattr(self, "_xyz_ptr", None) or getattr(self, "_inten_ptr", None)):
+            return        # (nothing to free, or the interpreter is shutting down)
         lib = L.load()
         for name in ("_xyz_ptr", "_inten_ptr"):
             p = getattr(self, name, None)
