@@ -585,25 +585,31 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   const int ox = rbx0 * p.B;  // region origin in M-shifted cell coordinates
   const int oy = rby0 * p.B;
 
-  const bool geom_ok = nrb <= kMaxRegionRows && ncell <= p.lds_cells;
-  if (geom_ok && tid < nrb) {
-    const uint32_t* row = start + (size_t)(rby0 + tid) * p.nbx;
-    const uint32_t gs = row[rbx0];
-    s_rowg[tid] = gs;
-    s_rowp[tid + 1] = row[rbx1 + 1] - gs;
+  // (as in gather_tile_f32: the cell table is cleared / scanned / rewritten in whole quads while
+  // wave 0 reads the region's bin rows and prefixes their lengths across its lanes)
+  const bool geom_ok = nrb <= 64 && ncell + 3 <= p.lds_cells;
+  {
+    uint4* q = reinterpret_cast<uint4*>(s_off);
+    const int nq0 = geom_ok ? (ncell + 4) >> 2 : 0;
+    for (int k = tid; k < nq0; k += NT) q[k] = make_uint4(0u, 0u, 0u, 0u);
   }
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    s_rowp[0] = 0;
-    if (geom_ok) {
-      for (int r = 0; r < nrb; ++r) {
-        run += s_rowp[r + 1];
-        s_rowp[r + 1] = run;
-      }
+  if (wid == 0) {
+    uint32_t gs = 0, cnt = 0;
+    if (geom_ok && lane < nrb) {
+      const uint32_t* row = start + (size_t)(rby0 + lane) * p.nbx;
+      gs = row[rbx0];
+      cnt = row[rbx1 + 1] - gs;
     }
-    s_ctl[0] = run;
-    s_ctl[1] = 0;
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    if (lane < nrb && geom_ok) {
+      s_rowg[lane] = gs;
+      s_rowp[lane + 1] = incl;
+    }
+    if (lane == 63) s_ctl[0] = incl;
+    if (lane == 0) {
+      s_rowp[0] = 0;
+      s_ctl[1] = 0;
+    }
   }
   __syncthreads();
   const int np = (int)s_ctl[0];
@@ -620,8 +626,6 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
 
   // ---- stage + cell-bin the region's points in LDS --------------------------
   // pass 1: count per cell (LDS atomics), remember (cell, rank) per point
-  for (int k = tid; k <= ncell; k += NT) s_off[k] = 0;
-  __syncthreads();
   static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
   constexpr int kMaxK = (kCap + NT - 1) / NT;  // p.lds_cap == kCap
   uint32_t pslot[kMaxK];                       // cell << 13 | rank  (rank < kCap <= 8192)
@@ -655,20 +659,35 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   }
   __syncthreads();
   {
-    // exclusive scan of the ncell counters, in place
-    const int per = (ncell + NT - 1) / NT;
-    const int lo = tid * per;
-    const int hi = min(lo + per, ncell);
-    unsigned sum = 0;
-    for (int k = lo; k < hi; ++k) sum += s_off[k];
-    unsigned total;
-    unsigned run = block_excl_scan<NT>(sum, &total, s_scan);
-    for (int k = lo; k < hi; ++k) {
-      const unsigned t = s_off[k];
-      s_off[k] = run;
-      run += t;
+    // exclusive scan of the counters, in place: a thread owns consecutive whole quads, a wave
+    // their prefix (DPP scan), the wave totals meet in LDS
+    const int nq = (ncell + 4) >> 2;
+    const int qper = (nq + NT - 1) / NT;
+    const int q0 = tid * qper, q1 = min(q0 + qper, nq);
+    uint4* const qoff = reinterpret_cast<uint4*>(s_off);
+    unsigned qsum = 0;
+    for (int k = q0; k < q1; ++k) {
+      const uint4 v = qoff[k];
+      qsum += (v.x + v.y) + (v.z + v.w);
     }
-    if (tid == 0) s_off[ncell] = total;
+    const unsigned qincl = wave_incl_scan(qsum, lane);
+    if (lane == 63) s_scan[wid] = qincl;
+    __syncthreads();
+    const int mywave = __builtin_amdgcn_readfirstlane(wid);
+    unsigned run = qincl - qsum;
+#pragma unroll
+    for (int w = 0; w < kWaves - 1; ++w)
+      if (w < mywave) run += s_scan[w];
+    for (int k = q0; k < q1; ++k) {
+      const uint4 v = qoff[k];
+      uint4 e;
+      e.x = run;
+      e.y = run + v.x;
+      e.z = e.y + v.y;
+      e.w = e.z + v.z;
+      run = e.w + v.w;
+      qoff[k] = e;  // (entry ncell, an empty count, receives the total)
+    }
   }
   __syncthreads();
   // pass 2: drop the points into their sorted slot
@@ -1450,7 +1469,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // search window: wide radii / coarse grids leave less room for points; a class
       // that cannot hold more than the one below it stays empty)
       const long fixed_bytes = (long)p.lds_bytes - ((long)cap0 + 2) * 24;
-      auto cap_fit = [&](long limit) { return (int)((limit - fixed_bytes) / 24 - 2); };
+      // (even: the cell table behind the points is read and written in 16-byte quads)
+      auto cap_fit = [&](long limit) { return (int)((limit - fixed_bytes) / 24 - 2) & ~1; };
       const int cap1 = std::max(cap0, std::min(p.tile_j == 16 ? 2752 : 2432, cap_fit(80 * 1024)));
       const int cap2 = std::max(cap1, std::min(p.tile_j == 16 ? 5600 : 5200, cap_fit(150 * 1024)));
       {
