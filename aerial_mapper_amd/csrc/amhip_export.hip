@@ -67,6 +67,24 @@ k_layer_to_image(const float* __restrict__ layer, int rows, int cols, float lowe
     s_tile[jj][lane] = out;
   }
   __syncthreads();
+  if (!kBgr && (step & 3u) == 0 && (reinterpret_cast<size_t>(image) & 3u) == 0) {
+    // gray: a thread packs four neighbouring pixels of an image row into one 4-byte store
+    // (16 threads per row of the tile, 16 rows per sweep)
+    const int g = threadIdx.x & 15, r0 = threadIdx.x >> 4;
+    for (int ii = r0; ii < 64; ii += 16) {
+      const int i = ti + ii, j = tj + 4 * g;
+      if (i >= rows || j >= cols) continue;
+      uint8_t* px = image + (size_t)i * step + j;
+      if (j + 3 < cols) {
+        const uint32_t v = s_tile[4 * g][ii] | (s_tile[4 * g + 1][ii] << 8) |
+                           (s_tile[4 * g + 2][ii] << 16) | (s_tile[4 * g + 3][ii] << 24);
+        *reinterpret_cast<uint32_t*>(px) = v;
+      } else {
+        for (int q = 0; j + q < cols; ++q) px[q] = (uint8_t)s_tile[4 * g + q][ii];
+      }
+    }
+    return;
+  }
   for (int ii = w; ii < 64; ii += 4) {
     const int i = ti + ii, j = tj + lane;
     if (i < rows && j < cols) {
