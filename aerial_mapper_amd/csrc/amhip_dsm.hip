@@ -449,7 +449,7 @@ k_dsm_gather_knn(DsmParams p, const uint32_t* __restrict__ start,
 constexpr int kTileI = 64;
 constexpr int kMaxRegionRows = 96;  // bin rows of a region
 constexpr int kListHdr = 8;         // counters in front of the tile lists
-constexpr int kNumLists = 5;
+constexpr int kNumLists = 7;
 // s_setreg operand: HW_REG_MODE (id 1), offset 6, width 2 = FP_DENORM for f64 / f16
 constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 
@@ -467,6 +467,8 @@ constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 //     list k  class-k tiles (k = 1, 2, 3)
 //     list 4  class-0 tiles the single-precision gather hands to the FP64 kernel
 //             (filled by k_dsm_gather_f32, not here)
+//     list 5  class-1 / class-2 tiles of the single-precision list launches handed to the
+//             FP64 kernel's largest LDS image, list 6: those beyond it (wave-per-block kernel)
 __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
@@ -950,7 +952,10 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
                                                 const uint8_t* __restrict__ tile_occ, const CellOut& o,
                                                 const int tile, unsigned char* smem, int my_class,
                                                 int* __restrict__ exact_list,
-                                                unsigned* __restrict__ exact_count) {
+                                                unsigned* __restrict__ exact_count,
+                                                int* __restrict__ big_list = nullptr,
+                                                unsigned* __restrict__ big_count = nullptr,
+                                                int big_np = 0x7FFFFFFF) {
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
   // [rec: cap+1 uint4 (U, V, dz, -)][cell offsets][rows][scan][ctl][z range][flags]
@@ -1169,7 +1174,12 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   // (a trip of a dense tile brings up to ~20 candidates: below that the FP64 kernel takes
   // the whole tile -- staging it twice is cheaper than redoing most of its cells)
   if (n_allowed < 48) {
-    if (tid == 0) exact_list[atomicAdd(exact_count, 1u)] = tile;
+    // (a tile of a larger capacity class may hold more points than the FP64 kernel's LDS
+    // image takes: those go to the wave-per-block kernel's list)
+    if (tid == 0) {
+      if (np > big_np) big_list[atomicAdd(big_count, 1u)] = tile;
+      else exact_list[atomicAdd(exact_count, 1u)] = tile;
+    }
     return;
   }
   __syncthreads();
@@ -1347,12 +1357,13 @@ k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
                       const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
                       const int* __restrict__ tile_list, const unsigned* __restrict__ tile_count,
                       CellOut o, int* __restrict__ exact_list,
-                      unsigned* __restrict__ exact_count) {
+                      unsigned* __restrict__ exact_count, int* __restrict__ big_list,
+                      unsigned* __restrict__ big_count, int big_np) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned count = *tile_count;
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     gather_tile_f32<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem, -1,
-                                      exact_list, exact_count);
+                                      exact_list, exact_count, big_list, big_count, big_np);
     __syncthreads();
   }
 }
@@ -1482,7 +1493,17 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
       int* const lists = c->tile_list;
       AMHIP_TRY(hipMemsetAsync(tile_count, 0, kListHdr * sizeof(unsigned), c->stream));
-      int ccap0 = cap0, ccap1 = cap1, ccap2 = cap2;  // classification thresholds
+      const bool f32 = p.fx_ok && !p.pcl_mode && !p.only_unfilled && !mask && !unfilled;
+      // Single-precision mode: its records take 16 bytes against the FP64 kernel's 24, so the
+      // same two LDS budgets (two workgroups per CU / one) hold more points: classes 1 and 2
+      // are cut at capf1 / capf2 and walked by list launches of the single-precision kernel
+      // (4096- / 7680-point register instances); what those hand back goes to the FP64
+      // kernel's largest image (list 5) or, beyond it, to the wave-per-block kernel (list 6).
+      const long fixed32 = (long)p.lds_bytes_f32 - ((long)cap0 + 2) * 16;
+      auto cap_fit32 = [&](long limit) { return (int)((limit - fixed32) / 16 - 2) & ~1; };
+      const int capf1 = std::max(cap0, std::min(4096, cap_fit32(80 * 1024)));
+      const int capf2 = std::max(capf1, std::min(7680, cap_fit32(150 * 1024)));
+      int ccap0 = cap0, ccap1 = f32 ? capf1 : cap1, ccap2 = f32 ? capf2 : cap2;  // classification
       if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
         sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
@@ -1532,7 +1553,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
       hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(8192), dim3(512),      \
                          p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
-                         lists + kListHdr, tile_count, cell_out, xl, tile_count + 4);         \
+                         lists + kListHdr, tile_count, cell_out, xl, tile_count + 4,          \
+                         (int*)nullptr, (unsigned*)nullptr, 0x7FFFFFFF);                      \
     } else if (f32_variant && (TJ_) == 16 && (CAP_) == 1024) {                                \
       AMHIP_F32_DENSE(16, 1024, f32_variant);                                                 \
     } else {                                                                                  \
@@ -1545,7 +1567,6 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     }                                                                                         \
     AMHIP_LAUNCH_LIST_EX(512, TJ_, CAP_, cap0, 4, 4096);                                      \
   } while (0)
-      const bool f32 = p.fx_ok && !p.pcl_mode && !p.only_unfilled && !mask && !unfilled;
       static const int f32_variant = getenv("AMHIP_F32_VARIANT") ? atoi(getenv("AMHIP_F32_VARIANT")) : 0;
       // (A-B variants / timing probes of the 64 x 16 / 1024-point instance)
 #define AMHIP_F32_DENSE_V(V_)                                                                 \
@@ -1566,28 +1587,58 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   } while (0)
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
+      // single-precision list launch of class CLS_ (1, 2): image of CAPV_ points, register
+      // instance CAP_; rejected tiles -> list 5 (FP64, image cap2) / list 6 (wave per block)
+#define AMHIP_LAUNCH_F32_CLASS(TJ_, CAP_, CAPV_, CLS_, GRID_)                                 \
+  do {                                                                                        \
+    DsmParams q = p;                                                                          \
+    q.lds_cap = (CAPV_);                                                                      \
+    q.lds_bytes_f32 = (unsigned)((int)p.lds_bytes_f32 + ((CAPV_) - cap0) * 16);               \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),                 \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes_f32));                   \
+    hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(GRID_), dim3(512),       \
+                       q.lds_bytes_f32, c->stream, q, c->bin_start, c->sorted, c->tile_occ,   \
+                       lists + kListHdr + (size_t)(CLS_) * ntiles, tile_count + (CLS_),       \
+                       cell_out, lists + kListHdr + (size_t)5 * ntiles, tile_count + 5,       \
+                       lists + kListHdr + (size_t)6 * ntiles, tile_count + 6, cap2);          \
+  } while (0)
       if (p.tile_j == 16 && cap0 == 1024) {
         if (f32) AMHIP_LAUNCH_F32(16, 1024);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 16, 1024);
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
-        AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
-        AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else if (p.tile_j == 16) {
         if (f32) AMHIP_LAUNCH_F32(16, 2048);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
         else AMHIP_LAUNCH_DENSE(512, 16, 2048);
-        AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
-        AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
       } else {
         if (f32) AMHIP_LAUNCH_F32(32, 2048);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
         else if (nt == 1024) AMHIP_LAUNCH_DENSE(1024, 32, 2048);
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
-        AMHIP_LAUNCH_LIST(512, 32, 2432, 1, 2048);
-        AMHIP_LAUNCH_LIST(512, 32, 5200, 2, 1024);
       }
+      if (p.tile_j == 16) {
+        if (f32) {
+          AMHIP_LAUNCH_F32_CLASS(16, 4096, capf1, 1, 2048);
+          AMHIP_LAUNCH_F32_CLASS(16, 7680, capf2, 2, 1024);
+          AMHIP_LAUNCH_LIST_EX(512, 16, 5600, cap2, 5, 1024);
+        } else {
+          AMHIP_LAUNCH_LIST(512, 16, 2752, 1, 2048);
+          AMHIP_LAUNCH_LIST(512, 16, 5600, 2, 1024);
+        }
+      } else {
+        if (f32) {
+          AMHIP_LAUNCH_F32_CLASS(32, 4096, capf1, 1, 2048);
+          AMHIP_LAUNCH_F32_CLASS(32, 7680, capf2, 2, 1024);
+          AMHIP_LAUNCH_LIST_EX(512, 32, 5200, cap2, 5, 1024);
+        } else {
+          AMHIP_LAUNCH_LIST(512, 32, 2432, 1, 2048);
+          AMHIP_LAUNCH_LIST(512, 32, 5200, 2, 1024);
+        }
+      }
+#undef AMHIP_LAUNCH_F32_CLASS
 #undef AMHIP_LAUNCH_DENSE
 #undef AMHIP_LAUNCH_LIST
 #undef AMHIP_LAUNCH_LIST_EX
@@ -1597,6 +1648,10 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
                          c->bin_start, c->sorted, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
                          cell_out);
+      if (f32)
+        hipLaunchKernelGGL(k_dsm_gather_dense, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
+                           c->bin_start, c->sorted, lists + kListHdr + (size_t)6 * ntiles,
+                           tile_count + 6, cell_out);
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       if (p.knn_k > 0)
