@@ -1403,6 +1403,135 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
   }
 }
 
+// block_wave() in single precision under the guards of gather_tile_f32: the
+// candidate's position becomes 32-bit fixed point relative to the block's first cell (units of
+// 2^-(fx_S - 1) cells: one bit coarser than the tile kernel's, because the differences formed
+// here reach w0 + 4.5 cells and must stay clear of the 32-bit wrap), its height an f32 offset
+// from the first candidate's; per (cell, candidate): exact integer difference -> f32 -> d2, the
+// reciprocal weight, sums per lane, one butterfly per block.  Cells with an ambiguous hit (d2
+// within 2e-6 of the radius), a point nearer than theta, no neighbour at all or non-finite sums
+// take cell_global() (the reference's doubles); a block whose height spread leaves no room for
+// its additions under the 1e-4 m budget is redone by block_wave() as a whole.
+__device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_t* __restrict__ start,
+                                               const double* __restrict__ sorted, int bi0, int bi1,
+                                               int bj0, int bj1, const CellOut& o) {
+  const int lane = threadIdx.x & 63;
+  const int w = p.w[0];
+  const int S = p.fx_S - 1;
+  const double scale = (double)(1u << S);
+  const float thi = p.fx_thi * 0.25f, tlo = p.fx_tlo * 0.25f;  // (squared scale: one bit -> 1/4)
+  const float denmax = p.fx_denmax * 4.0f;
+  const int bx0 = (bi0 - w + p.M) / p.B, bx1 = (bi1 + w + p.M) / p.B;
+  const int by0 = (bj0 - w + p.M) / p.B, by1 = (bj1 + w + p.M) / p.B;
+  // reference height: the first candidate's (wave-uniform)
+  double z0 = 0.0;
+  unsigned ncand = 0;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    if (e0 > s0 && ncand == 0) z0 = sorted[3 * (size_t)s0 + 2];
+    ncand += e0 - s0;
+  }
+  float num[16], den[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0f;
+  unsigned amb = 0;      // bit c: cell c has a hit inside the band around the radius
+  float zspread = 0.0f;  // max |z - z0| over the lane's candidates
+  // block origin in the continuous cell coordinates of point_bin(): cell bi0 / bj0
+  const double ox = (double)(bi0 + p.i_off), oy = (double)(bj0 + p.j_off);
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    for (uint32_t k = s0 + lane; k < e0; k += 64) {
+      const double px = sorted[3 * (size_t)k + 0];
+      const double py = sorted[3 * (size_t)k + 1];
+      const float zf = (float)(sorted[3 * (size_t)k + 2] - z0);
+      zspread = fmaxf(zspread, fabsf(zf));
+      // (cell coordinate of the point, as in point_bin(), relative to the block's first cell)
+      const double rx = (p.base_x - px) * p.inv_res - ox;
+      const double ry = (p.base_y - py) * p.inv_res - oy;
+      const uint32_t U = (uint32_t)(int)rint(rx * scale);
+      const uint32_t V = (uint32_t)(int)rint(ry * scale);
+      float dx2[4], dy2[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        // (cells beyond the block repeat nothing: they are computed and never written)
+        const float dx = (float)(int)(((uint32_t)a << S) - U);
+        const float dy = (float)(int)(((uint32_t)a << S) - V);
+        dx2[a] = dx * dx;
+        dy2[a] = dy * dy;
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const float d2 = dx2[c & 3] + dy2[c >> 2];
+        const bool hit = d2 < thi;
+        const float r = hit ? __builtin_amdgcn_rcpf(d2) : 0.0f;
+        den[c] += r;
+        num[c] = fmaf(r, zf, num[c]);
+        amb |= (hit & (d2 >= tlo)) ? (1u << c) : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    amb |= __shfl_xor(amb, d, 64);
+    zspread = fmaxf(zspread, __shfl_xor(zspread, d, 64));
+  }
+  // ---- the block's error budget (as in gather_tile_f32): additions per accumulator = the lane's
+  // candidates + the six levels of the butterfly
+  {
+    const float zabs = fabsf((float)z0) + zspread;
+    const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+    const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
+    const float S_half = zspread * 1.000001f + zabs * 1.2e-7f;
+    const float epsw = 2.0f * (p.fx_epsw - 4e-7f) + 4e-7f;  // (one bit coarser positions)
+    const float n_add = (float)((ncand + 63u) / 64u + 8u);
+    const bool ok = (S_half <= 3.0e38f) &&
+                    (S_half == 0.0f || 2.0f * (epsw + (n_add + 2.0f) * 5.9604645e-8f) * S_half <= allowed);
+    if (!ok) {  // (wave-uniform)
+      block_wave(p, start, sorted, bi0, bi1, bj0, bj1, o);
+      return;
+    }
+  }
+  // butterfly with halving (see block_wave): lane l ends with value l >> 1
+  float v[32];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    v[c] = num[c];
+    v[16 + c] = den[c];
+  }
+#pragma unroll
+  for (int half = 16, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+    const bool up = (lane & bit) != 0;
+#pragma unroll
+    for (int k = 0; k < half; ++k) {
+      const float send = up ? v[k] : v[k + half];
+      const float keep = up ? v[k + half] : v[k];
+      v[k] = keep + __shfl_xor(send, bit, 64);
+    }
+  }
+  v[0] += __shfl_xor(v[0], 1, 64);
+  const float my_num = v[0];
+  const float my_den = __shfl(v[0], (lane & 31) | 32, 64);
+  const int cidx = (lane & 31) >> 1;
+  const int a = cidx & 3, bq = cidx >> 2;
+  const bool owner = lane < 32 && !(lane & 1) && bi0 + a <= bi1 && bj0 + bq <= bj1;
+  // an ambiguous hit, a point nearer than theta (the weight sum says so; rcp(0) = inf), no
+  // neighbour (the ladder) or non-finite sums: the reference's doubles decide -- a whole wave
+  // per such cell (cell_wave_exact), not one lane over hundreds of candidates
+  const bool redo = owner && (((amb >> cidx) & 1u) || !(my_den > 0.0f) || !(my_den < denmax) ||
+                              !(my_num == my_num));
+  if (owner && !redo)
+    emit_value(p, o, bi0 + a, bj0 + bq, z0 + (double)(my_num * __builtin_amdgcn_rcpf(my_den)));
+  unsigned long long todo = __ballot(redo);
+  while (todo) {  // (wave-uniform)
+    const int l = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int cc = (l & 31) >> 1;
+    cell_wave_exact(p, start, sorted, bi0 + (cc & 3), bj0 + (cc >> 2), o);
+  }
+}
+
 // Class-3 tiles (more points than any LDS image holds): a fixed grid walks their
 // list; the four waves of a workgroup share a tile's blocks of 4 x 4 cells
 // (block_wave).  No LDS, its own register budget.
@@ -1412,7 +1541,7 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AMHIP_DENSE_WAVES)))
 k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                    const double* __restrict__ sorted, const int* __restrict__ tile_list,
-                   const unsigned* __restrict__ tile_count, CellOut o) {
+                   const unsigned* __restrict__ tile_count, CellOut o, int f32) {
   const unsigned count = *tile_count;
   const int wid = threadIdx.x >> 6;
   for (unsigned t = blockIdx.x; t < count; t += gridDim.x) {
@@ -1433,7 +1562,8 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
             const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + p.B - 1), i_hi);
             const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + p.B - 1), j_hi);
             if (a0 > a1 || b0 > b1) continue;
-            block_wave(p, start, sorted, a0, a1, b0, b1, o);
+            if (f32) block_wave_f32(p, start, sorted, a0, a1, b0, b1, o);
+            else block_wave(p, start, sorted, a0, a1, b0, b1, o);
           }
     (void)nbi;
     (void)nbj;
@@ -1647,11 +1777,12 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 #undef AMHIP_F32_DENSE_V
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
                          c->bin_start, c->sorted, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
-                         cell_out);
+                         cell_out, f32 ? 1 : 0);
+      // (list 6: tiles the single-precision list launches handed back for their height spread)
       if (f32)
         hipLaunchKernelGGL(k_dsm_gather_dense, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
                            c->bin_start, c->sorted, lists + kListHdr + (size_t)6 * ntiles,
-                           tile_count + 6, cell_out);
+                           tile_count + 6, cell_out, 0);
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       if (p.knn_k > 0)

@@ -144,3 +144,56 @@ def test_utm_magnitudes_and_non_dyadic_resolutions(res, radius):
     want = _oracle(sc, radius)
     _check(_run(sc, False, radius), want)
     _check(_run(sc, True, radius), want)
+
+
+# ---- the denser capacity classes (list launches of the single-precision kernel) and the
+# ---- wave-per-block kernel in single precision (block_wave_f32) ------------------------------
+def _dense_scene(pts_per_cell, seed, lx=60.0, ly=48.0, res=0.25):
+    n = int(pts_per_cell * (lx / res + 24) * (ly / res + 24))
+    return S.Scene(lx, ly, res, n, seed=seed)
+
+
+@pytest.mark.parametrize("ppc", [2.0, 5.0, 12.0, 24.0])
+def test_dense_clouds_in_single_precision(ppc):
+    # 2 / 5 points per cell: classes 1 / 2 (f32 list launches); 12 / 24: the wave-per-block kernel
+    sc = _dense_scene(ppc, 311)
+    want = _oracle(sc)
+    frac, err = _check(_run(sc, False), want)
+    assert frac < 1.0 or err == 0.0          # (single precision did run: not all floats identical)
+    _check(_run(sc, True), want)
+
+
+@pytest.mark.parametrize("ppc", [5.0, 12.0])
+def test_dense_clouds_with_rough_heights_fall_back_to_fp64(ppc):
+    # +-30 m of noise: the class launches hand every tile back (lists 5 / 6), the wave-per-block
+    # kernel redoes every block with block_wave()
+    sc = _dense_scene(ppc, 312)
+    rng = np.random.default_rng(7)
+    sc.points[:, 2] += rng.uniform(-30.0, 30.0, sc.points.shape[0])
+    want = _oracle(sc)
+    frac, _ = _check(_run(sc, False), want)
+    assert frac > 0.999
+
+
+@pytest.mark.parametrize("ppc", [5.0, 12.0])
+def test_dense_clouds_guards_near_centres_and_near_the_radius(ppc):
+    # points 1e-9 .. 1e-2 m from cell centres with heights metres off, points at the search
+    # radius (1 +- 1e-15 .. 3e-6) from centres: the cells concerned take the FP64 routines
+    sc = _dense_scene(ppc, 313)
+    g = sc.grid
+    rng = np.random.default_rng(8)
+    extra = []
+    for k in range(400):
+        i, j = int(rng.integers(8, g.rows - 8)), int(rng.integers(8, g.cols - 8))
+        cx, cy = O.cell_position(g, i, j)
+        if k % 2 == 0:
+            d = 10.0 ** rng.uniform(-9, -2)
+            a = rng.uniform(0, 2 * np.pi)
+            extra.append((cx + d * np.cos(a), cy + d * np.sin(a), 400.0 + rng.uniform(-5, 5)))
+        else:
+            r = 1.0 * (1.0 + rng.choice([-1, 1]) * 10.0 ** rng.uniform(-15, -5.5))
+            a = rng.uniform(0, 2 * np.pi)
+            extra.append((cx + r * np.cos(a), cy + r * np.sin(a), 400.0 + rng.uniform(-5, 5)))
+    sc.points = np.concatenate([sc.points, np.asarray(extra)], 0)
+    want = _oracle(sc)
+    _check(_run(sc, False), want)
