@@ -308,15 +308,21 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       const double e = rho * (double)(bi * B) * (double)(bj * B);
       return e + 5.0 * std::sqrt(e);
     };
+    // (single-precision mode: 16-byte records, so 4096 points still leave two workgroups per
+    // CU -- clouds of ~1.2 .. 2.2 points per cell keep the one-workgroup-per-tile launch)
+    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_knn;
     if (need(16) <= 1024.0) {
       kTileJ = 16;
       cap = 1024;
     } else if (need(32) <= 2048.0) {
       kTileJ = 32;
       cap = 2048;
-    } else {
+    } else if (need(16) <= 2048.0 || !want_f32 || need(16) > 7680.0) {
       kTileJ = 16;
       cap = 2048;
+    } else {
+      kTileJ = 16;
+      cap = need(16) <= 4096.0 ? 4096 : 7680;  // (7680: one workgroup per CU)
     }
     if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
       kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
@@ -356,7 +362,9 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     const size_t bytes = ((size_t)p.lds_cap + 2) * 24 + ((size_t)p.lds_cells + 1) * 4 +
                          (96 + 97 + 24 + 4 + 4 * kMaxW0 + 4) * 4 + (size_t)kTileI * kTileJ * 2 + 64;
     p.lds_bytes = static_cast<unsigned>((bytes + 15) & ~size_t(15));
-    if (p.lds_bytes > 150 * 1024) p.lds_ok = 0;
+    // (a 4096- / 7680-point main launch exists in single precision only; the FP64 kernels then
+    // run on lists with images of their own size, amhip_dsm.hip: dsm_run)
+    if (p.lds_bytes > 150 * 1024 && cap <= 2048) p.lds_ok = 0;
   }
   // ---- single-precision gather with exact guards (amhip_dsm.hip: k_dsm_gather_f32) ----
   // Only for dsm::Dsm (heights): OrthoFromPcl interpolates 8-bit intensities whose spread

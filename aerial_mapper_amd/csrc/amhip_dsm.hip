@@ -1351,6 +1351,24 @@ k_dsm_gather_f32(DsmParams p, const uint32_t* __restrict__ start,
                                           exact_count);
 }
 
+// The same without the 64-register ceiling: instances whose threads keep more than two staged
+// points each (4096-point images: two workgroups per CU anyway).
+template <int NT, int kTileJ, int kCap>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_f32_wide(DsmParams p, const uint32_t* __restrict__ start,
+                      const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                      CellOut o, int* __restrict__ exact_list, unsigned* __restrict__ exact_count,
+                      int* __restrict__ big_list, unsigned* __restrict__ big_count, int big_np) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntiles = p.tiles_i * p.tiles_j;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, k = b >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  gather_tile_f32<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, 0, exact_list,
+                                    exact_count, big_list, big_count, big_np);
+}
+
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
@@ -1612,7 +1630,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const long fixed_bytes = (long)p.lds_bytes - ((long)cap0 + 2) * 24;
       // (even: the cell table behind the points is read and written in 16-byte quads)
       auto cap_fit = [&](long limit) { return (int)((limit - fixed_bytes) / 24 - 2) & ~1; };
-      const int cap1 = std::max(cap0, std::min(p.tile_j == 16 ? 2752 : 2432, cap_fit(80 * 1024)));
+      // (cap0 > 2048: a single-precision main launch -- the FP64 images keep their own sizes)
+      const int cap0_64 = std::min(cap0, 2048);
+      const int cap1 = std::max(cap0_64, std::min(p.tile_j == 16 ? 2752 : 2432, cap_fit(80 * 1024)));
       const int cap2 = std::max(cap1, std::min(p.tile_j == 16 ? 5600 : 5200, cap_fit(150 * 1024)));
       {
         int rc;
@@ -1697,6 +1717,33 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     }                                                                                         \
     AMHIP_LAUNCH_LIST_EX(512, TJ_, CAP_, cap0, 4, 4096);                                      \
   } while (0)
+      // (rejected tiles: the FP64 kernel with an image of cap0 points while that fits a CU --
+      // list 4 --, else its largest image -- list 5 -- or the wave-per-block kernel -- list 6)
+#define AMHIP_LAUNCH_F32_WIDE(TJ_, CAP_)                                                      \
+  do {                                                                                        \
+    const bool own = ((long)cap0 + 2) * 24 + fixed_bytes <= 150 * 1024;                       \
+    int* const xl = lists + kListHdr + (size_t)(own ? 4 : 5) * ntiles;                        \
+    unsigned* const xc = tile_count + (own ? 4 : 5);                                          \
+    int* const bl = lists + kListHdr + (size_t)6 * ntiles;                                    \
+    const int bnp = own ? 0x7FFFFFFF : cap2;                                                  \
+    if (sparse) {                                                                             \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),               \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
+      hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(8192), dim3(512),      \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         lists + kListHdr, tile_count, cell_out, xl, xc, bl, tile_count + 6,  \
+                         bnp);                                                                \
+    } else {                                                                                  \
+      AMHIP_TRY(hipFuncSetAttribute(                                                          \
+          reinterpret_cast<const void*>(k_dsm_gather_f32_wide<512, TJ_, CAP_>),               \
+          hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
+      hipLaunchKernelGGL((k_dsm_gather_f32_wide<512, TJ_, CAP_>), dim3(ntiles), dim3(512),    \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         cell_out, xl, xc, bl, tile_count + 6, bnp);                          \
+    }                                                                                         \
+    if (own) AMHIP_LAUNCH_LIST_EX(512, TJ_, 4096, cap0, 4, 4096);                             \
+  } while (0)
       static const int f32_variant = getenv("AMHIP_F32_VARIANT") ? atoi(getenv("AMHIP_F32_VARIANT")) : 0;
       // (A-B variants / timing probes of the 64 x 16 / 1024-point instance)
 #define AMHIP_F32_DENSE_V(V_)                                                                 \
@@ -1738,6 +1785,11 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 16, 1024);
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
+      } else if (p.tile_j == 16 && cap0 > 2048) {
+        // (make_dsm_params picks 4096 / 7680 only for the single-precision mode)
+        if (!f32) return arg_failure("internal: 4096-point tiles outside the single-precision mode");
+        if (cap0 == 4096) AMHIP_LAUNCH_F32_WIDE(16, 4096);
+        else AMHIP_LAUNCH_F32_WIDE(16, 7680);
       } else if (p.tile_j == 16) {
         if (f32) AMHIP_LAUNCH_F32(16, 2048);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 2048, 0, 8192);
@@ -1773,6 +1825,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 #undef AMHIP_LAUNCH_LIST
 #undef AMHIP_LAUNCH_LIST_EX
 #undef AMHIP_LAUNCH_F32
+#undef AMHIP_LAUNCH_F32_WIDE
 #undef AMHIP_F32_DENSE
 #undef AMHIP_F32_DENSE_V
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
