@@ -4,16 +4,21 @@
 // inputs, through the drop-in C++ classes of this repository.  No ROS, no file
 // I/O, no oracle: product code only.
 //
-//   make -C examples && examples/demo_backward_grid [cells_per_side] [frames]
+//   make -C examples && examples/demo_backward_grid [cells_per_side] [frames] [output_dir]
+// With an output directory: the mosaic as a GeoTiff (io::AerialMapperIO::toGeoTiff) and the
+// map as the serialized grid_map_msgs/GridMap message AerialGridMap::publishOnce would send.
 #include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <fstream>
 #include <memory>
+#include <string>
 
 #include "aerial-mapper-dsm/dsm.h"
 #include "aerial-mapper-grid-map/aerial-mapper-grid-map.h"
+#include "aerial-mapper-io/aerial-mapper-io.h"
 #include "aerial-mapper-ortho/ortho-backward-grid.h"
 
 static uint64_t g_state = 42;
@@ -101,5 +106,24 @@ int main(int argc, char** argv) {
               100.0 * filled / cells);
   std::printf("ortho %.1f ms (host buffers in/out)   cells with a view:   %.1f %%\n", 1e3 * t_ortho,
               100.0 * seen / cells);
+  if (argc > 3) {
+    // the ortho layer as the 8-bit image grid_map_cv's toImage makes of it (image row = grid
+    // index 0), written like aerial-mapper-io.cc:349-431 does, and the map as a ROS message
+    const std::string dir = argv[3];
+    const grid_map::Matrix& ortho_layer = (*map.getMutable())["ortho"];
+    cv::Mat image(side, side, 1);
+    for (int i = 0; i < side; ++i)
+      for (int j = 0; j < side; ++j) {
+        const float v = ortho_layer(i, j);
+        image.at<uint8_t>(i, j) = std::isfinite(v) ? static_cast<uint8_t>(std::fmin(std::fmax(v, 0.f), 255.f)) : 0;
+      }
+    io::AerialMapperIO io_handler;
+    io_handler.toGeoTiff(image, Eigen::Vector2d(0.0, 0.0), dir + "/orthomosaic.tif");
+    const std::vector<uint8_t> msg = map.serializeMessage(0);
+    std::ofstream(dir + "/grid_map.msg", std::ios::binary)
+        .write(reinterpret_cast<const char*>(msg.data()), static_cast<std::streamsize>(msg.size()));
+    std::printf("wrote %s/orthomosaic.tif and %s/grid_map.msg (%zu bytes)\n", dir.c_str(), dir.c_str(),
+                msg.size());
+  }
   return 0;
 }
