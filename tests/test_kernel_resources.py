@@ -43,6 +43,12 @@ BUDGETS = [
     ("14k_dsm_p3_placeE", 4, 0),
     ("21k_ortho_backward_fastE", 3, 0),
     ("22k_ortho_backward_fast4E", 4, 12),                 # the default mosaic kernel (two cells per lane)
+    # denser clouds in single precision: 4096-point images run two workgroups per CU (4 waves per
+    # SIMD), the wave-per-block kernel three waves per SIMD
+    ("k_dsm_gather_f32_wideILi512ELi16ELi4096E", 4, 0),
+    ("k_dsm_gather_f32_listILi512ELi16ELi4096E", 4, 0),
+    ("k_dsm_gather_f32_wideILi512ELi16ELi7680E", 2, 0),
+    ("18k_dsm_gather_denseE", 3, 0),
 ]
 
 
