@@ -116,6 +116,46 @@ void amo_fwd_distance_l1(const uint8_t* mask, int w, int h, float* out) {
   std::memcpy(out, d.data(), d.size() * sizeof(float));
 }
 
+/* ---- test hooks for the restated OpenCV / aslam pieces (tests/test_oracle_forward.py pins each
+ * against an independent numpy / scipy evaluation of the operation it stands for) ---- */
+
+/* cv::getPerspectiveTransform: src, dst = 4 x (x, y) float; M = 3 x 3 row-major, M[8] = 1 */
+int amo_cv_get_perspective_transform(const float* src8, const float* dst8, double* M9) {
+  float s[4][2], d[4][2];
+  for (int k = 0; k < 4; ++k) {
+    s[k][0] = src8[2 * k];
+    s[k][1] = src8[2 * k + 1];
+    d[k][0] = dst8[2 * k];
+    d[k][1] = dst8[2 * k + 1];
+  }
+  return amo::get_perspective_transform(s, d, M9) ? AMO_OK : AMO_ERR_ARG;
+}
+
+/* cv::invert of a 3 x 3 double matrix */
+int amo_cv_invert3(const double* S9, double* D9) { return amo::invert3(S9, D9) ? AMO_OK : AMO_ERR_ARG; }
+
+/* cv::warpPerspective(src, dst, M, Size(w, h), INTER_NEAREST, BORDER_CONSTANT (0)) */
+int amo_cv_warp_nearest(const uint8_t* src, size_t step, int sw, int sh, int channels,
+                        const double* M9, int w, int h, uint8_t* dst) {
+  const amo::Image8 im = {src, step, sw, sh, channels};
+  std::vector<uint8_t> out;
+  if (!amo::warp_nearest(im, M9, w, h, &out)) return AMO_ERR_ARG;
+  std::memcpy(dst, out.data(), out.size());
+  return AMO_OK;
+}
+
+/* aslam MappedUndistorter::processImage = cv::remap(INTER_LINEAR, BORDER_CONSTANT) over the
+ * camera's distortion map; out: height x width x channels bytes */
+int amo_cv_undistort_image(const amo_camera* cam, const uint8_t* src, size_t step, int channels,
+                           uint8_t* dst) {
+  if (!cam) return AMO_ERR_ARG;
+  const amo::Image8 im = {src, step, cam->width, cam->height, channels};
+  std::vector<uint8_t> out;
+  amo::undistort_image(*cam, im, &out);
+  std::memcpy(dst, out.data(), out.size());
+  return AMO_OK;
+}
+
 void* amo_fwd_create(const amo_camera* cam, const amo_mosaic_desc* desc) {
   if (!cam || !desc || desc->width_mosaic_pixels <= 0 || desc->height_mosaic_pixels <= 0)
     return nullptr;

@@ -152,3 +152,116 @@ def test_l1_distance_transform_equals_scipys_taxicab_transform():
         want = ndimage.distance_transform_cdt(m != 0, metric="taxicab").astype(np.float32)
         got = O.fwd_distance_l1(np.ascontiguousarray(m))
         assert np.array_equal(got, want)
+
+
+# ---- the restated OpenCV / aslam pieces against independent numpy / scipy evaluations of the
+# ---- operations they stand for (OpenCV itself is not in the image: what CAN be pinned) ---------
+import ctypes as C
+
+
+def _cv():
+    lib = O.lib()
+    lib.amo_cv_get_perspective_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.amo_cv_invert3.argtypes = [C.c_void_p, C.c_void_p]
+    lib.amo_cv_warp_nearest.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.amo_cv_undistort_image.argtypes = [C.POINTER(O.Camera), C.c_void_p, C.c_size_t, C.c_int,
+                                           C.c_void_p]
+    return lib
+
+
+def test_get_perspective_transform_solves_the_four_point_system():
+    """cv::getPerspectiveTransform: the homography through four correspondences, M[8] = 1 --
+    against numpy.linalg.solve of the same 8 x 8 system, and by mapping the points."""
+    lib = _cv()
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        src = np.array([[0, 0], [1919, 0], [1919, 1079], [0, 1079]], np.float32) + \
+            rng.uniform(-40, 40, (4, 2)).astype(np.float32)
+        dst = (np.array([[100, 100], [900, 140], [860, 700], [120, 650]]) +
+               rng.uniform(-60, 60, (4, 2))).astype(np.float32)
+        M = np.zeros(9)
+        assert lib.amo_cv_get_perspective_transform(src.ctypes.data, dst.ctypes.data, M.ctypes.data) == O.OK
+        A, b = [], []
+        for (sx, sy), (dx, dy) in zip(src.astype(np.float64), dst.astype(np.float64)):
+            A += [[sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx], [0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy]]
+            b += [dx, dy]
+        want = np.append(np.linalg.solve(np.array(A), np.array(b)), 1.0)
+        np.testing.assert_allclose(M, want, rtol=1e-9, atol=1e-12)
+        p = (M.reshape(3, 3) @ np.c_[src.astype(np.float64), np.ones(4)].T).T
+        np.testing.assert_allclose(p[:, :2] / p[:, 2:], dst, atol=1e-6)
+
+
+def test_invert3_is_the_matrix_inverse():
+    lib = _cv()
+    rng = np.random.default_rng(12)
+    for _ in range(200):
+        S = rng.standard_normal((3, 3)) + 2.0 * np.eye(3)
+        D = np.zeros((3, 3))
+        assert lib.amo_cv_invert3(S.ctypes.data, D.ctypes.data) == O.OK
+        np.testing.assert_allclose(D, np.linalg.inv(S), rtol=1e-10, atol=1e-12)
+    Z = np.zeros((3, 3))
+    assert lib.amo_cv_invert3(Z.ctypes.data, Z.copy().ctypes.data) != O.OK
+
+
+def test_warp_nearest_is_the_inverse_mapped_nearest_pixel():
+    """cv::warpPerspective(INTER_NEAREST, BORDER_CONSTANT): dst(x, y) = src(round(M^-1 (x, y, 1)))
+    with round-half-even and 0 outside -- against a float64 numpy evaluation; pixels whose source
+    coordinate lies within 1e-6 of a rounding tie may legitimately differ (evaluation order)."""
+    lib = _cv()
+    rng = np.random.default_rng(13)
+    for ch in (1, 3):
+        sh, sw, h, w = 90, 120, 150, 170
+        src = rng.integers(1, 256, (sh, sw, ch), dtype=np.uint8)
+        for _ in range(6):
+            M = np.array([[1.2, 0.1, 15.0], [-0.08, 1.1, 20.0], [1e-4, -5e-5, 1.0]]) + \
+                rng.standard_normal((3, 3)) * [[0.05, 0.05, 5], [0.05, 0.05, 5], [2e-5, 2e-5, 0]]
+            dst = np.zeros((h, w, ch), np.uint8)
+            assert lib.amo_cv_warp_nearest(src.ctypes.data, src.strides[0], sw, sh, ch,
+                                           M.ctypes.data, w, h, dst.ctypes.data) == O.OK
+            Mi = np.linalg.inv(M)
+            ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+            X = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
+            Y = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+            Wd = Mi[2, 0] * xs + Mi[2, 1] * ys + Mi[2, 2]
+            fx, fy = X / Wd, Y / Wd
+            ix, iy = np.rint(fx).astype(np.int64), np.rint(fy).astype(np.int64)
+            inside = (ix >= 0) & (iy >= 0) & (ix < sw) & (iy < sh)
+            want = np.zeros_like(dst)
+            want[inside] = src[iy[inside], ix[inside]]
+            tie = (np.abs(np.abs(fx - np.floor(fx)) - 0.5) < 1e-6) | (np.abs(np.abs(fy - np.floor(fy)) - 0.5) < 1e-6)
+            differ = (dst != want).any(axis=2)
+            assert not (differ & ~tie).any()
+            assert inside.mean() > 0.2
+
+
+def test_undistort_is_a_bilinear_remap_with_five_fractional_bits():
+    """aslam's MappedUndistorter = cv::remap(INTER_LINEAR, BORDER_CONSTANT): coordinates quantised
+    to 1/32 pixel, (sum + 2^14) >> 15.  On a smooth image it stays within 1 grey level of
+    scipy.ndimage.map_coordinates(order=1) at the exact map; with no distortion it is the identity."""
+    from scipy import ndimage
+    lib = _cv()
+    H, W = 96, 128
+    v, u = np.mgrid[0:H, 0:W].astype(np.float64)
+    img = np.clip(120 + 60 * np.sin(0.05 * u) * np.cos(0.07 * v) + 0.3 * u, 0, 255).astype(np.uint8)
+    cam = O.Camera()
+    cam.fu, cam.fv, cam.cu, cam.cv, cam.width, cam.height = 100.0, 100.0, 63.5, 47.5, W, H
+    cam.distortion = O.DIST_NONE
+    out = np.zeros_like(img)
+    assert lib.amo_cv_undistort_image(C.byref(cam), img.ctypes.data, img.strides[0], 1, out.ctypes.data) == O.OK
+    assert np.array_equal(out, img)
+    cam.distortion = O.DIST_RADTAN
+    for k, val in enumerate((-0.12, 0.03, 1e-3, -5e-4)):
+        cam.dist[k] = val
+    assert lib.amo_cv_undistort_image(C.byref(cam), img.ctypes.data, img.strides[0], 1, out.ctypes.data) == O.OK
+    x, y = (u - cam.cu) / cam.fu, (v - cam.cv) / cam.fv
+    r2 = x * x + y * y
+    k1, k2, p1, p2 = (cam.dist[k] for k in range(4))
+    rad = 1 + k1 * r2 + k2 * r2 * r2
+    xd = x * rad + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * rad + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    mx, my = cam.fu * xd + cam.cu, cam.fv * yd + cam.cv
+    want = ndimage.map_coordinates(img.astype(np.float64), [my, mx], order=1, mode="constant", cval=0.0)
+    interior = (mx > 1) & (my > 1) & (mx < W - 2) & (my < H - 2)
+    assert interior.mean() > 0.8
+    assert np.abs(out.astype(np.float64) - want)[interior].max() <= 1.0
