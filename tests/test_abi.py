@@ -148,3 +148,16 @@ def test_every_entry_point_is_mapped_in_integration_md():
         if not found:
             missing.append(name)
     assert not missing, missing
+
+
+def test_catkin_package_builds_the_same_sources():
+    """catkin/aerial_mapper_hip/CMakeLists.txt compiles the sources aerial_mapper_amd/build.py
+    compiles (a new .hip / .cc file must reach the workspace build too)."""
+    from aerial_mapper_amd import build
+    cm = open(os.path.join(ROOT, "catkin", "aerial_mapper_hip", "CMakeLists.txt")).read()
+    for src in build.HIP_SOURCES:
+        assert "/" + src in cm, src
+    cpp = os.path.join(ROOT, "aerial_mapper_amd", "cpp")
+    for f in sorted(os.listdir(cpp)):
+        if f.endswith(".cc"):
+            assert f in cm or "*.cc" in cm or "GLOB" in cm, f
