@@ -356,3 +356,68 @@ def test_port_reproduces_golden_densify_bitwise(name):
                            d["R_G_C"], d["t_G_C1"])
     assert np.array_equal(pts.view(np.uint64), d["points"].view(np.uint64))
     assert np.array_equal(inten, d["intensities"])
+
+
+# ---- the adopted external-library formulas (oracle/amo_compat.h: minkindr poses, aslam pinhole
+# ---- projection + distortion) against independent evaluations: scipy's Rotation for the
+# ---- quaternion algebra, the published radial-tangential / equidistant models in numpy.  The
+# ---- libraries themselves are not in the image; this pins the MATHEMATICS of what was adopted.
+def test_adopted_pose_algebra_matches_scipy_rotation():
+    from scipy.spatial.transform import Rotation as R
+    rng = np.random.default_rng(21)
+    cam = S.camera()
+    for _ in range(200):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)                     # (w, x, y, z), Hamilton
+        t = rng.uniform(-500, 500, 3)
+        L = t + rng.uniform(-300, 300, 3)
+        Rm = R.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+        want = Rm.T @ (L - t)                      # T_G_C^-1 * L
+        got = O.project_probe(cam, np.concatenate([t, q]), L)["C"]
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+        # T_G_C = T_G_B * T_C_B^-1
+        q2 = rng.normal(size=4)
+        q2 /= np.linalg.norm(q2)
+        t2 = rng.uniform(-1, 1, 3)
+        T_G_C = O.compose_T_G_C(np.concatenate([t, q])[None], np.concatenate([t2, q2]))[0]
+        R_CB = R.from_quat([q2[1], q2[2], q2[3], q2[0]]).as_matrix()
+        R_GC = Rm @ R_CB.T
+        t_GC = t - R_GC @ t2
+        np.testing.assert_allclose(T_G_C[:3], t_GC, rtol=0, atol=1e-10)
+        got_R = R.from_quat([T_G_C[4], T_G_C[5], T_G_C[6], T_G_C[3]]).as_matrix()
+        np.testing.assert_allclose(got_R, R_GC, rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("model", ["none", "radtan", "equidistant"])
+def test_adopted_camera_models_match_their_published_formulas(model):
+    rng = np.random.default_rng(22)
+    cam = S.camera()
+    d = [0.0] * 4
+    if model == "radtan":
+        cam.distortion, d = O.DIST_RADTAN, [-0.21, 0.06, 8e-4, -3e-4]
+    elif model == "equidistant":
+        cam.distortion, d = O.DIST_EQUIDISTANT, [-0.012, 0.004, -0.002, 5e-4]
+    for k in range(4):
+        cam.dist[k] = d[k]
+    T = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])          # camera frame = world frame
+    for _ in range(300):
+        z = rng.uniform(50, 400)
+        x, y = rng.uniform(-0.5, 0.5, 2) * z
+        r = O.project_probe(cam, T, [x, y, z])
+        xn, yn = x / z, y / z
+        if model == "radtan":                    # OpenCV's radial-tangential model
+            r2 = xn * xn + yn * yn
+            rad = 1 + d[0] * r2 + d[1] * r2 * r2
+            xd = xn * rad + 2 * d[2] * xn * yn + d[3] * (r2 + 2 * xn * xn)
+            yd = yn * rad + d[2] * (r2 + 2 * yn * yn) + 2 * d[3] * xn * yn
+        elif model == "equidistant":             # Kannala-Brandt: theta_d = theta (1 + k1 th^2 + ...)
+            rr = np.hypot(xn, yn)
+            th = np.arctan(rr)
+            thd = th * (1 + d[0] * th**2 + d[1] * th**4 + d[2] * th**6 + d[3] * th**8)
+            s = thd / rr if rr > 1e-12 else 1.0
+            xd, yd = xn * s, yn * s
+        else:
+            xd, yd = xn, yn
+        assert abs(r["u"] - (cam.fu * xd + cam.cu)) < 1e-8
+        assert abs(r["v"] - (cam.fv * yd + cam.cv)) < 1e-8
+        assert abs(r["alpha"] - np.arctan2(abs(z), np.hypot(x, y))) < 1e-12
