@@ -76,3 +76,24 @@ def test_rectification_properties():
     assert (c["left"][inside] == 77).all()
     outside = (c["maps"][0] < -2) | (c["maps"][0] > W + 1) | (c["maps"][1] < -2) | (c["maps"][1] > H + 1)
     assert (c["left"][outside] == 0).all()        # BORDER_CONSTANT 0
+
+
+def test_remap_is_bilinear_sampling_of_the_maps():
+    """cv::remap(INTER_LINEAR, BORDER_CONSTANT) as restated (5 fractional bits, (sum + 2^14) >> 15):
+    within one grey level of scipy.ndimage.map_coordinates(order=1) at the returned maps on a smooth
+    image pair (OpenCV is not in the image: what an independent implementation can pin)."""
+    from scipy import ndimage
+    K, R1, R2, t1, t2, _, _ = rig(9)
+    H, W = 120, 160
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    left = (128 + 70 * np.sin(0.05 * xx) * np.cos(0.04 * yy)).astype(np.uint8)
+    right = (120 + 60 * np.cos(0.03 * xx + 0.5) * np.sin(0.06 * yy)).astype(np.uint8)
+    rc, r = O.rectify_stereo_pair(K, R1, R2, t1, t2, left, right)
+    assert rc == O.OK
+    for img, out, mx, my in ((left, r["left"], r["maps"][0], r["maps"][1]),
+                             (right, r["right"], r["maps"][2], r["maps"][3])):
+        want = ndimage.map_coordinates(img.astype(np.float64), [my.astype(np.float64), mx.astype(np.float64)],
+                                       order=1, mode="constant", cval=0.0)
+        interior = (mx > 1) & (my > 1) & (mx < W - 2) & (my < H - 2)
+        assert interior.mean() > 0.5
+        assert np.abs(out.astype(np.float64) - want)[interior].max() <= 1.0
