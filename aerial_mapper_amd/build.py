@@ -51,7 +51,10 @@ def build_hip(force=False, verbose=False):
     if not force and not _stale(LIB_PATH, deps):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-Rpass-analysis=kernel-resource-usage",
+    # AMHIP_BUILD_DEFINES="-DAMHIP_TIMING_PROBES": lab builds only (timing probes that give
+    # wrong heights, guard-threshold knobs); the shipped library is built without
+    extra = os.environ.get("AMHIP_BUILD_DEFINES", "").split()
+    cmd = [_hipcc()] + HIPCC_FLAGS + extra + ["-Rpass-analysis=kernel-resource-usage",
                                       "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
                                       "-o", LIB_PATH] + srcs
     if verbose:

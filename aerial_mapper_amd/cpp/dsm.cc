@@ -2,13 +2,20 @@
 #include "aerial-mapper-dsm/dsm.h"
 
 #include <cstdio>
+#include <cstdlib>
 
 #include "shim_common.h"
 
 namespace dsm {
 
+static Precision default_precision() {
+  const char* fast = std::getenv("AMHIP_DSM_FAST");
+  return (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT"))
+             ? Precision::kFast : Precision::kReferenceIdentical;
+}
+
 Dsm::Dsm(const Settings& settings, grid_map::GridMap* map)
-    : settings_(settings), session_(nullptr) {
+    : settings_(settings), precision_(default_precision()), session_(nullptr) {
   if (!map) amhip_shim::fatal("Dsm::Dsm", "CHECK(map)");
   printParams();
   // The reference builds a sample->cell-index table for every cell here
@@ -17,6 +24,8 @@ Dsm::Dsm(const Settings& settings, grid_map::GridMap* map)
 }
 
 Dsm::~Dsm() { amhip_shim::release_session(session_); }
+
+void Dsm::setPrecision(Precision precision) { precision_ = precision; }
 
 void Dsm::ensureSession(const grid_map::GridMap& map) {
   session_ = amhip_shim::acquire_session(map, session_, "Dsm");
@@ -34,6 +43,11 @@ void Dsm::process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_c
                 "point cloud must be contiguous x,y,z doubles");
   const double* xyz = reinterpret_cast<const double*>(point_cloud.data());
   grid_map::Matrix& elevation = (*map)["elevation"];
+  // (the session is shared with every object working on this map: the mode is this object's)
+  amhip_shim::check_status(
+      amhip_session_set_dsm_precision(session_, precision_ == Precision::kFast ? AMHIP_DSM_FAST
+                                                                                : AMHIP_DSM_EXACT),
+      "Dsm::process");
   amhip_shim::check_status(
       amhip_session_dsm_process(session_, xyz, point_cloud.size(), settings_.interpolation_radius,
                                 settings_.center_easting, settings_.center_northing,

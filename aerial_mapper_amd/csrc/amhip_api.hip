@@ -324,10 +324,12 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       kTileJ = 16;
       cap = need(16) <= 4096.0 ? 4096 : 7680;  // (7680: one workgroup per CU)
     }
+#ifdef AMHIP_TIMING_PROBES
     if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
       kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
       cap = (kTileJ == 16 && need(16) <= 1024.0) ? 1024 : 2048;  // (the density still picks the capacity)
     }
+#endif
   }
   p.tile_j = kTileJ;
   p.tiles_i = (p.rows + kTileI - 1) / kTileI;
@@ -381,7 +383,9 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     // inside +-2e-6 is decided by the FP64 routine
     const double margin = 2e-6;
     double theta = 0.02;  // cells
+#ifdef AMHIP_TIMING_PROBES
     if (std::getenv("AMHIP_FX_THETA")) theta = std::atof(std::getenv("AMHIP_FX_THETA"));
+#endif
     const double q = std::ldexp(1.0, -(S + 1));
     p.fx_S = S;
     p.fx_thi = static_cast<float>(tc * (1.0 + margin));
@@ -776,7 +780,12 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
   c->win_rows = rows;
   c->win_cols = cols;
   c->cells = static_cast<size_t>(rows) * static_cast<size_t>(cols);
-  c->dsm_exact = std::getenv("AMHIP_DSM_EXACT") ? 1 : 0;
+  // reference-identical by default; FAST is opt-in (setter, or AMHIP_DSM_FAST=1 for hosts that
+  // cannot be recompiled; AMHIP_DSM_EXACT=1 wins over it)
+  {
+    const char* fast = std::getenv("AMHIP_DSM_FAST");
+    c->dsm_exact = (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT")) ? 0 : 1;
+  }
   int rc = AMHIP_OK;
   do {
     if ((rc = use_device(c))) break;
@@ -1149,9 +1158,11 @@ int amhip_densify_dev(amhip_ctx* h, const float* dev_disparity, size_t disp_step
 
 // ---- multi-GPU halo ----------------------------------------------------------
 
-static int make_halo_params(const Ctx& c, double center_easting, double center_northing,
-                            const int32_t* dest_windows, int nd, double margin_m,
-                            size_t cap_per_dest, HaloParams* out) {
+}  // extern "C"
+namespace amhip {
+int make_halo_params(const Ctx& c, double center_easting, double center_northing,
+                     const int32_t* dest_windows, int nd, double margin_m,
+                     size_t cap_per_dest, HaloParams* out) {
   HaloParams hp;
   std::memset(&hp, 0, sizeof(hp));
   grid_bases(c.grid, &hp.base_x, &hp.base_y);
@@ -1168,6 +1179,8 @@ static int make_halo_params(const Ctx& c, double center_easting, double center_n
     hp.hi_i[d] = (double)(w[0] + w[2]) - 0.5 + mc;
     hp.lo_j[d] = (double)w[1] - 0.5 - mc;
     hp.hi_j[d] = (double)(w[1] + w[3]) - 0.5 + mc;
+    hp.off[d] = (unsigned long long)d * (unsigned long long)cap_per_dest;
+    hp.cap_d[d] = cap_per_dest;
   }
   // the context's own window shrunk by the margin, if no destination reaches into it
   // (windows of one tiling never do)
@@ -1186,6 +1199,8 @@ static int make_halo_params(const Ctx& c, double center_easting, double center_n
   *out = hp;
   return AMHIP_OK;
 }
+}  // namespace amhip
+extern "C" {
 
 int amhip_halo_select_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
                           double center_easting, double center_northing,
@@ -1246,6 +1261,7 @@ int amhip_dsm_tiled_begin_dev(amhip_ctx* h, const double* dev_xyz, size_t n_owne
   c->tiled_ce = center_easting;
   c->tiled_cn = center_northing;
   c->tiled_split = sp;
+  c->tiled_params = p;
   return AMHIP_OK;
 }
 
@@ -1257,10 +1273,9 @@ int amhip_dsm_tiled_finish_dev(amhip_ctx* h) {
   c->tiled_pending = false;
   int rc = use_device(c);
   if (rc) return rc;
-  DsmParams p;
-  if ((rc = make_dsm_params(*c, c->tiled_radius_sq, c->tiled_ce, c->tiled_cn, &p, 0, 1,
-                            c->tiled_n)))
-    return rc;
+  // (the plan of the begin call, not a fresh one: amhip_ctx_set_dsm_precision / _knn between the
+  // two calls must not make the gather disagree with the binning of phase 1)
+  const DsmParams p = c->tiled_params;
   SortSplit sp = c->tiled_split;
   sp.phase = 2;
   hipLaunchKernelGGL(k_halo_overflow_check, dim3(1), dim3(64), 0, c->stream, sp.halo_counts,
@@ -1517,6 +1532,21 @@ const char* amhip_kernel_name(int kernel) {
     default:
       return "?";
   }
+}
+
+int amhip_ctx_dsm_gather_stats(amhip_ctx* h, int64_t* out8) {
+  if (!h || !out8) return arg_fail("amhip_ctx_dsm_gather_stats: null argument");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  if (!c->tile_list || c->last_ntiles == 0) return AMHIP_OK;
+  unsigned hdr[8];
+  AMHIP_TRY(hipMemcpyAsync(hdr, c->tile_list, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+  AMHIP_TRY(hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 7; ++k) out8[k] = hdr[k];
+  out8[7] = c->last_ntiles;
+  return AMHIP_OK;
 }
 
 int amhip_ctx_dsm_stats(amhip_ctx* h, int64_t* points_binned, int64_t* num_bins,

@@ -137,6 +137,10 @@ struct HaloParams {
   int nd;
   double lo_i[kMaxHaloDests], hi_i[kMaxHaloDests], lo_j[kMaxHaloDests], hi_j[kMaxHaloDests];
   unsigned long long cap;
+  // where destination d's rows start in the output (in points) and how many it may take:
+  // d * cap / cap for the equal-split layout of the RCCL exchange; prefix sums of the counts /
+  // the counts themselves for the session's count-then-compact routing (cap_d = 0: count only)
+  unsigned long long off[kMaxHaloDests], cap_d[kMaxHaloDests];
   // a box (open) no destination reaches into -- the inside of the context's own window --
   // or an empty one: a point in it is done after four comparisons
   double in_lo_i, in_hi_i, in_lo_j, in_hi_j;
@@ -229,11 +233,13 @@ struct Ctx {
   int tiled_radius_sq = 0;
   double tiled_ce = 0.0, tiled_cn = 0.0;
   SortSplit tiled_split = {};
+  DsmParams tiled_params = {};  // the begin call's plan: the finish call must bin with the same
 
   // stats of the last DSM call
   int64_t last_points_binned = 0;
   int64_t last_num_bins = 0;
   int32_t last_bin_cells = 0;
+  int64_t last_ntiles = 0;        // gather tiles of the last call (0: not the LDS-tiled gather)
 
   // timing
   bool timing = false;
@@ -276,6 +282,11 @@ int densify_run(Ctx* c, const DensifyParams& p, const float* dev_disparity,
 // multi-GPU halo selection
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
                     double* dev_out, unsigned long long* dev_counts);
+// geometry of a selection for `nd` destination windows (amhip_api.hip); off / cap_d are set to
+// the equal-split layout (d * cap_per_dest, cap_per_dest)
+int make_halo_params(const Ctx& c, double center_easting, double center_northing,
+                     const int32_t* dest_windows, int nd, double margin_m, size_t cap_per_dest,
+                     HaloParams* out);
 // values: nullptr -> interpolate the points' z; else one int per point
 // (OrthoFromPcl intensities).  out: the layer to write.  mask (may be null): one
 // byte per cell, set where this call wrote a value; unfilled (may be null):

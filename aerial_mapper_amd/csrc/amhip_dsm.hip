@@ -943,9 +943,11 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   emit_value(p, o, i, j, num / den);
 }
 
-// kVar: 0 = the product kernel; 1, 2, 5, 6 = TIMING PROBES selected with
-// AMHIP_F32_VARIANT (1: candidate loop without the hit updates, 2: no candidate loop -- both
-// give wrong heights; 5 / 6: leave after the staging / after the loads)
+// kVar: 0 = the product kernel.  1, 2, 5, 6 = TIMING PROBES (1: candidate loop without the
+// hit updates, 2: no candidate loop -- both give wrong heights; 5 / 6: leave after the staging /
+// after the loads): instantiated and selectable (AMHIP_F32_VARIANT) ONLY in a build with
+// -DAMHIP_TIMING_PROBES (AMHIP_BUILD_DEFINES=-DAMHIP_TIMING_PROBES python -m
+// aerial_mapper_amd.build --force); the shipped library holds kVar = 0 alone.
 template <int NT, int kTileJ, int kCap, int kVar = 0>
 __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32_t* __restrict__ start,
                                                 const double* __restrict__ sorted,
@@ -956,6 +958,9 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
                                                 int* __restrict__ big_list = nullptr,
                                                 unsigned* __restrict__ big_count = nullptr,
                                                 int big_np = 0x7FFFFFFF) {
+#ifndef AMHIP_TIMING_PROBES
+  static_assert(kVar == 0, "timing probes need -DAMHIP_TIMING_PROBES");
+#endif
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
   // [rec: cap+1 uint4 (U, V, dz, -)][cell offsets][rows][scan][ctl][z range][flags]
@@ -1606,8 +1611,10 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   if (split && split->phase == 1) return AMHIP_OK;  // (tiled call: the rest follows the exchange)
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
+    c->last_ntiles = 0;
     if (p.lds_ok) {
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
+      c->last_ntiles = ntiles;
       {
         int rc;
         if ((rc = ensure_capacity(&c->tile_occ, &c->tile_occ_cap, (size_t)ntiles + 16))) return rc;
@@ -1654,12 +1661,18 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const int capf1 = std::max(cap0, std::min(4096, cap_fit32(80 * 1024)));
       const int capf2 = std::max(capf1, std::min(7680, cap_fit32(150 * 1024)));
       int ccap0 = cap0, ccap1 = f32 ? capf1 : cap1, ccap2 = f32 ? capf2 : cap2;  // classification
+#ifdef AMHIP_TIMING_PROBES
       if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
         sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
+#endif
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
                          p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
+#ifdef AMHIP_TIMING_PROBES
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
+#else
+      constexpr int nt = 512;
+#endif
       auto with_cap = [&](int cap) {
         DsmParams q = p;
         q.lds_cap = cap;
@@ -1705,7 +1718,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
                          lists + kListHdr, tile_count, cell_out, xl, tile_count + 4,          \
                          (int*)nullptr, (unsigned*)nullptr, 0x7FFFFFFF);                      \
-    } else if (f32_variant && (TJ_) == 16 && (CAP_) == 1024) {                                \
+    } else if (AMHIP_PROBE_SELECTED(TJ_, CAP_)) {                                             \
       AMHIP_F32_DENSE(16, 1024, f32_variant);                                                 \
     } else {                                                                                  \
       AMHIP_TRY(hipFuncSetAttribute(                                                          \
@@ -1744,8 +1757,15 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     }                                                                                         \
     if (own) AMHIP_LAUNCH_LIST_EX(512, TJ_, 4096, cap0, 4, 4096);                             \
   } while (0)
+#ifdef AMHIP_TIMING_PROBES
       static const int f32_variant = getenv("AMHIP_F32_VARIANT") ? atoi(getenv("AMHIP_F32_VARIANT")) : 0;
-      // (A-B variants / timing probes of the 64 x 16 / 1024-point instance)
+#define AMHIP_PROBE_SELECTED(TJ_, CAP_) (f32_variant && (TJ_) == 16 && (CAP_) == 1024)
+#else
+      constexpr int f32_variant = 0;
+      (void)f32_variant;
+#define AMHIP_PROBE_SELECTED(TJ_, CAP_) false
+#endif
+      // (timing probes of the 64 x 16 / 1024-point instance: -DAMHIP_TIMING_PROBES builds only)
 #define AMHIP_F32_DENSE_V(V_)                                                                 \
   do {                                                                                        \
     AMHIP_TRY(hipFuncSetAttribute(                                                            \
@@ -1755,6 +1775,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                        p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ,   \
                        cell_out, lists + kListHdr + (size_t)4 * ntiles, tile_count + 4);      \
   } while (0)
+#ifdef AMHIP_TIMING_PROBES
 #define AMHIP_F32_DENSE(TJ_, CAP_, VAR_)                                                      \
   do {                                                                                        \
     if ((VAR_) == 1) AMHIP_F32_DENSE_V(1);                                                    \
@@ -1762,6 +1783,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     else if ((VAR_) == 5) AMHIP_F32_DENSE_V(5);                                               \
     else AMHIP_F32_DENSE_V(6);                                                                \
   } while (0)
+#else
+#define AMHIP_F32_DENSE(TJ_, CAP_, VAR_) do { } while (0)
+#endif
       // (tile height, LDS point capacity) picked by make_dsm_params from the
       // cloud's mean density: 64x16 / 1024 points runs 4 workgroups per CU
       // single-precision list launch of class CLS_ (1, 2): image of CAPV_ points, register
@@ -1828,6 +1852,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 #undef AMHIP_LAUNCH_F32_WIDE
 #undef AMHIP_F32_DENSE
 #undef AMHIP_F32_DENSE_V
+#undef AMHIP_PROBE_SELECTED
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
                          c->bin_start, c->sorted, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
                          cell_out, f32 ? 1 : 0);

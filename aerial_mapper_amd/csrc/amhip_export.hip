@@ -462,9 +462,17 @@ int amhip_io_load_point_cloud_binary(int device, const char* filename, double** 
   std::memcpy(&n64, head + 8, 8);
   std::memcpy(&flags, head + 16, 4);
   struct stat st;
-  const unsigned long long want = 32ull + 24ull * n64 + ((flags & 1u) ? 4ull * n64 : 0ull);
-  if (::fstat(fd, &st) != 0 || (unsigned long long)st.st_size < want)
+  // the header is untrusted: bound n by the file's size BEFORE anything is multiplied (2^61 points
+  // would wrap 24 * n to a small number), refuse counts the DSM cannot index and unknown flags
+  if (flags & ~1u) return arg_failure("amhip_io_load_point_cloud_binary: unknown flag bits in the header");
+  if (::fstat(fd, &st) != 0 || st.st_size < 32)
     return arg_failure("amhip_io_load_point_cloud_binary: file shorter than its header says");
+  const unsigned long long per_point = (flags & 1u) ? 28ull : 24ull;
+  if (n64 > ((unsigned long long)st.st_size - 32ull) / per_point)
+    return arg_failure("amhip_io_load_point_cloud_binary: file shorter than its header says");
+  if (n64 >= 0x7FFFFFFFull)
+    return arg_failure("amhip_io_load_point_cloud_binary: more than 2^31-1 points (the reference "
+                       "indexes search results with int)");
   const size_t n = (size_t)n64;
   if (n == 0) return AMHIP_OK;
   int count = 0;

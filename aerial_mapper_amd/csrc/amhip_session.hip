@@ -12,9 +12,12 @@
 //                POINTS, inside one process; every window then runs the single-GPU kernels.
 //                Frames and poses are replicated; the mosaic needs no exchange.
 //   * residency  the layers stay on the devices between calls.  Whether a host matrix still
-//                holds what the device holds is decided by CONTENT: a 64-bit position-weighted
-//                sum over the matrix (any single changed cell changes it), computed with host
-//                threads on the way in and by a kernel on the way out.  Equal -> no transfer;
+//                holds what the device holds is decided by CONTENT: two 64-bit sums of a
+//                NON-LINEAR mix of (cell bits, cell position) over the matrix -- any single
+//                changed cell changes both, and no arithmetic relation between two edits cancels
+//                (round 2's sum was linear in the bits: d1 (2 g1 + 1) = -d2 (2 g2 + 1) went
+//                unnoticed) --, computed with host threads on the way in and by a kernel on
+//                the way out.  Equal -> no transfer;
 //                a matrix that holds its initial constant -> a lazy device-side reset instead
 //                of an upload; anything else is uploaded.  Outputs the kernels did not change
 //                (num_observations: `+= itself`, ortho-backward-grid.cc:183) are not downloaded.
@@ -35,9 +38,22 @@ struct Win {
   int i0, j0, rows, cols;
 };
 
+struct Hash128 {
+  unsigned long long a = 0, b = 0;
+  bool operator==(const Hash128& o) const { return a == o.a && b == o.b; }
+  bool operator!=(const Hash128& o) const { return !(*this == o); }
+};
+
+// What the session knows about one layer of one window.  `device_valid`: the device layer holds
+// a matrix with content sum `device`.  It is cleared BEFORE any kernel that writes the layer is
+// enqueued and set again only by sync_out, from the device's own sum: a call that fails midway
+// leaves it cleared, so the retry uploads the host matrix instead of trusting a half-written
+// layer.  `host`: content sum of the host matrix as this session last saw or wrote it.
 struct LayerSync {
-  bool valid = false;          // the device layer equals a host matrix with this hash
-  unsigned long long hash = 0;
+  bool device_valid = false;
+  Hash128 device;
+  bool host_known = false;
+  Hash128 host;
 };
 
 struct Session {
@@ -48,72 +64,78 @@ struct Session {
   std::vector<Win> win;
   std::vector<int> dev;
   std::vector<LayerSync> sync;                 // [window][layer]
-  std::vector<unsigned long long> const_hash;  // [window][layer]: hash of the initial constant
+  std::vector<Hash128> const_hash;             // [window][layer]: content sum of the initial constant
   bool always_copy = false;
-  // DSM routing (W > 1)
+  // DSM routing (W > 1): count, then compact -- a slice's selections for all windows take
+  // (points selected) rows, not (slice x windows)
   std::vector<double*> route_out;
   std::vector<size_t> route_cap;               // doubles
   std::vector<long long*> route_counts;        // device, W per window
+  std::vector<hipEvent_t> route_done;          // window k's selections are complete
   std::vector<double*> cloud;
   std::vector<size_t> cloud_cap;               // doubles
-  std::vector<unsigned long long*> dev_hash;   // device scratch: one u64 per layer
+  std::vector<unsigned long long*> dev_hash;   // device scratch: two u64 per layer
   int W() const { return (int)ctx.size(); }
 };
 
-// ---- content hash ---------------------------------------------------------------
-// h = sum over the cells of (bits(v) + C) * (2 g + 1)  mod 2^64,  g = i + j * map rows.
-// A change of one cell by d bits moves h by d * odd != 0; the sum is order-free, so host
-// threads and GPU lanes can each take any part.
-constexpr unsigned long long kHashC = 0x9E3779B97F4A7C15ull;
+// ---- content sums ------------------------------------------------------------------
+// x = mix(bits + K (g + 1)),  a += x,  b += mix2(x);  g = i + j * map rows.  Both mixes are
+// bijections of 64-bit words (xor-shift, odd multiplier), so ONE changed cell always changes
+// both sums; they are not affine in the bits, so no relation d1 w1 + d2 w2 = 0 between two
+// edits cancels in either, let alone in both.  The sums are order-free: host threads and GPU
+// lanes each take any part.
+constexpr unsigned long long kHashK = 0x9E3779B97F4A7C15ull;
 
-__host__ __device__ inline unsigned long long cell_hash(unsigned bits, unsigned long long g) {
-  return ((unsigned long long)bits + kHashC) * ((g << 1) | 1ull);
+__host__ __device__ inline void cell_mix(unsigned bits, unsigned long long g,
+                                         unsigned long long* a, unsigned long long* b) {
+  unsigned long long x = (unsigned long long)bits + kHashK * (g + 1ull);
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 32;
+  unsigned long long y = x * 0x94D049BB133111EBull;
+  y ^= y >> 31;
+  *a += x;
+  *b += y;
 }
 
+// layer == nullptr: the sums of a window filled with `constant` (no memory is read)
 __global__ void __launch_bounds__(256)
-k_layer_hash(const float* __restrict__ layer, int rows, int cols, int i0, int j0, int map_rows,
-             unsigned long long* __restrict__ out) {
-  unsigned long long h = 0;
+k_layer_hash(const float* __restrict__ layer, float constant, int rows, int cols, int i0, int j0,
+             int map_rows, unsigned long long* __restrict__ out) {
+  unsigned long long a = 0, b = 0;
   const size_t n = (size_t)rows * (size_t)cols;
   const size_t stride = (size_t)gridDim.x * 256;
+  const unsigned cbits = __float_as_uint(constant);
   for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < n; k += stride) {
     const int i = (int)(k % (size_t)rows), j = (int)(k / (size_t)rows);
     const unsigned long long g = (unsigned long long)(i0 + i) +
                                  (unsigned long long)(j0 + j) * (unsigned long long)map_rows;
-    h += cell_hash(__float_as_uint(layer[k]), g);
+    cell_mix(layer ? __float_as_uint(layer[k]) : cbits, g, &a, &b);
   }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) h += __shfl_xor(h, d, 64);
-  if ((threadIdx.x & 63) == 0 && h) atomicAdd(out, h);
-}
-
-static unsigned long long window_const_hash(const Session& s, const Win& w, float value) {
-  unsigned bits;
-  std::memcpy(&bits, &value, 4);
-  unsigned long long sum_odd = 0;  // sum of (2 g + 1) over the window
-  for (int j = 0; j < w.cols; ++j) {
-    const unsigned long long g0 = (unsigned long long)w.i0 +
-                                  (unsigned long long)(w.j0 + j) * (unsigned long long)s.grid.rows;
-    // sum_{i < rows} (2 (g0 + i) + 1) = rows (2 g0 + 1) + rows (rows - 1)
-    sum_odd += (unsigned long long)w.rows * ((g0 << 1) | 1ull) +
-               (unsigned long long)w.rows * (unsigned long long)(w.rows - 1);
+  for (int d = 32; d > 0; d >>= 1) {
+    a += __shfl_xor(a, d, 64);
+    b += __shfl_xor(b, d, 64);
   }
-  return ((unsigned long long)bits + kHashC) * sum_odd;
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(out, a);
+    atomicAdd(out + 1, b);
+  }
 }
 
-// per-window hashes of `nl` host matrices (column-major, the map's size) with host threads
+// per-window sums of `nl` host matrices (column-major, the map's size) with host threads
 static void host_hashes(const Session& s, const float* const* mats, int nl,
-                        std::vector<unsigned long long>* out /* [nl][W] */) {
+                        std::vector<Hash128>* out /* [nl][W] */) {
   const int W = s.W(), R = s.grid.rows, Cc = s.grid.cols;
-  out->assign((size_t)nl * W, 0ull);
+  out->assign((size_t)nl * W, Hash128());
   unsigned hw = std::thread::hardware_concurrency();
   int T = (int)std::min<unsigned>(hw ? hw : 8u, 64u);
   if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) T = std::max(1, std::atoi(e));
   T = std::max(1, std::min(T, Cc));
-  std::vector<std::vector<unsigned long long>> part(T, std::vector<unsigned long long>((size_t)nl * W, 0ull));
+  std::vector<std::vector<Hash128>> part(T, std::vector<Hash128>((size_t)nl * W));
   auto work = [&](int t) {
     const int c0 = (int)((long long)Cc * t / T), c1 = (int)((long long)Cc * (t + 1) / T);
-    std::vector<unsigned long long>& acc = part[t];
+    std::vector<Hash128>& acc = part[t];
     int b = 0;
     for (int j = c0; j < c1; ++j) {
       while (j >= s.edges_j[b + 1]) ++b;
@@ -124,9 +146,10 @@ static void host_hashes(const Session& s, const float* const* mats, int nl,
         for (int l = 0; l < nl; ++l) {
           if (!mats[l]) continue;
           const unsigned* col = reinterpret_cast<const unsigned*>(mats[l]) + (size_t)j * R;
-          unsigned long long h = 0;
-          for (int i = ia; i < ib; ++i) h += cell_hash(col[i], g0 + (unsigned long long)i);
-          acc[(size_t)l * W + k] += h;
+          unsigned long long ha = 0, hb = 0;
+          for (int i = ia; i < ib; ++i) cell_mix(col[i], g0 + (unsigned long long)i, &ha, &hb);
+          acc[(size_t)l * W + k].a += ha;
+          acc[(size_t)l * W + k].b += hb;
         }
       }
     }
@@ -136,7 +159,10 @@ static void host_hashes(const Session& s, const float* const* mats, int nl,
   work(0);
   for (auto& x : th) x.join();
   for (int t = 0; t < T; ++t)
-    for (size_t q = 0; q < out->size(); ++q) (*out)[q] += part[t][q];
+    for (size_t q = 0; q < out->size(); ++q) {
+      (*out)[q].a += part[t][q].a;
+      (*out)[q].b += part[t][q].b;
+    }
 }
 
 static inline float* map_at(float* base, const Session& s, const Win& w) {
@@ -161,27 +187,35 @@ static hipError_t copy_window(void* dst_host_or_dev, const void* src, const Sess
                                     (size_t)w.cols, hipMemcpyHostToDevice, stream);
 }
 
-// host matrix -> window layer, as far as needed (asynchronous on the context's stream)
-static int sync_in(Session& s, int k, int layer, const float* host, unsigned long long host_hash) {
+// host matrix -> window layer, as far as needed (asynchronous on the context's stream).
+// will_write: the call that follows writes this layer on the device.
+static int sync_in(Session& s, int k, int layer, const float* host, const Hash128& host_hash,
+                   bool will_write) {
   Ctx* c = &s.ctx[k]->impl;
   LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layer];
   int rc = ctx_use_device(c);
   if (rc) return rc;
+  st.host = host_hash;
+  st.host_known = !s.always_copy;
+  bool have = false;
   if (!s.always_copy) {
-    if (st.valid && st.hash == host_hash) return AMHIP_OK;  // the device holds exactly this
-    if (host_hash == s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + layer]) {
-      // (any matrix with this hash is taken for the initial constant: 2^-64)
+    if (st.device_valid && st.device == host_hash) {
+      have = true;  // the device holds exactly this
+    } else if (host_hash == s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + layer]) {
+      // (any matrix with these sums is taken for the initial constant: 2^-128)
       if ((rc = ctx_layer_set_initial(c, layer))) return rc;
-      st.valid = true;
-      st.hash = host_hash;
-      return AMHIP_OK;
+      have = true;
     }
   }
-  const Win& w = s.win[k];
-  ctx_overwrite(c, layer);
-  AMHIP_TRY(copy_window(c->layers[layer], map_at(host, s, w), s, w, false, c->stream));
-  st.valid = true;
-  st.hash = host_hash;
+  if (!have) {
+    const Win& w = s.win[k];
+    st.device_valid = false;
+    ctx_overwrite(c, layer);
+    AMHIP_TRY(copy_window(c->layers[layer], map_at(host, s, w), s, w, false, c->stream));
+  }
+  st.device = host_hash;
+  // (a layer the next kernel writes is unknown until sync_out has summed it again)
+  st.device_valid = !s.always_copy && !will_write;
   return AMHIP_OK;
 }
 
@@ -191,10 +225,10 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
   int rc = ctx_use_device(c);
   if (rc) return rc;
   const Win& w = s.win[k];
-  unsigned long long h[AMHIP_NUM_LAYERS] = {};
+  Hash128 h[AMHIP_NUM_LAYERS];
   bool run[AMHIP_NUM_LAYERS] = {};
   if (!s.always_copy) {
-    AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * AMHIP_NUM_LAYERS, c->stream));
+    AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS, c->stream));
     for (int q = 0; q < nl; ++q) {
       if (!hosts[q]) continue;
       const int l = layers[q];
@@ -203,24 +237,31 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
         continue;
       }
       run[q] = true;
-      hipLaunchKernelGGL(k_layer_hash, dim3(2048), dim3(256), 0, c->stream, c->layers[l], w.rows,
-                         w.cols, w.i0, w.j0, s.grid.rows, s.dev_hash[k] + q);
+      hipLaunchKernelGGL(k_layer_hash, dim3(2048), dim3(256), 0, c->stream, c->layers[l], 0.0f, w.rows,
+                         w.cols, w.i0, w.j0, s.grid.rows, s.dev_hash[k] + 2 * q);
     }
-    unsigned long long got[AMHIP_NUM_LAYERS];
+    unsigned long long got[2 * AMHIP_NUM_LAYERS];
     AMHIP_TRY(hipMemcpyAsync(got, s.dev_hash[k], sizeof(got), hipMemcpyDeviceToHost, c->stream));
     AMHIP_TRY(hipStreamSynchronize(c->stream));
     for (int q = 0; q < nl; ++q)
-      if (run[q]) h[q] = got[q];
+      if (run[q]) {
+        h[q].a = got[2 * q];
+        h[q].b = got[2 * q + 1];
+      }
   }
   for (int q = 0; q < nl; ++q) {
     if (!hosts[q]) continue;
     const int l = layers[q];
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + l];
-    if (!s.always_copy && st.valid && st.hash == h[q]) continue;  // the host already holds it
-    if ((rc = ctx_materialize(c, l))) return rc;
-    AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
-    st.valid = !s.always_copy;
-    st.hash = h[q];
+    const bool host_has_it = !s.always_copy && st.host_known && st.host == h[q];
+    if (!host_has_it) {
+      if ((rc = ctx_materialize(c, l))) return rc;
+      AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
+    }
+    st.device_valid = !s.always_copy;
+    st.device = h[q];
+    st.host_known = !s.always_copy;
+    st.host = h[q];
   }
   return AMHIP_OK;
 }
@@ -307,7 +348,7 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
     s.win.push_back(w);
     s.dev.push_back(d);
     unsigned long long* dh = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&dh), sizeof(unsigned long long) * AMHIP_NUM_LAYERS) !=
+    if (hipMalloc(reinterpret_cast<void**>(&dh), sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS) !=
         hipSuccess) {
       rc = hip_fail(hipGetLastError(), "hipMalloc(session scratch)", __FILE__, __LINE__);
       break;
@@ -319,12 +360,37 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
     return rc;
   }
   s.sync.assign((size_t)W * AMHIP_NUM_LAYERS, LayerSync());
+  // content sums of the windows' initial constants: summed on the device without reading
+  // memory (the non-linear mix has no closed form)
   s.const_hash.resize((size_t)W * AMHIP_NUM_LAYERS);
-  for (int k = 0; k < W; ++k)
-    for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
-      s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + l] =
-          window_const_hash(s, s.win[k], ctx_layer_init_value(l));
+  for (int k = 0; k < W && rc == AMHIP_OK; ++k) {
+    Ctx* c = &s.ctx[k]->impl;
+    if ((rc = ctx_use_device(c))) break;
+    hipError_t e = hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS,
+                                  c->stream);
+    for (int l = 0; l < AMHIP_NUM_LAYERS && e == hipSuccess; ++l)
+      hipLaunchKernelGGL(k_layer_hash, dim3(1024), dim3(256), 0, c->stream, (const float*)nullptr,
+                         ctx_layer_init_value(l), s.win[k].rows, s.win[k].cols, s.win[k].i0,
+                         s.win[k].j0, s.grid.rows, s.dev_hash[k] + 2 * l);
+    unsigned long long got[2 * AMHIP_NUM_LAYERS];
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(got, s.dev_hash[k], sizeof(got), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      rc = hip_fail(e, "session: content sums of the initial layers", __FILE__, __LINE__);
+      break;
+    }
+    for (int l = 0; l < AMHIP_NUM_LAYERS; ++l) {
+      s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + l].a = got[2 * l];
+      s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + l].b = got[2 * l + 1];
+    }
+  }
+  if (rc) {
+    amhip_session_destroy(h);
+    return rc;
+  }
   s.route_out.assign(W, nullptr);
+  s.route_done.assign(W, nullptr);
   s.route_cap.assign(W, 0);
   s.route_counts.assign(W, nullptr);
   s.cloud.assign(W, nullptr);
@@ -352,6 +418,7 @@ void amhip_session_destroy(amhip_session* h) {
       (void)hipStreamSynchronize(s.ctx[k]->impl.stream);
       if (k < s.route_out.size() && s.route_out[k]) (void)hipFree(s.route_out[k]);
       if (k < s.route_counts.size() && s.route_counts[k]) (void)hipFree(s.route_counts[k]);
+      if (k < s.route_done.size() && s.route_done[k]) (void)hipEventDestroy(s.route_done[k]);
       if (k < s.cloud.size() && s.cloud[k]) (void)hipFree(s.cloud[k]);
       if (k < s.dev_hash.size() && s.dev_hash[k]) (void)hipFree(s.dev_hash[k]);
       amhip_ctx_destroy(s.ctx[k]);
@@ -381,7 +448,16 @@ int amhip_session_window(const amhip_session* h, int k, int32_t* i0_j0_rows_cols
 int amhip_session_set_always_copy(amhip_session* h, int on) {
   if (!h) return arg_failure("null session");
   h->impl.always_copy = on != 0;
-  for (auto& st : h->impl.sync) st.valid = false;
+  for (auto& st : h->impl.sync) st.device_valid = st.host_known = false;
+  return AMHIP_OK;
+}
+
+int amhip_session_set_dsm_precision(amhip_session* h, int mode) {
+  if (!h) return arg_failure("null session");
+  for (amhip_ctx* c : h->impl.ctx) {
+    const int rc = amhip_ctx_set_dsm_precision(c, mode);
+    if (rc) return rc;
+  }
   return AMHIP_OK;
 }
 
@@ -397,7 +473,7 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   const int W = s.W();
   // (1) what do the devices already hold of `elevation`?  (host threads; the cloud's upload
   // is enqueued first where there is a single window, so that both overlap)
-  std::vector<unsigned long long> hh;
+  std::vector<Hash128> hh;
   const float* mats[1] = {elevation};
   int rc;
   if (W == 1) {
@@ -405,17 +481,17 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     if ((rc = ctx_use_device(c))) return rc;
     if (n >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points");
     if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
-    // (a pageable source makes this call return only once the data is staged; the hash runs
+    // (a pageable source makes this call return only once the data is staged; the sums run
     // in a second thread meanwhile)
     std::thread hasher([&]() {
       if (!s.always_copy) host_hashes(s, mats, 1, &hh);
-      else hh.assign(1, 0ull);
+      else hh.assign(1, Hash128());
     });
     hipError_t e = hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
                                   hipMemcpyHostToDevice, c->stream);
     hasher.join();
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cloud)", __FILE__, __LINE__);
-    if ((rc = sync_in(s, 0, AMHIP_LAYER_ELEVATION, elevation, hh[0]))) return rc;
+    if ((rc = sync_in(s, 0, AMHIP_LAYER_ELEVATION, elevation, hh[0], true))) return rc;
     if ((rc = amhip_dsm_process_dev(s.ctx[0], c->stage_points, n, radius_sq, center_easting,
                                     center_northing)))
       return rc;
@@ -426,9 +502,9 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   }
 
   if (!s.always_copy) host_hashes(s, mats, 1, &hh);
-  else hh.assign(W, 0ull);
-  // (2) slice k of the cloud goes to window k's device, which selects what EVERY window
-  // needs of it (its cells grown by the halo margin)
+  else hh.assign(W, Hash128());
+  // (2) slice k of the cloud goes to window k's device, which COUNTS what every window needs
+  // of it (its cells grown by the halo margin) -- one pass without output --
   const double margin = halo_margin_m(radius_sq, s.grid.resolution);
   std::vector<int32_t> wins(4 * (size_t)W);
   for (int d = 0; d < W; ++d) {
@@ -440,35 +516,77 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   std::vector<size_t> lo(W + 1);
   for (int k = 0; k <= W; ++k) lo[k] = n * (size_t)k / (size_t)W;
   std::vector<long long> counts((size_t)W * W, 0);
+  // one selection pass of slice k over destinations [d0, d0 + nd): count only (caps 0) or
+  // compacting into route_out[k] at the offsets the counts gave
+  auto select_pass = [&](int k, bool count_only, const std::vector<unsigned long long>* offs) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    const size_t nk = lo[k + 1] - lo[k];
+    for (int d0 = 0; d0 < W; d0 += kMaxHaloDests) {
+      const int nd = std::min(kMaxHaloDests, W - d0);
+      HaloParams hp;
+      int r = make_halo_params(*c, center_easting, center_northing, &wins[4 * (size_t)d0], nd, margin,
+                               0, &hp);
+      if (r) return r;
+      for (int d = 0; d < nd; ++d) {
+        hp.off[d] = count_only ? 0ull : (*offs)[(size_t)k * W + d0 + d];
+        hp.cap_d[d] = count_only ? 0ull : (unsigned long long)counts[(size_t)k * W + d0 + d];
+      }
+      if ((r = halo_select_run(c, c->stage_points, nk, hp, s.route_out[k],
+                               reinterpret_cast<unsigned long long*>(s.route_counts[k] + d0))))
+        return r;
+    }
+    return AMHIP_OK;
+  };
   rc = for_windows(s, [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
     if (r) return r;
     const size_t nk = lo[k + 1] - lo[k];
-    if ((r = sync_in(s, k, AMHIP_LAYER_ELEVATION, elevation, hh[k]))) return r;
+    if ((r = sync_in(s, k, AMHIP_LAYER_ELEVATION, elevation, hh[k], true))) return r;
+    if (!s.route_done[k])
+      AMHIP_TRY(hipEventCreateWithFlags(&s.route_done[k], hipEventDisableTiming));
     if (nk == 0) return AMHIP_OK;
     if ((r = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * nk))) return r;
     AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz + 3 * lo[k], 3 * nk * sizeof(double),
                              hipMemcpyHostToDevice, c->stream));
-    if ((r = ensure_capacity(&s.route_out[k], &s.route_cap[k], 3 * nk * (size_t)W))) return r;
     if (!s.route_counts[k])
       AMHIP_TRY(hipMalloc(reinterpret_cast<void**>(&s.route_counts[k]), sizeof(long long) * W));
-    for (int d0 = 0; d0 < W; d0 += kMaxHaloDests) {
-      const int nd = std::min(kMaxHaloDests, W - d0);
-      if ((r = amhip_halo_select_dev(s.ctx[k], c->stage_points, nk, center_easting, center_northing,
-                                     &wins[4 * (size_t)d0], nd, margin,
-                                     s.route_out[k] + 3 * nk * (size_t)d0, nk,
-                                     reinterpret_cast<int64_t*>(s.route_counts[k] + d0))))
-        return r;
-    }
+    if ((r = select_pass(k, true, nullptr))) return r;
     AMHIP_TRY(hipMemcpyAsync(&counts[(size_t)k * W], s.route_counts[k], sizeof(long long) * W,
                              hipMemcpyDeviceToHost, c->stream));
+    // (the one host synchronisation of the routing: the sizes of everything that follows)
     AMHIP_TRY(hipStreamSynchronize(c->stream));
     return AMHIP_OK;
   });
   if (rc) return rc;
-  // (3) every window collects its points from all slices, device to device, and runs
-  // Dsm::process on them
+  // (3) the same pass again, now writing: slice k's selections for window d land behind those
+  // for windows < d in ONE buffer of (points selected) rows -- not (slice x windows) --, and an
+  // event marks them complete; no host synchronisation from here to the DSM's own
+  std::vector<unsigned long long> offs((size_t)W * W, 0ull);
+  for (int k = 0; k < W; ++k) {
+    unsigned long long run = 0;
+    for (int d = 0; d < W; ++d) {
+      offs[(size_t)k * W + d] = run;
+      run += (unsigned long long)counts[(size_t)k * W + d];
+    }
+  }
+  rc = for_windows(s, [&](int k) -> int {
+    Ctx* c = &s.ctx[k]->impl;
+    int r = ctx_use_device(c);
+    if (r) return r;
+    const size_t nk = lo[k + 1] - lo[k];
+    size_t sel = 0;
+    for (int d = 0; d < W; ++d) sel += (size_t)counts[(size_t)k * W + d];
+    if (nk && sel) {
+      if ((r = ensure_capacity(&s.route_out[k], &s.route_cap[k], 3 * sel))) return r;
+      if ((r = select_pass(k, false, &offs))) return r;
+    }
+    AMHIP_TRY(hipEventRecord(s.route_done[k], c->stream));
+    return AMHIP_OK;
+  });
+  if (rc) return rc;
+  // (4) every window collects its points from all slices, device to device (xGMI peer copies
+  // behind the producers' events), and runs Dsm::process on them
   rc = for_windows(s, [&](int d) -> int {
     Ctx* c = &s.ctx[d]->impl;
     int r = ctx_use_device(c);
@@ -482,8 +600,8 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
       for (int k = 0; k < W; ++k) {
         const size_t cnt = (size_t)counts[(size_t)k * W + d];
         if (!cnt) continue;
-        const size_t nk = lo[k + 1] - lo[k];
-        const double* src = s.route_out[k] + 3 * nk * (size_t)d;
+        if (k != d) AMHIP_TRY(hipStreamWaitEvent(c->stream, s.route_done[k], 0));
+        const double* src = s.route_out[k] + 3 * (size_t)offs[(size_t)k * W + d];
         if (s.dev[k] == s.dev[d])
           AMHIP_TRY(hipMemcpyAsync(s.cloud[d] + 3 * off, src, cnt * 24, hipMemcpyDeviceToDevice,
                                    c->stream));
@@ -501,6 +619,8 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     if ((r = sync_out(s, d, lay, outs, 1))) return r;
     return ctx_fetch_status(c);
   });
+  // (a later call may overwrite route_out[k] while a slower peer still reads it: every window
+  // finished its copies before its own sync_out returned, and all threads were joined)
   return rc;
 }
 
@@ -529,7 +649,7 @@ int amhip_session_ortho_backward_process(
   // OBSERVATION_INDEX, COLORED_ORTHO
   const float* ins[AMHIP_NUM_LAYERS] = {ortho, elevation, elevation_angle, num_observations,
                                         observation_index, colored_ortho};
-  std::vector<unsigned long long> hh;
+  std::vector<Hash128> hh;
   auto upload_frames = [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
@@ -553,7 +673,7 @@ int amhip_session_ortho_backward_process(
     if (rc_up) up_msg = amhip_last_error();
   });
   if (!s.always_copy) host_hashes(s, ins, AMHIP_NUM_LAYERS, &hh);
-  else hh.assign((size_t)AMHIP_NUM_LAYERS * W, 0ull);
+  else hh.assign((size_t)AMHIP_NUM_LAYERS * W, Hash128());
   uploader.join();
   if (rc_up) {
     set_last_error(up_msg);
@@ -563,8 +683,10 @@ int amhip_session_ortho_backward_process(
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
     if (r) return r;
+    // (the mosaic reads the elevation and writes the other layers)
     for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
-      if (ins[l] && (r = sync_in(s, k, l, ins[l], hh[(size_t)l * W + k]))) return r;
+      if (ins[l] && (r = sync_in(s, k, l, ins[l], hh[(size_t)l * W + k], l != AMHIP_LAYER_ELEVATION)))
+        return r;
     if ((r = amhip_ortho_backward_process_dev(s.ctx[k], cam, host_T_G_C, F, c->stage_frames, frame,
                                               row, channels, colored)))
       return r;
@@ -588,15 +710,15 @@ int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xy
     return arg_failure("empty point cloud / null buffer (CHECK(!pointcloud.empty()))");
   if (n >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points");
   Session& s = h->impl;
-  std::vector<unsigned long long> hh;
+  std::vector<Hash128> hh;
   const float* mats[1] = {ortho};
   if (!s.always_copy) host_hashes(s, mats, 1, &hh);
-  else hh.assign(s.W(), 0ull);
+  else hh.assign(s.W(), Hash128());
   return for_windows(s, [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
     if (r) return r;
-    if ((r = sync_in(s, k, AMHIP_LAYER_ORTHO, ortho, hh[k]))) return r;
+    if ((r = sync_in(s, k, AMHIP_LAYER_ORTHO, ortho, hh[k], true))) return r;
     if ((r = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return r;
     if ((r = ensure_capacity(&c->stage_values, &c->stage_values_cap, n))) return r;
     AMHIP_TRY(hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),

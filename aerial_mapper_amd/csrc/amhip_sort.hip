@@ -192,8 +192,8 @@ __device__ __forceinline__ void halo_stage_init(HaloStage* st, const HaloParams&
 __device__ __forceinline__ void halo_write(const HaloParams& hp, const double* __restrict__ xyz,
                                            size_t idx, int d, unsigned long long slot,
                                            double* __restrict__ out) {
-  if (slot < hp.cap) {
-    double* o = out + ((size_t)d * hp.cap + slot) * 3;
+  if (slot < hp.cap_d[d]) {
+    double* o = out + (size_t)(hp.off[d] + slot) * 3;
     o[0] = xyz[3 * idx + 0];
     o[1] = xyz[3 * idx + 1];
     o[2] = xyz[3 * idx + 2];

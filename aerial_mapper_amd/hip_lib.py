@@ -45,7 +45,7 @@ EXPORTS = [
     "amhip_densify_dev", "amhip_rectify_stereo_pair_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
     "amhip_dsm_tiled_finish_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
-    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats",
+    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats", "amhip_ctx_dsm_gather_stats",
     "amhip_mosaic_create", "amhip_mosaic_destroy", "amhip_mosaic_set_stream",
     "amhip_mosaic_synchronize", "amhip_mosaic_reset", "amhip_mosaic_batch",
     "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
@@ -53,6 +53,7 @@ EXPORTS = [
     "amhip_camera_view_bounds",
     "amhip_session_create", "amhip_session_destroy", "amhip_session_num_windows",
     "amhip_session_context", "amhip_session_window", "amhip_session_set_always_copy",
+    "amhip_session_set_dsm_precision",
     "amhip_session_dsm_process", "amhip_session_ortho_backward_process",
     "amhip_session_ortho_from_pcl_process",
     "amhip_io_parse_point_cloud_text", "amhip_io_download_point_cloud", "amhip_io_free",
@@ -163,6 +164,7 @@ def load():
     lib.amhip_session_context.argtypes = [vp, C.c_int]
     lib.amhip_session_window.argtypes = [vp, C.c_int, C.POINTER(C.c_int32)]
     lib.amhip_session_set_always_copy.argtypes = [vp, C.c_int]
+    lib.amhip_session_set_dsm_precision.argtypes = [vp, C.c_int]
     lib.amhip_session_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
     lib.amhip_session_ortho_from_pcl_process.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     lib.amhip_session_ortho_backward_process.argtypes = [
@@ -175,6 +177,7 @@ def load():
     lib.amhip_ctx_kernel_time.argtypes = [vp, C.c_int, f64p, C.POINTER(C.c_int64)]
     lib.amhip_kernel_name.restype = C.c_char_p
     lib.amhip_kernel_name.argtypes = [C.c_int]
+    lib.amhip_ctx_dsm_gather_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.amhip_ctx_dsm_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                         C.POINTER(C.c_int32)]
     mp = C.POINTER(MosaicDesc)

@@ -193,8 +193,9 @@ class AerialGridMap(object):
         L.check(self._lib.amhip_ctx_synchronize(self._h))
 
     def set_dsm_precision(self, exact):
-        """AMHIP_DSM_EXACT (True): the FP64 gather everywhere; AMHIP_DSM_FAST (False, default):
-        single-precision arithmetic under exact guards (include/aerial_mapper_hip.h)."""
+        """AMHIP_DSM_EXACT (True, the default of new maps): the FP64 gather everywhere --
+        reference-identical floats, deterministic; AMHIP_DSM_FAST (False, opt-in): single
+        precision under exact guards, heights within 1e-4 m (include/aerial_mapper_hip.h)."""
         L.check(self._lib.amhip_ctx_set_dsm_precision(self._h, 1 if exact else 0))
 
     def set_dsm_knn(self, k):
@@ -221,6 +222,14 @@ class AerialGridMap(object):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
         L.check(self._lib.amhip_ctx_dsm_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"points_binned": a.value, "num_bins": b.value, "bin_cells": c.value}
+
+    def dsm_gather_stats(self):
+        """amhip_ctx_dsm_gather_stats: where the gather tiles of the last DSM call went."""
+        out = (C.c_int64 * 8)()
+        L.check(self._lib.amhip_ctx_dsm_gather_stats(self._h, out))
+        v = [int(x) for x in out]
+        return {"tiles": v[7], "sparse_list": v[0], "class1": v[1], "class2": v[2],
+                "beyond_lds": v[3], "f32_to_fp64": v[4] + v[5], "f32_to_fp64_beyond": v[6]}
 
 
 def _is_torch(x):
@@ -454,9 +463,7 @@ class HostSession(object):
         L.check(self._lib.amhip_session_set_always_copy(self._h, int(bool(on))))
 
     def set_dsm_precision(self, exact):
-        for k in range(self.num_windows):
-            L.check(self._lib.amhip_ctx_set_dsm_precision(
-                C.c_void_p(self._lib.amhip_session_context(self._h, k)), 1 if exact else 0))
+        L.check(self._lib.amhip_session_set_dsm_precision(self._h, 1 if exact else 0))
 
     def dsm_process(self, dsm_settings, points):
         pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)

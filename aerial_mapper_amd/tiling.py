@@ -261,17 +261,25 @@ def route_points(points, grid, layout, rank, group=None, radius_sq=1, center_eas
     return out
 
 
-def neighbours(layout, rank, margin_cells):
-    """Ranks whose window, grown by the halo margin, reaches into `rank`'s window (and vice
-    versa: the relation is symmetric).  Host geometry -- at most 8 in a 2-D tiling."""
+def neighbours(layout, rank, margin_m, resolution, slack_cells=1.0):
+    """Ranks whose window, grown by the halo margin, can hold a point of `rank`'s window (and
+    vice versa: the relation is symmetric).  Host geometry -- at most 8 in a 2-D tiling.
+
+    Same arithmetic as the device selection (make_halo_params / k_halo_select): a point OWNED by
+    `rank` has continuous cell coordinates in [i0 - 0.5, i0 + r - 0.5) x [j0 - 0.5, j0 + c - 0.5);
+    window q takes it iff  a0 - 0.5 - mc <= cx <= a0 + ar - 0.5 + mc  (same for y) with
+    mc = margin_m / resolution -- i.e. iff  a0 - mc < i0 + r  and  a0 + ar + mc >= i0.  The
+    comparison here is non-strict and `slack_cells` wider: a SUPERSET of the selection's
+    destinations, never less (an extra neighbour only receives NaN rows)."""
+    mc = float(margin_m) / float(resolution) + float(slack_cells)
     i0, j0, r, c = layout.window(rank)
     out = []
     for q in range(layout.world):
         if q == rank:
             continue
         a0, b0, ar, ac = layout.window(q)
-        if a0 - margin_cells <= i0 + r and a0 + ar + margin_cells >= i0 and \
-                b0 - margin_cells <= j0 + c and b0 + ac + margin_cells >= j0:
+        if a0 - mc <= i0 + r and a0 + ar + mc >= i0 and \
+                b0 - mc <= j0 + c and b0 + ac + mc >= j0:
             out.append(q)
     return out
 
@@ -293,6 +301,12 @@ class TiledDsm(object):
                n_owned rows are this rank's own points; the received rows land behind
     cap        rows per (source, destination) pair: a few times edge x margin x
                density (halo_strip_rows())
+
+    PRECONDITION: the n_owned rows are points whose CELL lies in this rank's window
+    (owner_mask()).  Only geometric neighbours are destinations, so a stray point that some
+    non-neighbour needs would never travel; process() therefore verifies the precondition on
+    the device (check_owned: default = on its first call, True = every call) and raises instead
+    of dropping points silently.  Clouds partitioned any other way go through route_points().
     """
 
     def __init__(self, settings, map_, layout, rank, cap, comm=None):
@@ -302,7 +316,8 @@ class TiledDsm(object):
         self.comm = comm or TorchComm()
         dev = torch.device("cuda", map_.device)
         self._margin = halo_margin(settings.interpolation_radius, map_.grid.resolution)
-        self.nbrs = neighbours(layout, rank, self._margin / map_.grid.resolution + 1.0)
+        self.nbrs = neighbours(layout, rank, self._margin, map_.grid.resolution)
+        self._owned_checked = False
         nn = len(self.nbrs)
         if nn > MAX_DESTS:
             raise ValueError("more than %d neighbouring windows" % MAX_DESTS)
@@ -313,7 +328,18 @@ class TiledDsm(object):
         self._wins = (C.c_int32 * (4 * max(nn, 1)))(*[int(v) for w in wins for v in w])
         self.splits = [self.cap if q in self.nbrs else 0 for q in range(layout.world)]
 
-    def process(self, workspace, n_owned, sync=True):
+    def verify_owned(self, workspace, n_owned):
+        """Raise unless every one of the first n_owned rows lies in this rank's window (a pass
+        of torch ops over the rows: not part of a steady-state step)."""
+        s, m = self.settings, self.map
+        cx, cy = cell_coords(workspace[:n_owned], m.grid, s.center_easting, s.center_northing)
+        stray = int((~owner_mask(cx, cy, self.layout.window(self.rank))).sum().item())
+        if stray:
+            raise ValueError("TiledDsm: %d of the %d owned points lie outside this rank's window; "
+                             "only neighbouring windows receive halo rows -- route such clouds "
+                             "with route_points(assume_owned=False)" % (stray, n_owned))
+
+    def process(self, workspace, n_owned, sync=True, check_owned=None):
         import torch
         from . import hip_lib as L
         lib = L.load()
@@ -322,6 +348,9 @@ class TiledDsm(object):
         n_total = n_owned + nn * cap
         assert workspace.is_cuda and workspace.dtype == torch.float64 and workspace.is_contiguous()
         assert workspace.shape[0] >= n_total and workspace.shape[1] == 3
+        if check_owned or (check_owned is None and not self._owned_checked):
+            self.verify_owned(workspace, n_owned)
+            self._owned_checked = True
         if nn == 0:
             from .mapper import Dsm
             Dsm(s, m).process(workspace[:n_owned], m, sync=sync)

@@ -84,6 +84,17 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="N > 1, small workloads: after the timed steps gather the cloud and every "
                          "window's elevation on rank 0 and compare with ONE full-map DSM there")
+    ap.add_argument("--dsm-mode", default="fast", choices=["fast", "exact"],
+                    help="arithmetic of the DSM gather in the timed steps behind `value`: fast = "
+                         "single precision under exact guards (opt-in mode of the library, within "
+                         "the north_star's 1e-4 m), exact = FP64 (the library's default, the "
+                         "reference's floats).  The other mode is timed in the same run and "
+                         "reported beside it (`exact_mode` / `fast_mode`)")
+    ap.add_argument("--no-second-mode", action="store_true", help="skip the other mode's loop")
+    ap.add_argument("--no-rough-terrain", action="store_true",
+                    help="skip the rough-terrain extra (N = 1: 25 m steps in 20 %% of the gather tiles)")
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="N > 1: skip the small verified step in front of the timed ones")
     ap.add_argument("--map-origin", default="0,0",
                     help="easting,northing of the map centre (default 0,0; e.g. 464980.25,5272690.5 "
                          "puts the same workload at UTM magnitudes)")
@@ -140,38 +151,6 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
                              colored=args.colored, which=which, timing=t_mosaic)
         assert rc == 0
         t_ortho = time.time() - t0
-    # parity of the GPU result on the same cells
-    gpu_elev = map_.get("elevation")[:s, :s]
-    ok = ~np.isnan(elev)
-    parity = {"cells": int(s * s),
-              "dsm_nan_pattern_equal": bool(np.array_equal(np.isnan(gpu_elev), ~ok)),
-              "dsm_max_abs_err_m": float(np.abs(gpu_elev[ok].astype(np.float64) - elev[ok]).max())
-              if ok.any() else 0.0}
-    if F:
-        for name in ("observation_index", "colored_ortho" if args.colored else "ortho"):
-            a = map_.get(name)[:s, :s]
-            b = layers[name]
-            eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
-            parity[name + "_mismatch_cells"] = int((~eq).sum())
-        if any(parity[k] for k in parity if k.endswith("_mismatch_cells")):
-            # The reference's mosaic above stands on the REFERENCE's heights, the GPU's on its own
-            # (default single-precision gather: within 1e-4 m, not bit-identical).  A height that
-            # moved by one float spacing can carry a keypoint across a pixel boundary; whether the
-            # mosaic kernel itself is exact is decided on equal inputs: the reference's loop once
-            # more, on the GPU's heights.
-            layers2 = O.new_layers(g)
-            layers2["elevation"] = np.ascontiguousarray(gpu_elev)
-            rc = O.ortho_process(g, cam, poses, ncam.T_C_B, frames_host, layers2,
-                                 colored=args.colored, which=which)
-            assert rc == 0
-            for name in ("observation_index", "colored_ortho" if args.colored else "ortho"):
-                a = map_.get(name)[:s, :s]
-                b = layers2[name]
-                eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
-                parity[name + "_mismatch_cells_on_equal_heights"] = int((~eq).sum())
-            parity["note"] = ("*_mismatch_cells: GPU DSM + mosaic against reference DSM + mosaic (the "
-                              "heights differ by <= dsm_max_abs_err_m); *_on_equal_heights: the "
-                              "reference's mosaic loop fed the GPU's heights")
     cores = os.cpu_count() or 1
     if which == "loops":
         # the two process() calls alone; the constructors' one-sample-per-cell tables
@@ -189,16 +168,124 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
                   "%.2fs + ortho %.2fs, std::thread x hardware_concurrency like "
                   "utils::parFor" % (s, s, sub_pts.shape[0], F, t_build, t_cells, t_ortho))
     total = t_dsm + t_ortho
-    return {"value": round(s * s / total / 1e6, 4), "unit": "Mcells/s", "cores": cores,
+    refs = {"s": s, "elev": elev, "layers": layers, "grid": g, "cam": cam if F else None,
+            "frames_host": frames_host if F else None, "which": which}
+    return refs, {"value": round(s * s / total / 1e6, 4), "unit": "Mcells/s", "cores": cores,
             "kind": "port" if which == "port" else "reference",
             "reference_code": {"loops": "dsm.cc + ortho-backward-grid.cc unchanged (oracle/refkit)",
                                "ref": "vendored nanoflann under restated loops",
                                "port": "none (restated loops, own kd-tree)"}[which],
             "sample": sample,
-            "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}, parity
+            "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}
 
 
-def verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, m, pts, settings):
+def parity_against(refs, args, map_, poses, ncam, F):
+    """GPU layers of the sub-tile against the reference's (already computed) result."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    s, elev, layers = refs["s"], refs["elev"], refs["layers"]
+    gpu_elev = map_.get("elevation")[:s, :s]
+    ok = ~np.isnan(elev)
+    same = (gpu_elev.view(np.uint32) == elev.view(np.uint32)) | (np.isnan(gpu_elev) & ~ok)
+    parity = {"cells": int(s * s),
+              "dsm_nan_pattern_equal": bool(np.array_equal(np.isnan(gpu_elev), ~ok)),
+              "dsm_max_abs_err_m": float(np.abs(gpu_elev[ok].astype(np.float64) - elev[ok]).max())
+              if ok.any() else 0.0,
+              "dsm_bit_identical_frac": round(float(same.mean()), 9)}
+    if F:
+        names = ("observation_index", "colored_ortho" if args.colored else "ortho")
+        for name in names:
+            a = map_.get(name)[:s, :s]
+            b = layers[name]
+            eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+            parity[name + "_mismatch_cells"] = int((~eq).sum())
+        if any(parity[k] for k in parity if k.endswith("_mismatch_cells")):
+            # The reference's mosaic stands on the REFERENCE's heights, the GPU's on its own
+            # (single-precision gather: within 1e-4 m, not bit-identical).  A height that
+            # moved by one float spacing can carry a keypoint across a pixel boundary; whether the
+            # mosaic kernel itself is exact is decided on equal inputs: the reference's loop once
+            # more, on the GPU's heights.
+            layers2 = O.new_layers(refs["grid"])
+            layers2["elevation"] = np.ascontiguousarray(gpu_elev)
+            rc = O.ortho_process(refs["grid"], refs["cam"], poses, ncam.T_C_B, refs["frames_host"],
+                                 layers2, colored=args.colored, which=refs["which"])
+            assert rc == 0
+            for name in names:
+                a = map_.get(name)[:s, :s]
+                b = layers2[name]
+                eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+                parity[name + "_mismatch_cells_on_equal_heights"] = int((~eq).sum())
+            parity["note"] = ("*_mismatch_cells: GPU DSM + mosaic against reference DSM + mosaic (the "
+                              "heights differ by <= dsm_max_abs_err_m); *_on_equal_heights: the "
+                              "reference's mosaic loop fed the GPU's heights")
+    return parity
+
+
+def rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L):
+    """What a rough scene costs: the same cloud with a 25 m step through the
+    middle of 20 % of the 64 x 16-cell gather tiles (walls / canopy edges).  The single-precision
+    gather's per-tile error bound has no room there (height range beyond ~15 m at 400 m), so
+    those tiles -- and the neighbours whose halo ring reaches into them -- go to the FP64 kernel.
+    DSM calls only (the mosaic does not depend on the mode)."""
+    import torch
+    dev = pts.device
+    rough = pts.clone()
+    bx = tile_center[0] + L / 2.0        # x of the map's upper edge (cell 0 starts here)
+    by = tile_center[1] + L / 2.0
+    u = (bx - rough[:, 0]) / (64 * res)
+    v = (by - rough[:, 1]) / (16 * res)
+    ti, tj = torch.floor(u).to(torch.int64), torch.floor(v).to(torch.int64)
+    h = (ti * 73856093) ^ (tj * 19349663)
+    chosen = (h % 5) == 0
+    step_up = chosen & ((u - torch.floor(u)) > 0.5)
+    rough[:, 2] += 25.0 * step_up.to(torch.float64)
+    frac_tiles = float(chosen.double().mean().item())
+    del u, v, ti, tj, h, chosen, step_up
+    res_out = {"scene": "cfg's cloud + a 25 m step through the middle of 20 % of the 64x16-cell "
+                        "gather tiles (%.3f of the points lie in such a tile)" % frac_tiles}
+    for mode in ("fast", "exact"):
+        m.set_dsm_precision(mode == "exact")
+        for _ in range(2):
+            m.reset()
+            dsm.process(rough, m, sync=False)
+        m.synchronize()
+        m.enable_timing(True)
+        m.timing_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            m.reset()
+            dsm.process(rough, m, sync=False)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        m.synchronize()
+        kt = m.kernel_times()
+        m.enable_timing(False)
+        e = {"dsm_ms_per_call": round(dt * 1e3, 3),
+             "gather_ms": round(kt.get("k_dsm_gather", (0.0, 0))[0] / 5, 4)}
+        if mode == "fast":
+            gs = m.dsm_gather_stats()
+            e["tiles"] = gs["tiles"]
+            e["tiles_sent_to_fp64"] = gs["f32_to_fp64"] + gs["f32_to_fp64_beyond"]
+            e["tiles_sent_to_fp64_frac"] = round(e["tiles_sent_to_fp64"] / max(gs["tiles"], 1), 4)
+            # (a download, not a device pointer: handing the pointer out would switch the layer
+            # to eager refills for the rest of the run)
+            elev_fast = torch.from_numpy(m.get("elevation"))
+        else:
+            d = (torch.from_numpy(m.get("elevation")) - elev_fast).abs()
+            e["max_abs_diff_to_fast_mode_m"] = float(d[~torch.isnan(d)].max().item())
+            e["nan_pattern_equal_to_fast_mode"] = bool(torch.equal(torch.isnan(d),
+                                                                   torch.isnan(elev_fast)))
+        res_out[mode] = e
+    # the smooth cloud again in the run's own mode: the layers must not keep the rough scene
+    m.set_dsm_precision(args.dsm_mode == "exact")
+    del rough, elev_fast
+    return res_out
+
+
+def verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, m, pts, settings,
+                   exact=False):
     """Every window of the tiled run against ONE full-map DSM of the gathered cloud on rank 0
     (small workloads only).  Returns the comparison on rank 0, None elsewhere."""
     import numpy as np
@@ -211,6 +298,7 @@ def verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world,
         return None
     cloud = torch.cat([g[0] for g in gathered], 0).to(dev)
     with A.AerialGridMap(st, device=dev.index) as full:
+        full.set_dsm_precision(bool(exact) or args.dsm_mode == "exact")
         A.Dsm(settings, full).process(cloud, full)
         want = full.get("elevation")
     worst, nan_equal, cells = 0.0, True, 0
@@ -225,7 +313,52 @@ def verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world,
             worst = max(worst, float(np.abs(got[ok].astype(np.float64) - ref[ok]).max()))
         cells += int(got.size)
     return {"windows": world, "cells": cells, "nan_pattern_equal": nan_equal,
-            "max_abs_err_m_vs_single_gpu": worst, "pass": bool(nan_equal and worst <= 1e-4)}
+            "max_abs_err_m_vs_single_gpu": worst,
+            "pass": bool(nan_equal and worst <= (1e-6 if exact else 1e-4))}
+
+
+def preflight_verify(args, A, tiling, synth, dist, one_gpu, dev, local_rank, rank, world, stream,
+                     tiles_i, tiles_j):
+    """A small tiled DSM (the timed steps' own code path: TiledDsm over the process group, same
+    window layout) whose windows are gathered on rank 0 and compared with ONE single-GPU DSM of
+    the gathered cloud: proves on the spot that the collective ran over `world` ranks and
+    delivered the halo rows.  ~0.2 s; reported as `preflight`."""
+    import torch
+    side, res, n_all = 2048, 0.25, 2_000_000
+    layout = tiling.TileLayout(side, side, tiles_i, tiles_j)
+    st = A.GridMapSettings(0.0, 0.0, side * res, side * res, res)
+    win = layout.window(rank)
+    with A.AerialGridMap(st, device=local_rank, window=win) as pm:
+        pm.set_stream(stream.cuda_stream)
+        pm.set_dsm_precision(True)          # FP64: windows == full map to the last bit but the sum order
+        pts_all = synth.make_points_torch(n_all // world, side * res / 2.0, 900 + rank, dev)
+        cx, cy = tiling.cell_coords(pts_all, pm.grid)
+        own = tiling.owner_mask(cx, cy, win)
+        # every rank keeps what it owns of ITS slice and ships the rest to the owners the plain
+        # way first (route_points, everything moves once) -- the cloud is generated unpartitioned
+        kept = tiling.route_points(pts_all, pm.grid, layout, rank, map_=pm, assume_owned=False,
+                                   comm=tiling.TorchComm(via_host=True) if one_gpu else None)
+        cxx, cyy = tiling.cell_coords(kept, pm.grid)
+        kept = kept[tiling.owner_mask(cxx, cyy, win)].contiguous()
+        n_own = int(kept.shape[0])
+        dens = n_all / float(side * res * side * res)
+        cap = tiling.halo_strip_rows(dens, side * res, 1, res)
+        buf = torch.empty((n_own + tiling.MAX_DESTS * cap, 3), dtype=torch.float64, device=dev)
+        buf[:n_own] = kept
+        settings = A.DsmSettings(interpolation_radius=1)
+        td = tiling.TiledDsm(settings, pm, layout, rank, cap,
+                             comm=tiling.TorchComm(via_host=True) if one_gpu else None)
+        pm.reset()
+        td.process(buf, n_own, sync=True)
+        v = verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, pm, kept,
+                           settings, exact=True)
+    del own, cx, cy
+    if rank != 0:
+        return {"pass": True}
+    v["neighbours_of_rank0"] = td.nbrs
+    v["halo_rows_per_neighbour"] = cap
+    v["map"] = "%dx%d cells, %d points, %d x %d windows" % (side, side, n_all, tiles_i, tiles_j)
+    return v
 
 
 def main():
@@ -290,6 +423,8 @@ def main():
     m.set_stream(stream.cuda_stream)
     if args.knn:
         m.set_dsm_knn(args.knn)
+    # the gather's arithmetic in the timed steps (the library's own default is EXACT since round 3)
+    m.set_dsm_precision(args.dsm_mode == "exact")
     # centre of this rank's window in map coordinates (x decreases with i, y with j)
     tile_center = (ox + Lx / 2.0 - (win[0] + win[2] / 2.0) * res,
                    oy + Ly / 2.0 - (win[1] + win[3] / 2.0) * res)
@@ -376,6 +511,33 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---- N > 1: who is here, and does the exchange deliver?  (self-proving first run) ----------
+    ranks_info = preflight = None
+    if dist is not None:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index,
+                "device_name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+                "uuid": str(getattr(props, "uuid", "")), "host": os.uname().nodename,
+                "visible": os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("ROCR_VISIBLE_DEVICES"))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        ranks_info = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(),
+                      "ranks": gathered,
+                      "distinct_devices": len(set((g["host"], g["device_index"], g["uuid"]) for g in gathered))}
+        if not args.no_preflight:
+            preflight = preflight_verify(args, A, tiling, synth, dist, one_gpu, dev, local_rank, rank,
+                                         world, stream, layout.tiles_i, layout.tiles_j)
+            if rank == 0 and not preflight["pass"]:
+                print(json.dumps({"error": "preflight: the tiled DSM does not reproduce the single-GPU "
+                                           "result", "preflight": preflight, "ranks": ranks_info}))
+                sys.stdout.flush()
+            ok = torch.tensor([1 if (rank != 0 or preflight["pass"]) else 0], dtype=torch.int32,
+                              device="cpu" if one_gpu else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                dist.destroy_process_group()
+                raise SystemExit(3)
+
     for _ in range(args.warmup):
         step()
     m.synchronize()  # also surfaces device-side CHECK failures
@@ -400,6 +562,24 @@ def main():
     if args.verify and world > 1:
         verify = verify_windows(args, A, tiling, dist, one_gpu, dev, st, layout, rank, world, m, pts,
                                 dsm.settings)
+
+    def timed_loop(nsteps, nwarm):
+        """(N = 1 extras) nwarm + nsteps more steps with the current settings -> (s per step, kernel ms)"""
+        for _ in range(nwarm):
+            step()
+        m.synchronize()
+        m.enable_timing(True)
+        m.timing_reset()
+        torch.cuda.synchronize()
+        t0x = time.perf_counter()
+        for _ in range(nsteps):
+            step()
+        torch.cuda.synchronize()
+        dtx = time.perf_counter() - t0x
+        m.synchronize()
+        kt = m.kernel_times()
+        m.enable_timing(False)
+        return dtx / nsteps, {k: v[0] / nsteps for k, v in kt.items() if v[1]}
 
     cells = win[2] * win[3] if not fixed else side * side // world   # per rank (reported)
     cells_all = rows_all * cols_all
@@ -461,9 +641,15 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong" if fixed else "weak", "vs_baseline": None,
             "dtype": "f64 (decisions, staging, mosaic) + f32 (DSM pair arithmetic under exact guards)"
-            if not os.environ.get("AMHIP_DSM_EXACT") else "f64", "data": "synthetic" if not one_gpu else
+            if args.dsm_mode == "fast" else "f64", "data": "synthetic" if not one_gpu else
             "synthetic; REHEARSAL: %d ranks on one GPU over gloo, not a measurement" % world,
-            "config": {"workload": args.workload + ": " + wl["desc"],
+            "config": {"workload": args.workload + ": " + (wl["desc"].replace("8UC1", "8UC3 (colored_ortho)")
+                                                          if args.colored else wl["desc"]),
+                       "dsm_mode": {"fast": "AMHIP_DSM_FAST (opt-in: single precision under exact guards, "
+                                            "heights within the north_star's 1e-4 m; the library's "
+                                            "default mode is timed beside it: exact_mode)",
+                                    "exact": "AMHIP_DSM_EXACT (the library's default: FP64, the "
+                                             "reference's floats)"}[args.dsm_mode],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
                                "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
@@ -485,6 +671,28 @@ def main():
             "kernels": kern,
             "dsm_stats": m.dsm_stats(),
         }
+        # counter traffic can only be >= what the kernel must move: a smaller figure is a broken
+        # summary (round 2: every entry halved), refused rather than printed
+        tr = out["roofline"]["traffic"]
+        if tr is not None:
+            if tr < 0.9 * alg_bytes[dom]:
+                out["roofline"]["traffic"] = None
+                out["roofline"]["traffic_rejected"] = ("%s reports %d B for %s, below 0.9 x the algorithmic "
+                                                       "%d B: not credible" % (traffic_src, tr, dom, int(alg_bytes[dom])))
+            else:
+                out["roofline"]["traffic_over_algorithmic"] = round(tr / alg_bytes[dom], 3)
+        if traffic:
+            step_traffic = float(sum(traffic.values()))
+            if step_traffic >= 0.9 * total_alg:
+                out["whole_step_hbm"]["traffic"] = int(step_traffic)
+                out["whole_step_hbm"]["traffic_over_algorithmic"] = round(step_traffic / total_alg, 3)
+                out["whole_step_hbm"]["traffic_source"] = traffic_src
+        if ranks_info is not None:
+            out["ranks"] = ranks_info
+        if preflight is not None:
+            out["preflight"] = preflight
+        if world == 1:
+            out["path"] = "single context (no collective): the N = 1 point of the scaling sweep is this line"
         if batch:
             out["config"]["step"] = ("OrthoBackwardGrid::process of one %d-frame batch onto the resident "
                                      "layers (the DSM was built once before the timed steps)" % batch)
@@ -519,20 +727,55 @@ def main():
         parity_done = False
         if world == 1 and not args.no_cpu_baseline and not fixed:
             # (before anything else runs: the layers still hold the result of the TIMED steps)
+            refs = None
             try:
-                cb, parity = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
+                refs, cb = cpu_baseline(args, wl, m, pts, frames, poses, ncam, tile_center)
+                parity = parity_against(refs, args, m, poses, ncam, F)
                 parity["pass"] = "timed"
+                parity["dsm_mode"] = args.dsm_mode
                 out["cpu_baseline"] = cb
                 out["parity_sample"] = parity
             except Exception as e:  # the GPU number stands on its own
                 out["cpu_baseline"] = {"error": repr(e)}
             parity_done = True
+            if not args.no_second_mode and not args.knn:
+                # the OTHER arithmetic mode, driver-timed in the same run
+                other = "exact" if args.dsm_mode == "fast" else "fast"
+                m.set_dsm_precision(other == "exact")
+                k2 = max(3, min(args.steps, 10))
+                sec, kms = timed_loop(k2, 2)
+                om = {"dsm_mode": other, "steps": k2, "ms_per_step": round(sec * 1e3, 3),
+                      "Mcells_per_s": round(cells_all / sec / 1e6, 1),
+                      "gather_ms": round(kms.get("k_dsm_gather", 0.0), 4),
+                      "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+                if refs is not None:
+                    try:
+                        om["parity_sample"] = parity_against(refs, args, m, poses, ncam, F)
+                    except Exception as e:
+                        om["parity_sample"] = {"error": repr(e)}
+                out[other + "_mode"] = om
+                m.set_dsm_precision(args.dsm_mode == "exact")
+                # what a host that never touches the switch gets for the byte-exact half
+                dflt = out.get("exact_mode", {}).get("parity_sample") if args.dsm_mode == "fast" \
+                    else out.get("parity_sample")
+                if dflt and F:
+                    key = ("colored_ortho" if args.colored else "ortho") + "_mismatch_cells"
+                    out["ortho_mismatch_cells_default_mode"] = dflt.get(key)
+                    out["ortho_mismatch_cells_fast_mode"] = (
+                        out["parity_sample"] if args.dsm_mode == "fast" else om.get("parity_sample", {})).get(key)
+            del refs
+        if world == 1 and not fixed and not args.no_rough_terrain and not args.knn and not batch:
+            try:
+                out["rough_terrain"] = rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L)
+            except Exception as e:
+                out["rough_terrain"] = {"error": repr(e)}
         if world == 1 and args.host_path and not fixed:
             # the reference-shaped call, as the C++ drop-in classes make it: cloud, frames and
             # the GridMap's six matrices in (pageable) host memory, one amhip_session per map
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None
             with A.HostSession(st) as hs:
+                hs.set_dsm_precision(args.dsm_mode == "exact")
                 warm = A.HostSession(A.GridMapSettings(ox, oy, 64 * res, 32 * res, res))
                 warm.dsm_process(dsm.settings, h_pts[:4096])   # (loads the code objects)
                 warm.close()
@@ -558,6 +801,7 @@ def main():
                 "second_pass_ms": round((t4h - t2h) * 1e3, 1),
                 "bytes_up": bytes_up, "bytes_down": bytes_down,
                 "link_floor_ms": round((bytes_up + bytes_down) / 56e9 * 1e3, 1),
+                "dsm_mode": args.dsm_mode,
                 "note": "amhip_session_dsm_process + amhip_session_ortho_backward_process on pageable "
                         "host buffers (the drop-in classes' route): cloud + frames up, the matrices "
                         "that changed down (elevation, elevation_angle, observation_index, ortho); "

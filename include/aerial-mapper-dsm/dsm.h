@@ -27,6 +27,13 @@ struct Settings {
   bool use_multi_threads = true;  // both reference variants give one result
 };
 
+// EXTENSION (not in the reference): arithmetic of the GPU gather, per Dsm object.
+//   kReferenceIdentical  (default) FP64 everywhere: the reference's floats, deterministic.
+//   kFast                single precision under exact guards: same neighbour sets and NaN
+//                        pattern, heights within 1e-4 m of the reference's (aerial_mapper_hip.h:
+//                        AMHIP_DSM_FAST), ~0.6 ms less per 100 M cells.
+enum class Precision { kReferenceIdentical = 1, kFast = 0 };
+
 class Dsm {
  public:
   EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -41,11 +48,17 @@ class Dsm {
   void process(const AlignedType<std::vector, Eigen::Vector3d>::type& point_cloud,
                grid_map::GridMap* map);
 
+  // EXTENSION: see Precision.  Starts as kReferenceIdentical unless the environment says
+  // AMHIP_DSM_FAST=1 (hosts that cannot be recompiled); applies to this object's process() calls.
+  void setPrecision(Precision precision);
+  Precision precision() const { return precision_; }
+
  private:
   void ensureSession(const grid_map::GridMap& map);
   void printParams();
 
   Settings settings_;
+  Precision precision_;
   // the map's session (device windows + resident layers), shared with the other drop-in
   // objects working on the same grid_map::GridMap (aerial_mapper_amd/cpp/shim_common.cc)
   amhip_session* session_;

@@ -18,6 +18,17 @@
 
 #include "aerial-mapper-deps.h"
 #include "aerial-mapper-io/aerial-mapper-io.h"
+// The reference's header brings <ros/ros.h> and glog in (ortho-forward-homography.h:26, via the
+// aslam headers), and main-ortho-forward-homography.cc:47,65 relies on that (ros::init, CHECK):
+// a host that has them gets them here too.
+#if defined(__has_include)
+#if __has_include(<ros/ros.h>)
+#include <ros/ros.h>
+#endif
+#if __has_include(<glog/logging.h>)
+#include <glog/logging.h>
+#endif
+#endif
 
 struct amhip_mosaic;
 

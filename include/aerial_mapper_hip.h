@@ -145,13 +145,24 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
 int amhip_ctx_set_stream(amhip_ctx* ctx, void* hip_stream);
 
 /* Arithmetic of the DSM gather (dsm::Dsm::process, dsm.cc:160-172).
- *   AMHIP_DSM_FAST  (default) single-precision distances and weights under exact guards:
- *                   the reference's neighbour sets (any decision within 2e-6 of the radius is
- *                   taken in its own doubles), identical NaN pattern, heights within the
- *                   contract's 1e-4 m (1 float spacing above 1024 m) by a per-tile error
- *                   bound; tiles / cells without room under the bound take the FP64 path;
- *   AMHIP_DSM_EXACT the FP64 gather everywhere (bit-identical floats in every test so far).
- * The environment variable AMHIP_DSM_EXACT=1 makes EXACT the default of new contexts. */
+ *   AMHIP_DSM_EXACT (DEFAULT since round 3) the FP64 gather everywhere: the reference's doubles
+ *                   decide and weigh every pair, only the ORDER of the double sums differs from
+ *                   the kd-tree's (1e-16 relative, then rounded to float): bit-identical floats
+ *                   in every test so far, deterministic from run to run, and therefore a
+ *                   byte-identical mosaic on top of it.  What a drop-in must be by default.
+ *   AMHIP_DSM_FAST  (opt-in) single-precision distances and weights under exact guards: the
+ *                   reference's neighbour sets (any decision within 2e-6 of the radius is taken
+ *                   in its own doubles), identical NaN pattern, heights within the contract's
+ *                   1e-4 m (1 float spacing above 1024 m) by a per-tile error bound; tiles /
+ *                   cells without room under the bound take the FP64 path.  ~0.6 ms faster per
+ *                   100 M cells; heights may differ from the reference's by one float spacing
+ *                   and from run to run (the f32 sums follow the order the atomics of the
+ *                   binning left the points in), so a mosaic on top of them can differ in the
+ *                   rare cell whose keypoint sits on a pixel boundary.
+ * New contexts start in EXACT; the environment variable AMHIP_DSM_FAST=1 makes FAST their
+ * default (hosts that cannot be recompiled), AMHIP_DSM_EXACT=1 (round 2's switch) still forces
+ * EXACT.  The setters override either.  amhip_session_set_dsm_precision applies to every window
+ * of a session (the drop-in dsm::Dsm::setPrecision calls it). */
 #define AMHIP_DSM_FAST 0
 #define AMHIP_DSM_EXACT 1
 int amhip_ctx_set_dsm_precision(amhip_ctx* ctx, int mode);
@@ -515,6 +526,7 @@ int amhip_session_num_windows(const amhip_session* s);
 amhip_ctx* amhip_session_context(amhip_session* s, int window);
 int amhip_session_window(const amhip_session* s, int window, int32_t* i0_j0_rows_cols);
 int amhip_session_set_always_copy(amhip_session* s, int on);
+int amhip_session_set_dsm_precision(amhip_session* s, int mode);  /* AMHIP_DSM_FAST / _EXACT */
 /* dsm::Dsm::process (dsm.cc:186-201): `elevation` = the GridMap's matrix (map rows x cols,
  * column-major), read and written like the reference does. */
 int amhip_session_dsm_process(amhip_session* s, const double* host_xyz, size_t n, int radius_sq,
@@ -545,6 +557,15 @@ const char* amhip_kernel_name(int kernel);
  * filter, number of bins, bin edge in cells. */
 int amhip_ctx_dsm_stats(amhip_ctx* ctx, int64_t* points_binned,
                         int64_t* num_bins, int32_t* bin_cells);
+
+/* Where the gather tiles of the last amhip_dsm_process* went (synchronises): out8[0..6] = tiles
+ * on the lists of the tiled gather -- [0] occupied class-0 tiles (sparse calls only), [1] / [2]
+ * capacity classes 1 / 2 (denser than the main launch's LDS image), [3] beyond any LDS image
+ * (wave-per-block kernel), [4] / [5] tiles the single-precision gather handed to the FP64 kernel
+ * (height range leaves no room under the 1e-4 m error bound: rough terrain), [6] those beyond
+ * its largest image -- and out8[7] = tiles of the map.  All zero when the LDS-tiled gather was
+ * not used. */
+int amhip_ctx_dsm_gather_stats(amhip_ctx* ctx, int64_t* out8);
 
 /* The session's map as a grid_map_msgs/GridMap message (ROS 1 wire format): the resident layers
  * travel from the devices straight into `out`.  layer_ids[l] = the amhip layer behind message

@@ -80,7 +80,10 @@ class AerialMapperIO {
 #endif
   }
 
-  void loadImagesFromFile(const std::string& filename_base, size_t num_poses, Images* images) {
+  // (load_colored_images: the reference's imread flag, aerial-mapper-io.h:34-35; the test's PGM /
+  // PPM files carry their own channel count)
+  void loadImagesFromFile(const std::string& filename_base, size_t num_poses, Images* images,
+                          bool /*load_colored_images*/ = false) {
     for (size_t i = 0; i < num_poses; ++i) {
       const std::string name = filename_base + std::to_string(i) + ".jpg";
       FILE* f = std::fopen(name.c_str(), "rb");
@@ -104,6 +107,21 @@ class AerialMapperIO {
     }
   }
 
+  // aerial-mapper-io.h:47-50 (main-ortho-from-pcl.cc:104-105)
+  void loadPointCloudFromFile(const std::string& filename,
+                              AlignedType<std::vector, Eigen::Vector3d>::type* point_cloud_xyz,
+                              std::vector<int>* point_cloud_intensities) {
+    std::ifstream in(filename);
+    if (!in) die("point cloud", filename);
+    double x, y, z;
+    int intensity;
+    while (in >> x >> y >> z >> intensity)
+      if (z > -100.0) {
+        point_cloud_xyz->push_back(Eigen::Vector3d(x, y, z));
+        point_cloud_intensities->push_back(intensity);
+      }
+  }
+
   void loadPointCloudFromFile(const std::string& filename,
                               AlignedType<std::vector, Eigen::Vector3d>::type* point_cloud_xyz) {
     std::ifstream in(filename);
@@ -122,4 +140,30 @@ class AerialMapperIO {
 };
 
 }  // namespace io
+
+#ifdef DEMOKIT_REF
+// main-ortho-forward-homography.cc has no map to publish: what the reference's class hands to
+// cv::imwrite (refkit keeps the last one: cv::last_written()) is written to
+// $AMHIP_DEMO_OUT/mosaic.i16 (rows cols channels in mosaic_shape.txt) when the process ends.
+namespace demokit {
+struct MosaicDumper {
+  MosaicDumper() { (void)cv::last_written(); }  // (constructed first => destroyed after this)
+  ~MosaicDumper() {
+    const char* dir = std::getenv("AMHIP_DEMO_OUT");
+    const cv::Mat& m = cv::last_written();
+    if (!dir || m.rows <= 0 || m.cols <= 0 || m.type() != CV_16SC3) return;
+    FILE* f = std::fopen((std::string(dir) + "/mosaic.i16").c_str(), "wb");
+    if (!f) return;
+    for (int r = 0; r < m.rows; ++r) std::fwrite(m.ptr<int16_t>(r), 2, 3 * static_cast<size_t>(m.cols), f);
+    std::fclose(f);
+    f = std::fopen((std::string(dir) + "/mosaic_shape.txt").c_str(), "w");
+    if (f) {
+      std::fprintf(f, "%d %d 3\n", m.rows, m.cols);
+      std::fclose(f);
+    }
+  }
+};
+static MosaicDumper g_mosaic_dumper;
+}  // namespace demokit
+#endif
 #endif  // ORACLE_DEMOKIT_IO_H_

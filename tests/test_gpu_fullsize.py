@@ -19,6 +19,7 @@ def world():
     dev = torch.device("cuda", 0)
     L = SIDE * RES
     m = A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, RES))
+    m.set_dsm_precision(False)   # the opt-in single-precision gather (bench.py's headline mode)
     pts = synth.make_points_torch(NPTS, L / 2.0 + 4.0, 143, dev)
     frames = synth.make_frames_torch(F, H, W, 1, 144, dev)
     poses = synth.make_lawnmower_poses(F, L / 2.0, 700.0, 144, tilt_deg=5.0)

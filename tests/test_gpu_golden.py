@@ -15,18 +15,26 @@ def _map(A, d):
     return A.AerialGridMap(A.GridMapSettings(px, py, lx, ly, res))
 
 
+@pytest.mark.parametrize("mode", ["default", "fast"])
 @pytest.mark.parametrize("name", G.names("dsm"))
-def test_hip_dsm_matches_golden(name):
+def test_hip_dsm_matches_golden(name, mode):
+    """default = AMHIP_DSM_EXACT (what a new map / the drop-in classes start in): the reference's
+    floats, >= 99.9 % of the cells bit for bit (only the order of the double sums may move a
+    value that sits on a float rounding boundary); fast (opt-in): within the contract's 1e-4 m."""
     import aerial_mapper_amd as A
     d = G.load(name)
     with _map(A, d) as m:
+        if mode == "fast":
+            m.set_dsm_precision(False)
         if d["elevation_init"].size:
             m.set("elevation", d["elevation_init"])
         st = A.DsmSettings(int(d["radius_sq"]), False, float(d["center_easting"]),
                            float(d["center_northing"]))
         A.Dsm(st, m).process(d["points"], m)
         got = m.get("elevation")
-    S.assert_dsm_close(got, d["elevation"], tol=1e-4)
+    same = S.assert_dsm_close(got, d["elevation"], tol=1e-4 if mode == "fast" else 1e-6)
+    if mode == "default":
+        assert same >= 0.999, same
 
 
 @pytest.mark.parametrize("name", G.names("ortho"))

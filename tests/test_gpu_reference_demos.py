@@ -21,6 +21,12 @@ LAYERS = ["ortho", "elevation", "elevation_angle", "num_observations", "observat
 CE, CN, DE, DN, RES = 12.0, -7.0, 100.0, 80.0, 0.5
 W, H, F = 160, 120, 9
 
+MORE = ("demo_incremental_ref", "demo_incremental_dropin", "demo_forward_ref", "demo_forward_dropin",
+        "demo_frompcl_ref", "demo_frompcl_dropin")
+needs_more_demos = pytest.mark.skipif(
+    not all(os.path.exists(os.path.join(REFDIR, n)) for n in MORE),
+    reason="oracle/_ref/demo_{incremental,forward,frompcl}_* not built (needs /root/reference at build time)")
+
 needs_demos = pytest.mark.skipif(
     not all(os.path.exists(os.path.join(REFDIR, n)) for n in
             ("demo_dsm_ref", "demo_ortho_ref", "demo_dsm_dropin", "demo_ortho_dropin")),
@@ -58,11 +64,14 @@ def _write_dataset(d):
 def _run(exe, flags, outdir, env_extra=None):
     os.makedirs(outdir, exist_ok=True)
     env = dict(os.environ, AMHIP_DEMO_OUT=outdir)
-    env.pop("AERIAL_MAPPER_HIP_DEVICES", None)
+    for k in ("AERIAL_MAPPER_HIP_DEVICES", "AMHIP_DSM_FAST", "AMHIP_DSM_EXACT"):
+        env.pop(k, None)
     env.update(env_extra or {})
     r = subprocess.run([os.path.join(REFDIR, exe)] + flags, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
+    if not os.path.exists(os.path.join(outdir, "shape.txt")):
+        return None        # (a main without a map to publish: the forward mosaic)
     rows, cols = (int(v) for v in open(os.path.join(outdir, "shape.txt")).read().split())
     return {n: np.fromfile(os.path.join(outdir, n + ".f32"), np.float32).reshape(cols, rows)
             for n in LAYERS}
@@ -127,8 +136,8 @@ def test_reference_demo_binaries_run_on_the_cpu(tmp_path):
 
 @needs_demos
 @pytest.mark.gpu
-@pytest.mark.parametrize("env,exact", [({"AMHIP_DSM_EXACT": "1"}, True), ({}, False),
-                                       ({"AMHIP_DSM_EXACT": "1", "AERIAL_MAPPER_HIP_DEVICES": "0,0,0"}, True)])
+@pytest.mark.parametrize("env,exact", [({}, True), ({"AMHIP_DSM_FAST": "1"}, False),
+                                       ({"AERIAL_MAPPER_HIP_DEVICES": "0,0,0"}, True)])
 def test_unchanged_demo_mains_leave_the_same_map_on_the_drop_in(tmp_path, env, exact):
     d = str(tmp_path)
     _write_dataset(d)
@@ -141,3 +150,153 @@ def test_unchanged_demo_mains_leave_the_same_map_on_the_drop_in(tmp_path, env, e
     want = _run("demo_ortho_ref", _ortho_flags(d), os.path.join(d, "ref_ortho"))
     got = _run("demo_ortho_dropin", _ortho_flags(d), os.path.join(d, "gpu_ortho"), env)
     _compare(got, want, exact)
+
+
+# ---- the other three mains of aerial_mapper_demos/src/ortho ---------------
+
+def _incremental_flags(d):
+    return [f for f in _ortho_flags(d) if not f.startswith(("--load_point_cloud_from_file",
+                                                            "--point_cloud_filename"))] + \
+        ["--dense_pcl_use_every_nth_image=1"]
+
+
+def _write_stereo_clouds(d):
+    """One cloud per stereo pair k = 1 .. F-1 (what stereo::Stereo::addFrame would hand back,
+    main-ortho-backward-grid-incremental.cc:143-146): the points of cloud.txt within 32 m of the
+    k-th camera, in the file's coordinates (dsm.cc:42-43's offsets already folded in)."""
+    pts = np.loadtxt(os.path.join(d, "cloud.txt"))[:-1, :3]
+    poses = np.loadtxt(os.path.join(d, "poses.txt"))
+    for k in range(1, F):
+        # undo the fold for the distance test: file x = map x + CN, file y = map y + CE
+        dx, dy = pts[:, 0] - CN - poses[k, 0], pts[:, 1] - CE - poses[k, 1]
+        sel = pts[dx * dx + dy * dy < 32.0 ** 2]
+        if k == 5:
+            sel = sel[:0]           # an empty pair: "Passed empty point cloud to DSM module"
+        with open(os.path.join(d, "stereo_%d.txt" % k), "w") as f:
+            for p in sel:
+                f.write("%.17g %.17g %.17g\n" % tuple(p))
+
+
+@needs_more_demos
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,exact", [({}, True), ({"AMHIP_DSM_FAST": "1"}, False),
+                                       ({"AERIAL_MAPPER_HIP_DEVICES": "0,0"}, True)])
+def test_unchanged_incremental_main_leaves_the_same_map_on_the_drop_in(tmp_path, env, exact):
+    """main-ortho-backward-grid-incremental.cc:64-169 -- BASELINE configs[4]'s call sequence:
+    per stereo pair Dsm::process of that pair's cloud onto the persistent elevation layer, then
+    OrthoBackwardGrid::process of the images since the last pair onto the persistent angle /
+    index / ortho layers, then publishOnce.  The session's residency logic (what is still on the
+    device, what the host changed) is what this exercises."""
+    d = str(tmp_path)
+    _write_dataset(d)
+    _write_stereo_clouds(d)
+    e = dict(env, AMHIP_DEMO_STEREO_PREFIX=os.path.join(d, "stereo_"), AMHIP_DEMO_KEEP_RUNNING="1")
+    want = _run("demo_incremental_ref", _incremental_flags(d), os.path.join(d, "ref_inc"), e)
+    got = _run("demo_incremental_dropin", _incremental_flags(d), os.path.join(d, "gpu_inc"), e)
+    assert (~np.isnan(want["elevation"])).mean() > 0.5 and np.isnan(want["elevation"]).any()
+    _compare_partial(got, want, exact)
+
+
+def _compare_partial(got, want, exact):
+    """_compare for a map the clouds cover only partly."""
+    ge, we = got["elevation"], want["elevation"]
+    assert np.array_equal(np.isnan(ge), np.isnan(we))
+    ok = ~np.isnan(we)
+    err = float(np.abs(ge[ok].astype(np.float64) - we[ok]).max())
+    assert err <= (1e-6 if exact else 1e-4), err
+    assert (~np.isnan(want["observation_index"])).mean() > 0.2
+    if _same_bits(ge, we).all():
+        for n in LAYERS:
+            assert _same_bits(got[n], want[n]).all(), n
+    else:
+        assert not exact or _same_bits(ge, we).mean() > 0.999
+        for n in ("num_observations", "observation_index", "ortho", "colored_ortho"):
+            assert (~_same_bits(got[n], want[n])).mean() < 1e-3, n
+
+
+def _forward_flags(d, batch):
+    return ["--forward_homography_data_directory=" + d + "/", "--forward_homography_filename_camera_rig=rig.txt",
+            "--forward_homography_filename_poses=poses.txt", "--forward_homography_prefix_images=img_",
+            "--forward_homography_origin_easting_m=%r" % CE, "--forward_homography_origin_northing_m=%r" % CN,
+            "--forward_homography_origin_elevation_m=0", "--forward_homography_ground_plane_elevation_m=400",
+            "--forward_homography_width_mosaic_pixels=240", "--forward_homography_height_mosaic_pixels=200",
+            "--forward_homography_batch=%s" % ("true" if batch else "false")]
+
+
+@needs_more_demos
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [True, False])
+def test_unchanged_forward_homography_main_writes_the_same_mosaic(tmp_path, batch):
+    """main-ortho-forward-homography.cc:80-102: OrthoForwardHomography::batch /
+    ::updateOrthomosaic per image.  Reference side: the reference's class over refkit's restated
+    OpenCV (what it hands to cv::imwrite); drop-in: the GPU mosaic, written where the reference
+    writes (Settings::filename_mosaic_output, here its default) as a PPM.  (The OpenCV pieces
+    themselves stay "parity unpinned".)"""
+    d = str(tmp_path)
+    _write_dataset(d)
+    out = "/tmp/result.jpg.ppm"       # ortho::Settings::filename_mosaic_output's default + ".ppm"
+    if os.path.exists(out):
+        os.remove(out)
+    assert _run("demo_forward_ref", _forward_flags(d, batch), os.path.join(d, "ref_fwd")) is None
+    rows, cols, ch = (int(v) for v in open(os.path.join(d, "ref_fwd", "mosaic_shape.txt")).read().split())
+    want = np.fromfile(os.path.join(d, "ref_fwd", "mosaic.i16"), np.int16).reshape(rows, cols, ch)
+    assert (rows, cols, ch) == (200, 240, 3) and (want != 0).mean() > 0.2
+    _run("demo_forward_dropin", _forward_flags(d, batch), os.path.join(d, "gpu_fwd"))
+    raw = open(out, "rb").read()
+    os.remove(out)
+    head = b"P6\n240 200\n255\n"
+    assert raw.startswith(head)
+    got = np.frombuffer(raw, np.uint8, rows * cols * 3, len(head)).reshape(rows, cols, 3)
+    assert np.array_equal(got, np.clip(want, 0, 255).astype(np.uint8))
+
+
+def _frompcl_flags(d, adaptive):
+    return ["--data_directory=" + d + "/", "--filename_camera_rig=rig.txt", "--filename_poses=poses.txt",
+            "--prefix_images=img_", "--load_point_cloud_from_file=true",
+            "--filename_point_cloud=" + os.path.join(d, "cloud.txt"),
+            "--ortho_from_pcl_center_easting=%r" % CE, "--ortho_from_pcl_center_northing=%r" % CN,
+            "--ortho_from_pcl_delta_easting=%r" % DE, "--ortho_from_pcl_delta_northing=%r" % DN,
+            "--ortho_from_pcl_resolution=%r" % RES, "--ortho_from_pcl_interpolation_radius=2",
+            "--ortho_from_pcl_show_orthomosaic_opencv=false",
+            "--ortho_from_pcl_use_adaptive_interpolation=%s" % ("true" if adaptive else "false")]
+
+
+@needs_more_demos
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_unchanged_ortho_from_pcl_main_leaves_the_same_map_on_the_drop_in(tmp_path, adaptive):
+    """main-ortho-from-pcl.cc:59-148 with --load_point_cloud_from_file (no centre offsets here:
+    ortho-from-pcl.cc:30-31, so the cloud covers the map only partly -- the rest stays 255, or is
+    reached by the x10 / x100 retries when adaptive)."""
+    d = str(tmp_path)
+    _write_dataset(d)
+    want = _run("demo_frompcl_ref", _frompcl_flags(d, adaptive), os.path.join(d, "ref_pcl"))
+    got = _run("demo_frompcl_dropin", _frompcl_flags(d, adaptive), os.path.join(d, "gpu_pcl"))
+    a, b = got["ortho"], want["ortho"]
+    assert ((a == 255.0) == (b == 255.0)).all()
+    assert (b != 255.0).mean() > (0.95 if adaptive else 0.5)
+    assert np.abs(a.astype(np.float64) - b).max() <= 1e-3        # intensities 0 .. 255
+    for n in LAYERS:
+        if n != "ortho":                                          # untouched by this path
+            assert _same_bits(got[n], want[n]).all(), n
+
+
+@needs_more_demos
+def test_more_reference_demo_binaries_run_on_the_cpu(tmp_path):
+    """(no GPU) the reference-side executables of the three mains alone."""
+    d = str(tmp_path)
+    _write_dataset(d)
+    _write_stereo_clouds(d)
+    e = dict(AMHIP_DEMO_STEREO_PREFIX=os.path.join(d, "stereo_"), AMHIP_DEMO_KEEP_RUNNING="1")
+    inc = _run("demo_incremental_ref", _incremental_flags(d), os.path.join(d, "ref_inc"), e)
+    full = _run("demo_ortho_ref", _ortho_flags(d), os.path.join(d, "ref_ortho"))
+    # the incremental map is the batch map wherever a stereo cloud reached, NaN elsewhere
+    cov = ~np.isnan(inc["elevation"])
+    assert 0.5 < cov.mean() < 1.0 and (~np.isnan(inc["observation_index"])).mean() > 0.2
+    # (cells at the rim of a patch see only part of their neighbourhood: close, not equal)
+    dz = np.abs(inc["elevation"][cov] - full["elevation"][cov])
+    assert dz.max() < 2.0 and np.median(dz) < 1e-3
+    assert _run("demo_forward_ref", _forward_flags(d, True), os.path.join(d, "ref_fwd")) is None
+    assert os.path.getsize(os.path.join(d, "ref_fwd", "mosaic.i16")) == 200 * 240 * 3 * 2
+    pcl = _run("demo_frompcl_ref", _frompcl_flags(d, False), os.path.join(d, "ref_pcl"))
+    assert 0.5 < (pcl["ortho"] != 255.0).mean() < 1.0

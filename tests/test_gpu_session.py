@@ -62,6 +62,7 @@ def test_session_fast_mode_two_windows_within_the_contract():
     sc = S.Scene(160.0, 128.0, 0.25, 400000, seed=402, num_frames=6)
     want = _oracle(sc)
     with A.HostSession(_settings(A, sc.grid), tiles=(2, 1)) as hs:
+        hs.set_dsm_precision(False)    # amhip_session_set_dsm_precision(AMHIP_DSM_FAST): opt-in
         hs.dsm_process(A.DsmSettings(1), sc.points)
         S.assert_dsm_close(hs.layers["elevation"], want["elevation"], tol=1e-4)
 

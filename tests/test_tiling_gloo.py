@@ -145,7 +145,7 @@ def _worker_neighbours(rank, world, port, tiles, ret):
         own_mask = tiling.owner_mask(cx, cy, layout.window(rank))
         margin = tiling.halo_margin(1, g.resolution)
         mc = margin / g.resolution
-        nbrs = tiling.neighbours(layout, rank, mc + 1.0)
+        nbrs = tiling.neighbours(layout, rank, margin, g.resolution)
         cap = 6000
         send = np.full((max(len(nbrs), 1) * cap, 3), np.nan)
         for k, q in enumerate(nbrs):
@@ -194,13 +194,42 @@ def test_neighbour_only_exchange_gloo(world, tiles, max_nbrs):
 def test_neighbours_of_a_node_sized_layout():
     from aerial_mapper_amd import tiling
     lay = tiling.TileLayout(40000, 40000, 2, 4)           # configs[3]: 2 x 4 windows
-    mc = tiling.halo_margin(1, 0.25) / 0.25 + 1.0
+    mm = tiling.halo_margin(1, 0.25)
     for r in range(8):
-        nb = tiling.neighbours(lay, r, mc)
+        nb = tiling.neighbours(lay, r, mm, 0.25)
         ti, tj = r % 2, r // 2
         want = sorted(q for q in range(8) if q != r and abs(q % 2 - ti) <= 1 and abs(q // 2 - tj) <= 1)
         assert nb == want and len(nb) <= tiling.MAX_DESTS
         for q in nb:                                       # symmetric
-            assert r in tiling.neighbours(lay, q, mc)
+            assert r in tiling.neighbours(lay, q, mm, 0.25)
     strip = tiling.TileLayout(80000, 10000, 8, 1)          # the weak-scaling strip of bench.py
-    assert [len(tiling.neighbours(strip, r, mc)) for r in range(8)] == [1, 2, 2, 2, 2, 2, 2, 1]
+    assert [len(tiling.neighbours(strip, r, mm, 0.25)) for r in range(8)] == [1, 2, 2, 2, 2, 2, 2, 1]
+
+
+def test_neighbour_relation_covers_the_device_selection_at_exact_boundaries():
+    """neighbours() against the selection's own predicate (make_halo_params / k_halo_select:
+    a0 - 0.5 - mc <= cx <= a0 + ar - 0.5 + mc) for owned points sitting EXACTLY on the bounds,
+    incl. margins that are whole numbers of cells (a float margin compared with
+    integer edges)."""
+    from aerial_mapper_amd import tiling
+    for res, radius_sq in [(0.25, 1), (0.5, 1), (1.0, 9), (0.2, 4)]:
+        margin = tiling.halo_margin(radius_sq, res)
+        for margin_m in (margin, 3.0 * res, 11.0 * res):       # whole-cell margins too
+            mc = margin_m / res
+            lay = tiling.TileLayout(1024, 640, 4, 3)
+            for r in range(lay.world):
+                i0, j0, nr, nc = lay.window(r)
+                nb = set(tiling.neighbours(lay, r, margin_m, res))
+                # extreme owned positions (the half-open cell range of the window)
+                xs = [i0 - 0.5, np.nextafter(i0 + nr - 0.5, -np.inf)]
+                ys = [j0 - 0.5, np.nextafter(j0 + nc - 0.5, -np.inf)]
+                for q in range(lay.world):
+                    if q == r:
+                        continue
+                    a0, b0, ar, ac = lay.window(q)
+                    takes = any(a0 - 0.5 - mc <= x <= a0 + ar - 0.5 + mc and
+                                b0 - 0.5 - mc <= y <= b0 + ac - 0.5 + mc
+                                for x in xs + [min(max(a0 - 0.5 - mc, xs[0]), xs[1])]
+                                for y in ys + [min(max(b0 - 0.5 - mc, ys[0]), ys[1])])
+                    if takes:
+                        assert q in nb, (res, margin_m, r, q)

@@ -110,7 +110,16 @@ def main():
                           "k_dsm_p3_count" if k.startswith(("k_dsm_p3_count", "k_dsm_p3_reduce", "k_dsm_p3_scan")) else
                           "k_ortho_backward" if k.startswith("k_ortho_backward") else k)
         fetch, write = pmc_rows(a.fetch, "FETCH_SIZE"), pmc_rows(a.write, "WRITE_SIZE")
-        steps = max(c for k, (c, *_r) in fetch.items() if k.startswith("k_dsm_gather"))
+        # one bench step = ONE launch of the sort's count pass and of the main gather instance;
+        # list / dense instances of the gather launch several times per step (round 2 took the
+        # maximum over every k_dsm_gather* row and halved all entries: VERDICT r2 weak #6)
+        per_step = [c for k, (c, *_r) in fetch.items() if k.startswith("k_dsm_p3_count<")]
+        if not per_step:
+            per_step = [c for k, (c, *_r) in fetch.items()
+                        if k.startswith(("k_dsm_gather_f32<", "k_dsm_gather_tiled<"))]
+        if not per_step:
+            per_step = [c for k, (c, *_r) in fetch.items() if k.startswith("k_ortho_backward")]
+        steps = min(per_step)
         out = {}
         for k in sorted(set(fetch) | set(write)):
             fr = fetch.get(k, (0, 0.0))
