@@ -51,3 +51,48 @@ def test_four_ranks_two_by_two_windows_with_diagonal_neighbours():
     v = d["verify"]
     assert v["windows"] == 4 and v["pass"], v
     assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("one map, 2 x 2 windows")
+
+
+def test_the_line_identifies_its_ranks_and_carries_the_preflight():
+    """ the N > 1 line proves by itself who took part: the backend, the world
+    size torch.distributed reports, every rank's device, and a small verified tiled step in front
+    of the timed ones (windows == one single-GPU DSM of the gathered cloud)."""
+    d = _run(2, "small")
+    r = d["ranks"]
+    assert r["backend"] == "gloo" and r["world_size_reported"] == 2 and len(r["ranks"]) == 2
+    assert sorted(x["rank"] for x in r["ranks"]) == [0, 1]
+    assert r["distinct_devices"] == 1          # (the rehearsal: both ranks on the box's one GPU)
+    p = d["preflight"]
+    assert p["pass"] and p["windows"] == 2 and p["nan_pattern_equal"]
+    assert p["max_abs_err_m_vs_single_gpu"] <= 1e-6 and p["neighbours_of_rank0"] == [1]
+
+
+def _run_rccl(nproc, workload):
+    """One rank per DEVICE over backend nccl (= RCCL), device buffers handed to the collective."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("AMHIP_BENCH_ONE_GPU", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--workload", workload,
+           "--steps", "2", "--warmup", "1", "--verify"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_device_buffer_exchange_over_rccl_when_the_node_has_two_gpus():
+    """The device-buffer all_to_all (TorchComm(via_host=False)) over RCCL between DISTINCT devices.
+    Skipped on the 1-GPU test box; the driver's multi-GPU node runs it."""
+    import torch
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        pytest.skip("one visible device: RCCL needs one device per rank")
+    n = 4 if nd >= 4 else 2
+    d = _run_rccl(n, "small4" if n == 4 else "small")
+    r = d["ranks"]
+    assert r["backend"] == "nccl" and r["world_size_reported"] == n and r["distinct_devices"] == n
+    assert d["preflight"]["pass"] and d["verify"]["pass"], (d["preflight"], d["verify"])
+    assert "REHEARSAL" not in d["data"]
