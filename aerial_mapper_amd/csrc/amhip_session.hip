@@ -129,7 +129,9 @@ static void host_hashes(const Session& s, const float* const* mats, int nl,
   const int W = s.W(), R = s.grid.rows, Cc = s.grid.cols;
   out->assign((size_t)nl * W, Hash128());
   unsigned hw = std::thread::hardware_concurrency();
-  int T = (int)std::min<unsigned>(hw ? hw : 8u, 64u);
+  // (the non-linear mix costs three multiplies per cell: 128 threads keep the six matrices of a
+  // mosaic call -- 2.4 GB at cfg3 -- near the host's memory bandwidth)
+  int T = (int)std::min<unsigned>(hw ? hw : 8u, 128u);
   if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) T = std::max(1, std::atoi(e));
   T = std::max(1, std::min(T, Cc));
   std::vector<std::vector<Hash128>> part(T, std::vector<Hash128>((size_t)nl * W));

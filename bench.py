@@ -242,7 +242,7 @@ def rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L):
     rough[:, 2] += 25.0 * step_up.to(torch.float64)
     frac_tiles = float(chosen.double().mean().item())
     del u, v, ti, tj, h, chosen, step_up
-    res_out = {"scene": "cfg's cloud + a 25 m step through the middle of 20 % of the 64x16-cell "
+    res_out = {"scene": "cfg's cloud + a 25 m step through the middle of one in five of the 64x16-cell "
                         "gather tiles (%.3f of the points lie in such a tile)" % frac_tiles}
     for mode in ("fast", "exact"):
         m.set_dsm_precision(mode == "exact")
