@@ -802,6 +802,10 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
       e = hipMalloc(reinterpret_cast<void**>(&c->dev_zrange), 2 * sizeof(unsigned long long));
     if (e == hipSuccess)
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_err), sizeof(unsigned), 0);
+    if (e == hipSuccess) {
+      e = hipHostMalloc(reinterpret_cast<void**>(&c->host_tile_stats), 8 * sizeof(unsigned), 0);
+      if (e == hipSuccess) std::memset(c->host_tile_stats, 0, 8 * sizeof(unsigned));
+    }
     if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
     if (e != hipSuccess) {
       rc = hip_fail(e, "context allocation", __FILE__, __LINE__);
@@ -831,11 +835,12 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->host_err) (void)hipHostFree(c->host_err);
+  if (c->host_tile_stats) (void)hipHostFree(c->host_tile_stats);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
 }
@@ -1545,6 +1550,7 @@ int amhip_ctx_dsm_gather_stats(amhip_ctx* h, int64_t* out8) {
   AMHIP_TRY(hipMemcpyAsync(hdr, c->tile_list, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
   AMHIP_TRY(hipStreamSynchronize(c->stream));
   for (int k = 0; k < 7; ++k) out8[k] = hdr[k];
+  out8[4] += hdr[7];  // (pre-classified tiles the dense FP64 launch took instead of list 4)
   out8[7] = c->last_ntiles;
   return AMHIP_OK;
 }

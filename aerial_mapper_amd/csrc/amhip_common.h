@@ -198,6 +198,9 @@ struct Ctx {
   size_t rank_cap = 0;
   uint32_t* bin_start = nullptr; // nbins + 1 (+ scan partials behind it)
   size_t bin_cap = 0;
+  uint32_t* bin_z = nullptr;     // per bin: ordered keys of its lowest / highest height (uint2)
+  size_t bin_z_cap = 0;
+  bool bin_z_valid = false;      // written by the last sort (three-pass, single-precision mode)
   uint32_t* scan_partials = nullptr;
   size_t partial_cap = 0;
   double* tmp_points = nullptr;    // stripe-ordered points (level 1 of the sort)
@@ -240,6 +243,7 @@ struct Ctx {
   int64_t last_num_bins = 0;
   int32_t last_bin_cells = 0;
   int64_t last_ntiles = 0;        // gather tiles of the last call (0: not the LDS-tiled gather)
+  unsigned* host_tile_stats = nullptr;  // pinned mirror of the last call's tile-list counters
 
   // timing
   bool timing = false;

@@ -453,6 +453,42 @@ constexpr int kNumLists = 7;
 // s_setreg operand: HW_REG_MODE (id 1), offset 6, width 2 = FP_DENORM for f64 / f16
 constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 
+// Ordered 32-bit keys of floats (monotone: a < b  <=>  key(a) < key(b)); LDS / global atomicMin /
+// atomicMax on heights.
+__device__ __forceinline__ uint32_t zkey_of(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float zkey_to_float(uint32_t k) {
+  return __uint_as_float((k >> 31) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// The single-precision gather's error budget for a region whose heights span [zmin_f, zmax_f]
+// (floats: the rounded extremes of the staged points): how many f32 additions may accumulate
+// between two flushes of the running sums so that
+//   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24,
+// stays below 0.8 x (1e-4 m - one spacing of the stored float) -- above 1024 m, where a float
+// spacing alone exceeds 1e-4 m, "1 LSB" is the bar and a quarter of a spacing the budget.
+// Returns the allowed additions (-1: no finite range, 1 << 20: flat), the middle height in *z0w.
+// ONE definition for the gather kernel and for the occupancy pre-pass that sorts tiles without
+// room (< 48 additions) straight onto the FP64 lists.
+__device__ __forceinline__ int fx_allowed_additions(float zmin_f, float zmax_f, float epsw, double* z0w) {
+  const double zmin = (double)zmin_f, zmax = (double)zmax_f;
+  *z0w = 0.5 * zmin + 0.5 * zmax;
+  // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
+  const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
+                       (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
+  const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
+  // spacing of the stored floats at that height
+  const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+  const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
+  if (!(S_half <= 3.0e38f)) return -1;
+  if (S_half == 0.0f) return 1 << 20;
+  const float room = (0.5f * allowed / S_half - epsw) * 16777216.0f - 2.0f;
+  return room > 1.0e6f ? (1 << 20) : (int)room;
+}
+constexpr int kFxMinAdditions = 48;  // a trip of a dense tile brings up to ~20 candidates; below: FP64
+
 // One lane per gather tile (tile numbering: ti + tj * tiles_i, as in the gather):
 //   occ[tile] = 0          no binned point within the LAST fallback radius of the tile
 //             = 1 + class  otherwise; class = which LDS capacity the points of the
@@ -469,43 +505,111 @@ constexpr int kHwRegModeFpDenormF64 = 1 | (6 << 6) | ((2 - 1) << 11);
 //             (filled by k_dsm_gather_f32, not here)
 //     list 5  class-1 / class-2 tiles of the single-precision list launches handed to the
 //             FP64 kernel's largest LDS image, list 6: those beyond it (wave-per-block kernel)
+//   bin_z (may be null; single-precision mode after the three-pass sort): per bin the ordered
+//     keys of its lowest / highest (float-rounded) height, written by the placement pass.  The
+//     tile's region then has a known height range BEFORE anything is staged: a tile whose error
+//     budget has no room (rough terrain: walls, canopy) gets occ = 1 + 4 -- no single-precision
+//     launch takes it -- and goes straight onto the FP64 list the kernel itself would have handed
+//     it to (rej_own: list 4, else 5, or 6 beyond rej_big_np points), instead of being staged,
+//     rejected and staged again (bench.py rough_terrain: 5.7 -> 4.8 ms per DSM call).
+// Append `tile` to list `lst` (-1: none) of every lane of the wave with ONE returning atomic per
+// (wave, list): tens of thousands of returning atomics on one counter serialise in L2 (0.86 ms
+// for the 73 K tiles of a rough scene, measured; 0.02 ms this way).
+__device__ __forceinline__ void wave_append_tile(int* __restrict__ lists, int ntiles, int lst, int tile) {
+  unsigned* cnt = reinterpret_cast<unsigned*>(lists);
+  const int lane = threadIdx.x & 63;
+  for (int L = 0; L < kNumLists; ++L) {
+    const unsigned long long m = __ballot(lst == L);
+    if (!m) continue;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&cnt[L], (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (lst == L)
+      lists[kListHdr + (size_t)L * ntiles + base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = tile;
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
-                     int cap1, int cap2) {
+                     int cap1, int cap2, const uint2* __restrict__ bin_z, int rej_own,
+                     int rej_big_np, int rej_dense) {
   const int ntiles = p.tiles_i * p.tiles_j;
   const int tile = blockIdx.x * 256 + threadIdx.x;
-  if (tile >= ntiles) return;
-  const int ti = tile % p.tiles_i, tj = tile / p.tiles_i;
-  const int i0 = ti * kTileI, j0 = tj * tile_j;
-  const int i_hi = min(i0 + kTileI, p.rows) - 1;
-  const int j_hi = min(j0 + tile_j, p.cols) - 1;
-  const int wl = p.w[p.nlevels - 1];
-  const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
-  const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
-  uint32_t tot = 0;
-  for (int by = ey0; by <= ey1; ++by) {
-    const uint32_t* row = start + (size_t)by * p.nbx;
-    tot += row[ex1 + 1] - row[ex0];
+  int lst = -1;       // list this tile is appended to
+  int rejected = 0;   // pre-classified for the FP64 kernel
+  if (tile < ntiles) {
+    const int ti = tile % p.tiles_i, tj = tile / p.tiles_i;
+    const int i0 = ti * kTileI, j0 = tj * tile_j;
+    const int i_hi = min(i0 + kTileI, p.rows) - 1;
+    const int j_hi = min(j0 + tile_j, p.cols) - 1;
+    const int wl = p.w[p.nlevels - 1];
+    const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
+    const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
+    uint32_t tot = 0;
+    for (int by = ey0; by <= ey1; ++by) {
+      const uint32_t* row = start + (size_t)by * p.nbx;
+      tot += row[ex1 + 1] - row[ex0];
+    }
+    if (tot == 0) {
+      occ[tile] = 0;
+    } else {
+      // the first-level region, exactly as gather_tile() sums it
+      const int w0 = p.w[0];
+      const int rbx0 = (i0 - w0 + p.M) / p.B, rbx1 = (i_hi + w0 + p.M) / p.B;
+      const int rby0 = (j0 - w0 + p.M) / p.B, rby1 = (j_hi + w0 + p.M) / p.B;
+      uint32_t np = 0;
+      for (int by = rby0; by <= rby1; ++by) {
+        const uint32_t* row = start + (size_t)by * p.nbx;
+        np += row[rbx1 + 1] - row[rbx0];
+      }
+      const int cls = np <= (uint32_t)cap0 ? 0 : (np <= (uint32_t)cap1 ? 1 : (np <= (uint32_t)cap2 ? 2 : 3));
+      if (bin_z && lists && cls < 3 && np > 0) {
+        uint32_t klo = 0xFFFFFFFFu, khi = 0u;
+        // (six independent loads in flight per step: one lane walks ~108 bins, and a serial
+        // chain of that many L2 round trips was 0.045 ms of the pre-pass)
+        const int nbxr = rbx1 - rbx0 + 1;
+        for (int by = rby0; by <= rby1; ++by) {
+          const uint2* row = bin_z + (size_t)by * p.nbx + rbx0;
+          int k = 0;
+          for (; k + 6 <= nbxr; k += 6) {
+            const uint2 v0 = row[k], v1 = row[k + 1], v2 = row[k + 2], v3 = row[k + 3], v4 = row[k + 4],
+                        v5 = row[k + 5];
+            klo = min(min(min(klo, v0.x), min(v1.x, v2.x)), min(min(v3.x, v4.x), v5.x));
+            khi = max(max(max(khi, v0.y), max(v1.y, v2.y)), max(max(v3.y, v4.y), v5.y));
+          }
+          for (; k < nbxr; ++k) {
+            const uint2 v = row[k];
+            klo = min(klo, v.x);
+            khi = max(khi, v.y);
+          }
+        }
+        if (klo <= khi) {
+          double z0w;
+          const int na = fx_allowed_additions(zkey_to_float(klo), zkey_to_float(khi), p.fx_epsw, &z0w);
+          if (na < kFxMinAdditions) {
+            rejected = 1;
+            const int own = (cls == 0) && rej_own;
+            // (rej_dense: the own-image tiles are taken by a dense launch that filters on occ
+            // instead of walking list 4 -- dsm_run decides, from the previous call's counts)
+            lst = own ? (rej_dense ? -1 : 4) : ((int)np > rej_big_np ? 6 : 5);
+            occ[tile] = (uint8_t)(own ? 1 + 4 : 1 + 5);
+          }
+        }
+      }
+      if (!rejected) {
+        occ[tile] = (uint8_t)(1 + cls);
+        if (lists && (cls > 0 || list0)) lst = cls;
+      }
+    }
   }
-  if (tot == 0) {
-    occ[tile] = 0;
-    return;
-  }
-  // the first-level region, exactly as gather_tile() sums it
-  const int w0 = p.w[0];
-  const int rbx0 = (i0 - w0 + p.M) / p.B, rbx1 = (i_hi + w0 + p.M) / p.B;
-  const int rby0 = (j0 - w0 + p.M) / p.B, rby1 = (j_hi + w0 + p.M) / p.B;
-  uint32_t np = 0;
-  for (int by = rby0; by <= rby1; ++by) {
-    const uint32_t* row = start + (size_t)by * p.nbx;
-    np += row[rbx1 + 1] - row[rbx0];
-  }
-  const int cls = np <= (uint32_t)cap0 ? 0 : (np <= (uint32_t)cap1 ? 1 : (np <= (uint32_t)cap2 ? 2 : 3));
-  occ[tile] = (uint8_t)(1 + cls);
-  if (lists && (cls > 0 || list0)) {
-    unsigned* cnt = reinterpret_cast<unsigned*>(lists);
-    lists[kListHdr + (size_t)cls * ntiles + atomicAdd(&cnt[cls], 1u)] = tile;  // (order is irrelevant)
+  if (lists) {
+    wave_append_tile(lists, ntiles, lst, tile);
+    // [7]: pre-classified tiles that are on NO list (the dense launch takes them)
+    const unsigned long long m = __ballot(rejected != 0 && lst < 0);
+    if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
+      atomicAdd(reinterpret_cast<unsigned*>(lists) + 7, (unsigned)__popcll(m));
   }
 }
 
@@ -554,9 +658,11 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   // every cell stays untouched.  In incremental mapping this is most of the map,
   // so the test is one byte, read before anything else.
   const int occ = tile_occ[tile];
-  // (dense launch: tiles of another capacity class belong to another launch)
+  // (dense launch: tiles of another capacity class belong to another launch; my_class 4 = the
+  // dense launch over the tiles the occupancy pre-pass classified for this kernel: nothing else)
   if (my_class >= 0 && occ != 0 && occ - 1 != my_class) return;
   if (occ == 0) {
+    if (my_class == 4) return;
     if (o.unfilled && tid == 0)
       atomicAdd(o.unfilled, (unsigned)((i_hi - i0 + 1) * (j_hi - j0 + 1)));
     if (o.fill_untouched) {
@@ -1101,9 +1207,8 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     // (+-inf where the thread had no point; six DPP steps each, result in lane 63)
     const float flo = wave_min_to_lane63((float)zlo), fhi = wave_max_to_lane63((float)zhi);
     if (lane == 63 && flo <= fhi) {
-      const uint32_t klo = __float_as_uint(flo), khi = __float_as_uint(fhi);
-      atomicMin(&s_zkey[0], (klo >> 31) ? ~klo : (klo | 0x80000000u));
-      atomicMax(&s_zkey[1], (khi >> 31) ? ~khi : (khi | 0x80000000u));
+      atomicMin(&s_zkey[0], zkey_of(flo));
+      atomicMax(&s_zkey[1], zkey_of(fhi));
     }
   }
   __syncthreads();
@@ -1122,34 +1227,14 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   if (lane == 63) s_scan[wid] = qincl;
   if (wid == kWaves - 1) {
     // ---- the tile's error budget ----------------------------------------------------
-    //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24, n = hits
-    //   accumulated between two flushes of the running sums (a trip's, plus one add per trip)
+    //   (fx_allowed_additions(): the bound the occupancy pre-pass applies to the same heights)
     float zmin_f = 0.f, zmax_f = 0.f;
     if (np) {
-      const uint32_t a = s_zkey[0], b = s_zkey[1];
-      zmin_f = __uint_as_float((a >> 31) ? (a & 0x7FFFFFFFu) : ~a);
-      zmax_f = __uint_as_float((b >> 31) ? (b & 0x7FFFFFFFu) : ~b);
+      zmin_f = zkey_to_float(s_zkey[0]);
+      zmax_f = zkey_to_float(s_zkey[1]);
     }
-    const double zmin = (double)zmin_f, zmax = (double)zmax_f;
-    const double z0w = 0.5 * zmin + 0.5 * zmax;
-    // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
-    const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
-                         (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
-    int na;
-    {
-      const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
-      // spacing of the stored floats at that height
-      const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
-      // north_star: 1e-4 m; above 1024 m one float spacing is already more than that:
-      // there "1 LSB" is the bar, and a quarter of a spacing the budget
-      const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
-      if (!(S_half <= 3.0e38f)) na = -1;
-      else if (S_half == 0.0f) na = 1 << 20;
-      else {
-        const float room = (0.5f * allowed / S_half - p.fx_epsw) * 16777216.0f - 2.0f;
-        na = room > 1.0e6f ? (1 << 20) : (int)room;
-      }
-    }
+    double z0w;
+    const int na = fx_allowed_additions(zmin_f, zmax_f, p.fx_epsw, &z0w);
     if (lane == 0) {
       s_ctl[2] = (uint32_t)na;
       s_zkey[2] = (uint32_t)__double2loint(z0w);
@@ -1178,7 +1263,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   const double z0 = __hiloint2double((int)s_zkey[3], (int)s_zkey[2]);
   // (a trip of a dense tile brings up to ~20 candidates: below that the FP64 kernel takes
   // the whole tile -- staging it twice is cheaper than redoing most of its cells)
-  if (n_allowed < 48) {
+  if (n_allowed < kFxMinAdditions) {
     // (a tile of a larger capacity class may hold more points than the FP64 kernel's LDS
     // image takes: those go to the wave-per-block kernel's list)
     if (tid == 0) {
@@ -1399,14 +1484,14 @@ template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
                    const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
-                   CellOut o) {
+                   CellOut o, int my_class) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ntiles = p.tiles_i * p.tiles_j;
   const int b = blockIdx.x;
   const int xcd = b & 7, k = b >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, 0);
+  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, my_class);
 }
 
 // List launch: a fixed grid walks a list of tiles -- the occupied tiles of a
@@ -1611,6 +1696,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   if (split && split->phase == 1) return AMHIP_OK;  // (tiled call: the rest follows the exchange)
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
+    const int64_t prev_ntiles = c->last_ntiles;
     c->last_ntiles = 0;
     if (p.lds_ok) {
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
@@ -1665,8 +1751,28 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
         sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
 #endif
+      // single-precision mode after the three-pass sort: tiles whose height range leaves no room
+      // under the error bound go straight onto the FP64 list the kernel would hand them to --
+      // list 4 while the FP64 kernel's image of cap0 points fits a CU (rej_own), else list 5, or
+      // list 6 beyond its largest image
+      const bool rej_own = cap0 <= 2048 || ((long)cap0 + 2) * 24 + fixed_bytes <= 150 * 1024;
+      const uint2* bin_z = (f32 && c->bin_z_valid) ? reinterpret_cast<const uint2*>(c->bin_z) : nullptr;
+      // Rough scenes: when the PREVIOUS call on this context pre-classified more than a tenth
+      // of its tiles for the FP64 kernel, that kernel is launched densely over the tiles (one
+      // workgroup each, filtering on occ) instead of walking a list of tens of thousands with a
+      // fixed grid; a tenth or less: the list (an empty dense launch would cost 0.18 ms of
+      // idle workgroups on smooth terrain).  Either is correct for any count -- the counts only
+      // pick the faster one; they come from a pinned mirror the previous call filled (no
+      // synchronisation: a value one call late is as good).
+      bool rej_dense = false;
+      if (bin_z && cap0 <= 2048 && !sparse && c->host_tile_stats && prev_ntiles > 0) {
+        const volatile unsigned* hs = c->host_tile_stats;
+        const double rejected = (double)hs[4] + (double)hs[5] + (double)hs[6] + (double)hs[7];
+        rej_dense = rejected * 10.0 > (double)prev_ntiles;
+      }
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
-                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2);
+                         p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2,
+                         bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
@@ -1686,7 +1792,20 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
                        p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,       \
-                       cell_out);                                                             \
+                       cell_out, 0);                                                          \
+  } while (0)
+      // the FP64 kernel, one workgroup per tile, over the tiles the pre-pass classified for it
+      // (occ = 1 + 4) and nothing else: hardware dispatch and the XCD-aware order instead of a
+      // fixed grid walking list 4 (28 ns per tile against 37, and no serial list)
+#define AMHIP_LAUNCH_REJECTED_DENSE(TJ_, CAP_)                                                \
+  do {                                                                                        \
+    const DsmParams q = with_cap(cap0);                                                       \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_tiled<512, TJ_, CAP_>),                    \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
+    hipLaunchKernelGGL((k_dsm_gather_tiled<512, TJ_, CAP_>), dim3(ntiles), dim3(512),         \
+                       q.lds_bytes, c->stream, q, c->bin_start, c->sorted, c->tile_occ,       \
+                       cell_out, 4);                                                          \
   } while (0)
       // FP64 list launch: list LIST_ with an LDS image of CAPV_ points (CAP_ sizes the
       // instance's registers; the LDS image holds what fits)
@@ -1728,6 +1847,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
                          cell_out, xl, tile_count + 4);                                       \
     }                                                                                         \
+    if (rej_dense) AMHIP_LAUNCH_REJECTED_DENSE(TJ_, CAP_);                                    \
     AMHIP_LAUNCH_LIST_EX(512, TJ_, CAP_, cap0, 4, 4096);                                      \
   } while (0)
       // (rejected tiles: the FP64 kernel with an image of cap0 points while that fits a CU --
@@ -1861,6 +1981,10 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_gather_dense, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
                            c->bin_start, c->sorted, lists + kListHdr + (size_t)6 * ntiles,
                            tile_count + 6, cell_out, 0);
+      // (what the next call's choice between list and dense launch reads; never waited for)
+      if (c->host_tile_stats)
+        AMHIP_TRY(hipMemcpyAsync(c->host_tile_stats, tile_count, kListHdr * sizeof(unsigned),
+                                 hipMemcpyDeviceToHost, c->stream));
     } else {
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       if (p.knn_k > 0)

@@ -470,15 +470,24 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
 }
 
 // Pass 3: one workgroup per (k1, k2) sub-partition.
+// bin_z (may be null): per bin the ordered keys (zkey_of) of its lowest / highest float-rounded
+// height -- the occupancy pre-pass of the single-precision gather reads them (amhip_dsm.hip)
+__device__ __forceinline__ uint32_t place_zkey(double z) {
+  const uint32_t b = __float_as_uint((float)z);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
 template <int THREADS, int PER>
 __device__ __forceinline__ void place_subpartition(const double* __restrict__ src, const DsmParams& p,
                                                    int cap, const uint32_t* __restrict__ start2,
                                                    uint32_t* __restrict__ bin_start,
                                                    double* __restrict__ sorted, int sp,
-                                                   unsigned skip_lo, unsigned skip_hi) {
+                                                   unsigned skip_lo, unsigned skip_hi,
+                                                   uint2* __restrict__ bin_z) {
   extern __shared__ double s_pts[];                                  // 3 * cap
   uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
   uint32_t* s_scan = s_bins + p.p3_w;                                // 24
+  uint32_t* s_zlo = s_scan + 24;                                     // p3_w (bin_z only)
+  uint32_t* s_zhi = s_zlo + p.p3_w;                                  // p3_w
   const int tid = threadIdx.x;
   const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
   const int rr = k2 / p.p3_c;
@@ -489,7 +498,13 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
     bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
   if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
-  for (int k = tid; k < nbw; k += THREADS) s_bins[k] = 0;
+  for (int k = tid; k < nbw; k += THREADS) {
+    s_bins[k] = 0;
+    if (bin_z) {
+      s_zlo[k] = 0xFFFFFFFFu;
+      s_zhi[k] = 0u;
+    }
+  }
   __syncthreads();
   // (skip_lo, skip_hi]: sub-partitions the other launch takes
   if ((g1 - g0) > skip_lo && (g1 - g0) <= skip_hi) return;
@@ -511,6 +526,11 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
         point_bin_xy(p, px[k], py[k], &bx, &by);
         pb[k] = bx - bx0;
         atomicAdd(&s_bins[pb[k]], 1u);
+        if (bin_z) {
+          const uint32_t zk = place_zkey(pz[k]);
+          atomicMin(&s_zlo[pb[k]], zk);
+          atomicMax(&s_zhi[pb[k]], zk);
+        }
       }
     }
   } else {
@@ -538,6 +558,10 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
   __syncthreads();
   uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
   for (int k = tid; k < nbw; k += THREADS) out_start[k] = g0 + s_bins[k];
+  if (bin_z && in_lds) {
+    uint2* zrow = bin_z + (size_t)row * p.nbx + bx0;
+    for (int k = tid; k < nbw; k += THREADS) zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
+  }
   __syncthreads();
   if (!in_lds) {
     // over-full sub-partition (clustered cloud): second read, direct placement
@@ -551,6 +575,16 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
       sorted[3 * o + 0] = x;
       sorted[3 * o + 1] = y;
       sorted[3 * o + 2] = z;
+      if (bin_z) {
+        const uint32_t zk = place_zkey(z);
+        atomicMin(&s_zlo[bx - bx0], zk);
+        atomicMax(&s_zhi[bx - bx0], zk);
+      }
+    }
+    if (bin_z) {
+      __syncthreads();
+      uint2* zrow = bin_z + (size_t)row * p.nbx + bx0;
+      for (int k = tid; k < nbw; k += THREADS) zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
     }
     return;
   }
@@ -575,9 +609,10 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
 __global__ void __launch_bounds__(kP3PlaceThreads)
 k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
                const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
-               double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi) {
+               double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
+               uint2* __restrict__ bin_z) {
   place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted,
-                                                   (int)blockIdx.x, skip_lo, skip_hi);
+                                                   (int)blockIdx.x, skip_lo, skip_hi, bin_z);
 }
 
 // The same with 1024 threads and a whole CU's LDS (kP3BigCap points), walking
@@ -585,11 +620,12 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
 __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
-                   double* __restrict__ sorted, const uint32_t* __restrict__ big_list) {
+                   double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
+                   uint2* __restrict__ bin_z) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted,
-                                                 (int)big_list[1 + k], 0u, 0u);
+                                                 (int)big_list[1 + k], 0u, 0u, bin_z);
     __syncthreads();
   }
 }
@@ -774,6 +810,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   }
   c->last_num_bins = (int64_t)nbins;
   c->last_bin_cells = p.B;
+  c->bin_z_valid = false;
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
   const bool three_pass = p.p3_n1 > 0 && !force_one_level;
@@ -858,17 +895,28 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     }
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCAN);
-      const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+      // single-precision gather: the placement pass also leaves every bin's height range
+      // (the occupancy pre-pass sorts tiles without room under the error bound onto the FP64
+      // lists before anything is staged); bins no sub-partition covers keep "empty"
+      uint2* bin_z = nullptr;
+      if (p.fx_ok && !p.pcl_mode && !dev_values) {
+        int rc2;
+        if ((rc2 = ensure_capacity(&c->bin_z, &c->bin_z_cap, 2 * (nbins + 4)))) return rc2;
+        bin_z = reinterpret_cast<uint2*>(c->bin_z);
+      }
+      const size_t zlds = bin_z ? 2 * (size_t)p.p3_w * sizeof(uint32_t) : 0;
+      const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds;
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         (unsigned)p.p3_cap, (unsigned)kP3BigCap);
-      const size_t lds_big = (size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+                         (unsigned)p.p3_cap, (unsigned)kP3BigCap, bin_z);
+      const size_t lds_big = (size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds;
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list);
+                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z);
+      c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }
   } else {

@@ -1,5 +1,5 @@
 """GPU tests of the DSM gather's single-precision mode (amhip_ctx_set_dsm_precision,
-AMHIP_DSM_FAST, the default): its guards -- error budget per tile, near-centre points, decisions
+AMHIP_DSM_FAST, opt-in since round 3): its guards -- error budget per tile, near-centre points, decisions
 within 2e-6 of the search radius -- must hand exactly the right work to the FP64 routines, so
 that the contract holds everywhere: the reference's NaN pattern, heights within 1e-4 m (one
 float spacing of the stored height where that is larger, i.e. above 1024 m).
@@ -197,3 +197,94 @@ def test_dense_clouds_guards_near_centres_and_near_the_radius(ppc):
     sc.points = np.concatenate([sc.points, np.asarray(extra)], 0)
     want = _oracle(sc)
     _check(_run(sc, False), want)
+
+
+def _run_stats(scene, exact, radius=1):
+    import aerial_mapper_amd as A
+    g = scene.grid
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    with A.AerialGridMap(st) as m:
+        m.set_dsm_precision(exact)
+        A.Dsm(A.DsmSettings(radius), m).process(scene.points, m)
+        return m.get("elevation"), m.dsm_gather_stats()
+
+
+def test_rough_tiles_are_sorted_onto_the_fp64_lists_before_they_are_staged(monkeypatch):
+    """Round 3: after the three-pass sort the placement pass leaves every bin's height range, and
+    the occupancy pre-pass applies the gather's own error bound to a tile's region BEFORE anything
+    is staged -- tiles without room go straight to the FP64 lists (amhip_ctx_dsm_gather_stats
+    counts them) and the result is what the kernel's own late rejection gave (one-level sort:
+    no bin ranges)."""
+    sc = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=311)
+    x, y = sc.points[:, 0], sc.points[:, 1]
+    sc.points[:, 2] += np.where((np.abs(x) < 30.0) & (np.abs(y) < 20.0), 25.0, 0.0)   # a "building"
+    want = _oracle(sc)
+    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")       # three-pass sort for this small cloud
+    got3, st3 = _run_stats(sc, False)
+    monkeypatch.delenv("AMHIP_P3_MIN_POINTS")               # (< 2^20 points: the one-level sort)
+    got1, st1 = _run_stats(sc, False)
+    for got in (got3, got1):
+        frac, _ = _check(got, want)
+        assert 0.3 < frac < 1.0
+    assert st3["tiles"] == st1["tiles"] > 0
+    # the same tiles end on the FP64 lists either way: pre-classified, or handed back by the kernel
+    assert st3["f32_to_fp64"] + st3["f32_to_fp64_beyond"] == st1["f32_to_fp64"] + st1["f32_to_fp64_beyond"]
+    assert 0 < st3["f32_to_fp64"] < 0.5 * st3["tiles"]
+    # smooth terrain: nothing is rejected, by either route
+    sm = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=312)
+    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    got, st = _run_stats(sm, False)
+    _check(got, _oracle(sm))
+    assert st["f32_to_fp64"] == 0 and st["f32_to_fp64_beyond"] == 0
+
+
+@pytest.mark.parametrize("density", [2.5, 6.0])
+def test_rough_dense_tiles_of_the_capacity_classes_are_pre_classified_too(monkeypatch, density):
+    """Denser clouds (capacity classes 1 / 2 and the wide main launch) with +-30 m of noise: every
+    occupied tile is rejected up front, onto list 5 / 6 where the FP64 image of the main launch
+    does not fit a CU."""
+    n = int(density * (4 * 88) * (4 * 68))
+    sc = S.Scene(80.0, 60.0, 0.25, n, seed=313)
+    rng = np.random.default_rng(9)
+    sc.points[:, 2] += rng.uniform(-30.0, 30.0, sc.points.shape[0])
+    want = _oracle(sc)
+    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    got, st = _run_stats(sc, False)
+    frac, _ = _check(got, want)
+    assert frac > 0.999                                   # all of it is the FP64 arithmetic
+    assert st["f32_to_fp64"] + st["f32_to_fp64_beyond"] + st["beyond_lds"] > 0.8 * st["tiles"]
+
+
+def test_rough_scene_second_call_takes_the_dense_fp64_launch(monkeypatch):
+    """When the previous call pre-classified more than a tenth of its tiles, the FP64 kernel is
+    launched densely over them (filtering on the occupancy byte) instead of walking list 4: same
+    heights, same counts."""
+    import aerial_mapper_amd as A
+    sc = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=314)
+    rng = np.random.default_rng(11)
+    rough = sc.points[:, 0] < 10.0                                   # two thirds of the map
+    sc.points[rough, 2] += rng.uniform(-30.0, 30.0, int(rough.sum()))
+    want = _oracle(sc)
+    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    g = sc.grid
+    with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
+        m.set_dsm_precision(False)
+        dsm = A.Dsm(A.DsmSettings(1), m)
+        outs, stats = [], []
+        for _ in range(3):
+            m.reset()
+            dsm.process(sc.points, m)
+            outs.append(m.get("elevation"))
+            stats.append(m.dsm_gather_stats())
+    for got in outs:
+        _check(got, want)
+    assert 0.4 * stats[0]["tiles"] < stats[0]["f32_to_fp64"] < stats[0]["tiles"]
+    assert stats[1]["f32_to_fp64"] == stats[0]["f32_to_fp64"] == stats[2]["f32_to_fp64"]
+    # the rough two thirds are the FP64 arithmetic in either launch form: the reference's floats
+    # (cells well inside the rough part: their whole tile region is rough)
+    inner = np.zeros_like(want, bool)
+    i_lo = int((g.length_x / 2.0 - (10.0 - 20.0)) / g.resolution) + 1     # x < -10 m  <=>  i > i_lo
+    inner[:, i_lo:] = True
+    for got in outs:
+        same = got.view(np.uint32)[inner] == want.view(np.uint32)[inner]
+        assert same.mean() > 0.999

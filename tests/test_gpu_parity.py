@@ -428,8 +428,10 @@ def test_dsm_every_sort_path_matches(knobs):
         "    rc, want, _ = O.dsm_process(sc.points, sc.grid)\n"
         "    g = sc.grid\n"
         "    m = A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution))\n"
-        "    A.Dsm(A.DsmSettings(), m).process(sc.points, m)\n"
-        "    S.assert_dsm_close(m.get('elevation'), want)\n"
+        "    for exact in (True, False):\n"
+        "        m.reset(); m.set_dsm_precision(exact)\n"
+        "        A.Dsm(A.DsmSettings(), m).process(sc.points, m)\n"
+        "        S.assert_dsm_close(m.get('elevation'), want, tol=1e-6 if exact else 1e-4)\n"
         "    inten = (np.arange(sc.points.shape[0]) %% 251).astype(np.int32)\n"
         "    rc, want_o = O.ortho_from_pcl(sc.points, inten, g)\n"
         "    A.OrthoFromPcl(A.OrthoFromPclSettings()).process(sc.points, inten, m)\n"
