@@ -718,10 +718,17 @@ def main():
                             "HBM bound; no MFMA-shaped work on this path",
                     "frac": round(lane_ops / (dom_ms * 1e-3) / peak_valu, 4),
                     "lane_instructions_per_launch": lane_ops, "peak_lane_instructions_per_s": peak_valu,
-                    # wave-instructions per SIMD and clock; the guide's 2 clocks per wave64 f32
-                    # instruction would make 0.5 the ceiling, tools/ubench/ubench2.hip measures 3.3
-                    # (v_fma_f32) to 4.7 (v_cmp / v_cvt / v_cndmask) clocks on this part: 0.21 - 0.30
+                    # wave-instructions per SIMD and clock.  What one costs, measured in real shader
+                    # cycles (s_memtime; tools/ubench/ubench3.hip, profiles/r03_ubench3_real_cycles.jsonl):
+                    # fma / mul / add / sub_u32 2.3 - 2.5 (the guide's 2-cycle class), cvt / cmp(x) /
+                    # max and all FP64 4.4, v_rcp_f32 8.2 -> the gather's mix averages ~3.1 cycles, i.e.
+                    # a ceiling of ~0.32 for this kernel (0.5 only for a pure full-rate stream)
                     "wave_instructions_per_simd_clock": round(v["SQ_INSTS_VALU"] / 1024.0 / busy, 3),
+                    "issue_cycles_per_wave_instruction_measured": {
+                        "full_rate (v_fma/mul/add_f32, v_sub_u32)": 2.4,
+                        "half_rate (v_cvt_f32_i32, v_cmp/cmpx_f32, v_max_f32, FP64 fma/mul/add)": 4.4,
+                        "v_rcp_f32": 8.2, "candidate_loop_body_per_candidate": 75,
+                        "source": "profiles/r03_ubench3_real_cycles.jsonl"},
                     "lanes_active_frac": round(lanes, 3),
                     "source": "profiles/" + valu[0] + " (counters); kernel_ms live"}
         parity_done = False

@@ -5,14 +5,14 @@
 #   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh v1 r02'
 set -u
 TAG=${1:-vX}
-RND=${2:-r02}
+RND=${2:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=/tmp/amhip_prof_$$
 OUT=$R/gpurun_out/profiles_out
 rm -rf "$O" "$OUT"; mkdir -p "$O" "$OUT"
 cd /tmp && export TMPDIR=/tmp
 timeout 900 python "$R/bench.py" --steps 10 --warmup 3 > "$OUT/${RND}_bench_cfg3_n1.json" 2> "$O/bench.err"
-B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path"
+B="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path --no-second-mode --no-rough-terrain"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$O/trace" -o t -- $B > "$OUT/${RND}_${TAG}_cfg3_bench_under_rocprof.json" 2> "$O/trace.err"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$O/fetch" -o f -- $B > /dev/null 2> "$O/fetch.err"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d "$O/write" -o w -- $B > /dev/null 2> "$O/write.err"

@@ -70,7 +70,7 @@ def main():
                 for k, (n, avg, mn, mx) in pmc_rows(path, c).items():
                     out.setdefault(k, {})[c] = avg
         text = {"_comment": "rocprofv3 PMC SQ / GRBM counters, average per launch summed over XCDs / SEs, "
-                            "cfg3, round 1 %s build (python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
+                            "cfg3, %s build (python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                             "--no-host-path; separate --pmc passes with --kernel-trace only). SQ_* cycle "
                             "counters tick every 4 clocks." % a.tag, "kernels": out}
         if a.sq_json:
