@@ -71,6 +71,20 @@ DEF_KERNEL(k_cvt, "v_cvt_f32_i32 %0, %1\n v_cvt_f32_i32 %1, %2\n v_cvt_f32_i32 %
 DEF_KERNEL(k_rcp, "v_rcp_f32 %0, %1\n v_rcp_f32 %1, %2\n v_rcp_f32 %2, %3\n v_rcp_f32 %3, %4\n v_rcp_f32 %4, %5\n v_rcp_f32 %5, %6\n v_rcp_f32 %6, %7\n v_rcp_f32 %7, %0\n")
 DEF_KERNEL(k_cmp, "v_cmp_gt_f32 vcc, %0, %1\n v_cmp_gt_f32 vcc, %1, %2\n v_cmp_gt_f32 vcc, %2, %3\n v_cmp_gt_f32 vcc, %3, %4\n v_cmp_gt_f32 vcc, %4, %5\n v_cmp_gt_f32 vcc, %5, %6\n v_cmp_gt_f32 vcc, %6, %7\n v_cmp_gt_f32 vcc, %7, %0\n")
 DEF_KERNEL(k_cnd, "v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %1, %1, %2, vcc\n v_cndmask_b32 %2, %2, %3, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n v_cndmask_b32 %4, %4, %5, vcc\n v_cndmask_b32 %5, %5, %6, vcc\n v_cndmask_b32 %6, %6, %7, vcc\n v_cndmask_b32 %7, %7, %0, vcc\n")
+// integer / logical forms of the half-rate float instructions (non-negative floats order like
+// their bit patterns): are they full rate?
+DEF_KERNEL(k_maxu, "v_max_u32 %0, %0, %1\n v_max_u32 %1, %1, %2\n v_max_u32 %2, %2, %3\n v_max_u32 %3, %3, %4\n v_max_u32 %4, %4, %5\n v_max_u32 %5, %5, %6\n v_max_u32 %6, %6, %7\n v_max_u32 %7, %7, %0\n")
+DEF_KERNEL(k_maxi, "v_max_i32 %0, %0, %1\n v_max_i32 %1, %1, %2\n v_max_i32 %2, %2, %3\n v_max_i32 %3, %3, %4\n v_max_i32 %4, %4, %5\n v_max_i32 %5, %5, %6\n v_max_i32 %6, %6, %7\n v_max_i32 %7, %7, %0\n")
+DEF_KERNEL(k_max3, "v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %1, %1, %2, %3\n v_max3_f32 %2, %2, %3, %4\n v_max3_f32 %3, %3, %4, %5\n v_max3_f32 %4, %4, %5, %6\n v_max3_f32 %5, %5, %6, %7\n v_max3_f32 %6, %6, %7, %0\n v_max3_f32 %7, %7, %0, %1\n")
+DEF_KERNEL(k_max3u, "v_max3_u32 %0, %0, %1, %2\n v_max3_u32 %1, %1, %2, %3\n v_max3_u32 %2, %2, %3, %4\n v_max3_u32 %3, %3, %4, %5\n v_max3_u32 %4, %4, %5, %6\n v_max3_u32 %5, %5, %6, %7\n v_max3_u32 %6, %6, %7, %0\n v_max3_u32 %7, %7, %0, %1\n")
+DEF_KERNEL(k_cmpu, "v_cmp_gt_u32 vcc, %0, %1\n v_cmp_gt_u32 vcc, %1, %2\n v_cmp_gt_u32 vcc, %2, %3\n v_cmp_gt_u32 vcc, %3, %4\n v_cmp_gt_u32 vcc, %4, %5\n v_cmp_gt_u32 vcc, %5, %6\n v_cmp_gt_u32 vcc, %6, %7\n v_cmp_gt_u32 vcc, %7, %0\n")
+DEF_KERNEL(k_and, "v_and_b32 %0, %0, %1\n v_and_b32 %1, %1, %2\n v_and_b32 %2, %2, %3\n v_and_b32 %3, %3, %4\n v_and_b32 %4, %4, %5\n v_and_b32 %5, %5, %6\n v_and_b32 %6, %6, %7\n v_and_b32 %7, %7, %0\n")
+DEF_KERNEL(k_or3, "v_or3_b32 %0, %0, %1, %2\n v_or3_b32 %1, %1, %2, %3\n v_or3_b32 %2, %2, %3, %4\n v_or3_b32 %3, %3, %4, %5\n v_or3_b32 %4, %4, %5, %6\n v_or3_b32 %5, %5, %6, %7\n v_or3_b32 %6, %6, %7, %0\n v_or3_b32 %7, %7, %0, %1\n")
+DEF_KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %2\n v_add3_u32 %1, %1, %2, %3\n v_add3_u32 %2, %2, %3, %4\n v_add3_u32 %3, %3, %4, %5\n v_add3_u32 %4, %4, %5, %6\n v_add3_u32 %5, %5, %6, %7\n v_add3_u32 %6, %6, %7, %0\n v_add3_u32 %7, %7, %0, %1\n")
+DEF_KERNEL(k_lshl, "v_lshlrev_b32 %0, 3, %1\n v_lshlrev_b32 %1, 3, %2\n v_lshlrev_b32 %2, 3, %3\n v_lshlrev_b32 %3, 3, %4\n v_lshlrev_b32 %4, 3, %5\n v_lshlrev_b32 %5, 3, %6\n v_lshlrev_b32 %6, 3, %7\n v_lshlrev_b32 %7, 3, %0\n")
+DEF_KERNEL(k_cnds, "v_cndmask_b32 %0, %0, %1, %9\n v_cndmask_b32 %1, %1, %2, %9\n v_cndmask_b32 %2, %2, %3, %9\n v_cndmask_b32 %3, %3, %4, %9\n v_cndmask_b32 %4, %4, %5, %9\n v_cndmask_b32 %5, %5, %6, %9\n v_cndmask_b32 %6, %6, %7, %9\n v_cndmask_b32 %7, %7, %0, %9\n")
+DEF_KERNEL(k_fmaclamp, "v_fma_f32 %0, %0, %1, %2 clamp\n v_fma_f32 %1, %1, %2, %3 clamp\n v_fma_f32 %2, %2, %3, %4 clamp\n v_fma_f32 %3, %3, %4, %5 clamp\n v_fma_f32 %4, %4, %5, %6 clamp\n v_fma_f32 %5, %5, %6, %7 clamp\n v_fma_f32 %6, %6, %7, %0 clamp\n v_fma_f32 %7, %7, %0, %1 clamp\n")
+DEF_KERNEL(k_cmpxu, "s_mov_b64 %9, exec\n v_cmpx_gt_u32 %0, %1\n v_max_u32 %2, %2, %3\n s_mov_b64 exec, %9\n v_cmpx_gt_u32 %1, %2\n v_max_u32 %3, %3, %4\n s_mov_b64 exec, %9\n v_cmpx_gt_u32 %4, %5\n v_max_u32 %6, %6, %7\n s_mov_b64 exec, %9\n v_cmpx_gt_u32 %5, %6\n v_max_u32 %7, %7, %0\n s_mov_b64 exec, %9\n")
 // v_cmpx + one masked VALU + s_mov restore, four times (unit = one cmpx/op/restore group)
 DEF_KERNEL(k_cmpx, "s_mov_b64 %9, exec\n v_cmpx_gt_f32 %0, %1\n v_max_f32 %2, %2, %3\n s_mov_b64 exec, %9\n v_cmpx_gt_f32 %1, %2\n v_max_f32 %3, %3, %4\n s_mov_b64 exec, %9\n v_cmpx_gt_f32 %4, %5\n v_max_f32 %6, %6, %7\n s_mov_b64 exec, %9\n v_cmpx_gt_f32 %5, %6\n v_max_f32 %7, %7, %0\n s_mov_b64 exec, %9\n")
 // the product kernel's hit block, twice (unit = one block: cmpx, rcp, max, add, fmac + exec restore)
@@ -322,14 +336,25 @@ int main(int argc, char** argv) {
         {"v_cmpx+v_max+s_mov exec (group)", k_cmpx, 16},
         {"hit block: cmpx rcp max add fmac + exec restore", k_hit, 8},
         {"v_fma_f64", k_fma64, 32}, {"v_mul_f64", k_mul64, 32},     {"v_add_f64", k_add64, 32},
+        {"v_max_u32", k_maxu, 32},  {"v_max_i32", k_maxi, 32},      {"v_max3_f32", k_max3, 32},
+        {"v_max3_u32", k_max3u, 32}, {"v_cmp_gt_u32", k_cmpu, 32},  {"v_and_b32", k_and, 32},
+        {"v_or3_b32", k_or3, 32},   {"v_add3_u32", k_add3, 32},     {"v_lshlrev_b32", k_lshl, 32},
+        {"v_cndmask_b32 (sgpr mask)", k_cnds, 32}, {"v_fma_f32 clamp", k_fmaclamp, 32},
+        {"v_cmpx_gt_u32+v_max_u32+s_mov exec (group)", k_cmpxu, 16},
     };
+    const bool only_new = strchr(which, 'N') != nullptr;   // "AN": the round-3 additions only
+    int tindex = 0;
     for (auto& t : tests) {
+      if (only_new && tindex++ < 14) continue;
       printf("{\"part\": \"A\", \"instr\": \"%s\"", t.name);
       for (int w : {1, 2, 4, 8}) {
         Stat st;
         if (run_a(t.fn, w, t.units_x4, 2048, out, stamps, &st)) return 1;
-        printf(", \"w%d\": {\"cyc\": %.3f, \"GHz\": %.3f, \"ms\": %.3f, \"spread\": %.2f}", w, st.cyc_per_unit_simd,
-               st.ghz, st.wall_ms, st.spread);
+        // wall: wall time x measured clock / wave-instructions per SIMD (what a saturated SIMD pays
+        // per instruction, incl. the launch); cyc: from the waves' own s_memtime spans
+        const double wall_cyc = st.wall_ms * 1e-3 * st.ghz * 1e9 / ((double)w * 2048 * t.units_x4);
+        printf(", \"w%d\": {\"wall_cyc\": %.2f, \"cyc\": %.3f, \"GHz\": %.3f, \"ms\": %.3f, \"spread\": %.2f}", w,
+               wall_cyc, st.cyc_per_unit_simd, st.ghz, st.wall_ms, st.spread);
       }
       printf("}\n");
     }
