@@ -289,6 +289,20 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     }
   }
 
+  // ---- division-free keys for the sort passes (DsmParams::mul_*) --------------------------
+  {
+    auto magic = [](unsigned long long n_max, int d) -> unsigned {
+      if (d <= 1) return 0u;
+      if (n_max * (unsigned long long)d >= (1ull << 32)) return 0xFFFFFFFFu;
+      return (unsigned)((1ull << 32) / (unsigned long long)d) + 1u;
+    };
+    const unsigned long long cells_max =
+        (unsigned long long)std::max(p.rows, p.cols) + 2ull * (unsigned long long)p.M + 1ull;
+    p.mul_B = magic(cells_max, p.B);
+    p.mul_r1 = p.p3_n1 ? magic((unsigned long long)p.nby + 1ull, p.p3_r1) : 0xFFFFFFFFu;
+    p.mul_w = p.p3_n1 ? magic((unsigned long long)p.nbx + 1ull, p.p3_w) : 0xFFFFFFFFu;
+  }
+
   // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
   const int kTileI = 64;
   // Tile height and LDS point capacity from the cloud's MEAN density (points

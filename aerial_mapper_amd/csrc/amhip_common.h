@@ -61,6 +61,11 @@ struct DsmParams {
   int p3_c, p3_w;             // column blocks per bin row, bins per column block
   int p3_n1, p3_n2;           // partitions of pass 1; sub-partitions of each (= p3_r1 * p3_c)
   int p3_cap;                 // points a pass-3 workgroup can sort in LDS
+  // Every sort pass turns every point into its keys again: four integer divisions by
+  // B / p3_r1 / p3_w per point and pass were ~half of the passes' VALU time.  Multipliers
+  // m = floor(2^32 / d) + 1: n / d == umulhi(n, m) for n * d < 2^32 (0: d == 1; ~0: n * d may
+  // reach 2^32 on this grid -> the real division); div_by() in amhip_sort.hip
+  unsigned mul_B, mul_r1, mul_w;
   int wr[2 * kMaxW0 + 1];
   int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
   int wrp[kMaxW0 + 1];        // per trip (window rows 2k, 2k+1 of the pair): max of wr2

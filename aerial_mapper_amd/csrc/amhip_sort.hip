@@ -25,6 +25,14 @@ namespace amhip {
 // ---------------------------------------------------------------------------
 constexpr uint32_t kNoRank = 0xFFFFFFFFu;
 
+// n / d through the host's multiplier (DsmParams::mul_*): one v_mul_hi_u32 instead of the ~20
+// instructions of a 32-bit division by a run-time divisor; n >= 0.
+__device__ __forceinline__ int div_by(int n, int d, unsigned m) {
+  if (m == 0u) return n;
+  if (m == 0xFFFFFFFFu) return n / d;
+  return (int)__umulhi((unsigned)n, m);
+}
+
 // Bin of a (centre-shifted) point, or false if it lies more than M cells
 // outside the grid (it can then never be inside any cell's last fallback
 // radius).  Cell i has its centre at continuous coordinate ci == i.
@@ -40,8 +48,8 @@ __device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
   int iy = (int)floor(cy + 0.5) + p.M;
   ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
   iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
-  const int bx = ix / p.B;
-  const int by = iy / p.B;
+  const int bx = div_by(ix, p.B, p.mul_B);
+  const int by = div_by(iy, p.B, p.mul_B);
   *bin = (uint32_t)by * (uint32_t)p.nbx + (uint32_t)bx;
   return true;
 }
@@ -104,8 +112,8 @@ __device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, doub
   int iy = (int)floor(cy + 0.5) + p.M;
   ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
   iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
-  *bx = ix / p.B;
-  *by = iy / p.B;
+  *bx = div_by(ix, p.B, p.mul_B);
+  *by = div_by(iy, p.B, p.mul_B);
   return true;
 }
 
@@ -152,9 +160,9 @@ __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py
                                         int* k2) {
   int bx, by;
   if (!point_bin_xy(p, px, py, &bx, &by)) return false;
-  const int a = by / p.p3_r1;
+  const int a = div_by(by, p.p3_r1, p.mul_r1);
   *k1 = a;
-  *k2 = (by - a * p.p3_r1) * p.p3_c + bx / p.p3_w;
+  *k2 = (by - a * p.p3_r1) * p.p3_c + div_by(bx, p.p3_w, p.mul_w);
   return true;
 }
 

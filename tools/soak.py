@@ -19,11 +19,16 @@ for seed in range(first, first + count):
                      ("from_pcl", P.test_from_pcl_random_configurations)):
         if fn is None:
             continue
-        try:
-            fn(seed)
-        except Exception as e:  # keep going: report every failing seed
-            bad.append((name, seed, repr(e)[:200]))
-            traceback.print_exc()
+        # (the DSM generators in both arithmetic modes of the gather: FP64 = the library's default,
+        # single precision = the opt-in mode; the other tests do not depend on it)
+        for exact in ((True, False) if name == "dsm" else (False,)):
+            T._EXACT = exact
+            try:
+                fn(seed)
+            except Exception as e:  # keep going: report every failing seed
+                bad.append((name + ("/exact" if exact else "/fast" if name == "dsm" else ""), seed, repr(e)[:200]))
+                traceback.print_exc()
+            T._EXACT = False
 
 # ---- larger, rougher configurations than the suite's generators reach ----------------
 import numpy as np
@@ -56,12 +61,22 @@ def big_dsm(seed):
     pts = np.empty((xy.shape[0], 3))
     pts[:, :2] = xy
     pts[:, 2] = synth.terrain_height(xy[:, 0], xy[:, 1]) + rng.uniform(-1.0, 1.0, xy.shape[0])
+    if seed % 4 == 1:                              # walls / canopy: +-25 m in a third of the map, a 30 m step
+        rough = xy[:, 1] > g.pos_y + ly / 6
+        pts[rough, 2] += rng.uniform(-25.0, 25.0, int(rough.sum()))
+        pts[xy[:, 0] > g.pos_x + lx / 4, 2] += 30.0
     rc, want, _ = O.dsm_process(pts, g, radius)
     assert rc == O.OK
     with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, lx, ly, res)) as m:
-        A.Dsm(A.DsmSettings(radius), m).process(pts, m)
-        got = m.get("elevation")
-    S.assert_dsm_close(got, want)
+        for exact in (True, False):
+            m.reset()
+            m.set_dsm_precision(exact)
+            for rep in range(2 if not exact else 1):    # (fast: the second call may take the dense FP64 launch)
+                m.reset()
+                A.Dsm(A.DsmSettings(radius), m).process(pts, m)
+                got = m.get("elevation")
+                same = S.assert_dsm_close(got, want, tol=1e-6 if exact else 1e-4)
+                assert not exact or same > 0.999, same
 
 
 def big_ortho(seed):
