@@ -88,6 +88,20 @@ struct DsmParams {
   unsigned lds_bytes_f32;
 };
 
+// The binned cloud as the gather sees it (amhip_dsm.hip: pts_x / pts_y / pts_z; filled by
+// dsm_sort): the doubles pipeline (sorted), the record pipeline of the single-precision
+// gather (rec + sidx + cloud), or both.
+struct PtsView {
+  const double* sorted;   // 3 doubles per sorted point (px, py, z), or null
+  const uint4* rec;       // 16-byte record per sorted point, or null: x = cell ix | iy << 16
+                          // (map cells + margin M), y / z = offsets from the cell centre in
+                          // units of 2^-fx_S cells (int32), w = f32 bits of z - zref[0]
+  const uint32_t* sidx;   // row of the caller's cloud behind sorted point g (with rec)
+  const double* cloud;    // the caller's cloud (AoS x, y, z), untouched
+  const double* zref;     // device: [0] the reference height of the records' offsets
+  double sub_x, sub_y;    // dsm.cc:42-43's centre offsets (applied when reading `cloud`)
+};
+
 // FramePose / FrameFast (per-frame inverse pose T_C_G = T_G_C^-1): amhip_ortho_fold.h
 
 struct OrthoParams {
@@ -197,6 +211,7 @@ struct Ctx {
   unsigned* host_err = nullptr;  // pinned mirror
 
   // DSM workspaces (grow on demand)
+  PtsView pts = {};              // what the last dsm_sort left for the gather
   double* sorted = nullptr;      // 3 doubles per binned point (px, py, z)
   size_t sorted_cap = 0;         // in points
   uint32_t* rank = nullptr;      // per input point: rank inside its bin

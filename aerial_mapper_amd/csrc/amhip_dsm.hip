@@ -57,6 +57,26 @@ int launch_fill(Ctx* c, float* dst, size_t n, float value) {
 // ---------------------------------------------------------------------------
 // gather
 // ---------------------------------------------------------------------------
+// The binned cloud as the gather's routines see it (amhip_common.h: PtsView).  Two pipelines
+// fill it (amhip_sort.hip):
+//   doubles    sorted != null: (px, py, z) of sorted point g at sorted[3 g ..], centre offsets of
+//              dsm.cc:42-43 applied -- the FP64 mode, OrthoFromPcl, small clouds;
+//   records    rec != null: 16-byte records of the single-precision gather (cell, fixed-point
+//              offsets from the cell centre, f32 height offset from zref[0]); the reference's
+//              doubles of sorted point g are then those of row sidx[g] of the caller's UNTOUCHED
+//              cloud -- fetched only by the routines that redo a cell or a tile in FP64 (a few
+//              per tile).  Small clouds (one-level sort) carry both.
+using Pts = PtsView;
+__device__ __forceinline__ double pts_x(const Pts& P, size_t g) {
+  return P.sorted ? P.sorted[3 * g + 0] : P.cloud[3 * (size_t)P.sidx[g] + 0] - P.sub_x;
+}
+__device__ __forceinline__ double pts_y(const Pts& P, size_t g) {
+  return P.sorted ? P.sorted[3 * g + 1] : P.cloud[3 * (size_t)P.sidx[g] + 1] - P.sub_y;
+}
+__device__ __forceinline__ double pts_z(const Pts& P, size_t g) {
+  return P.sorted ? P.sorted[3 * g + 2] : P.cloud[3 * (size_t)P.sidx[g] + 2];
+}
+
 struct Accum {
   double num, den;
   unsigned cnt;
@@ -84,7 +104,7 @@ __device__ __forceinline__ void idw_add(double d2, double z, double* num,
 template <int MODE>
 __device__ __forceinline__ void scan_window(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
-                                            const double* __restrict__ sorted,
+                                            const Pts P,
                                             double qx, double qy, int i, int j,
                                             int w, double T, Accum* acc,
                                             double* dmin) {
@@ -97,8 +117,8 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
     const uint32_t s = row[bx0];
     const uint32_t e = row[bx1 + 1];
     for (uint32_t k = s; k < e; ++k) {
-      const double px = sorted[3 * (size_t)k + 0];
-      const double py = sorted[3 * (size_t)k + 1];
+      const double px = pts_x(P, (size_t)k);
+      const double py = pts_y(P, (size_t)k);
       // L2_Adaptor with size == 2 (nanoflann.hpp:319-322): 0 + dx*dx, + dy*dy
       const double dx = qx - px;
       const double dy = qy - py;
@@ -107,10 +127,10 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
       if (MODE == 0) {
         if (d2 < T) {  // RadiusResultSet::addPoint, strict (nanoflann.hpp:157)
           if (d2 > 0.0) {
-            idw_add(d2, sorted[3 * (size_t)k + 2], &acc->num, &acc->den);
+            idw_add(d2, pts_z(P, (size_t)k), &acc->num, &acc->den);
           } else {
             acc->exact = true;  // dsm.cc:165 CHECK / ortho-from-pcl.cc:91-96
-            acc->exact_z = sorted[3 * (size_t)k + 2];
+            acc->exact_z = pts_z(P, (size_t)k);
           }
           acc->cnt++;
         }
@@ -172,14 +192,14 @@ __device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& 
 // that threshold.  Works on the global bin structure.
 __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
                                                      const uint32_t* __restrict__ start,
-                                                     const double* __restrict__ sorted, int i,
+                                                     const Pts P, int i,
                                                      int j, double qx, double qy,
                                                      const CellOut& o) {
   if (p.nlevels <= 1) return false;
   Accum acc = {0.0, 0.0, 0u, false, 0.0};
   const int last = p.nlevels - 1;
   double dmin = __builtin_huge_val();
-  scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
+  scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
   int level = -1;
   for (int k = 1; k <= last; ++k) {
     if (dmin < p.T[k]) {
@@ -188,7 +208,7 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
     }
   }
   if (level < 0) return false;  // nothing within the last radius: cell untouched
-  scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
+  scan_window<0>(p, start, P, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
   return finish_accum(p, o, i, j, acc);
 }
 
@@ -225,7 +245,7 @@ __device__ __forceinline__ void knn_add(KnnSet* s, int k, double d2, double z) {
 }
 
 __device__ __forceinline__ void knn_scan(const DsmParams& p, const uint32_t* __restrict__ start,
-                                         const double* __restrict__ sorted, double qx, double qy,
+                                         const Pts P, double qx, double qy,
                                          int i, int j, int w, double T, KnnSet* s) {
   const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
   const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
@@ -233,18 +253,18 @@ __device__ __forceinline__ void knn_scan(const DsmParams& p, const uint32_t* __r
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t e = row[bx1 + 1];
     for (uint32_t k = row[bx0]; k < e; ++k) {
-      const double dx = qx - sorted[3 * (size_t)k + 0];
-      const double dy = qy - sorted[3 * (size_t)k + 1];
+      const double dx = qx - pts_x(P, (size_t)k);
+      const double dy = qy - pts_y(P, (size_t)k);
       double d2 = dx * dx;
       d2 = d2 + dy * dy;
-      if (d2 < T) knn_add(s, p.knn_k, d2, sorted[3 * (size_t)k + 2]);
+      if (d2 < T) knn_add(s, p.knn_k, d2, pts_z(P, (size_t)k));
     }
   }
 }
 
 __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
                                                 const uint32_t* __restrict__ start,
-                                                const double* __restrict__ sorted, int i, int j,
+                                                const Pts P, int i, int j,
                                                 const CellOut& o) {
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
@@ -252,15 +272,15 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
   s.n = 0;
 #pragma unroll
   for (int q = 0; q < kMaxKnn; ++q) s.d2[q] = s.z[q] = 0.0;
-  knn_scan(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &s);
+  knn_scan(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &s);
   if (s.n == 0 && p.nlevels > 1) {  // the ladder of dsm.cc:133-144, as in cell_fallback_global
     Accum acc = {0.0, 0.0, 0u, false, 0.0};
     const int last = p.nlevels - 1;
     double dmin = __builtin_huge_val();
-    scan_window<1>(p, start, sorted, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
+    scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
     for (int k = 1; k <= last; ++k)
       if (dmin < p.T[k]) {
-        knn_scan(p, start, sorted, qx, qy, i, j, p.w[k], p.T[k], &s);
+        knn_scan(p, start, P, qx, qy, i, j, p.w[k], p.T[k], &s);
         break;
       }
   }
@@ -289,7 +309,7 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
 // Whole cell through the global bins (first level + fallback).
 __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
-                                            const double* __restrict__ sorted, int i, int j,
+                                            const Pts P, int i, int j,
                                             const CellOut& o) {
   if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
@@ -297,9 +317,9 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
   Accum acc = {0.0, 0.0, 0u, false, 0.0};
   double dmin = 0.0;
-  scan_window<0>(p, start, sorted, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
+  scan_window<0>(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
   bool done = finish_accum(p, o, i, j, acc);
-  if (!done) done = cell_fallback_global(p, start, sorted, i, j, qx, qy, o);
+  if (!done) done = cell_fallback_global(p, start, P, i, j, qx, qy, o);
   if (!done) {
     leave_untouched(p, o, i, j);
     if (o.unfilled) atomicAdd(o.unfilled, 1u);
@@ -323,7 +343,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // does from the kd-tree's anyway).  Must be called by all 64 lanes of a wave
 // with the same block; bi0..bi1 x bj0..bj1 inclusive, <= 4 each way.
 __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* __restrict__ start,
-                                           const double* __restrict__ sorted, int bi0, int bi1,
+                                           const Pts P, int bi0, int bi1,
                                            int bj0, int bj1, const CellOut& o) {
   const int lane = threadIdx.x & 63;
   const int w = p.w[0];
@@ -345,9 +365,9 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double px = sorted[3 * (size_t)k + 0];
-      const double py = sorted[3 * (size_t)k + 1];
-      const double pz = sorted[3 * (size_t)k + 2];
+      const double px = pts_x(P, (size_t)k);
+      const double py = pts_y(P, (size_t)k);
+      const double pz = pts_z(P, (size_t)k);
       double dx2[4], dy2[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -406,7 +426,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
   if (((exact >> cidx) & 1u) || !(my_den > 0.0)) {
     // exact hit (CHECK failure / OrthoFromPcl's perfect match, which depends on
     // the scan order) or an empty first search (the ladder): the scalar routine
-    cell_global(p, start, sorted, i, j, o);
+    cell_global(p, start, P, i, j, o);
     return;
   }
   emit_value(p, o, i, j, my_num / my_den);
@@ -416,11 +436,11 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
 // the LDS image (very fine grids) and by the adaptive OrthoFromPcl passes.
 __global__ void __launch_bounds__(256)
 k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
-             const double* __restrict__ sorted, CellOut o) {
+             const Pts P, CellOut o) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
-  cell_global(p, start, sorted, i, j, o);
+  cell_global(p, start, P, i, j, o);
 }
 
 // The optional capped mode has a kernel of its own: its register-resident result set
@@ -428,12 +448,12 @@ k_dsm_gather(DsmParams p, const uint32_t* __restrict__ start,
 // kernel that can reach cell_global.
 __global__ void __launch_bounds__(256)
 k_dsm_gather_knn(DsmParams p, const uint32_t* __restrict__ start,
-                 const double* __restrict__ sorted, CellOut o) {
+                 const Pts P, CellOut o) {
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
   if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
-  cell_global_knn(p, start, sorted, i, j, o);
+  cell_global_knn(p, start, P, i, j, o);
 }
 
 // ---------------------------------------------------------------------------
@@ -627,7 +647,7 @@ __device__ __forceinline__ bool exponent_far_from_one(double v) {
 
 template <int NT, int kTileJ, int kCap>
 __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* __restrict__ start,
-                                            const double* __restrict__ sorted,
+                                            const Pts P,
                                             const uint8_t* __restrict__ tile_occ, const CellOut& o,
                                             const int tile, unsigned char* smem, int my_class) {
   constexpr int kWaves = NT / 64;
@@ -727,7 +747,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     // not fit this launch's LDS image: one lane per cell on the global bins
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
+      if (i <= i_hi && j <= j_hi) cell_global(p, start, P, i, j, o);
     }
     return;
   }
@@ -746,11 +766,11 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       int r = 0;
       while (idx >= (int)s_rowp[r + 1]) ++r;
       const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      const double px = sorted[3 * g + 0];
-      const double py = sorted[3 * g + 1];
+      const double px = pts_x(P, g);
+      const double py = pts_y(P, g);
       ppx[k] = px;
       ppy[k] = py;
-      ppz[k] = sorted[3 * g + 2];
+      ppz[k] = pts_z(P, g);
       // same arithmetic as point_bin(): the point's cell in shifted coordinates
       const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
       const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
@@ -961,11 +981,11 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     const int fi = i0 + (code % kTileI);
     const int fj = j0 + (code / kTileI);
     if (p.pcl_mode || redo) {
-      cell_global(p, start, sorted, fi, fj, o);
+      cell_global(p, start, P, fi, fj, o);
     } else {
       const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
       const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
-      const bool done = cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, o);
+      const bool done = cell_fallback_global(p, start, P, fi, fj, fqx, fqy, o);
       if (!done) {
         leave_untouched(p, o, fi, fj);
         if (o.unfilled) atomicAdd(o.unfilled, 1u);
@@ -1011,7 +1031,7 @@ __device__ __forceinline__ void wave_minmax_d(double* lo, double* hi) {
 // first-level window (FP64, reciprocal weights): the guard path of the f32 gather.
 // Same decisions as cell_global(); all 64 lanes must call it with the same cell.
 __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32_t* __restrict__ start,
-                                                const double* __restrict__ sorted, int i, int j,
+                                                const Pts P, int i, int j,
                                                 const CellOut& o) {
   const int lane = threadIdx.x & 63;
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
@@ -1026,12 +1046,12 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double dx = qx - sorted[3 * (size_t)k + 0];
-      const double dy = qy - sorted[3 * (size_t)k + 1];
+      const double dx = qx - pts_x(P, (size_t)k);
+      const double dy = qy - pts_y(P, (size_t)k);
       double d2 = dx * dx;
       d2 = d2 + dy * dy;       // L2_Adaptor (nanoflann.hpp:319-322)
       if (d2 < T) {            // strict (nanoflann.hpp:157)
-        if (d2 > 0.0) idw_add(d2, sorted[3 * (size_t)k + 2], &num, &den);
+        if (d2 > 0.0) idw_add(d2, pts_z(P, (size_t)k), &num, &den);
         else exact = 1;
       }
     }
@@ -1043,7 +1063,7 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   if (lane != 0) return;
   if (exact || !(den > 0.0)) {
     // exact hit (dsm.cc:165 CHECK) or an empty first search (the ladder): scalar routine
-    cell_global(p, start, sorted, i, j, o);
+    cell_global(p, start, P, i, j, o);
     return;
   }
   emit_value(p, o, i, j, num / den);
@@ -1056,7 +1076,7 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
 // aerial_mapper_amd.build --force); the shipped library holds kVar = 0 alone.
 template <int NT, int kTileJ, int kCap, int kVar = 0>
 __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32_t* __restrict__ start,
-                                                const double* __restrict__ sorted,
+                                                const Pts P,
                                                 const uint8_t* __restrict__ tile_occ, const CellOut& o,
                                                 const int tile, unsigned char* smem, int my_class,
                                                 int* __restrict__ exact_list,
@@ -1152,7 +1172,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     // (cannot happen for the class this launch serves; kept for safety) FP64 global path
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-      if (i <= i_hi && j <= j_hi) cell_global(p, start, sorted, i, j, o);
+      if (i <= i_hi && j <= j_hi) cell_global(p, start, P, i, j, o);
     }
     return;
   }
@@ -1173,9 +1193,9 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
       int r = 0;
       while (idx >= (int)s_rowp[r + 1]) ++r;
       const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      const double px = sorted[3 * g + 0];
-      const double py = sorted[3 * g + 1];
-      const double pz = sorted[3 * g + 2];
+      const double px = pts_x(P, g);
+      const double py = pts_y(P, g);
+      const double pz = pts_z(P, g);
       ppz[k] = pz;
       zlo = fmin(zlo, pz);
       zhi = fmax(zhi, pz);
@@ -1410,7 +1430,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     const int fj = j0 + (code / kTileI);
     const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
     const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
-    const bool done = cell_fallback_global(p, start, sorted, fi, fj, fqx, fqy, o);
+    const bool done = cell_fallback_global(p, start, P, fi, fj, fqx, fqy, o);
     if (!done) {
       leave_untouched(p, o, fi, fj);
       if (o.unfilled) atomicAdd(o.unfilled, 1u);
@@ -1419,7 +1439,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   for (int f = wid; f < nflag; f += kWaves) {
     if (!(s_flag[f] & 0x8000)) continue;
     const int code = s_flag[f] & 0x7FFF;
-    cell_wave_exact(p, start, sorted, i0 + (code % kTileI), j0 + (code / kTileI), o);
+    cell_wave_exact(p, start, P, i0 + (code % kTileI), j0 + (code / kTileI), o);
   }
 }
 
@@ -1429,7 +1449,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
 template <int NT, int kTileJ, int kCap, int kVar = 0>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(AMHIP_F32_WAVES, AMHIP_F32_WAVES)))
 k_dsm_gather_f32(DsmParams p, const uint32_t* __restrict__ start,
-                 const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                 const Pts P, const uint8_t* __restrict__ tile_occ,
                  CellOut o, int* __restrict__ exact_list, unsigned* __restrict__ exact_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ntiles = p.tiles_i * p.tiles_j;
@@ -1437,7 +1457,7 @@ k_dsm_gather_f32(DsmParams p, const uint32_t* __restrict__ start,
   const int xcd = b & 7, k = b >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  gather_tile_f32<NT, kTileJ, kCap, kVar>(p, start, sorted, tile_occ, o, tile, smem, 0, exact_list,
+  gather_tile_f32<NT, kTileJ, kCap, kVar>(p, start, P, tile_occ, o, tile, smem, 0, exact_list,
                                           exact_count);
 }
 
@@ -1446,7 +1466,7 @@ k_dsm_gather_f32(DsmParams p, const uint32_t* __restrict__ start,
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_f32_wide(DsmParams p, const uint32_t* __restrict__ start,
-                      const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                      const Pts P, const uint8_t* __restrict__ tile_occ,
                       CellOut o, int* __restrict__ exact_list, unsigned* __restrict__ exact_count,
                       int* __restrict__ big_list, unsigned* __restrict__ big_count, int big_np) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1455,14 +1475,14 @@ k_dsm_gather_f32_wide(DsmParams p, const uint32_t* __restrict__ start,
   const int xcd = b & 7, k = b >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  gather_tile_f32<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, 0, exact_list,
+  gather_tile_f32<NT, kTileJ, kCap>(p, start, P, tile_occ, o, tile, smem, 0, exact_list,
                                     exact_count, big_list, big_count, big_np);
 }
 
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
-                      const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                      const Pts P, const uint8_t* __restrict__ tile_occ,
                       const int* __restrict__ tile_list, const unsigned* __restrict__ tile_count,
                       CellOut o, int* __restrict__ exact_list,
                       unsigned* __restrict__ exact_count, int* __restrict__ big_list,
@@ -1470,7 +1490,7 @@ k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned count = *tile_count;
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-    gather_tile_f32<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem, -1,
+    gather_tile_f32<NT, kTileJ, kCap>(p, start, P, tile_occ, o, tile_list[k], smem, -1,
                                       exact_list, exact_count, big_list, big_count, big_np);
     __syncthreads();
   }
@@ -1483,7 +1503,7 @@ k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
-                   const double* __restrict__ sorted, const uint8_t* __restrict__ tile_occ,
+                   const Pts P, const uint8_t* __restrict__ tile_occ,
                    CellOut o, int my_class) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ntiles = p.tiles_i * p.tiles_j;
@@ -1491,7 +1511,7 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   const int xcd = b & 7, k = b >> 3;
   const int q = ntiles >> 3, r = ntiles & 7;
   const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile, smem, my_class);
+  gather_tile<NT, kTileJ, kCap>(p, start, P, tile_occ, o, tile, smem, my_class);
 }
 
 // List launch: a fixed grid walks a list of tiles -- the occupied tiles of a
@@ -1500,13 +1520,13 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
 template <int NT, int kTileJ, int kCap>
 __global__ void __launch_bounds__(NT)
 k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
-                          const double* __restrict__ sorted,
+                          const Pts P,
                           const uint8_t* __restrict__ tile_occ, const int* __restrict__ tile_list,
                           const unsigned* __restrict__ tile_count, CellOut o) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned count = *tile_count;
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-    gather_tile<NT, kTileJ, kCap>(p, start, sorted, tile_occ, o, tile_list[k], smem, -1);
+    gather_tile<NT, kTileJ, kCap>(p, start, P, tile_occ, o, tile_list[k], smem, -1);
     __syncthreads();
   }
 }
@@ -1521,7 +1541,7 @@ k_dsm_gather_tiled_sparse(DsmParams p, const uint32_t* __restrict__ start,
 // take cell_global() (the reference's doubles); a block whose height spread leaves no room for
 // its additions under the 1e-4 m budget is redone by block_wave() as a whole.
 __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_t* __restrict__ start,
-                                               const double* __restrict__ sorted, int bi0, int bi1,
+                                               const Pts P, int bi0, int bi1,
                                                int bj0, int bj1, const CellOut& o) {
   const int lane = threadIdx.x & 63;
   const int w = p.w[0];
@@ -1537,7 +1557,7 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
-    if (e0 > s0 && ncand == 0) z0 = sorted[3 * (size_t)s0 + 2];
+    if (e0 > s0 && ncand == 0) z0 = pts_z(P, (size_t)s0);
     ncand += e0 - s0;
   }
   float num[16], den[16];
@@ -1551,9 +1571,9 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double px = sorted[3 * (size_t)k + 0];
-      const double py = sorted[3 * (size_t)k + 1];
-      const float zf = (float)(sorted[3 * (size_t)k + 2] - z0);
+      const double px = pts_x(P, (size_t)k);
+      const double py = pts_y(P, (size_t)k);
+      const float zf = (float)(pts_z(P, (size_t)k) - z0);
       zspread = fmaxf(zspread, fabsf(zf));
       // (cell coordinate of the point, as in point_bin(), relative to the block's first cell)
       const double rx = (p.base_x - px) * p.inv_res - ox;
@@ -1597,7 +1617,7 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
     const bool ok = (S_half <= 3.0e38f) &&
                     (S_half == 0.0f || 2.0f * (epsw + (n_add + 2.0f) * 5.9604645e-8f) * S_half <= allowed);
     if (!ok) {  // (wave-uniform)
-      block_wave(p, start, sorted, bi0, bi1, bj0, bj1, o);
+      block_wave(p, start, P, bi0, bi1, bj0, bj1, o);
       return;
     }
   }
@@ -1636,7 +1656,7 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
     const int l = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
     const int cc = (l & 31) >> 1;
-    cell_wave_exact(p, start, sorted, bi0 + (cc & 3), bj0 + (cc >> 2), o);
+    cell_wave_exact(p, start, P, bi0 + (cc & 3), bj0 + (cc >> 2), o);
   }
 }
 
@@ -1648,7 +1668,7 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AMHIP_DENSE_WAVES)))
 k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
-                   const double* __restrict__ sorted, const int* __restrict__ tile_list,
+                   const Pts P, const int* __restrict__ tile_list,
                    const unsigned* __restrict__ tile_count, CellOut o, int f32) {
   const unsigned count = *tile_count;
   const int wid = threadIdx.x >> 6;
@@ -1670,8 +1690,8 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
             const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + p.B - 1), i_hi);
             const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + p.B - 1), j_hi);
             if (a0 > a1 || b0 > b1) continue;
-            if (f32) block_wave_f32(p, start, sorted, a0, a1, b0, b1, o);
-            else block_wave(p, start, sorted, a0, a1, b0, b1, o);
+            if (f32) block_wave_f32(p, start, P, a0, a1, b0, b1, o);
+            else block_wave(p, start, P, a0, a1, b0, b1, o);
           }
     (void)nbi;
     (void)nbj;
@@ -1696,6 +1716,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   if (split && split->phase == 1) return AMHIP_OK;  // (tiled call: the rest follows the exchange)
   {
     ScopedTimer t(c, AMHIP_K_DSM_GATHER);
+    const PtsView pts_view = c->pts;   // what dsm_sort left: doubles, records or both
     const int64_t prev_ntiles = c->last_ntiles;
     c->last_ntiles = 0;
     if (p.lds_ok) {
@@ -1791,7 +1812,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         reinterpret_cast<const void*>(k_dsm_gather_tiled<NT_, TJ_, CAP_>),                    \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
-                       p.lds_bytes, c->stream, p, c->bin_start, c->sorted, c->tile_occ,       \
+                       p.lds_bytes, c->stream, p, c->bin_start, pts_view, c->tile_occ,       \
                        cell_out, 0);                                                          \
   } while (0)
       // the FP64 kernel, one workgroup per tile, over the tiles the pre-pass classified for it
@@ -1804,7 +1825,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         reinterpret_cast<const void*>(k_dsm_gather_tiled<512, TJ_, CAP_>),                    \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled<512, TJ_, CAP_>), dim3(ntiles), dim3(512),         \
-                       q.lds_bytes, c->stream, q, c->bin_start, c->sorted, c->tile_occ,       \
+                       q.lds_bytes, c->stream, q, c->bin_start, pts_view, c->tile_occ,       \
                        cell_out, 4);                                                          \
   } while (0)
       // FP64 list launch: list LIST_ with an LDS image of CAPV_ points (CAP_ sizes the
@@ -1816,7 +1837,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         reinterpret_cast<const void*>(k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>),             \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled_sparse<NT_, TJ_, CAP_>), dim3(GRID_), dim3(NT_),   \
-                       q.lds_bytes, c->stream, q, c->bin_start, c->sorted, c->tile_occ,       \
+                       q.lds_bytes, c->stream, q, c->bin_start, pts_view, c->tile_occ,       \
                        lists + kListHdr + (size_t)(LIST_) * ntiles, tile_count + (LIST_),     \
                        cell_out);                                                             \
   } while (0)
@@ -1834,7 +1855,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
           reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),               \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
       hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(8192), dim3(512),      \
-                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, pts_view, c->tile_occ, \
                          lists + kListHdr, tile_count, cell_out, xl, tile_count + 4,          \
                          (int*)nullptr, (unsigned*)nullptr, 0x7FFFFFFF);                      \
     } else if (AMHIP_PROBE_SELECTED(TJ_, CAP_)) {                                             \
@@ -1844,7 +1865,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
           reinterpret_cast<const void*>(k_dsm_gather_f32<512, TJ_, CAP_>),                    \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
       hipLaunchKernelGGL((k_dsm_gather_f32<512, TJ_, CAP_>), dim3(ntiles), dim3(512),         \
-                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, pts_view, c->tile_occ, \
                          cell_out, xl, tile_count + 4);                                       \
     }                                                                                         \
     if (rej_dense) AMHIP_LAUNCH_REJECTED_DENSE(TJ_, CAP_);                                    \
@@ -1864,7 +1885,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
           reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),               \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
       hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(8192), dim3(512),      \
-                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, pts_view, c->tile_occ, \
                          lists + kListHdr, tile_count, cell_out, xl, xc, bl, tile_count + 6,  \
                          bnp);                                                                \
     } else {                                                                                  \
@@ -1872,7 +1893,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
           reinterpret_cast<const void*>(k_dsm_gather_f32_wide<512, TJ_, CAP_>),               \
           hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                 \
       hipLaunchKernelGGL((k_dsm_gather_f32_wide<512, TJ_, CAP_>), dim3(ntiles), dim3(512),    \
-                         p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ, \
+                         p.lds_bytes_f32, c->stream, p, c->bin_start, pts_view, c->tile_occ, \
                          cell_out, xl, xc, bl, tile_count + 6, bnp);                          \
     }                                                                                         \
     if (own) AMHIP_LAUNCH_LIST_EX(512, TJ_, 4096, cap0, 4, 4096);                             \
@@ -1892,7 +1913,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         reinterpret_cast<const void*>(k_dsm_gather_f32<512, 16, 1024, V_>),                   \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_f32));                   \
     hipLaunchKernelGGL((k_dsm_gather_f32<512, 16, 1024, V_>), dim3(ntiles), dim3(512),        \
-                       p.lds_bytes_f32, c->stream, p, c->bin_start, c->sorted, c->tile_occ,   \
+                       p.lds_bytes_f32, c->stream, p, c->bin_start, pts_view, c->tile_occ,   \
                        cell_out, lists + kListHdr + (size_t)4 * ntiles, tile_count + 4);      \
   } while (0)
 #ifdef AMHIP_TIMING_PROBES
@@ -1919,7 +1940,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         reinterpret_cast<const void*>(k_dsm_gather_f32_list<512, TJ_, CAP_>),                 \
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)q.lds_bytes_f32));                   \
     hipLaunchKernelGGL((k_dsm_gather_f32_list<512, TJ_, CAP_>), dim3(GRID_), dim3(512),       \
-                       q.lds_bytes_f32, c->stream, q, c->bin_start, c->sorted, c->tile_occ,   \
+                       q.lds_bytes_f32, c->stream, q, c->bin_start, pts_view, c->tile_occ,   \
                        lists + kListHdr + (size_t)(CLS_) * ntiles, tile_count + (CLS_),       \
                        cell_out, lists + kListHdr + (size_t)5 * ntiles, tile_count + 5,       \
                        lists + kListHdr + (size_t)6 * ntiles, tile_count + 6, cap2);          \
@@ -1974,12 +1995,12 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 #undef AMHIP_F32_DENSE_V
 #undef AMHIP_PROBE_SELECTED
       hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
-                         c->bin_start, c->sorted, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
+                         c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
                          cell_out, f32 ? 1 : 0);
       // (list 6: tiles the single-precision list launches handed back for their height spread)
       if (f32)
         hipLaunchKernelGGL(k_dsm_gather_dense, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
-                           c->bin_start, c->sorted, lists + kListHdr + (size_t)6 * ntiles,
+                           c->bin_start, pts_view, lists + kListHdr + (size_t)6 * ntiles,
                            tile_count + 6, cell_out, 0);
       // (what the next call's choice between list and dense launch reads; never waited for)
       if (c->host_tile_stats)
@@ -1989,10 +2010,10 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       if (p.knn_k > 0)
         hipLaunchKernelGGL(k_dsm_gather_knn, grid, dim3(256), 0, c->stream, p, c->bin_start,
-                           c->sorted, cell_out);
+                           pts_view, cell_out);
       else
         hipLaunchKernelGGL(k_dsm_gather, grid, dim3(256), 0, c->stream, p, c->bin_start,
-                           c->sorted, cell_out);
+                           pts_view, cell_out);
     }
     AMHIP_TRY(hipGetLastError());
   }

@@ -819,6 +819,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   c->last_num_bins = (int64_t)nbins;
   c->last_bin_cells = p.B;
   c->bin_z_valid = false;
+  c->pts = PtsView{c->sorted, nullptr, nullptr, dev_xyz, nullptr, p.sub_x, p.sub_y};
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
   const bool three_pass = p.p3_n1 > 0 && !force_one_level;
