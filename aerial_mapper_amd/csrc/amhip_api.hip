@@ -388,7 +388,11 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.knn_k = mode == 0 ? c.dsm_knn : 0;
   if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
   p.fx_ok = 0;
-  if (p.lds_ok && mode == 0 && !c.dsm_exact) {
+  // (the records hold a cell in 16 + 16 bits and a row of the cloud in 32: larger maps / clouds
+  // stay in FP64)
+  const bool rec_fits = (long long)p.rows + 2LL * p.M <= 65535 && (long long)p.cols + 2LL * p.M <= 65535 &&
+                        num_points < 0xFFFFFFFFull;
+  if (p.lds_ok && mode == 0 && !c.dsm_exact && rec_fits) {
     int S = 28;
     while (((long long)(w0 + 2) << S) >= (1LL << 31)) --S;
     const double scale2 = std::ldexp(1.0, 2 * S);
@@ -396,7 +400,10 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     // |d2_f32 - d2_reference| <= 3e-7 relative at the search radius; anything
     // inside +-2e-6 is decided by the FP64 routine
     const double margin = 2e-6;
-    double theta = 0.02;  // cells
+    // (cells within theta of a point go to the FP64 routine: 0.02 -> 0.005 takes 0.07 ms of
+    // redo tails off the 50 M-point gather and costs the error budget a factor 2.2 in eps_w --
+    // a tile's height half-range limit goes from 7.6 to 6.2 m; measured)
+    double theta = 0.005;  // cells
 #ifdef AMHIP_TIMING_PROBES
     if (std::getenv("AMHIP_FX_THETA")) theta = std::atof(std::getenv("AMHIP_FX_THETA"));
 #endif
@@ -849,7 +856,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

@@ -80,7 +80,9 @@ struct DsmParams {
   // OPTIONAL capped mode (not a reference code path): only the knn_k nearest points of a
   // cell's search result take part (0 = off = the reference's behaviour)
   int knn_k;
-  int fx_ok;                  // 0 -> the FP64 gather only
+  int fx_ok;                  // 0 -> the FP64 gather only; 1 -> the sort leaves 16-byte records
+                              // (amhip_sort.hip, "the record pipeline") and the single-precision
+                              // gather runs on them
   int fx_S;
   float fx_thi, fx_tlo;       // T[0] in those units, widened / narrowed by the decision margin
   float fx_denmax;            // a hit nearer than fx_theta cells makes the weight sum exceed this
@@ -218,6 +220,20 @@ struct Ctx {
   size_t rank_cap = 0;
   uint32_t* bin_start = nullptr; // nbins + 1 (+ scan partials behind it)
   size_t bin_cap = 0;
+  // record pipeline (single-precision gather): 20-byte records between the sort passes, the
+  // 16-byte records + rows the gather reads, the records' reference height
+  uint32_t* rec_a = nullptr;
+  size_t rec_a_cap = 0;
+  uint32_t* rec_b = nullptr;
+  size_t rec_b_cap = 0;
+  uint32_t* rec16 = nullptr;     // (uint4 per point)
+  size_t rec16_cap = 0;
+  uint32_t* sidx = nullptr;
+  size_t sidx_cap = 0;
+  double* zref = nullptr;        // [0] reference height, [1] / [2] range of the cloud's heights
+  size_t zref_cap = 0;
+  double* zall = nullptr;        // per-wave [min, max] partials of the count pass
+  size_t zall_cap = 0;
   uint32_t* bin_z = nullptr;     // per bin: ordered keys of its lowest / highest height (uint2)
   size_t bin_z_cap = 0;
   bool bin_z_valid = false;      // written by the last sort (three-pass, single-precision mode)

@@ -489,22 +489,34 @@ __device__ __forceinline__ float zkey_to_float(uint32_t k) {
 //   |dh| <= 2 (eps_w + (n + 2) u) S,  S = half the height range, u = 2^-24,
 // stays below 0.8 x (1e-4 m - one spacing of the stored float) -- above 1024 m, where a float
 // spacing alone exceeds 1e-4 m, "1 LSB" is the bar and a quarter of a spacing the budget.
-// Returns the allowed additions (-1: no finite range, 1 << 20: flat), the middle height in *z0w.
+// Returns the allowed additions (-1: no finite range / no room at all, 1 << 20: flat), the middle
+// of the range in *z0w (relative to zoff).
 // ONE definition for the gather kernel and for the occupancy pre-pass that sorts tiles without
 // room (< 48 additions) straight onto the FP64 lists.
-__device__ __forceinline__ int fx_allowed_additions(float zmin_f, float zmax_f, float epsw, double* z0w) {
+__device__ __forceinline__ int fx_allowed_additions(float zmin_f, float zmax_f, float epsw, double zoff,
+                                                   double* z0w) {
+  // (record pipeline: zmin_f / zmax_f are f32 OFFSETS from zoff = zref; the stored float is the
+  // height zoff + offset, and every offset carries the rounding of its own conversion)
   const double zmin = (double)zmin_f, zmax = (double)zmax_f;
-  *z0w = 0.5 * zmin + 0.5 * zmax;
-  // max |z - z0| over the region: half the f32 range, plus what the two conversions lost
+  // the middle, as a float: the staging subtracts it from the f32 offsets in single precision
+  *z0w = (double)(float)(0.5 * zmin + 0.5 * zmax);
+  // max |z - z0| over the region: half the f32 range, plus what the conversions lost
   const float S_half = (float)(0.5 * zmax - 0.5 * zmin) * 1.000001f +
                        (fabsf(zmin_f) + fabsf(zmax_f)) * 1.2e-7f;
-  const float zabs = fmaxf(fabsf((float)zmin), fabsf((float)zmax));
-  // spacing of the stored floats at that height
-  const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
-  const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
-  if (!(S_half <= 3.0e38f)) return -1;
+  // spacing of the stored floats: at the largest height of the region for the 1e-4 m regime,
+  // at the smallest for the "1 LSB" regime (above 1024 m) -- conservative both ways
+  const double alo = zoff + zmin, ahi = zoff + zmax;
+  const float zabs_hi = (float)fmax(fabs(alo), fabs(ahi));
+  const float zabs_lo = (alo <= 0.0 && ahi >= 0.0) ? 0.0f : (float)fmin(fabs(alo), fabs(ahi));
+  const float ulp_hi = __uint_as_float((__float_as_uint(fmaxf(zabs_hi, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+  const float ulp_lo = __uint_as_float((__float_as_uint(fmaxf(zabs_lo, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+  float allowed = 0.8f * (ulp_hi < 1e-4f * 0.6f ? 1e-4f - ulp_hi : 0.25f * ulp_lo);
+  // the records' own rounding: every offset is (float)(z - zref), half a spacing at most
+  allowed -= fmaxf(fabsf(zmin_f), fabsf(zmax_f)) * 6.0e-8f;
+  if (!(S_half <= 3.0e38f) || !(allowed > 0.0f)) return -1;
   if (S_half == 0.0f) return 1 << 20;
-  const float room = (0.5f * allowed / S_half - epsw) * 16777216.0f - 2.0f;
+  // (n + 3: the hits of a trip, the add of the trip's sum, and the staging's f32 subtraction)
+  const float room = (0.5f * allowed / S_half - epsw) * 16777216.0f - 3.0f;
   return room > 1.0e6f ? (1 << 20) : (int)room;
 }
 constexpr int kFxMinAdditions = 48;  // a trip of a dense tile brings up to ~20 candidates; below: FP64
@@ -554,8 +566,9 @@ __global__ void __launch_bounds__(256)
 k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
                      int cap1, int cap2, const uint2* __restrict__ bin_z, int rej_own,
-                     int rej_big_np, int rej_dense) {
+                     int rej_big_np, int rej_dense, const double* __restrict__ zref_dev) {
   const int ntiles = p.tiles_i * p.tiles_j;
+  const double zref = bin_z ? zref_dev[0] : 0.0;
   const int tile = blockIdx.x * 256 + threadIdx.x;
   int lst = -1;       // list this tile is appended to
   int rejected = 0;   // pre-classified for the FP64 kernel
@@ -607,7 +620,7 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
         }
         if (klo <= khi) {
           double z0w;
-          const int na = fx_allowed_additions(zkey_to_float(klo), zkey_to_float(khi), p.fx_epsw, &z0w);
+          const int na = fx_allowed_additions(zkey_to_float(klo), zkey_to_float(khi), p.fx_epsw, zref, &z0w);
           if (na < kFxMinAdditions) {
             rejected = 1;
             const int own = (cls == 0) && rej_own;
@@ -1177,14 +1190,14 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     return;
   }
 
-  // ---- stage: load, count per cell, height range -------------------------------
+  // ---- stage: load the region's 16-byte records (amhip_sort.hip: cell, fixed-point offsets
+  // from the cell centre, f32 height offset from zref), count per cell, height range ----------
   static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
   constexpr int kMaxK = (kCap + NT - 1) / NT;
   uint32_t pslot[kMaxK];
   uint32_t pU[kMaxK], pV[kMaxK];
-  double ppz[kMaxK];
-  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
-  const double fx_scale = (double)(1u << p.fx_S);
+  float pdz[kMaxK];
+  float zlo = __builtin_huge_valf(), zhi = -__builtin_huge_valf();
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     const int idx = tid + k * NT;
@@ -1193,26 +1206,17 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
       int r = 0;
       while (idx >= (int)s_rowp[r + 1]) ++r;
       const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      const double px = pts_x(P, g);
-      const double py = pts_y(P, g);
-      const double pz = pts_z(P, g);
-      ppz[k] = pz;
-      zlo = fmin(zlo, pz);
-      zhi = fmax(zhi, pz);
-      // the point's cell (same arithmetic as point_bin()) and its offset from that
-      // cell's centre, in cells
-      const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
-      const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
-      int ix = (int)floor(cx + 0.5) + p.M;
-      int iy = (int)floor(cy + 0.5) + p.M;
-      ix = min(max(ix, 0), p.rows + 2 * p.M - 1) - ox;
-      iy = min(max(iy, 0), p.cols + 2 * p.M - 1) - oy;
-      ix = min(max(ix, 0), RW - 1);
-      iy = min(max(iy, 0), RH - 1);
-      const double fx = (cx + (double)(p.M - ox)) - (double)ix;  // in [-0.5, 0.5]
-      const double fy = (cy + (double)(p.M - oy)) - (double)iy;
-      pU[k] = ((uint32_t)ix << p.fx_S) + (uint32_t)(int)rint(fx * fx_scale);
-      pV[k] = ((uint32_t)iy << p.fx_S) + (uint32_t)(int)rint(fy * fx_scale);
+      const uint4 rec = P.rec[g];
+      const float dz = __uint_as_float(rec.w);
+      pdz[k] = dz;
+      zlo = fminf(zlo, dz);
+      zhi = fmaxf(zhi, dz);
+      // position in the region's frame, 32-bit fixed point (wrapping: only differences count)
+      const int rx = (int)(rec.x & 0xFFFFu) - ox, ry = (int)(rec.x >> 16) - oy;
+      pU[k] = ((uint32_t)rx << p.fx_S) + rec.y;
+      pV[k] = ((uint32_t)ry << p.fx_S) + rec.z;
+      const int ix = min(max(rx, 0), RW - 1);
+      int iy = min(max(ry, 0), RH - 1);
       iy += sh;
       const uint32_t cell = (uint32_t)((iy >> 1) * RW2 + 2 * ix + (iy & 1));
       pslot[k] = (cell << 13) | atomicAdd(&s_off[cell], 1u);
@@ -1225,7 +1229,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   // address serialises: measured +0.5 ms.)
   {
     // (+-inf where the thread had no point; six DPP steps each, result in lane 63)
-    const float flo = wave_min_to_lane63((float)zlo), fhi = wave_max_to_lane63((float)zhi);
+    const float flo = wave_min_to_lane63(zlo), fhi = wave_max_to_lane63(zhi);
     if (lane == 63 && flo <= fhi) {
       atomicMin(&s_zkey[0], zkey_of(flo));
       atomicMax(&s_zkey[1], zkey_of(fhi));
@@ -1239,6 +1243,8 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   const int q0 = tid * qper, q1 = min(q0 + qper, nq);
   uint4* const qoff = reinterpret_cast<uint4*>(s_off);
   unsigned qsum = 0;
+  // (one quad per thread at the usual sizes: unrolled by eight the loop costs the kernel a spill)
+#pragma unroll 1
   for (int k = q0; k < q1; ++k) {
     const uint4 v = qoff[k];
     qsum += (v.x + v.y) + (v.z + v.w);
@@ -1254,7 +1260,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
       zmax_f = zkey_to_float(s_zkey[1]);
     }
     double z0w;
-    const int na = fx_allowed_additions(zmin_f, zmax_f, p.fx_epsw, &z0w);
+    const int na = fx_allowed_additions(zmin_f, zmax_f, p.fx_epsw, P.zref[0], &z0w);
     if (lane == 0) {
       s_ctl[2] = (uint32_t)na;
       s_zkey[2] = (uint32_t)__double2loint(z0w);
@@ -1280,7 +1286,10 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     }
   }
   const int n_allowed = (int)s_ctl[2];
-  const double z0 = __hiloint2double((int)s_zkey[3], (int)s_zkey[2]);
+  // (z0: the middle of the region's OFFSETS, exactly a float; heights = zref + z0 + N / D)
+  const double z0rel = __hiloint2double((int)s_zkey[3], (int)s_zkey[2]);
+  const float z0f = (float)z0rel;
+  const double z0 = P.zref[0] + z0rel;
   // (a trip of a dense tile brings up to ~20 candidates: below that the FP64 kernel takes
   // the whole tile -- staging it twice is cheaper than redoing most of its cells)
   if (n_allowed < kFxMinAdditions) {
@@ -1298,7 +1307,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   for (int k = 0; k < kMaxK; ++k) {
     if (pslot[k] != 0xFFFFFFFFu) {
       const uint32_t pos = s_off[pslot[k] >> 13] + (pslot[k] & 0x1FFFu);
-      s_rec[pos] = make_uint4(pU[k], pV[k], __float_as_uint((float)(ppz[k] - z0)), 0u);
+      s_rec[pos] = make_uint4(pU[k], pV[k], __float_as_uint(pdz[k] - z0f), 0u);
     }
   }
   __syncthreads();
@@ -1546,40 +1555,38 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
   const int lane = threadIdx.x & 63;
   const int w = p.w[0];
   const int S = p.fx_S - 1;
-  const double scale = (double)(1u << S);
   const float thi = p.fx_thi * 0.25f, tlo = p.fx_tlo * 0.25f;  // (squared scale: one bit -> 1/4)
   const float denmax = p.fx_denmax * 4.0f;
   const int bx0 = (bi0 - w + p.M) / p.B, bx1 = (bi1 + w + p.M) / p.B;
   const int by0 = (bj0 - w + p.M) / p.B, by1 = (bj1 + w + p.M) / p.B;
-  // reference height: the first candidate's (wave-uniform)
-  double z0 = 0.0;
+  // reference height: the first candidate's f32 offset from zref (wave-uniform)
+  float z0f = 0.0f;
   unsigned ncand = 0;
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
-    if (e0 > s0 && ncand == 0) z0 = pts_z(P, (size_t)s0);
+    if (e0 > s0 && ncand == 0) z0f = __uint_as_float(P.rec[s0].w);
     ncand += e0 - s0;
   }
+  const double z0 = P.zref[0] + (double)z0f;
   float num[16], den[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0f;
   unsigned amb = 0;      // bit c: cell c has a hit inside the band around the radius
   float zspread = 0.0f;  // max |z - z0| over the lane's candidates
-  // block origin in the continuous cell coordinates of point_bin(): cell bi0 / bj0
-  const double ox = (double)(bi0 + p.i_off), oy = (double)(bj0 + p.j_off);
+  // block origin in the records' cell frame (window cells + margin M)
+  const int ox = bi0 + p.M, oy = bj0 + p.M;
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double px = pts_x(P, (size_t)k);
-      const double py = pts_y(P, (size_t)k);
-      const float zf = (float)(pts_z(P, (size_t)k) - z0);
+      const uint4 rec = P.rec[k];
+      const float zf = __uint_as_float(rec.w) - z0f;
       zspread = fmaxf(zspread, fabsf(zf));
-      // (cell coordinate of the point, as in point_bin(), relative to the block's first cell)
-      const double rx = (p.base_x - px) * p.inv_res - ox;
-      const double ry = (p.base_y - py) * p.inv_res - oy;
-      const uint32_t U = (uint32_t)(int)rint(rx * scale);
-      const uint32_t V = (uint32_t)(int)rint(ry * scale);
+      // position relative to the block's first cell in units of 2^-S cells (S = fx_S - 1: the
+      // record's offset loses its last bit, rounded to nearest)
+      const uint32_t U = ((uint32_t)((int)(rec.x & 0xFFFFu) - ox) << S) + (uint32_t)(((int)rec.y + 1) >> 1);
+      const uint32_t V = ((uint32_t)((int)(rec.x >> 16) - oy) << S) + (uint32_t)(((int)rec.z + 1) >> 1);
       float dx2[4], dy2[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -1609,13 +1616,18 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
   // candidates + the six levels of the butterfly
   {
     const float zabs = fabsf((float)z0) + zspread;
+    const float zabs_lo = fmaxf(fabsf((float)z0) - zspread, 0.0f);
     const float ulp = __uint_as_float((__float_as_uint(fmaxf(zabs, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
-    const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp);
-    const float S_half = zspread * 1.000001f + zabs * 1.2e-7f;
-    const float epsw = 2.0f * (p.fx_epsw - 4e-7f) + 4e-7f;  // (one bit coarser positions)
+    const float ulp_lo = __uint_as_float((__float_as_uint(fmaxf(zabs_lo, 1e-30f)) & 0x7F800000u)) * 1.1920929e-7f;
+    // (minus the records' own rounding of z - zref: half a spacing of the offset at most)
+    const float allowed = 0.8f * (ulp < 1e-4f * 0.6f ? 1e-4f - ulp : 0.25f * ulp_lo) -
+                          (fabsf(z0f) + zspread) * 6.0e-8f;
+    const float S_half = zspread * 1.000001f + (fabsf(z0f) + zspread) * 1.2e-7f;
+    // (positions one bit coarser, and rounded twice: three times the tile kernel's quantum term)
+    const float epsw = 3.0f * (p.fx_epsw - 4e-7f) + 4e-7f;
     const float n_add = (float)((ncand + 63u) / 64u + 8u);
-    const bool ok = (S_half <= 3.0e38f) &&
-                    (S_half == 0.0f || 2.0f * (epsw + (n_add + 2.0f) * 5.9604645e-8f) * S_half <= allowed);
+    const bool ok = (S_half <= 3.0e38f) && allowed > 0.0f &&
+                    (S_half == 0.0f || 2.0f * (epsw + (n_add + 3.0f) * 5.9604645e-8f) * S_half <= allowed);
     if (!ok) {  // (wave-uniform)
       block_wave(p, start, P, bi0, bi1, bj0, bj1, o);
       return;
@@ -1662,14 +1674,14 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
 
 // Class-3 tiles (more points than any LDS image holds): a fixed grid walks their
 // list; the four waves of a workgroup share a tile's blocks of 4 x 4 cells
-// (block_wave).  No LDS, its own register budget.
-#ifndef AMHIP_DENSE_WAVES
-#define AMHIP_DENSE_WAVES 3
-#endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AMHIP_DENSE_WAVES)))
+// (block_wave).  No LDS, its own register budget: three waves per SIMD in FP64, two for the
+// single-precision instance (it carries the FP64 routines for its redos besides its own 16 x 2
+// accumulators: at three waves it spills 18 registers).
+template <bool kF32>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kF32 ? 2 : 3)))
 k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                    const Pts P, const int* __restrict__ tile_list,
-                   const unsigned* __restrict__ tile_count, CellOut o, int f32) {
+                   const unsigned* __restrict__ tile_count, CellOut o) {
   const unsigned count = *tile_count;
   const int wid = threadIdx.x >> 6;
   for (unsigned t = blockIdx.x; t < count; t += gridDim.x) {
@@ -1690,7 +1702,7 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
             const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + p.B - 1), i_hi);
             const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + p.B - 1), j_hi);
             if (a0 > a1 || b0 > b1) continue;
-            if (f32) block_wave_f32(p, start, P, a0, a1, b0, b1, o);
+            if (kF32) block_wave_f32(p, start, P, a0, a1, b0, b1, o);
             else block_wave(p, start, P, a0, a1, b0, b1, o);
           }
     (void)nbi;
@@ -1793,7 +1805,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       }
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
                          p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2,
-                         bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0);
+                         bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
@@ -1994,14 +2006,19 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
 #undef AMHIP_F32_DENSE
 #undef AMHIP_F32_DENSE_V
 #undef AMHIP_PROBE_SELECTED
-      hipLaunchKernelGGL(k_dsm_gather_dense, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
-                         c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles, tile_count + 3,
-                         cell_out, f32 ? 1 : 0);
+      if (f32)
+        hipLaunchKernelGGL(k_dsm_gather_dense<true>, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
+                           c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles,
+                           tile_count + 3, cell_out);
+      else
+        hipLaunchKernelGGL(k_dsm_gather_dense<false>, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
+                           c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles,
+                           tile_count + 3, cell_out);
       // (list 6: tiles the single-precision list launches handed back for their height spread)
       if (f32)
-        hipLaunchKernelGGL(k_dsm_gather_dense, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
+        hipLaunchKernelGGL(k_dsm_gather_dense<false>, dim3(1024), dim3(256), 0, c->stream, p, p.tile_j,
                            c->bin_start, pts_view, lists + kListHdr + (size_t)6 * ntiles,
-                           tile_count + 6, cell_out, 0);
+                           tile_count + 6, cell_out);
       // (what the next call's choice between list and dense launch reads; never waited for)
       if (c->host_tile_stats)
         AMHIP_TRY(hipMemcpyAsync(c->host_tile_stats, tile_count, kListHdr * sizeof(unsigned),

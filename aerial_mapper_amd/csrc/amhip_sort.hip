@@ -54,14 +54,22 @@ __device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
   return true;
 }
 
+// zall (may be null): per-wave [min, max] of all heights read (the records' reference height)
 __global__ void __launch_bounds__(256)
 k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
-                uint32_t* __restrict__ cnt, uint32_t* __restrict__ rank) {
+                uint32_t* __restrict__ cnt, uint32_t* __restrict__ rank,
+                double* __restrict__ zall) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
        idx += stride) {
     const double x = xyz[3 * idx + 0];
     const double y = xyz[3 * idx + 1];
+    if (zall) {
+      const double z = xyz[3 * idx + 2];
+      zlo = fmin(zlo, z);
+      zhi = fmax(zhi, z);
+    }
     const double px = x - p.sub_x;  // dsm.cc:42
     const double py = y - p.sub_y;  // dsm.cc:43
     uint32_t bin;
@@ -69,13 +77,20 @@ k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
     if (point_bin(p, px, py, &bin)) r = atomicAdd(&cnt[bin], 1u);
     rank[idx] = r;
   }
+  if (zall) range_commit_wave(zlo, zhi, zall, (size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 
+__device__ __forceinline__ bool make_record(const DsmParams& p, double px, double py, double z,
+                                            double zref, uint32_t row, uint32_t* w);
+
+// rec16 / sidx / zref (may be null): the single-precision gather's records next to the doubles
+// (small clouds carry both: the exact routines then read the doubles without the detour)
 __global__ void __launch_bounds__(256)
 k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values, size_t n,
               DsmParams p, const uint32_t* __restrict__ start,
               const uint32_t* __restrict__ rank, double* __restrict__ sorted,
-              double* __restrict__ zpart) {
+              double* __restrict__ zpart, uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
+              const double* __restrict__ zref) {
   const size_t stride = (size_t)gridDim.x * blockDim.x;
   double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n;
@@ -93,6 +108,12 @@ k_dsm_scatter(const double* __restrict__ xyz, const int32_t* __restrict__ values
     sorted[3 * slot + 0] = px;
     sorted[3 * slot + 1] = py;
     sorted[3 * slot + 2] = z;
+    if (rec16) {
+      uint32_t w[5];
+      make_record(p, px, py, z, zref[0], (uint32_t)idx, w);
+      rec16[slot] = make_uint4(w[0], w[1], w[2], w[3]);
+      sidx[slot] = w[4];
+    }
     zlo = fmin(zlo, z);
     zhi = fmax(zhi, z);
   }
@@ -258,11 +279,14 @@ __device__ __forceinline__ void halo_flush(HaloStage* st, const HaloParams& hp,
 
 // kHalo: the pass also copies the points other windows need into their send rows -- it
 // reads every point anyway (amhip_dsm_tiled_begin_dev).
+// zall (may be null; the record pipeline): every wave also leaves the [min, max] of ALL the
+// heights it reads (plain stores, range_commit_wave) -- the records' reference height zref is the
+// middle of that range and has to exist before the first scatter pass writes a record.
 template <bool kHalo>
 __global__ void __launch_bounds__(kP3CountThreads)
 k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
                uint32_t* __restrict__ hist_rows, HaloParams hp, double* __restrict__ halo_out,
-               unsigned long long* __restrict__ halo_counts) {
+               unsigned long long* __restrict__ halo_counts, double* __restrict__ zall) {
   extern __shared__ uint32_t s_hist[];
   const int nk = p.p3_n1 * p.p3_n2;
   // (kHalo: the staging area follows the histogram, 8-byte aligned)
@@ -273,6 +297,7 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
   const size_t stride = (size_t)gridDim.x * kP3CountThreads;
   // four points' loads in flight per lane before any of the (branchy) bookkeeping
   constexpr int kU = 4;
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   for (size_t base = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; base < n;
        base += kU * stride) {
     double x[kU], y[kU];
@@ -282,6 +307,11 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
       if (idx < n) {
         x[u] = xyz[3 * idx + 0];
         y[u] = xyz[3 * idx + 1];
+        if (zall) {  // (the same cache lines)
+          const double z = xyz[3 * idx + 2];
+          zlo = fmin(zlo, z);
+          zhi = fmax(zhi, z);
+        }
       }
     }
     unsigned look = 0;  // kHalo: which of the four may have to travel
@@ -306,6 +336,8 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
     }
   }
   if (kHalo) halo_flush(stage, hp, xyz, halo_out, halo_counts);
+  if (zall)
+    range_commit_wave(zlo, zhi, zall, (size_t)blockIdx.x * (kP3CountThreads / 64) + (threadIdx.x >> 6));
   __syncthreads();
   uint32_t* row = hist_rows + (size_t)blockIdx.x * nk;
   for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
@@ -334,7 +366,7 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
               uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
               uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
-              uint32_t* __restrict__ big_list) {
+              uint32_t* __restrict__ big_list, unsigned chunk) {
   __shared__ unsigned lds[1024 / 64 + 1];
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
@@ -367,7 +399,7 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
   if (k < n1) {
     start1[k] = s_start1[k];
     cursor1[k] = s_start1[k];
-    nblk = (s_start1[k + 1] - s_start1[k] + kP3Chunk - 1) / kP3Chunk;
+    nblk = (s_start1[k + 1] - s_start1[k] + chunk - 1) / chunk;
   }
   if (k == 0) start1[n1] = carry;
   unsigned total;
@@ -639,6 +671,340 @@ k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
 }
 
 // ---------------------------------------------------------------------------
+// the record pipeline of the single-precision gather (DsmParams::rec_mode)
+// ---------------------------------------------------------------------------
+// The single-precision gather turns every point into a cell, two fixed-point offsets from
+// that cell's centre and an f32 height offset anyway (amhip_dsm.hip, gather_tile_f32) -- so the
+// sort carries exactly that instead of the three doubles: 20-byte records
+//     w0 = ix | iy << 16   cell of the point in map cells + margin M (< 65536 each way)
+//     w1, w2               offsets from the cell centre, int32 in units of 2^-fx_S cells
+//     w3                   f32 bits of z - zref   (zref: the middle of the cloud's height range)
+//     w4                   row of the point in the caller's cloud
+// through the two scatter passes (44 + 40 bytes per point instead of 48 + 48; the keys of
+// passes 2 and 3 are integer arithmetic on w0, no FP64), and the placement pass splits them
+// into 16-byte records (w0 .. w3: what the gather stages) and the rows (w4: what the few
+// routines that redo a cell or a tile in the reference's doubles use to fetch them from the
+// untouched cloud).  ~0.3 ms less sort and ~0.1 ms less staging per 50 M points.
+// The reference's doubles are NOT lost: they stay where the caller put them.
+constexpr int kRecWords = 5;
+// (20-byte records: 3072 points per scatter workgroup fit the LDS budget of two workgroups per
+// CU that 2560 24-byte points use -- longer runs)
+constexpr int kRecPerThread = 6;
+constexpr int kRecChunk = kP3Threads * kRecPerThread;
+
+// zref[0] = middle of [min, max] over the partials the count pass left, [1] / [2] the range
+__global__ void __launch_bounds__(1024)
+k_dsm_zref(const double* __restrict__ part, size_t nparts, double* __restrict__ zref) {
+  __shared__ double s_pair[2 * 16];
+  double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+  for (size_t k = threadIdx.x; k < nparts; k += 1024) {
+    lo = fmin(lo, part[2 * k]);
+    hi = fmax(hi, part[2 * k + 1]);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, d, 64));
+    hi = fmax(hi, __shfl_xor(hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_pair[2 * (threadIdx.x >> 6)] = lo;
+    s_pair[2 * (threadIdx.x >> 6) + 1] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w) {
+      lo = fmin(lo, s_pair[2 * w]);
+      hi = fmax(hi, s_pair[2 * w + 1]);
+    }
+    const bool ok = lo <= hi && lo > -1.0e300 && hi < 1.0e300;
+    zref[0] = ok ? 0.5 * lo + 0.5 * hi : 0.0;
+    zref[1] = lo;
+    zref[2] = hi;
+  }
+}
+
+// the record of a (centre-shifted) point; false: outside the binned area (like point_bin)
+__device__ __forceinline__ bool make_record(const DsmParams& p, double px, double py, double z,
+                                            double zref, uint32_t row, uint32_t* w) {
+  const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+  const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+  const double lo = -(double)p.M - 0.5;
+  const double hx = (double)(p.rows + p.M) - 0.5;
+  const double hy = (double)(p.cols + p.M) - 0.5;
+  if (!(cx >= lo && cx < hx && cy >= lo && cy < hy)) return false;  // NaN too
+  int ix = (int)floor(cx + 0.5) + p.M;
+  int iy = (int)floor(cy + 0.5) + p.M;
+  ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
+  iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
+  const double scale = (double)(1u << p.fx_S);
+  // offset from the cell's centre in cells, in [-0.5, 0.5] (the same value gather_tile_f32
+  // formed from the doubles), rounded to the fixed-point grid
+  const double fx = (cx + (double)p.M) - (double)ix;
+  const double fy = (cy + (double)p.M) - (double)iy;
+  w[0] = (uint32_t)ix | ((uint32_t)iy << 16);
+  w[1] = (uint32_t)(int)rint(fx * scale);
+  w[2] = (uint32_t)(int)rint(fy * scale);
+  w[3] = __float_as_uint((float)(z - zref));
+  w[4] = row;
+  return true;
+}
+
+__device__ __forceinline__ void record_keys(const DsmParams& p, uint32_t w0, int* k1, int* k2,
+                                            int* bx_out) {
+  const int bx = div_by((int)(w0 & 0xFFFFu), p.B, p.mul_B);
+  const int by = div_by((int)(w0 >> 16), p.B, p.mul_B);
+  const int a = div_by(by, p.p3_r1, p.mul_r1);
+  *k1 = a;
+  *k2 = (by - a * p.p3_r1) * p.p3_c + div_by(bx, p.p3_w, p.mul_w);
+  *bx_out = bx;
+}
+
+// Passes 1 and 2 on records.  kFirst: chunk of the caller's cloud -> records, key k1; else:
+// chunk of one k1 partition of records, key k2.  Same structure as k_dsm_p3_scatter.
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter_rec(const double* __restrict__ cloud, const uint32_t* __restrict__ src, size_t n,
+                     DsmParams p, const double* __restrict__ zref,
+                     const uint32_t* __restrict__ start1, const uint32_t* __restrict__ blk2,
+                     uint32_t* __restrict__ cursor, uint32_t* __restrict__ dst,
+                     double* __restrict__ zpart) {
+  extern __shared__ uint32_t s_words[];                       // kRecWords * kRecChunk
+  uint32_t* s_dest = s_words + kRecWords * kRecChunk;          // kP3Chunk
+  uint32_t* s_cnt = s_dest + kRecChunk;                        // kP3MaxKeys
+  uint32_t* s_off = s_cnt + kP3MaxKeys;
+  uint32_t* s_base = s_off + kP3MaxKeys;
+  uint32_t* s_scan = s_base + kP3MaxKeys;  // 24
+  const int tid = threadIdx.x;
+  int nkeys;
+  size_t c0, c1;
+  if (kFirst) {
+    c0 = (size_t)blockIdx.x * kRecChunk;
+    c1 = min(c0 + (size_t)kRecChunk, n);
+    nkeys = p.p3_n1;
+  } else {
+    const int n1 = p.p3_n1;
+    const uint32_t b = blockIdx.x;
+    if (b >= blk2[n1]) return;
+    int lo = 0, hi = n1;  // blk2[lo] <= b < blk2[hi]
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (blk2[mid] <= b) lo = mid; else hi = mid;
+    }
+    c0 = (size_t)start1[lo] + (size_t)(b - blk2[lo]) * kRecChunk;
+    c1 = min(c0 + (size_t)kRecChunk, (size_t)start1[lo + 1]);
+    nkeys = p.p3_n2;
+    cursor += (size_t)lo * p.p3_n2;
+  }
+  if (tid < kP3MaxKeys) s_cnt[tid] = 0;
+  __syncthreads();
+  const double zr = kFirst ? zref[0] : 0.0;
+  uint32_t w[kRecPerThread][kRecWords];
+  double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
+  uint32_t slot[kRecPerThread];  // key << 13 | rank in the chunk's run of that key
+#pragma unroll
+  for (int k = 0; k < kRecPerThread; ++k) {
+    const size_t idx = c0 + tid + (size_t)k * kP3Threads;
+    slot[k] = 0xFFFFFFFFu;
+    if (idx < c1) {
+      bool in;
+      if (kFirst) {
+        const double x = cloud[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+        const double y = cloud[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+        const double z = cloud[3 * idx + 2];
+        in = make_record(p, x, y, z, zr, (uint32_t)idx, w[k]);
+        if (in) {
+          zlo = fmin(zlo, z);
+          zhi = fmax(zhi, z);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kRecWords; ++q) w[k][q] = src[kRecWords * idx + q];
+        in = true;
+      }
+      if (in) {
+        int k1, k2, bx;
+        record_keys(p, w[k][0], &k1, &k2, &bx);
+        const int key = kFirst ? k1 : k2;
+        slot[k] = ((uint32_t)key << 13) | atomicAdd(&s_cnt[key], 1u);
+      }
+    }
+  }
+  if (kFirst && zpart)
+    range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * (kP3Threads / 64) + (tid >> 6));
+  __syncthreads();
+  {
+    const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
+    unsigned total;
+    const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
+    if (tid < nkeys) {
+      s_off[tid] = ex;
+      s_base[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+    }
+    if (tid == 0) s_scan[23] = total;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kRecPerThread; ++k) {
+    if (slot[k] != 0xFFFFFFFFu) {
+      const uint32_t key = slot[k] >> 13, rank = slot[k] & 0x1FFFu;
+      const uint32_t q = s_off[key] + rank;
+#pragma unroll
+      for (int t = 0; t < kRecWords; ++t) s_words[kRecWords * q + t] = w[k][t];
+      s_dest[q] = s_base[key] + rank;
+    }
+  }
+  __syncthreads();
+  // copy-out: a lane per record (16 + 4 bytes; consecutive lanes of a run on consecutive records)
+  const uint32_t cnt = s_scan[23];
+  for (uint32_t q = tid; q < cnt; q += kP3Threads) {
+    uint32_t* o = dst + (size_t)kRecWords * s_dest[q];
+    const uint32_t* r = s_words + kRecWords * q;
+    const uint32_t a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
+    o[0] = a0;
+    o[1] = a1;
+    o[2] = a2;
+    o[3] = a3;
+    o[4] = a4;
+  }
+}
+
+// Pass 3 on records: one workgroup per (k1, k2) sub-partition; writes the 16-byte records and
+// the rows in bin order, bin_start and the bins' height ranges (keys of the f32 offsets: the
+// budget of a tile only needs the RANGE, and the offsets are what the gather sums).
+template <int THREADS, int PER>
+__device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, const DsmParams& p,
+                                              int cap, const uint32_t* __restrict__ start2,
+                                              uint32_t* __restrict__ bin_start,
+                                              uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
+                                              uint2* __restrict__ bin_z, int sp, unsigned skip_lo,
+                                              unsigned skip_hi) {
+  extern __shared__ uint32_t s_words[];                 // kRecWords * cap
+  uint32_t* s_bins = s_words + (size_t)kRecWords * cap; // p3_w
+  uint32_t* s_scan = s_bins + p.p3_w;                   // 24
+  uint32_t* s_zlo = s_scan + 24;                        // p3_w
+  uint32_t* s_zhi = s_zlo + p.p3_w;                     // p3_w
+  const int tid = threadIdx.x;
+  const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
+  const int rr = k2 / p.p3_c;
+  const int row = k1 * p.p3_r1 + rr;
+  const int bx0 = (k2 - rr * p.p3_c) * p.p3_w;
+  const int nbw = min(p.p3_w, p.nbx - bx0);
+  if (sp == 0 && tid == 0)
+    bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
+  if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
+  const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  for (int k = tid; k < nbw; k += THREADS) {
+    s_bins[k] = 0;
+    s_zlo[k] = 0xFFFFFFFFu;
+    s_zhi[k] = 0u;
+  }
+  __syncthreads();
+  if ((g1 - g0) > skip_lo && (g1 - g0) <= skip_hi) return;  // the other launch's
+  const bool in_lds = (int)(g1 - g0) <= cap && cap <= THREADS * PER;
+  auto zkey = [](uint32_t fbits) { return (fbits >> 31) ? ~fbits : (fbits | 0x80000000u); };
+  uint32_t w[PER][kRecWords];
+  int pb[PER];
+  if (in_lds) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
+      pb[k] = -1;
+      if (idx < g1) {
+#pragma unroll
+        for (int t = 0; t < kRecWords; ++t) w[k][t] = src[(size_t)kRecWords * idx + t];
+        pb[k] = div_by((int)(w[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
+        atomicAdd(&s_bins[pb[k]], 1u);
+        const uint32_t zk = zkey(w[k][3]);
+        atomicMin(&s_zlo[pb[k]], zk);
+        atomicMax(&s_zhi[pb[k]], zk);
+      }
+    }
+  } else {
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+      const uint32_t w0 = src[(size_t)kRecWords * idx], w3 = src[(size_t)kRecWords * idx + 3];
+      const int b = div_by((int)(w0 & 0xFFFFu), p.B, p.mul_B) - bx0;
+      atomicAdd(&s_bins[b], 1u);
+      const uint32_t zk = zkey(w3);
+      atomicMin(&s_zlo[b], zk);
+      atomicMax(&s_zhi[b], zk);
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (nbw + THREADS - 1) / THREADS;
+    const int lo = tid * per;
+    const int hi = min(lo + per, nbw);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<THREADS>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+  }
+  __syncthreads();
+  uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
+  uint2* zrow = bin_z + (size_t)row * p.nbx + bx0;
+  for (int k = tid; k < nbw; k += THREADS) {
+    out_start[k] = g0 + s_bins[k];
+    zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
+  }
+  __syncthreads();
+  if (!in_lds) {
+    // over-full sub-partition (clustered cloud): second read, direct placement
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+      uint32_t v[kRecWords];
+#pragma unroll
+      for (int t = 0; t < kRecWords; ++t) v[t] = src[(size_t)kRecWords * idx + t];
+      const int b = div_by((int)(v[0] & 0xFFFFu), p.B, p.mul_B) - bx0;
+      const size_t o = (size_t)g0 + atomicAdd(&s_bins[b], 1u);
+      rec16[o] = make_uint4(v[0], v[1], v[2], v[3]);
+      sidx[o] = v[4];
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    if (pb[k] >= 0) {
+      const uint32_t q = atomicAdd(&s_bins[pb[k]], 1u);
+#pragma unroll
+      for (int t = 0; t < kRecWords; ++t) s_words[kRecWords * q + t] = w[k][t];
+    }
+  }
+  __syncthreads();
+  const uint32_t cnt = g1 - g0;
+  for (uint32_t q = tid; q < cnt; q += THREADS) {
+    rec16[(size_t)g0 + q] = make_uint4(s_words[kRecWords * q], s_words[kRecWords * q + 1],
+                                      s_words[kRecWords * q + 2], s_words[kRecWords * q + 3]);
+    sidx[(size_t)g0 + q] = s_words[kRecWords * q + 4];
+  }
+}
+
+__global__ void __launch_bounds__(kP3PlaceThreads)
+k_dsm_p3_place_rec(const uint32_t* __restrict__ src, DsmParams p, int cap,
+                   const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+                   uint4* __restrict__ rec16, uint32_t* __restrict__ sidx, uint2* __restrict__ bin_z,
+                   unsigned skip_lo, unsigned skip_hi) {
+  place_records<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, rec16, sidx, bin_z,
+                                              (int)blockIdx.x, skip_lo, skip_hi);
+}
+
+__global__ void __launch_bounds__(kP3BigThreads)
+k_dsm_p3_place_rec_big(const uint32_t* __restrict__ src, DsmParams p,
+                       const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+                       uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
+                       uint2* __restrict__ bin_z, const uint32_t* __restrict__ big_list) {
+  const unsigned count = big_list[0];
+  for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
+    place_records<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, rec16, sidx, bin_z,
+                                            (int)big_list[1 + k], 0u, 0u);
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // multi-GPU: compact the points other windows need (their halo)
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -820,6 +1186,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   c->last_bin_cells = p.B;
   c->bin_z_valid = false;
   c->pts = PtsView{c->sorted, nullptr, nullptr, dev_xyz, nullptr, p.sub_x, p.sub_y};
+  // the record pipeline (the single-precision gather's mode): 16-byte records + rows + zref
+  const bool rec = p.fx_ok && !p.pcl_mode && !dev_values;
+  if (rec) {
+    int rc;
+    if ((rc = ensure_capacity(&c->rec16, &c->rec16_cap, 4 * n + 16))) return rc;
+    if ((rc = ensure_capacity(&c->sidx, &c->sidx_cap, n + 16))) return rc;
+    if ((rc = ensure_capacity(&c->zref, &c->zref_cap, (size_t)8))) return rc;
+  }
 
   static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
   const bool three_pass = p.p3_n1 > 0 && !force_one_level;
@@ -839,7 +1213,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     const size_t g_a = count_grid(n_a), g_b = n > n_a ? count_grid(n - n_a) : 0;
     const size_t gcount = g_a + g_b;
     int rc;
-    if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) return rc;
+    if (rec) {
+      if ((rc = ensure_capacity(&c->rec_a, &c->rec_a_cap, (size_t)kRecWords * n + 16))) return rc;
+      if ((rc = ensure_capacity(&c->rec_b, &c->rec_b_cap, (size_t)kRecWords * n + 16))) return rc;
+      if ((rc = ensure_capacity(&c->zall, &c->zall_cap, 2 * gcount * (kP3CountThreads / 64) + 16))) return rc;
+    } else if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) {
+      return rc;
+    }
+    double* const zall = rec ? c->zall : nullptr;
     const size_t ws_words = gcount * (size_t)nk + 4 * (size_t)nk + 3 * (size_t)n1 + 24;
     if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, ws_words))) return rc;
     uint32_t* hist_rows = c->stripe_ws;
@@ -864,24 +1245,73 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                  sizeof(unsigned long long) * split->hp.nd, c->stream));
         hipLaunchKernelGGL(k_dsm_p3_count<true>, dim3((unsigned)g_a), dim3(kP3CountThreads),
                            lds_halo, c->stream, dev_xyz, n_a, p, hist_rows, split->hp, split->halo_out,
-                           split->halo_counts);
+                           split->halo_counts, zall);
         AMHIP_TRY(hipGetLastError());
         return AMHIP_OK;  // amhip_dsm_tiled_finish_dev comes back with phase 2
       }
       if (!split)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz, n_a, p, hist_rows, no_halo, (double*)nullptr,
-                           (unsigned long long*)nullptr);
+                           (unsigned long long*)nullptr, zall);
       else if (g_b)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_b), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz + 3 * n_a, n - n_a, p, hist_rows + g_a * (size_t)nk,
-                           no_halo, (double*)nullptr, (unsigned long long*)nullptr);
+                           no_halo, (double*)nullptr, (unsigned long long*)nullptr,
+                           zall ? zall + 2 * g_a * (kP3CountThreads / 64) : nullptr);
+      // (the records' reference height: the middle of the range every count workgroup left --
+      // in a tiled call both parts', the second of which may be absent: its rows hold the first
+      // call's partials or the initial "empty" pairs)
+      if (rec)
+        hipLaunchKernelGGL(k_dsm_zref, dim3(1), dim3(1024), 0, c->stream, zall,
+                           (split && !g_b ? g_a : gcount) * (size_t)(kP3CountThreads / 64), c->zref);
       hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
-                         big_list);
+                         big_list, (unsigned)(rec ? kRecChunk : kP3Chunk));
       AMHIP_TRY(hipGetLastError());
+    }
+    if (rec) {
+      {
+        ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+        const size_t lds = (size_t)kRecChunk * (kRecWords + 1) * 4 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
+        AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter_rec<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_scatter_rec<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const size_t g1 = (n + kRecChunk - 1) / kRecChunk;
+        hipLaunchKernelGGL(k_dsm_p3_scatter_rec<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
+                           c->stream, dev_xyz, (const uint32_t*)nullptr, n, p, c->zref, start1, blk2,
+                           cursor1, c->rec_a, zpart);
+        if (zpart)
+          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
+                             (size_t)g1 * (kP3Threads / 64), zrange);
+        hipLaunchKernelGGL(k_dsm_p3_scatter_rec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
+                           lds, c->stream, (const double*)nullptr, c->rec_a, n, p, c->zref, start1, blk2,
+                           cursor2, c->rec_b, (double*)nullptr);
+        AMHIP_TRY(hipGetLastError());
+      }
+      {
+        ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+        if ((rc = ensure_capacity(&c->bin_z, &c->bin_z_cap, 2 * (nbins + 4)))) return rc;
+        uint2* bin_z = reinterpret_cast<uint2*>(c->bin_z);
+        uint4* rec16 = reinterpret_cast<uint4*>(c->rec16);
+        const size_t lds = (size_t)p.p3_cap * kRecWords * 4 + (3 * (size_t)p.p3_w + 32) * sizeof(uint32_t);
+        AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_rec),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_dsm_p3_place_rec, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
+                           c->stream, c->rec_b, p, p.p3_cap, start2, c->bin_start, rec16, c->sidx, bin_z,
+                           (unsigned)p.p3_cap, (unsigned)kP3BigCap);
+        const size_t lds_big = (size_t)kP3BigCap * kRecWords * 4 + (3 * (size_t)p.p3_w + 32) * sizeof(uint32_t);
+        AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_rec_big),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+        hipLaunchKernelGGL(k_dsm_p3_place_rec_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
+                           c->rec_b, p, start2, c->bin_start, rec16, c->sidx, bin_z, big_list);
+        AMHIP_TRY(hipGetLastError());
+        c->bin_z_valid = true;
+        c->pts = PtsView{nullptr, rec16, c->sidx, dev_xyz, c->zref, p.sub_x, p.sub_y};
+      }
+      return AMHIP_OK;
     }
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
@@ -907,12 +1337,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // single-precision gather: the placement pass also leaves every bin's height range
       // (the occupancy pre-pass sorts tiles without room under the error bound onto the FP64
       // lists before anything is staged); bins no sub-partition covers keep "empty"
-      uint2* bin_z = nullptr;
-      if (p.fx_ok && !p.pcl_mode && !dev_values) {
-        int rc2;
-        if ((rc2 = ensure_capacity(&c->bin_z, &c->bin_z_cap, 2 * (nbins + 4)))) return rc2;
-        bin_z = reinterpret_cast<uint2*>(c->bin_z);
-      }
+      uint2* bin_z = nullptr;  // (the record pipeline returned above; the doubles pipeline needs none)
       const size_t zlds = bin_z ? 2 * (size_t)p.p3_w * sizeof(uint32_t) : 0;
       const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds;
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
@@ -944,8 +1369,16 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     if (grid_pts > 256 * 16) grid_pts = 256 * 16;
     {
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+      double* zall = nullptr;
+      if (rec) {
+        int rc;
+        if ((rc = ensure_capacity(&c->zall, &c->zall_cap, 2 * grid_pts * 4 + 16))) return rc;
+        zall = c->zall;
+      }
       hipLaunchKernelGGL(k_dsm_bin_count, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
-                         dev_xyz, n, p, c->bin_start, c->rank);
+                         dev_xyz, n, p, c->bin_start, c->rank, zall);
+      if (rec)
+        hipLaunchKernelGGL(k_dsm_zref, dim3(1), dim3(1024), 0, c->stream, zall, grid_pts * 4, c->zref);
       AMHIP_TRY(hipGetLastError());
     }
     {
@@ -961,7 +1394,12 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     {
       ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
       hipLaunchKernelGGL(k_dsm_scatter, dim3((unsigned)grid_pts), dim3(block), 0, c->stream,
-                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted, zpart);
+                         dev_xyz, dev_values, n, p, c->bin_start, c->rank, c->sorted, zpart,
+                         rec ? reinterpret_cast<uint4*>(c->rec16) : (uint4*)nullptr,
+                         rec ? c->sidx : (uint32_t*)nullptr, rec ? c->zref : (const double*)nullptr);
+      if (rec)
+        c->pts = PtsView{c->sorted, reinterpret_cast<const uint4*>(c->rec16), c->sidx, dev_xyz, c->zref,
+                         p.sub_x, p.sub_y};
       if (zpart)
         hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
                            (size_t)grid_pts * 4, zrange);

@@ -316,7 +316,9 @@ def test_pipeline_dsm_then_ortho_on_device():
     # the mosaic ran on the GPU's own DSM: where both DSMs are bit-identical the
     # ortho layers must be too
     same = got_elev.view(np.uint32) == elevation.view(np.uint32)
-    assert same.mean() > 0.999
+    # (FP64 mode: the reference's floats; single-precision mode: within 1e-4 m -- checked above --,
+    # most of them still the reference's floats)
+    assert same.mean() > (0.9999 if _EXACT else 0.99)
     for n in ORTHO_LAYERS:
         a, b = got[n][same], layers[n][same]
         eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))

@@ -41,6 +41,9 @@ BUDGETS = [
     ("k_dsm_p3_scatterILb0E", 8, 0),
     ("k_dsm_p3_scatterILb1E", 8, 0),
     ("14k_dsm_p3_placeE", 4, 0),
+    ("k_dsm_p3_scatter_recILb0E", 8, 0),                  # the record pipeline (single-precision mode)
+    ("k_dsm_p3_scatter_recILb1E", 8, 0),
+    ("18k_dsm_p3_place_recE", 4, 0),
     ("21k_ortho_backward_fastE", 3, 0),
     ("22k_ortho_backward_fast4E", 4, 12),                 # the default mosaic kernel (two cells per lane)
     # denser clouds in single precision: 4096-point images run two workgroups per CU (4 waves per
@@ -48,7 +51,8 @@ BUDGETS = [
     ("k_dsm_gather_f32_wideILi512ELi16ELi4096E", 4, 0),
     ("k_dsm_gather_f32_listILi512ELi16ELi4096E", 4, 0),
     ("k_dsm_gather_f32_wideILi512ELi16ELi7680E", 2, 0),
-    ("18k_dsm_gather_denseE", 3, 0),
+    ("18k_dsm_gather_denseILb0E", 3, 0),
+    ("18k_dsm_gather_denseILb1E", 2, 0),
 ]
 
 
