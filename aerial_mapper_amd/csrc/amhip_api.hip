@@ -305,6 +305,10 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
 
   // ---- LDS-tiled gather set-up (amhip_dsm.hip: k_dsm_gather_tiled) ----------
   const int kTileI = 64;
+  // (the single-precision mode's sort records hold a cell in 16 + 16 bits and a row of the cloud
+  // in 32: larger maps / clouds stay in FP64)
+  const bool rec_fits = (long long)p.rows + 2LL * p.M <= 65535 && (long long)p.cols + 2LL * p.M <= 65535 &&
+                        num_points < 0xFFFFFFFFull;
   // Tile height and LDS point capacity from the cloud's MEAN density (points
   // per cell): the tile's region must hold E + 5 sqrt(E) points.  64x16 tiles
   // with 1024 slots need ~37 KB of LDS -> 4 workgroups per CU; denser clouds
@@ -324,7 +328,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     };
     // (single-precision mode: 16-byte records, so 4096 points still leave two workgroups per
     // CU -- clouds of ~1.2 .. 2.2 points per cell keep the one-workgroup-per-tile launch)
-    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_knn;
+    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_knn && rec_fits;
     if (need(16) <= 1024.0) {
       kTileJ = 16;
       cap = 1024;
@@ -388,10 +392,6 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.knn_k = mode == 0 ? c.dsm_knn : 0;
   if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
   p.fx_ok = 0;
-  // (the records hold a cell in 16 + 16 bits and a row of the cloud in 32: larger maps / clouds
-  // stay in FP64)
-  const bool rec_fits = (long long)p.rows + 2LL * p.M <= 65535 && (long long)p.cols + 2LL * p.M <= 65535 &&
-                        num_points < 0xFFFFFFFFull;
   if (p.lds_ok && mode == 0 && !c.dsm_exact && rec_fits) {
     int S = 28;
     while (((long long)(w0 + 2) << S) >= (1LL << 31)) --S;

@@ -288,3 +288,47 @@ def test_rough_scene_second_call_takes_the_dense_fp64_launch(monkeypatch):
     for got in outs:
         same = got.view(np.uint32)[inner] == want.view(np.uint32)[inner]
         assert same.mean() > 0.999
+
+
+# ---- the 20-byte sort records of the single-precision mode (amhip_sort.hip: make_record) ----------
+class _Strip(object):
+    """a long narrow map with its own cloud (scenarios.Scene spreads points over a square)"""
+
+    def __init__(self, lx, ly, res, ppc, seed, z=lambda x, y, rng: 400.0 + 0.0 * x):
+        self.grid = O.make_grid(lx, ly, res, 0.0, 0.0)
+        rng = np.random.default_rng(seed)
+        n = int(ppc * (lx + 8.0) * (ly + 8.0) / (res * res))
+        x = rng.uniform(-lx / 2 - 4.0, lx / 2 + 4.0, n)
+        y = rng.uniform(-ly / 2 - 4.0, ly / 2 + 4.0, n)
+        self.points = np.ascontiguousarray(np.c_[x, y, z(x, y, rng)])
+
+
+def test_relief_of_hundreds_of_metres_across_one_map():
+    # the records carry heights as f32 offsets from the middle of the CLOUD's height range: far
+    # from it the offsets' own rounding takes the budget and those tiles go to the FP64 kernel,
+    # near it the single-precision kernel runs -- the contract holds across the map
+    sc = _Strip(1600.0, 40.0, 0.25, 1.0, 311,
+                z=lambda x, y, rng: 400.0 + 0.5 * x + rng.uniform(-0.2, 0.2, x.shape[0]))
+    assert sc.points.shape[0] >= 1 << 20          # the three-pass sort
+    want = _oracle(sc)
+    frac, err = _check(_run(sc, False), want)
+    frac_e, _ = _check(_run(sc, True), want)
+    assert frac_e > 0.999 and 0.3 < frac < 1.0    # a mix of both kernels
+
+
+def test_negative_heights_and_a_cloud_far_below_zero():
+    sc = _Strip(300.0, 200.0, 0.25, 1.0, 312,
+                z=lambda x, y, rng: -412.3 + 0.05 * y + rng.uniform(-0.3, 0.3, x.shape[0]))
+    want = _oracle(sc)
+    frac, err = _check(_run(sc, False), want)
+    assert frac > 0.9
+
+
+def test_maps_longer_than_the_records_cell_field_fall_back_to_fp64():
+    # cells are 16-bit fields of the record: beyond 65 535 (incl. the margin) the single-precision
+    # mode is not taken at all -- same bits as the FP64 mode
+    sc = _Strip(17000.0, 6.0, 0.25, 0.5, 313)
+    assert sc.grid.rows > 65535 or sc.grid.cols > 65535
+    fast, exact = _run(sc, False), _run(sc, True)
+    assert np.array_equal(fast.view(np.uint32), exact.view(np.uint32))
+    _check(fast, _oracle(sc))
