@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from aerial_mapper_amd import synth
+import scenarios as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
@@ -103,8 +104,7 @@ def _compare(got, want, exact):
     assert np.array_equal(np.isnan(ge), np.isnan(we))
     ok = ~np.isnan(we)
     assert ok.mean() > 0.9
-    err = float(np.abs(ge[ok].astype(np.float64) - we[ok]).max())
-    assert err <= (1e-6 if exact else 1e-4), err
+    S.assert_dsm_close(ge, we, tol=1e-6 if exact else 1e-4)
     covered = ~np.isnan(want["observation_index"])
     assert covered.mean() > 0.3
     if _same_bits(ge, we).all():
@@ -145,8 +145,7 @@ def test_unchanged_demo_mains_leave_the_same_map_on_the_drop_in(tmp_path, env, e
     got_dsm = _run("demo_dsm_dropin", _dsm_flags(d), os.path.join(d, "gpu_dsm"), env)
     ge, we = got_dsm["elevation"], want_dsm["elevation"]
     assert np.array_equal(np.isnan(ge), np.isnan(we))
-    ok = ~np.isnan(we)
-    assert float(np.abs(ge[ok].astype(np.float64) - we[ok]).max()) <= (1e-6 if exact else 1e-4)
+    S.assert_dsm_close(ge, we, tol=1e-6 if exact else 1e-4)
     want = _run("demo_ortho_ref", _ortho_flags(d), os.path.join(d, "ref_ortho"))
     got = _run("demo_ortho_dropin", _ortho_flags(d), os.path.join(d, "gpu_ortho"), env)
     _compare(got, want, exact)
@@ -201,9 +200,7 @@ def _compare_partial(got, want, exact):
     """_compare for a map the clouds cover only partly."""
     ge, we = got["elevation"], want["elevation"]
     assert np.array_equal(np.isnan(ge), np.isnan(we))
-    ok = ~np.isnan(we)
-    err = float(np.abs(ge[ok].astype(np.float64) - we[ok]).max())
-    assert err <= (1e-6 if exact else 1e-4), err
+    S.assert_dsm_close(ge, we, tol=1e-6 if exact else 1e-4)
     assert (~np.isnan(want["observation_index"])).mean() > 0.2
     if _same_bits(ge, we).all():
         for n in LAYERS:

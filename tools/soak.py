@@ -75,8 +75,10 @@ def big_dsm(seed):
                 m.reset()
                 A.Dsm(A.DsmSettings(radius), m).process(pts, m)
                 got = m.get("elevation")
+                # (FP64 mode: one cell in ~1e8 sits on a float rounding boundary and comes out one
+                # spacing away -- the sums run in another order; assert_dsm_close allows two per map)
                 same = S.assert_dsm_close(got, want, tol=1e-6 if exact else 1e-4)
-                assert not exact or same > 0.999, same
+                assert not exact or same > 0.99999, same
 
 
 def big_ortho(seed):
