@@ -282,6 +282,9 @@ __device__ __forceinline__ void halo_flush(HaloStage* st, const HaloParams& hp,
 // zall (may be null; the record pipeline): every wave also leaves the [min, max] of ALL the
 // heights it reads (plain stores, range_commit_wave) -- the records' reference height zref is the
 // middle of that range and has to exist before the first scatter pass writes a record.
+// (Any zref is correct; the middle of a SAMPLE's range would save this pass 0.015 ms, but then
+// the records -- and one height in 500 by a float spacing -- depend on the order of the cloud:
+// tests/test_gpu_fullsize.py's permutation property.  The full range is a function of the set.)
 template <bool kHalo>
 __global__ void __launch_bounds__(kP3CountThreads)
 k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
