@@ -1,10 +1,10 @@
 #!/bin/bash
-# round 3, final evidence in one GPU call: the GPU suite, the default bench line (the file the
+# a round's final evidence in one GPU call: the GPU suite, the default bench line (the file the
 # driver's BENCH run should reproduce) and the whole-map parity record (every one of the 1e8 cells
 # against the reference's own compiled process() calls, both gather modes)
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3_final
+OUT=$R/gpurun_out/round_evidence
 mkdir -p "$OUT"
 cd "$R"
 ( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -25 ) > "$OUT/gpu_tests.log"
@@ -14,7 +14,7 @@ timeout 1200 python bench.py --steps 10 --warmup 3 --cpu-sample-side 10000 --no-
   > "$OUT/r03_bench_cfg3_full_parity.json" 2> "$OUT/full.err"
 python - <<'P'
 import json, os
-o = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r3_final/"
+o = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/round_evidence/"
 for f in ("r03_bench_cfg3_n1.json", "r03_bench_cfg3_full_parity.json"):
     try:
         d = json.loads(open(o + f).read().strip().splitlines()[-1])
