@@ -211,7 +211,10 @@ void* amhip_layer_device_ptr(amhip_ctx* ctx, int layer);
  * dsm::Settings::interpolation_radius (an int holding the SQUARED search
  * radius in m^2); center_* are dsm::Settings::center_easting/northing
  * (note dsm.cc:42-43 subtracts center_northing from x and center_easting
- * from y -- reproduced). */
+ * from y -- reproduced).
+ * dev_xyz is read until the LAST kernel of the call (in AMHIP_DSM_FAST mode the sort carries
+ * 20-byte records and the exact routines fetch a point's doubles from dev_xyz itself): work
+ * that overwrites or frees it has to be ordered after the call on the context's stream. */
 int amhip_dsm_process_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
                           int radius_sq, double center_easting,
                           double center_northing);
@@ -293,7 +296,8 @@ int amhip_halo_select_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n,
  *      Dsm::process on all n_total rows; the ELEVATION layer is as after
  *      amhip_dsm_process_dev(dev_xyz, n_total).
  * Both asynchronous on the context's stream; dev_xyz must stay valid and rows [0, n_owned)
- * unchanged in between.  Any other DSM / OrthoFromPcl call on the context in between cancels
+ * unchanged in between (and all n_total rows until the finish call's last kernel: see
+ * amhip_dsm_process_dev).  Any other DSM / OrthoFromPcl call on the context in between cancels
  * the pending call: amhip_dsm_tiled_finish_dev then returns AMHIP_ERR_ARG. */
 int amhip_dsm_tiled_begin_dev(amhip_ctx* ctx, const double* dev_xyz, size_t n_owned,
                               size_t n_total, int radius_sq, double center_easting,
