@@ -1055,17 +1055,88 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
   double num = 0.0, den = 0.0;
   unsigned exact = 0;
-  for (int by = by0; by <= by1; ++by) {
-    const uint32_t* row = start + (size_t)by * p.nbx;
-    const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
-    for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double dx = qx - pts_x(P, (size_t)k);
-      const double dy = qy - pts_y(P, (size_t)k);
-      double d2 = dx * dx;
-      d2 = d2 + dy * dy;       // L2_Adaptor (nanoflann.hpp:319-322)
-      if (d2 < T) {            // strict (nanoflann.hpp:157)
-        if (d2 > 0.0) idw_add(d2, pts_z(P, (size_t)k), &num, &den);
-        else exact = 1;
+  // The routine is a chain of dependent memory round trips, and it runs at the END of a tile
+  // while the workgroup's other waves have left (with one workgroup per CU -- the 7680-point
+  // images of dense clouds -- nothing else covers it).  Bin row after bin row, each with its
+  // own span -> (row index ->) point -> height chain, it was 9 round trips on sorted doubles
+  // and 12 through the records' row indices (+ 0.4 ms on 12 000 tiles at 4 points per cell).
+  // Now: the spans of ALL bin rows in one trip (one lane each), then the candidates of all rows
+  // as one range, four batches of 64 in flight, x, y AND z fetched together: 3 round trips.
+  constexpr int kRows = 8;  // (the first search radius spans <= 3 bin rows: B = that radius)
+  const int nrow = by1 - by0 + 1;
+  if (nrow <= kRows) {
+    uint32_t s0 = 0, len = 0;
+    if (lane < nrow) {
+      const uint32_t* row = start + (size_t)(by0 + lane) * p.nbx;
+      s0 = row[bx0];
+      len = row[bx1 + 1] - s0;
+    }
+    const uint32_t incl = wave_incl_scan(len, lane);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    uint32_t rs[kRows], re[kRows];  // (wave-uniform: first point and exclusive prefix per row)
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      rs[r] = (uint32_t)__builtin_amdgcn_readlane((int)s0, r);
+      re[r] = (uint32_t)__builtin_amdgcn_readlane((int)(incl - len), r);
+    }
+    constexpr int kU = 4;
+    for (uint32_t c0 = 0; c0 < total; c0 += 64 * kU) {
+      size_t g[kU];
+      bool ok[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const uint32_t c = c0 + 64u * u + lane;
+        ok[u] = c < total;
+        uint32_t gg = rs[0] + c;
+#pragma unroll
+        for (int r = 1; r < kRows; ++r)
+          if (r < nrow && c >= re[r]) gg = rs[r] + (c - re[r]);
+        g[u] = gg;
+      }
+      const double* q[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        q[u] = nullptr;
+        if (ok[u]) q[u] = P.sorted ? P.sorted + 3 * g[u] : P.cloud + 3 * (size_t)P.sidx[g[u]];
+      }
+      double x[kU], y[kU], z[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        x[u] = y[u] = z[u] = 0.0;
+        if (ok[u]) {
+          x[u] = q[u][0];
+          y[u] = q[u][1];
+          z[u] = q[u][2];
+        }
+      }
+      const double sx = P.sorted ? 0.0 : P.sub_x, sy = P.sorted ? 0.0 : P.sub_y;
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        if (ok[u]) {
+          const double dx = qx - (x[u] - sx);
+          const double dy = qy - (y[u] - sy);
+          double d2 = dx * dx;
+          d2 = d2 + dy * dy;       // L2_Adaptor (nanoflann.hpp:319-322)
+          if (d2 < T) {            // strict (nanoflann.hpp:157)
+            if (d2 > 0.0) idw_add(d2, z[u], &num, &den);
+            else exact = 1;
+          }
+        }
+      }
+    }
+  } else {
+    for (int by = by0; by <= by1; ++by) {
+      const uint32_t* row = start + (size_t)by * p.nbx;
+      const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+      for (uint32_t k = s0 + lane; k < e0; k += 64) {
+        const double dx = qx - pts_x(P, (size_t)k);
+        const double dy = qy - pts_y(P, (size_t)k);
+        double d2 = dx * dx;
+        d2 = d2 + dy * dy;
+        if (d2 < T) {
+          if (d2 > 0.0) idw_add(d2, pts_z(P, (size_t)k), &num, &den);
+          else exact = 1;
+        }
       }
     }
   }
@@ -1102,6 +1173,9 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
 #endif
   constexpr int kWaves = NT / 64;
   constexpr int kCellsPerLane = kTileJ / kWaves;
+  // (the 1024-point instance serves ~0.5 points per cell: a trip is ~10 candidates, one run)
+  constexpr bool kChunked = kCap > 1024 && kVar == 0;
+  constexpr int kFlush = 32;
   // [rec: cap+1 uint4 (U, V, dz, -)][cell offsets][rows][scan][ctl][z range][flags]
   uint4* s_rec = reinterpret_cast<uint4*>(smem);
   uint32_t* s_off = reinterpret_cast<uint32_t*>(smem + (size_t)(p.lds_cap + 2) * 16);
@@ -1397,13 +1471,33 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
                 [pad] "v"(rec.w), [one] "v"(one_cell), [thi] "v"(thi), [thiB] "v"(thiB)
               : "vcc");
         };
-        for (; pr < pe; ++pr) cand(*pr);
-        if (kVar == 2) dA = dB = 1.f;
-        NA += nA;
-        DA += dA;
-        NB += nB;
-        DB += dB;
+        if (kChunked) {
+          // denser clouds (the instances with larger LDS images): a trip brings 70 .. 400
+          // candidates, and that many additions into one f32 partial sum would eat the tile's
+          // error budget -- cells of steep tiles then went to the FP64 routine one by one.
+          // Runs of <= kFlush candidates, each flushed into the totals: the additions per
+          // accumulator are bounded by n_eff below whatever the density.
+          do {
+            const uint4* const pc = (pe - pr > kFlush) ? pr + kFlush : pe;
+            nA = dA = nB = dB = 0.f;
+            for (; pr < pc; ++pr) cand(*pr);
+            NA += nA;
+            DA += dA;
+            NB += nB;
+            DB += dB;
+          } while (pr < pe);
+        } else {
+          for (; pr < pe; ++pr) cand(*pr);
+          if (kVar == 2) dA = dB = 1.f;
+          NA += nA;
+          DA += dA;
+          NB += nB;
+          DB += dB;
+        }
       }
+      // additions one accumulator has seen at most: a run, then the flushes into the total
+      const int n_eff = kChunked ? min(nmax, kFlush) + (w0 + 1) * ((nmax + kFlush - 1) / kFlush)
+                                 : nmax + w0 + 1;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (h == 1 && !haveB) break;
@@ -1413,7 +1507,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
         if (Dd > 0.0f) {
           // (NaN / inf sums fail the first comparison)
           if (kVar != 1 && kVar != 2 &&
-              (!(Dd < p.fx_denmax) || mm >= tlo || nmax + w0 + 1 > n_allowed)) queue = 2;
+              (!(Dd < p.fx_denmax) || mm >= tlo || n_eff > n_allowed)) queue = 2;
           else emit_value(p, o, i, jj, z0 + (double)(Nn * __builtin_amdgcn_rcpf(Dd)));
         } else if (Dd == 0.0f) {
           queue = 1;
@@ -1674,11 +1768,15 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
 
 // Class-3 tiles (more points than any LDS image holds): a fixed grid walks their
 // list; the four waves of a workgroup share a tile's blocks of 4 x 4 cells
-// (block_wave).  No LDS, its own register budget: three waves per SIMD in FP64, two for the
-// single-precision instance (it carries the FP64 routines for its redos besides its own 16 x 2
-// accumulators: at three waves it spills 18 registers).
+// (block_wave).  No LDS, its own register budget: three waves per SIMD.  (The single-precision
+// instance carries the FP64 routines for its redos besides its own 16 x 2 accumulators and
+// spills 18 registers at three waves, all outside the candidate loop; at two waves it spills
+// nothing and is 18 % slower -- 8 / 16 points per cell: 4.12 / 4.52 ms against 3.48 / 3.70.)
+#ifndef AMHIP_DENSE_F32_WAVES
+#define AMHIP_DENSE_F32_WAVES 3
+#endif
 template <bool kF32>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kF32 ? 2 : 3)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kF32 ? AMHIP_DENSE_F32_WAVES : 3)))
 k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
                    const Pts P, const int* __restrict__ tile_list,
                    const unsigned* __restrict__ tile_count, CellOut o) {
