@@ -364,10 +364,21 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    // (the next candidate is on its way while this one is worked on: ~160 FP64 instructions per
+    // candidate against a memory round trip, three waves per SIMD to cover it)
+    double nx = 0.0, ny = 0.0, nz = 0.0;
+    if (s0 + lane < e0) {
+      nx = pts_x(P, (size_t)(s0 + lane));
+      ny = pts_y(P, (size_t)(s0 + lane));
+      nz = pts_z(P, (size_t)(s0 + lane));
+    }
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
-      const double px = pts_x(P, (size_t)k);
-      const double py = pts_y(P, (size_t)k);
-      const double pz = pts_z(P, (size_t)k);
+      const double px = nx, py = ny, pz = nz;
+      if (k + 64 < e0) {
+        nx = pts_x(P, (size_t)k + 64);
+        ny = pts_y(P, (size_t)k + 64);
+        nz = pts_z(P, (size_t)k + 64);
+      }
       double dx2[4], dy2[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -771,19 +782,27 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   constexpr int kMaxK = (kCap + NT - 1) / NT;  // p.lds_cap == kCap
   uint32_t pslot[kMaxK];                       // cell << 13 | rank  (rank < kCap <= 8192)
   double ppx[kMaxK], ppy[kMaxK], ppz[kMaxK];   // the thread's points (placed after the scan)
+  // (all loads first -- threads past the region's end re-read its last point: inside the loop
+  // below each waited for the one before, see gather_tile_f32)
+  if (np > 0) {
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      const int idx = min(tid + k * NT, np - 1);
+      int r = 0;
+      while (idx >= (int)s_rowp[r + 1]) ++r;
+      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
+      ppx[k] = pts_x(P, g);
+      ppy[k] = pts_y(P, g);
+      ppz[k] = pts_z(P, g);
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     const int idx = tid + k * NT;
     pslot[k] = 0xFFFFFFFFu;
     if (idx < np) {
-      int r = 0;
-      while (idx >= (int)s_rowp[r + 1]) ++r;
-      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      const double px = pts_x(P, g);
-      const double py = pts_y(P, g);
-      ppx[k] = px;
-      ppy[k] = py;
-      ppz[k] = pts_z(P, g);
+      const double px = ppx[k];
+      const double py = ppy[k];
       // same arithmetic as point_bin(): the point's cell in shifted coordinates
       const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
       const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
@@ -1272,15 +1291,26 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
   uint32_t pU[kMaxK], pV[kMaxK];
   float pdz[kMaxK];
   float zlo = __builtin_huge_valf(), zhi = -__builtin_huge_valf();
+  // ALL the thread's records first (threads past the region's end re-read its last record): with
+  // the load inside the loop below, between a row search in LDS and a returning LDS atomic, the
+  // compiler waited for each record before it asked for the next -- up to 15 dependent memory
+  // round trips per tile in the 7680-point instance.
+  uint4 recs[kMaxK];
+  if (np > 0) {
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k) {
+      const int idx = min(tid + k * NT, np - 1);
+      int r = 0;
+      while (idx >= (int)s_rowp[r + 1]) ++r;
+      recs[k] = P.rec[(size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r])];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kMaxK; ++k) {
     const int idx = tid + k * NT;
     pslot[k] = 0xFFFFFFFFu;
     if (idx < np) {
-      int r = 0;
-      while (idx >= (int)s_rowp[r + 1]) ++r;
-      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      const uint4 rec = P.rec[g];
+      const uint4 rec = recs[k];
       const float dz = __uint_as_float(rec.w);
       pdz[k] = dz;
       zlo = fminf(zlo, dz);
@@ -1673,6 +1703,8 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    // (no prefetch of the next candidate as in block_wave: four more live registers cost this
+    // instance more in spills than the overlap gains -- 3.27 -> 3.41 ms at 8 points per cell)
     for (uint32_t k = s0 + lane; k < e0; k += 64) {
       const uint4 rec = P.rec[k];
       const float zf = __uint_as_float(rec.w) - z0f;

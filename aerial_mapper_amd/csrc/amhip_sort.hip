@@ -487,23 +487,33 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
   double px[kP3PerThread], py[kP3PerThread], pz[kP3PerThread];
   double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   uint32_t slot[kP3PerThread];  // key << 13 | rank in the chunk's run of that key
+  // (all loads first, branch-free: see k_dsm_p3_scatter_rec)
+  if (c1 <= c0) return;
+#pragma unroll
+  for (int k = 0; k < kP3PerThread; ++k) {
+    const size_t ld = min(c0 + tid + (size_t)k * kP3Threads, c1 - 1);
+    px[k] = src[3 * ld + 0];
+    py[k] = src[3 * ld + 1];
+    pz[k] = src[3 * ld + 2];
+  }
+  if (kFirst && values) {  // (OrthoFromPcl: the intensities take the heights' place)
+#pragma unroll
+    for (int k = 0; k < kP3PerThread; ++k)
+      pz[k] = (double)values[min(c0 + tid + (size_t)k * kP3Threads, c1 - 1)];
+  }
 #pragma unroll
   for (int k = 0; k < kP3PerThread; ++k) {
     const size_t idx = c0 + tid + (size_t)k * kP3Threads;
     slot[k] = 0xFFFFFFFFu;
     if (idx < c1) {
-      double x = src[3 * idx + 0], y = src[3 * idx + 1];
-      double z;
+      double x = px[k], y = py[k];
+      const double z = pz[k];
       if (kFirst) {
         x -= p.sub_x;
         y -= p.sub_y;
-        z = values ? (double)values[idx] : src[3 * idx + 2];
-      } else {
-        z = src[3 * idx + 2];
       }
       px[k] = x;
       py[k] = y;
-      pz[k] = z;
       int k1, k2;
       if (p3_keys(p, x, y, &k1, &k2)) {
         const int key = kFirst ? k1 : k2;
@@ -518,13 +528,16 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
   if (kFirst && zpart)
     range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * (kP3Threads / 64) + (tid >> 6));
   __syncthreads();
+  unsigned my_base = 0;  // first slot of key `tid`'s run in the destination
   {
     const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
     unsigned total;
     const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
     if (tid < nkeys) {
       s_off[tid] = ex;
-      s_base[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+      // (the reservation's round trip to the counter runs under the placement below: its
+      // result is only stored -- and so only awaited -- after it)
+      if (c) my_base = atomicAdd(&cursor[tid], c);
     }
     if (tid == 0) s_scan[23] = total;
   }
@@ -537,14 +550,16 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
       s_pts[3 * q + 0] = px[k];
       s_pts[3 * q + 1] = py[k];
       s_pts[3 * q + 2] = pz[k];
-      s_dest[q] = s_base[key] + rank;
+      s_dest[q] = slot[k];
     }
   }
+  if (tid < nkeys) s_base[tid] = my_base;
   __syncthreads();
   const uint32_t ne = 3u * s_scan[23];
   for (uint32_t e = tid; e < ne; e += kP3Threads) {
     const uint32_t q = e / 3u;
-    dst[3 * (size_t)s_dest[q] + (e - 3u * q)] = s_pts[e];
+    const uint32_t d = s_dest[q];
+    dst[3 * (size_t)(s_base[d >> 13] + (d & 0x1FFFu)) + (e - 3u * q)] = s_pts[e];
   }
 }
 
@@ -593,14 +608,21 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
   double px[PER], py[PER], pz[PER];
   int pb[PER];
   if (in_lds) {
+    // (all loads first, branch-free: see k_dsm_p3_scatter_rec)
+    if (g1 > g0) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const size_t ld = min(g0 + tid + (uint32_t)k * THREADS, g1 - 1);
+        px[k] = src[3 * ld + 0];
+        py[k] = src[3 * ld + 1];
+        pz[k] = src[3 * ld + 2];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
       pb[k] = -1;
       if (idx < g1) {
-        px[k] = src[3 * (size_t)idx + 0];
-        py[k] = src[3 * (size_t)idx + 1];
-        pz[k] = src[3 * (size_t)idx + 2];
         int bx, by;
         point_bin_xy(p, px[k], py[k], &bx, &by);
         pb[k] = bx - bx0;
@@ -840,6 +862,23 @@ k_dsm_p3_scatter_rec(const double* __restrict__ cloud, const uint32_t* __restric
   uint32_t w[kRecPerThread][kRecWords];
   double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   uint32_t slot[kRecPerThread];  // key << 13 | rank in the chunk's run of that key
+  // ALL the thread's loads first, branch-free (rows past the chunk's end re-read its last row):
+  // with the loads inside the loop below -- whose key arithmetic branches -- the compiler
+  // waited for each before issuing the next, six dependent round trips per workgroup.
+  if (c1 <= c0) return;  // (workgroup-uniform; never for a launched block)
+  double cx[kFirst ? kRecPerThread : 1], cy[kFirst ? kRecPerThread : 1], cz[kFirst ? kRecPerThread : 1];
+#pragma unroll
+  for (int k = 0; k < kRecPerThread; ++k) {
+    const size_t ld = min(c0 + tid + (size_t)k * kP3Threads, c1 - 1);
+    if (kFirst) {
+      cx[k] = cloud[3 * ld + 0];
+      cy[k] = cloud[3 * ld + 1];
+      cz[k] = cloud[3 * ld + 2];
+    } else {
+#pragma unroll
+      for (int q = 0; q < kRecWords; ++q) w[k][q] = src[kRecWords * ld + q];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < kRecPerThread; ++k) {
     const size_t idx = c0 + tid + (size_t)k * kP3Threads;
@@ -847,17 +886,15 @@ k_dsm_p3_scatter_rec(const double* __restrict__ cloud, const uint32_t* __restric
     if (idx < c1) {
       bool in;
       if (kFirst) {
-        const double x = cloud[3 * idx + 0] - p.sub_x;  // dsm.cc:42
-        const double y = cloud[3 * idx + 1] - p.sub_y;  // dsm.cc:43
-        const double z = cloud[3 * idx + 2];
+        const double x = cx[k] - p.sub_x;  // dsm.cc:42
+        const double y = cy[k] - p.sub_y;  // dsm.cc:43
+        const double z = cz[k];
         in = make_record(p, x, y, z, zr, (uint32_t)idx, w[k]);
         if (in) {
           zlo = fmin(zlo, z);
           zhi = fmax(zhi, z);
         }
       } else {
-#pragma unroll
-        for (int q = 0; q < kRecWords; ++q) w[k][q] = src[kRecWords * idx + q];
         in = true;
       }
       if (in) {
@@ -871,13 +908,16 @@ k_dsm_p3_scatter_rec(const double* __restrict__ cloud, const uint32_t* __restric
   if (kFirst && zpart)
     range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * (kP3Threads / 64) + (tid >> 6));
   __syncthreads();
+  unsigned my_base = 0;  // first slot of key `tid`'s run in the destination
   {
     const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
     unsigned total;
     const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
     if (tid < nkeys) {
       s_off[tid] = ex;
-      s_base[tid] = c ? atomicAdd(&cursor[tid], c) : 0u;
+      // (the reservation's round trip to the counter runs under the placement below: its
+      // result is only stored -- and so only awaited -- after it)
+      if (c) my_base = atomicAdd(&cursor[tid], c);
     }
     if (tid == 0) s_scan[23] = total;
   }
@@ -889,14 +929,16 @@ k_dsm_p3_scatter_rec(const double* __restrict__ cloud, const uint32_t* __restric
       const uint32_t q = s_off[key] + rank;
 #pragma unroll
       for (int t = 0; t < kRecWords; ++t) s_words[kRecWords * q + t] = w[k][t];
-      s_dest[q] = s_base[key] + rank;
+      s_dest[q] = slot[k];
     }
   }
+  if (tid < nkeys) s_base[tid] = my_base;
   __syncthreads();
   // copy-out: a lane per record (16 + 4 bytes; consecutive lanes of a run on consecutive records)
   const uint32_t cnt = s_scan[23];
   for (uint32_t q = tid; q < cnt; q += kP3Threads) {
-    uint32_t* o = dst + (size_t)kRecWords * s_dest[q];
+    const uint32_t d = s_dest[q];
+    uint32_t* o = dst + (size_t)kRecWords * (s_base[d >> 13] + (d & 0x1FFFu));
     const uint32_t* r = s_words + kRecWords * q;
     const uint32_t a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
     o[0] = a0;
@@ -944,13 +986,20 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
   uint32_t w[PER][kRecWords];
   int pb[PER];
   if (in_lds) {
+    // (all loads first, branch-free: see k_dsm_p3_scatter_rec)
+    if (g1 > g0) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t ld = min(g0 + tid + (uint32_t)k * THREADS, g1 - 1);
+#pragma unroll
+        for (int t = 0; t < kRecWords; ++t) w[k][t] = src[(size_t)kRecWords * ld + t];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
       pb[k] = -1;
       if (idx < g1) {
-#pragma unroll
-        for (int t = 0; t < kRecWords; ++t) w[k][t] = src[(size_t)kRecWords * idx + t];
         pb[k] = div_by((int)(w[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
         atomicAdd(&s_bins[pb[k]], 1u);
         const uint32_t zk = zkey(w[k][3]);

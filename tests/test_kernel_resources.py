@@ -38,11 +38,13 @@ BUDGETS = [
     ("k_dsm_gather_f32ILi512ELi16ELi2048ELi0E", 8, 0),
     ("k_dsm_gather_tiledILi512ELi16ELi1024E", 7, 0),      # FP64 mode
     ("k_dsm_p3_countILb0E", 8, 0),
-    ("k_dsm_p3_scatterILb0E", 8, 0),
-    ("k_dsm_p3_scatterILb1E", 8, 0),
+    # (the scatter passes: 70+ KB of LDS per workgroup allow two of them = 4 waves per SIMD; all of a
+    # thread's loads are in flight at once, which takes more than 64 registers in the first pass)
+    ("k_dsm_p3_scatterILb0E", 4, 0),
+    ("k_dsm_p3_scatterILb1E", 4, 0),
     ("14k_dsm_p3_placeE", 4, 0),
-    ("k_dsm_p3_scatter_recILb0E", 8, 0),                  # the record pipeline (single-precision mode)
-    ("k_dsm_p3_scatter_recILb1E", 8, 0),
+    ("k_dsm_p3_scatter_recILb0E", 4, 0),                  # the record pipeline (single-precision mode)
+    ("k_dsm_p3_scatter_recILb1E", 4, 0),
     ("18k_dsm_p3_place_recE", 4, 0),
     ("21k_ortho_backward_fastE", 3, 0),
     ("22k_ortho_backward_fast4E", 4, 12),                 # the default mosaic kernel (two cells per lane)

@@ -6,5 +6,5 @@ export AMHIP_PROBE_DENSITIES=${1:-0.5,1,2,4,8,16}
 shift
 for lib in "$@"; do
   echo "== $lib"
-  AMHIP_LIB_PATH=$R/aerial_mapper_amd/lib/$lib timeout 600 python tools/density_probe.py 2>&1 | grep "f32"
+  AMHIP_LIB_PATH=$R/aerial_mapper_amd/lib/$lib timeout 600 python tools/density_probe.py 2>&1 | grep "pts/cell"
 done
