@@ -446,10 +446,37 @@ __device__ __forceinline__ void ortho_slab(
                             &angle[c]);
       if (!(i_ok && j < p.cols)) what[c] = -1;  // no such cell
     }
+    // (unconditional, so that the lane's reads leave together instead of one per branch: a cell
+    // without a settled winner reads pixel (0, 0) of frame 0 and drops it)
+    // (and the colour / gray branch OUTSIDE the loop over the cells: inside, the compiler waits
+    // for one cell's pixel before it asks for the next)
+    {
+      const uint8_t* px[kCellsPerLane];
 #pragma unroll
-    for (int c = 0; c < kCellsPerLane; ++c) {
-      pix[c] = 0.0f;
-      if (what[c] == kFoldDone) pix[c] = read_pixel(p, frames, st[c].best_f, ku[c], kv[c]);
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const bool done = what[c] == kFoldDone;
+        px[c] = frames + (size_t)(done ? st[c].best_f : 0) * p.frame_stride +
+                (size_t)(done ? kv[c] : 0) * p.row_step + (size_t)(done ? ku[c] : 0) * (p.colored ? 3u : 1u);
+      }
+      if (p.colored) {
+        // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B (read_pixel)
+        unsigned b0[kCellsPerLane], b1[kCellsPerLane], b2[kCellsPerLane];
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c) {
+          b0[c] = px[c][0];
+          b1[c] = px[c][1];
+          b2[c] = px[c][2];
+        }
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c)
+          pix[c] = __uint_as_float((b2[c] << 16) | (b1[c] << 8) | b0[c]);
+      } else {
+        unsigned g[kCellsPerLane];
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c) g[c] = px[c][0];
+#pragma unroll
+        for (int c = 0; c < kCellsPerLane; ++c) pix[c] = (float)g[c];
+      }
     }
 #pragma unroll
     for (int c = 0; c < kCellsPerLane; ++c) {
