@@ -303,18 +303,24 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
   double zlo = __builtin_huge_val(), zhi = -__builtin_huge_val();
   for (size_t base = (size_t)blockIdx.x * kP3CountThreads + threadIdx.x; base < n;
        base += kU * stride) {
-    double x[kU], y[kU];
+    double x[kU], y[kU], z[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const size_t idx = base + u * stride;
+      z[u] = __builtin_nan("");  // (fmin / fmax pass over it)
       if (idx < n) {
         x[u] = xyz[3 * idx + 0];
         y[u] = xyz[3 * idx + 1];
-        if (zall) {  // (the same cache lines)
-          const double z = xyz[3 * idx + 2];
-          zlo = fmin(zlo, z);
-          zhi = fmax(zhi, z);
-        }
+        if (zall) z[u] = xyz[3 * idx + 2];  // (the same cache lines)
+      }
+    }
+    // (the range AFTER the loads: with fmin / fmax next to each load the four waited for one
+    // another -- 0.245 ms against the 0.228 of the pass without heights)
+    if (zall) {
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        zlo = fmin(zlo, z[u]);
+        zhi = fmax(zhi, z[u]);
       }
     }
     unsigned look = 0;  // kHalo: which of the four may have to travel
