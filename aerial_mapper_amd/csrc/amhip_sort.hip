@@ -1008,9 +1008,8 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
       if (idx < g1) {
         pb[k] = div_by((int)(w[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
         atomicAdd(&s_bins[pb[k]], 1u);
-        const uint32_t zk = zkey(w[k][3]);
-        atomicMin(&s_zlo[pb[k]], zk);
-        atomicMax(&s_zhi[pb[k]], zk);
+        // (the bins' height ranges: read off the placed records below -- two more LDS atomics
+        // per point here cost more than one pass of a thread per bin there)
       }
     }
   } else {
@@ -1043,7 +1042,7 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
   uint2* zrow = bin_z + (size_t)row * p.nbx + bx0;
   for (int k = tid; k < nbw; k += THREADS) {
     out_start[k] = g0 + s_bins[k];
-    zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
+    if (!in_lds) zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
   }
   __syncthreads();
   if (!in_lds) {
@@ -1068,6 +1067,16 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
     }
   }
   __syncthreads();
+  // (after the placement s_bins[b] is the END of bin b: a thread per bin walks its records)
+  for (int b = tid; b < nbw; b += THREADS) {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (uint32_t q = b ? s_bins[b - 1] : 0u; q < s_bins[b]; ++q) {
+      const uint32_t zk = zkey(s_words[kRecWords * q + 3]);
+      lo = min(lo, zk);
+      hi = max(hi, zk);
+    }
+    zrow[b] = make_uint2(lo, hi);
+  }
   const uint32_t cnt = g1 - g0;
   for (uint32_t q = tid; q < cnt; q += THREADS) {
     rec16[(size_t)g0 + q] = make_uint4(s_words[kRecWords * q], s_words[kRecWords * q + 1],
