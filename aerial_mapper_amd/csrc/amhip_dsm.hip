@@ -785,15 +785,33 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   // (all loads first -- threads past the region's end re-read its last point: inside the loop
   // below each waited for the one before, see gather_tile_f32)
   if (np > 0) {
+    size_t pg[kMaxK];
 #pragma unroll
     for (int k = 0; k < kMaxK; ++k) {
       const int idx = min(tid + k * NT, np - 1);
       int r = 0;
       while (idx >= (int)s_rowp[r + 1]) ++r;
-      const size_t g = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      ppx[k] = pts_x(P, g);
-      ppy[k] = pts_y(P, g);
-      ppz[k] = pts_z(P, g);
+      pg[k] = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
+    }
+    // (the doubles / records choice of pts_x() outside the loop: inside, it is a branch per
+    // point and the loads of one point wait for the previous point's)
+    if (P.sorted) {
+#pragma unroll
+      for (int k = 0; k < kMaxK; ++k) {
+        ppx[k] = P.sorted[3 * pg[k] + 0];
+        ppy[k] = P.sorted[3 * pg[k] + 1];
+        ppz[k] = P.sorted[3 * pg[k] + 2];
+      }
+    } else {
+      const double* q[kMaxK];
+#pragma unroll
+      for (int k = 0; k < kMaxK; ++k) q[k] = P.cloud + 3 * (size_t)P.sidx[pg[k]];
+#pragma unroll
+      for (int k = 0; k < kMaxK; ++k) {
+        ppx[k] = q[k][0] - P.sub_x;
+        ppy[k] = q[k][1] - P.sub_y;
+        ppz[k] = q[k][2];
+      }
     }
   }
 #pragma unroll

@@ -17,33 +17,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "aerial_mapper_amd", "csrc")
 
 
-@pytest.fixture(scope="module")
-def isa(tmp_path_factory):
+def _isa_of(source, tmp_path_factory):
     hipcc = build._hipcc()
     if not hipcc:
         pytest.skip("no hipcc")
-    out = str(tmp_path_factory.mktemp("isa") / "sort.s")
+    out = str(tmp_path_factory.mktemp("isa") / (source + ".s"))
     flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
     r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-I" + os.path.join(ROOT, "include"),
-                                          "-I" + CSRC, os.path.join(CSRC, "amhip_sort.hip"), "-o", out],
+                                          "-I" + CSRC, os.path.join(CSRC, source), "-o", out],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     return open(out).read().splitlines()
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    return _isa_of("amhip_sort.hip", tmp_path_factory)
+
+
+@pytest.fixture(scope="module")
+def isa_gather(tmp_path_factory):
+    return _isa_of("amhip_dsm.hip", tmp_path_factory)
 
 
 def _body(lines, needle):
     start = [k for k, l in enumerate(lines) if re.match(r"^_Z\S*%s\S*:" % re.escape(needle), l)]
     assert len(start) == 1, (needle, len(start))
     k = start[0]
-    end = next(j for j in range(k, len(lines)) if "s_endpgm" in lines[j])
+    end = next(j for j in range(k, len(lines)) if lines[j].startswith(".Lfunc_end"))  # (not s_endpgm: early exits)
     return lines[k:end]
 
 
-def _longest_burst(body):
+def _longest_burst(body, what=r"\bglobal_load_"):
     """most global loads issued back to back without a full wait (s_waitcnt vmcnt(0)) between"""
     best = run = 0
     for l in body:
-        if re.search(r"\bglobal_load_", l):
+        if re.search(what, l):
             run += 1
             best = max(best, run)
         elif re.search(r"s_waitcnt[^\n]*vmcnt\(0\)", l):
@@ -67,4 +76,22 @@ CASES = [
 @pytest.mark.parametrize("needle,want", CASES)
 def test_all_loads_of_a_thread_leave_before_the_first_wait(isa, needle, want):
     got = _longest_burst(_body(isa, needle))
+    assert got >= want, "%s: %d loads in flight at most, %d expected" % (needle, got, want)
+
+
+# The gather's staging: a thread's records (one 16-byte load each) / points (16 + 8 bytes) of the
+# tile's region, all asked for before the first is waited for (kCap / 512 per thread).
+GATHER_CASES = [
+    ("21k_dsm_gather_f32_wideILi512ELi16ELi7680E", r"global_load_dwordx4", 15),
+    ("21k_dsm_gather_f32_wideILi512ELi16ELi4096E", r"global_load_dwordx4", 8),
+    ("16k_dsm_gather_f32ILi512ELi16ELi2048ELi0E", r"global_load_dwordx4", 4),
+    ("16k_dsm_gather_f32ILi512ELi16ELi1024ELi0E", r"global_load_dwordx4", 2),
+    ("18k_dsm_gather_tiledILi512ELi16ELi2048E", r"global_load_", 8),   # FP64 mode: 4 points x 2 loads
+    ("18k_dsm_gather_tiledILi512ELi16ELi1024E", r"global_load_", 4),
+]
+
+
+@pytest.mark.parametrize("needle,what,want", GATHER_CASES)
+def test_the_gathers_staging_asks_for_all_its_records_at_once(isa_gather, needle, what, want):
+    got = _longest_burst(_body(isa_gather, needle), what)
     assert got >= want, "%s: %d loads in flight at most, %d expected" % (needle, got, want)
