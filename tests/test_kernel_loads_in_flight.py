@@ -95,3 +95,15 @@ GATHER_CASES = [
 def test_the_gathers_staging_asks_for_all_its_records_at_once(isa_gather, needle, what, want):
     got = _longest_burst(_body(isa_gather, needle), what)
     assert got >= want, "%s: %d loads in flight at most, %d expected" % (needle, got, want)
+
+
+@pytest.fixture(scope="module")
+def isa_ortho(tmp_path_factory):
+    return _isa_of("amhip_ortho.hip", tmp_path_factory)
+
+
+def test_the_mosaics_pixel_reads_of_a_lane_leave_together(isa_ortho):
+    # two cells per lane in the default kernel: both winners' gray pixels (one byte each) asked for
+    # before the first is waited for (the colour / gray branch used to sit between them)
+    body = _body(isa_ortho, "22k_ortho_backward_fast4E")
+    assert _longest_burst(body, r"global_load_ubyte") >= 2
