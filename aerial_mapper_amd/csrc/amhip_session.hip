@@ -251,17 +251,31 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
         h[q].b = got[2 * q + 1];
       }
   }
+  // A download is asynchronous: until the stream has synchronised without an error the host
+  // matrix may be stale or half written, so the layers being downloaded are marked "host
+  // unknown" FIRST and "host == device sum" only after the wait (a failed copy must
+  // not leave the session believing the host holds h[q] -- the next call would skip it).
+  bool copied[AMHIP_NUM_LAYERS] = {};
+  bool any = false;
   for (int q = 0; q < nl; ++q) {
     if (!hosts[q]) continue;
     const int l = layers[q];
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + l];
     const bool host_has_it = !s.always_copy && st.host_known && st.host == h[q];
-    if (!host_has_it) {
-      if ((rc = ctx_materialize(c, l))) return rc;
-      AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
-    }
     st.device_valid = !s.always_copy;
     st.device = h[q];
+    if (!host_has_it) {
+      st.host_known = false;
+      if ((rc = ctx_materialize(c, l))) return rc;
+      AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
+      copied[q] = true;
+      any = true;
+    }
+  }
+  if (any) AMHIP_TRY(hipStreamSynchronize(c->stream));
+  for (int q = 0; q < nl; ++q) {
+    if (!hosts[q] || !copied[q]) continue;
+    LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layers[q]];
     st.host_known = !s.always_copy;
     st.host = h[q];
   }

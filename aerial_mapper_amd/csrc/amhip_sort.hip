@@ -54,7 +54,7 @@ __device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
   return true;
 }
 
-// zall (may be null): per-wave [min, max] of all heights read (the records' reference height)
+// zall (may be null): per-wave [min, max] of the binned points' heights (the records' reference height)
 __global__ void __launch_bounds__(256)
 k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
                 uint32_t* __restrict__ cnt, uint32_t* __restrict__ rank,
@@ -65,16 +65,17 @@ k_dsm_bin_count(const double* __restrict__ xyz, size_t n, DsmParams p,
        idx += stride) {
     const double x = xyz[3 * idx + 0];
     const double y = xyz[3 * idx + 1];
-    if (zall) {
-      const double z = xyz[3 * idx + 2];
-      zlo = fmin(zlo, z);
-      zhi = fmax(zhi, z);
-    }
+    const double z = zall ? xyz[3 * idx + 2] : 0.0;
     const double px = x - p.sub_x;  // dsm.cc:42
     const double py = y - p.sub_y;  // dsm.cc:43
     uint32_t bin;
     uint32_t r = kNoRank;
-    if (point_bin(p, px, py, &bin)) r = atomicAdd(&cnt[bin], 1u);
+    if (point_bin(p, px, py, &bin)) {
+      r = atomicAdd(&cnt[bin], 1u);
+      // (the range of the BINNED points only: a stray height far off the map must not move zref)
+      zlo = fmin(zlo, z);
+      zhi = fmax(zhi, z);
+    }
     rank[idx] = r;
   }
   if (zall) range_commit_wave(zlo, zhi, zall, (size_t)blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -279,8 +280,8 @@ __device__ __forceinline__ void halo_flush(HaloStage* st, const HaloParams& hp,
 
 // kHalo: the pass also copies the points other windows need into their send rows -- it
 // reads every point anyway (amhip_dsm_tiled_begin_dev).
-// zall (may be null; the record pipeline): every wave also leaves the [min, max] of ALL the
-// heights it reads (plain stores, range_commit_wave) -- the records' reference height zref is the
+// zall (may be null; the record pipeline): every wave also leaves the [min, max] of the heights
+// of the points it BINS (plain stores, range_commit_wave) -- the records' reference height zref is the
 // middle of that range and has to exist before the first scatter pass writes a record.
 // (Any zref is correct; the middle of a SAMPLE's range would save this pass 0.015 ms, but then
 // the records -- and one height in 500 by a float spacing -- depend on the order of the cloud:
@@ -315,14 +316,10 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
       }
     }
     // (the range AFTER the loads: with fmin / fmax next to each load the four waited for one
-    // another -- 0.245 ms against the 0.228 of the pass without heights)
-    if (zall) {
-#pragma unroll
-      for (int u = 0; u < kU; ++u) {
-        zlo = fmin(zlo, z[u]);
-        zhi = fmax(zhi, z[u]);
-      }
-    }
+    // another -- 0.245 ms against the 0.228 of the pass without heights.  Only BINNED points
+    // count: a stray height off the map -- a sentinel, an outlier -- would move zref away from
+    // the terrain, every record offset would be large and every tile's single-precision budget
+    // gone)
     unsigned look = 0;  // kHalo: which of the four may have to travel
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
@@ -331,7 +328,13 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
         const double px = x[u] - p.sub_x;  // dsm.cc:42
         const double py = y[u] - p.sub_y;  // dsm.cc:43
         int k1, k2;
-        if (p3_keys(p, px, py, &k1, &k2)) atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+        if (p3_keys(p, px, py, &k1, &k2)) {
+          atomicAdd(&s_hist[k1 * p.p3_n2 + k2], 1u);
+          if (zall) {
+            zlo = fmin(zlo, z[u]);
+            zhi = fmax(zhi, z[u]);
+          }
+        }
         if (kHalo && halo_candidate(hp, x[u], y[u])) look |= 1u << u;
       }
     }

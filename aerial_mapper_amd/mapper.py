@@ -260,7 +260,12 @@ class Dsm(object):
     def process(self, point_cloud, map, sync=True):
         """point_cloud: (N,3) float64 numpy array (host path, like the reference)
         or a CUDA torch tensor (device-resident path).  Updates map's
-        'elevation' layer."""
+        'elevation' layer.
+
+        sync=False (device path): returns with the kernels enqueued on the map's stream.  The
+        tensor must stay unchanged until they have run: work enqueued on the SAME stream
+        afterwards is ordered automatically (map.set_stream(torch's stream)); with any other
+        stream arrangement the call waits for the device itself."""
         if map is None:
             raise L.AmhipError(L.ERR_ARG, "CHECK(map) (dsm.cc:194)")
         s = self.settings
@@ -276,6 +281,15 @@ class Dsm(object):
                 s.interpolation_radius, s.center_easting, s.center_northing))
             if sync:
                 map.synchronize()
+            else:
+                # LIFETIME: until the call's last gather kernel has run, the library reads
+                # `point_cloud` itself (single-precision mode: the FP64 redo routines fetch the
+                # doubles from the caller's cloud through the records' row indices).  The call is
+                # ordered on the context's stream; when that is torch's current stream, later
+                # torch work on the tensor is ordered behind it.  On any OTHER stream torch
+                # knows nothing of these kernels: wait here rather than let a refill of the
+                # tensor race with the gather.
+                map.torch_waits()
             return
         pts = np.ascontiguousarray(point_cloud, np.float64).reshape(-1, 3)
         if pts.shape[0] == 0:

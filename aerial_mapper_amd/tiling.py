@@ -106,11 +106,26 @@ def in_window(cx, cy, window, margin_cells=0.0):
            (cy >= j0 - 0.5 - margin_cells) & (cy <= j0 + c - 0.5 + margin_cells)
 
 
-def owner_mask(cx, cy, window):
+def owner_mask(cx, cy, window, layout=None):
     """Points whose CELL lies in the window (half-open: each point has exactly
-    one owner)."""
+    one owner).  With `layout`, a window on the map's border also owns the points beyond that
+    border (its interval is open-ended on the map's outer sides): the reference's kd-tree uses
+    off-map points within the search radius for border cells (dsm.cc:36-52 keeps every point),
+    and so does the single-GPU path here, so a tiled run must not lose them -- every point of
+    a cloud that overhangs the map then has exactly one owner."""
     i0, j0, r, c = window
-    return (cx >= i0 - 0.5) & (cx < i0 + r - 0.5) & (cy >= j0 - 0.5) & (cy < j0 + c - 0.5)
+    lo_i, hi_i, lo_j, hi_j = i0 - 0.5, i0 + r - 0.5, j0 - 0.5, j0 + c - 0.5
+    if layout is not None:
+        inf = float("inf")
+        if i0 == 0:
+            lo_i = -inf
+        if i0 + r == layout.rows:
+            hi_i = inf
+        if j0 == 0:
+            lo_j = -inf
+        if j0 + c == layout.cols:
+            hi_j = inf
+    return (cx >= lo_i) & (cx < hi_i) & (cy >= lo_j) & (cy < hi_j)
 
 
 def select_for_windows(points, grid, windows, margin_m, center_easting=0.0,
@@ -303,7 +318,7 @@ class TiledDsm(object):
                density (halo_strip_rows())
 
     PRECONDITION: the n_owned rows are points whose CELL lies in this rank's window
-    (owner_mask()).  Only geometric neighbours are destinations, so a stray point that some
+    (owner_mask(..., layout): a border window also owns what lies beyond its outer sides).  Only geometric neighbours are destinations, so a stray point that some
     non-neighbour needs would never travel; process() therefore verifies the precondition on
     the device (check_owned: default = on its first call, True = every call) and raises instead
     of dropping points silently.  Clouds partitioned any other way go through route_points().
@@ -333,7 +348,9 @@ class TiledDsm(object):
         of torch ops over the rows: not part of a steady-state step)."""
         s, m = self.settings, self.map
         cx, cy = cell_coords(workspace[:n_owned], m.grid, s.center_easting, s.center_northing)
-        stray = int((~owner_mask(cx, cy, self.layout.window(self.rank))).sum().item())
+        # (border windows own the points beyond their outer sides: a cloud that overhangs the map
+        # is legitimate -- only a point in ANOTHER window's territory can fail to travel)
+        stray = int((~owner_mask(cx, cy, self.layout.window(self.rank), self.layout)).sum().item())
         if stray:
             raise ValueError("TiledDsm: %d of the %d owned points lie outside this rank's window; "
                              "only neighbouring windows receive halo rows -- route such clouds "
@@ -368,6 +385,10 @@ class TiledDsm(object):
         L.check(lib.amhip_dsm_tiled_finish_dev(m.handle))
         if sync:
             m.synchronize()   # raises AMHIP_ERR_HALO_OVERFLOW if a selection did not fit
+        else:
+            # (the gather still reads `workspace`: see Dsm.process -- ordered automatically when the
+            # map runs on torch's current stream, otherwise wait)
+            m.torch_waits()
 
     def check_overflow(self):
         """(kept for callers that run unsynchronised steps) the same check from the counts."""

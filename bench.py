@@ -2,7 +2,9 @@
 """bench.py -- DSM + backward-grid orthomosaic throughput on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: under python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ..., or
+   plainly -- bench.py then starts the N ranks itself; it never prints a line for fewer GPUs
+   than --gpus asked for)
 
 One "step" = one pass of the hot path over one batch of synthetic input that is
 already resident in HBM:  AerialGridMap::initialize() (layer reset) ->
@@ -21,6 +23,10 @@ Prints ONE JSON line on rank 0 (see the contract in the task description) with
 two extra objects: `roofline` (dominant kernel, algorithmic bytes / measured
 HIP-event time, vs 8 TB/s HBM) and `cpu_baseline` (the CPU oracle timed on a
 bounded sample of the same workload on this box's host cores).
+
+`value` is the library's DEFAULT arithmetic: the FP64 gather (the reference's doubles,
+dsm.cc:160-172).  The opt-in single-precision mode is timed in the same run and reported as
+the extra object `fast_mode`, with its own parity sample and roofline.
 """
 import argparse
 import json
@@ -84,17 +90,25 @@ def parse():
     ap.add_argument("--verify", action="store_true",
                     help="N > 1, small workloads: after the timed steps gather the cloud and every "
                          "window's elevation on rank 0 and compare with ONE full-map DSM there")
-    ap.add_argument("--dsm-mode", default="fast", choices=["fast", "exact"],
-                    help="arithmetic of the DSM gather in the timed steps behind `value`: fast = "
-                         "single precision under exact guards (opt-in mode of the library, within "
-                         "the north_star's 1e-4 m), exact = FP64 (the library's default, the "
-                         "reference's floats).  The other mode is timed in the same run and "
-                         "reported beside it (`exact_mode` / `fast_mode`)")
+    ap.add_argument("--dsm-mode", default="exact", choices=["fast", "exact"],
+                    help="arithmetic of the DSM gather in the timed steps behind `value`: exact = "
+                         "FP64 (the library's default: the reference's arithmetic, dsm.cc:160-172, and "
+                         "its floats), fast = single precision under exact guards (opt-in mode of the "
+                         "library, within the north_star's 1e-4 m).  The other mode is timed in the "
+                         "same run and reported beside it (`fast_mode` / `exact_mode`)")
     ap.add_argument("--no-second-mode", action="store_true", help="skip the other mode's loop")
     ap.add_argument("--no-rough-terrain", action="store_true",
                     help="skip the rough-terrain extra (N = 1: 25 m steps in 20 %% of the gather tiles)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the small verified step in front of the timed ones")
+    ap.add_argument("--route", default="auto", choices=["auto", "ranks", "session"],
+                    help="`value` is always the one-process-per-GPU route.  session: rank 0 ALSO times "
+                         "(after the timed steps) one pass of the whole map through ONE host process "
+                         "driving all N devices -- amhip_session on host buffers, the route "
+                         "AERIAL_MAPPER_HIP_DEVICES gives an unchanged C++ host (main-dsm.cc:103-107, "
+                         "main-ortho-backward-grid.cc:128-141) -- reported as `session_route` (N = 1: "
+                         "`pcie_inclusive`, the same thing), never as value.  auto (default): the same "
+                         "when the host has the memory for the whole map's matrices; ranks: never")
     ap.add_argument("--map-origin", default="0,0",
                     help="easting,northing of the map centre (default 0,0; e.g. 464980.25,5272690.5 "
                          "puts the same workload at UTM magnitudes)")
@@ -338,7 +352,7 @@ def preflight_verify(args, A, tiling, synth, dist, one_gpu, dev, local_rank, ran
         half = (win[2] * res / 2.0, win[3] * res / 2.0)
         pts = synth.make_points_torch(n_all // world, half, 900 + rank, dev, center=center)
         cx, cy = tiling.cell_coords(pts, pm.grid)
-        kept = pts[tiling.owner_mask(cx, cy, win)].contiguous()
+        kept = pts[tiling.owner_mask(cx, cy, win, layout)].contiguous()
         del pts, cx, cy
         n_own = int(kept.shape[0])
         wins_all = layout.windows()
@@ -362,18 +376,181 @@ def preflight_verify(args, A, tiling, synth, dist, one_gpu, dev, local_rank, ran
     return v
 
 
+def session_route(args, A, st, tiles, devices, dsm_settings, ncam, mosaic_settings, h_pts, poses, h_frames,
+                  cells_total, res, origin):
+    """One pass of the whole map the way the C++ drop-in classes make it: cloud, frames and the
+    GridMap's six matrices in (pageable) host memory, ONE amhip_session (one host process) over
+    `devices` -- one window per device (AERIAL_MAPPER_HIP_DEVICES).  PCIe included."""
+    import torch
+    F = len(h_frames) if h_frames is not None else 0
+    with A.HostSession(st, tiles=tiles, devices=devices) as hs:
+        hs.set_dsm_precision(args.dsm_mode == "exact")
+        for d in sorted(set(devices)):      # (loads the code objects on every device)
+            warm = A.HostSession(A.GridMapSettings(origin[0], origin[1], 64 * res, 32 * res, res), devices=[d])
+            warm.dsm_process(dsm_settings, h_pts[:4096])
+            warm.close()
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+        t0h = time.perf_counter()
+        hs.dsm_process(dsm_settings, h_pts)
+        t1h = time.perf_counter()
+        if F:
+            hs.ortho_process(ncam, mosaic_settings, poses, h_frames)
+        t2h = time.perf_counter()
+        # a second pass over the SAME map (incremental mapping: the layers are resident,
+        # the matrices unchanged since the session wrote them)
+        hs.dsm_process(dsm_settings, h_pts)
+        t3h = time.perf_counter()
+        if F:
+            hs.ortho_process(ncam, mosaic_settings, poses, h_frames)
+        t4h = time.perf_counter()
+        nwin = hs.num_windows
+    bytes_up = h_pts.nbytes + (sum(f.nbytes for f in h_frames) * len(set(devices)) if F else 0)
+    bytes_down = 4.0 * cells_total * (4 if F else 1)
+    return {"ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
+            "Mcells_per_s": round(cells_total / (t2h - t0h) / 1e6, 1),
+            "second_pass_ms": round((t4h - t2h) * 1e3, 1),
+            "windows": nwin, "devices": [int(d) for d in devices],
+            "bytes_up": bytes_up, "bytes_down": bytes_down,
+            "link_floor_ms": round((bytes_up + bytes_down) / 56e9 / len(set(devices)) * 1e3, 1),
+            "dsm_mode": args.dsm_mode,
+            "note": "amhip_session_dsm_process + amhip_session_ortho_backward_process on pageable "
+                    "host buffers (the drop-in classes' route, ONE host process): cloud (sliced over "
+                    "the devices, routed device to device) + frames (replicated) up, the matrices "
+                    "that changed down (elevation, elevation_angle, observation_index, ortho); "
+                    "initial-state matrices are recognised by content and not uploaded; "
+                    "link_floor_ms = those bytes at the 56 GB/s one device's link moves one way at a "
+                    "time, the devices' links in parallel (H2D and D2H of one synchronous call "
+                    "cannot overlap)"}
+
+
+def session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev, wl, fixed, pts_per_rank,
+                      ox, oy, Lx, Ly, res, L, dsm, ncam, mosaic, F, ch, cells_total):
+    """N > 1, rank 0 while the other ranks wait on the host: the WHOLE map (every rank's points,
+    regenerated here with the ranks' seeds; every rank's frames) through one amhip_session with
+    one window per device.  Skipped, with the reason, when the host lacks the memory."""
+    import numpy as np
+    import torch
+    from aerial_mapper_amd import hip_lib
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = None
+    need = 24.0 * pts_per_rank * world * 2 + 6 * 4.0 * cells_total * 1.2 + \
+        (F * (1 if fixed else world) * wl["W"] * wl["H"] * ch * 2.0 if F else 0.0)
+    if avail is not None and avail < 1.3 * need:
+        if args.route == "session":
+            raise SystemExit("--route session: the host has %.0f GB free, the whole map's host buffers "
+                             "need %.0f GB" % (avail / 1e9, need / 1e9))
+        return {"skipped": "host memory: %.0f GB free, %.0f GB needed for the whole map's matrices, "
+                           "cloud and frames" % (avail / 1e9, need / 1e9)}
+    try:
+        parts, posel, framel = [], [], []
+        for r in range(world):
+            w = layout.window(r)
+            center = (ox + Lx / 2.0 - (w[0] + w[2] / 2.0) * res, oy + Ly / 2.0 - (w[1] + w[3] / 2.0) * res)
+            half = (w[2] * res / 2.0, w[3] * res / 2.0)
+            p = synth.make_points_torch(pts_per_rank, half, 43 + r, dev, center=center)
+            grid_full = hip_lib.make_grid(st.delta_easting, st.delta_northing, st.resolution,
+                                            st.center_easting, st.center_northing)
+            cx, cy = tiling.cell_coords(p, grid_full)
+            parts.append(p[tiling.owner_mask(cx, cy, w, layout)].cpu().numpy())
+            del p, cx, cy
+            if F and (not fixed or r == 0):
+                fl_center = (ox, oy) if fixed else center
+                fr = synth.make_frames_torch(F, wl["H"], wl["W"], ch, 44 + (0 if fixed else r), dev)
+                framel += [f for f in fr.cpu().numpy()]
+                del fr
+                posel.append(synth.make_lawnmower_poses(F, L / 2.0, wl["altitude"], 44 + (0 if fixed else r),
+                                                        tilt_deg=5.0, center=fl_center))
+        h_pts = np.concatenate(parts, 0)
+        del parts
+        devices = [0] * world if one_gpu else list(range(world))
+        res_out = session_route(args, A, st, (layout.tiles_i, layout.tiles_j), devices, dsm.settings, ncam,
+                                mosaic.settings if F else None, h_pts,
+                                np.concatenate(posel, 0) if F else None, framel if F else None,
+                                cells_total, res, (ox, oy))
+        res_out["route"] = ("one host process, amhip_session over %d devices (AERIAL_MAPPER_HIP_DEVICES): what "
+                            "an unchanged reference host gets; the line's `value` is the one-process-per-GPU "
+                            "route with inputs resident in HBM" % len(set(devices)))
+        res_out["points"] = int(h_pts.shape[0])
+        res_out["frames"] = len(framel)
+        return res_out
+    except SystemExit:
+        raise
+    except Exception as e:   # the ranks' numbers stand on their own
+        return {"error": repr(e)}
+
+
+def valu_roofline(valu, dom, dom_ms, mode):
+    """The VALU-issue roofline of the dominant kernel from the committed SQ counters of the same
+    command in the same mode (lane-instructions per launch) over the LIVE kernel time."""
+    prefixes = {"k_dsm_gather": ("k_dsm_gather_tiled<",) if mode == "exact" else ("k_dsm_gather_f32<",),
+                "k_ortho_backward": ("k_ortho_backward",)}[dom]
+    rows = [(k, v) for k, v in valu[1].items() if k.startswith(prefixes) and v.get("GRBM_GUI_ACTIVE")]
+    if not rows:
+        return {}
+    kname, v = max(rows, key=lambda r: r[1].get("SQ_INSTS_VALU", 0))
+    busy = v["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
+    lanes = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(v["SQ_INSTS_VALU"], 1.0) / 64.0
+    # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s (one f32 op per lane
+    # and cycle; FP64 ops issue at half that: a pure FP64 stream tops out at frac 0.5)
+    peak_valu = 256 * 4 * 32 * 2.4e9
+    lane_ops = v["SQ_INSTS_VALU"] * 64.0 * lanes
+    fp64 = mode == "exact" or dom == "k_ortho_backward"
+    return {"bound": "valu", "valu": {
+        "kernel": kname,
+        "note": ("FP64 VALU-issue bound (every pair's test and weight in the reference's doubles: "
+                 "v_*_f64 issue at half rate, 4.4 cycles per wave-instruction measured), not HBM "
+                 "bound; no MFMA-shaped work on this path" if fp64 else
+                 "VALU-issue bound (f32 pair arithmetic + FP64 staging / decisions), not HBM bound; "
+                 "no MFMA-shaped work on this path"),
+        "frac": round(lane_ops / (dom_ms * 1e-3) / peak_valu, 4),
+        "frac_ceiling_for_this_instruction_mix": 0.5 if fp64 else 0.65,
+        "lane_instructions_per_launch": lane_ops, "peak_lane_instructions_per_s": peak_valu,
+        # wave-instructions per SIMD and clock.  What one costs, measured in real shader cycles
+        # (s_memtime; tools/ubench/ubench3.hip, profiles/r03_ubench3_real_cycles.jsonl)
+        "wave_instructions_per_simd_clock": round(v["SQ_INSTS_VALU"] / 1024.0 / busy, 3),
+        "issue_cycles_per_wave_instruction_measured": {
+            "full_rate (v_fma/mul/add_f32, v_sub_u32)": 2.4,
+            "half_rate (v_cvt_f32_i32, v_cmp/cmpx_f32, v_max_f32, FP64 fma/mul/add)": 4.4,
+            "v_rcp_f32": 8.2, "source": "profiles/r03_ubench3_real_cycles.jsonl"},
+        "lanes_active_frac": round(lanes, 3),
+        "source": valu[0] + " (counters of the same command in the same mode); kernel_ms live"}}
+
+
 def main():
     args = parse()
     import numpy as np
     import torch
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process
+        # per GPU over RCCL) instead of silently timing one.  The reference host is ONE process
+        # (main-dsm.cc:103-107); its own multi-device route is timed by --route session.
+        have = torch.cuda.device_count()
+        if have < args.gpus and os.environ.get("AMHIP_BENCH_ONE_GPU", "0") != "1":
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible; refusing to print a line "
+                             "for fewer GPUs than asked (AMHIP_BENCH_ONE_GPU=1 rehearses the N-rank "
+                             "path on one device, labelled as such)" % (args.gpus, have))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: refusing to print a line whose n_gpus differs "
+                         "from what was asked" % (args.gpus, world))
     # AMHIP_BENCH_ONE_GPU=1: rehearsal of the N > 1 code path on a 1-GPU box -- every rank
     # on device 0, gloo instead of RCCL (which refuses two ranks per device), the halo rows
     # staged through host memory.  Its numbers mean nothing; the line says so.
@@ -387,13 +564,17 @@ def main():
     # HIP events and -- for N > 1 -- the RCCL all_to_all are all ordered on it.
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    dist = None
+    dist = host_pg = None
     if world > 1:
         import torch.distributed as dist
         if one_gpu:
             dist.init_process_group("gloo")
+            host_pg = None
         else:
             dist.init_process_group("nccl", device_id=dev)
+            # a host-side group for the LAST wait: while rank 0 drives every device through one
+            # amhip_session (session_route) the other ranks must not spin in an RCCL kernel
+            host_pg = dist.new_group(backend="gloo")
 
     import aerial_mapper_amd as A
     from aerial_mapper_amd import synth
@@ -452,7 +633,7 @@ def main():
         # keep only points whose cell is inside the window (a point exactly on
         # the upper edge belongs to the neighbour)
         cxx, cyy = tiling.cell_coords(pts_buf[:n_pts], m.grid)
-        own = tiling.owner_mask(cxx, cyy, win)
+        own = tiling.owner_mask(cxx, cyy, win, layout)
         kept = pts_buf[:n_pts][own]
         n_pts = int(kept.shape[0])
         pts_buf[:n_pts] = kept
@@ -589,34 +770,42 @@ def main():
             b_dsm = 24.0 * N + 4.0 * cells
         b_ortho = (20.0 * cells + F_step * wl["W"] * wl["H"] * ch + 56.0 * F_step) if F else 0.0
         alg_bytes = {"k_dsm_gather": b_dsm, "k_ortho_backward": b_ortho}
-        # PMC evidence of the same command, collected by tools/collect_profiles.sh and committed
-        # under profiles/ (newest round first); never measured inside this run -- the line says so
+        # PMC evidence of the same command IN THE SAME ARITHMETIC MODE, collected by
+        # tools/collect_profiles.sh and committed under profiles/ (newest round first; the file
+        # name and a "dsm_mode" key inside both carry the mode, so the other mode's counters can
+        # never be picked); never measured inside this run -- the line says so
         import glob
         import re
 
         def newest(pattern):
             fs = glob.glob(os.path.join(ROOT, "profiles", pattern))
             def key(f):
-                m = re.search(r"r(\d+)_(?:v(\d+)_)?", os.path.basename(f))
-                return (int(m.group(1)), int(m.group(2) or 0)) if m else (0, 0)
+                mm = re.search(r"r(\d+)_", os.path.basename(f))
+                return int(mm.group(1)) if mm else 0
             return sorted(fs, key=key)[-1] if fs else None
 
-        traffic, traffic_src = {}, None
-        try:
-            f = newest("r*_pmc_traffic.json")
-            tj = json.load(open(f))
-            if tj.get("workload") == args.workload and not args.colored:
-                traffic = {k: v["bytes"] for k, v in tj["kernels"].items()}
-                traffic_src = "profiles/" + os.path.basename(f)
-        except Exception:
-            pass
-        valu = None
-        try:
-            f = newest("r*_cfg3_pmc_sq.json")
-            if f and args.workload in ("cfg3", "cfg2") and not args.colored:
-                valu = (os.path.basename(f), json.load(open(f))["kernels"])
-        except Exception:
-            pass
+        def evidence(mode):
+            """(traffic per slot, its file, SQ counters per kernel, their file) of `mode`"""
+            tr, tr_src, sq, sq_src = {}, None, None, None
+            try:
+                f = newest("r*_%s_pmc_traffic.json" % mode)
+                tj = json.load(open(f))
+                if tj.get("workload") == args.workload and tj.get("dsm_mode") == mode and not args.colored:
+                    tr = {k: v["bytes"] for k, v in tj["kernels"].items()}
+                    tr_src = "profiles/" + os.path.basename(f)
+            except Exception:
+                pass
+            try:
+                f = newest("r*_%s_cfg3_pmc_sq.json" % mode)
+                sj = json.load(open(f)) if f else {}
+                if f and sj.get("dsm_mode") == mode and args.workload in ("cfg3", "cfg2") and not args.colored:
+                    sq, sq_src = sj["kernels"], "profiles/" + os.path.basename(f)
+            except Exception:
+                pass
+            return tr, tr_src, sq, sq_src
+
+        traffic, traffic_src, valu_k, valu_src = evidence(args.dsm_mode)
+        valu = (valu_src, valu_k) if valu_k else None
         kern = {}
         for name, (ms, n) in ktimes.items():
             if n:
@@ -643,7 +832,8 @@ def main():
                                             "heights within the north_star's 1e-4 m; the library's "
                                             "default mode is timed beside it: exact_mode)",
                                     "exact": "AMHIP_DSM_EXACT (the library's default: FP64, the "
-                                             "reference's floats)"}[args.dsm_mode],
+                                             "reference's arithmetic and floats; the opt-in single-"
+                                             "precision mode is timed beside it: fast_mode)"}[args.dsm_mode],
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
                                "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
@@ -702,38 +892,7 @@ def main():
         if verify is not None:
             out["verify"] = verify
         if valu is not None:
-            prefixes = {"k_dsm_gather": ("k_dsm_gather_f32<", "k_dsm_gather_tiled<"),
-                        "k_ortho_backward": ("k_ortho_backward",)}[dom]
-            rows = [v for k, v in valu[1].items() if k.startswith(prefixes) and v.get("GRBM_GUI_ACTIVE")]
-            if rows:
-                v = max(rows, key=lambda r: r.get("SQ_INSTS_VALU", 0))
-                busy = v["GRBM_GUI_ACTIVE"] / 8.0           # summed over the 8 XCDs
-                lanes = v.get("SQ_THREAD_CYCLES_VALU", 0.0) / max(v["SQ_INSTS_VALU"], 1.0) / 64.0
-                # VALU roofline: lane-instructions the kernel issues per launch (committed SQ
-                # counters of the same command) over the LIVE kernel time, against 256 CUs x 4
-                # SIMDs x 32 lanes x 2.4 GHz = 78.6 T lane-instructions/s (one f32 op per lane
-                # and cycle; FP64 ops issue at half that)
-                peak_valu = 256 * 4 * 32 * 2.4e9
-                lane_ops = v["SQ_INSTS_VALU"] * 64.0 * lanes
-                out["roofline"]["bound"] = "valu"
-                out["roofline"]["valu"] = {
-                    "note": "VALU-issue bound (f32 pair arithmetic + FP64 staging / decisions), not "
-                            "HBM bound; no MFMA-shaped work on this path",
-                    "frac": round(lane_ops / (dom_ms * 1e-3) / peak_valu, 4),
-                    "lane_instructions_per_launch": lane_ops, "peak_lane_instructions_per_s": peak_valu,
-                    # wave-instructions per SIMD and clock.  What one costs, measured in real shader
-                    # cycles (s_memtime; tools/ubench/ubench3.hip, profiles/r03_ubench3_real_cycles.jsonl):
-                    # fma / mul / add / sub_u32 2.3 - 2.5 (the guide's 2-cycle class), cvt / cmp(x) /
-                    # max and all FP64 4.4, v_rcp_f32 8.2 -> the gather's mix averages ~3.1 cycles, i.e.
-                    # a ceiling of ~0.32 for this kernel (0.5 only for a pure full-rate stream)
-                    "wave_instructions_per_simd_clock": round(v["SQ_INSTS_VALU"] / 1024.0 / busy, 3),
-                    "issue_cycles_per_wave_instruction_measured": {
-                        "full_rate (v_fma/mul/add_f32, v_sub_u32)": 2.4,
-                        "half_rate (v_cvt_f32_i32, v_cmp/cmpx_f32, v_max_f32, FP64 fma/mul/add)": 4.4,
-                        "v_rcp_f32": 8.2, "candidate_loop_body_per_candidate": 75,
-                        "source": "profiles/r03_ubench3_real_cycles.jsonl"},
-                    "lanes_active_frac": round(lanes, 3),
-                    "source": "profiles/" + valu[0] + " (counters); kernel_ms live"}
+            out["roofline"].update(valu_roofline(valu, dom, dom_ms, args.dsm_mode))
         parity_done = False
         if world == 1 and not args.no_cpu_baseline and not fixed:
             # (before anything else runs: the layers still hold the result of the TIMED steps)
@@ -763,6 +922,19 @@ def main():
                         om["parity_sample"] = parity_against(refs, args, m, poses, ncam, F)
                     except Exception as e:
                         om["parity_sample"] = {"error": repr(e)}
+                # the same roofline object for this mode's gather, from ITS committed counters
+                if om["gather_ms"] > 0 and b_dsm > 0:
+                    o_tr, o_src, o_sq, o_sq_src = evidence(other)
+                    o_ach = b_dsm / (om["gather_ms"] * 1e-3) / 1e9
+                    orl = {"bound": "hbm", "kernel": "k_dsm_gather", "achieved": round(o_ach, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(o_ach / HBM_PEAK_GBS, 4),
+                           "traffic": o_tr.get("k_dsm_gather"), "traffic_source": o_src,
+                           "algorithmic_bytes_per_launch": b_dsm, "kernel_ms": om["gather_ms"]}
+                    if orl["traffic"]:
+                        orl["traffic_over_algorithmic"] = round(orl["traffic"] / b_dsm, 3)
+                    if o_sq:
+                        orl.update(valu_roofline((o_sq_src, o_sq), "k_dsm_gather", om["gather_ms"], other))
+                    om["roofline"] = orl
                 out[other + "_mode"] = om
                 m.set_dsm_precision(args.dsm_mode == "exact")
                 # what a host that never touches the switch gets for the byte-exact half
@@ -779,49 +951,21 @@ def main():
                 out["rough_terrain"] = rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L)
             except Exception as e:
                 out["rough_terrain"] = {"error": repr(e)}
-        if world == 1 and args.host_path and not fixed:
-            # the reference-shaped call, as the C++ drop-in classes make it: cloud, frames and
-            # the GridMap's six matrices in (pageable) host memory, one amhip_session per map
+        if world == 1 and args.host_path and not fixed and args.route != "ranks":
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None
-            with A.HostSession(st) as hs:
-                hs.set_dsm_precision(args.dsm_mode == "exact")
-                warm = A.HostSession(A.GridMapSettings(ox, oy, 64 * res, 32 * res, res))
-                warm.dsm_process(dsm.settings, h_pts[:4096])   # (loads the code objects)
-                warm.close()
-                torch.cuda.synchronize()
-                t0h = time.perf_counter()
-                hs.dsm_process(dsm.settings, h_pts)
-                t1h = time.perf_counter()
-                if F:
-                    hs.ortho_process(ncam, mosaic.settings, poses, h_frames)
-                t2h = time.perf_counter()
-                # a second pass over the SAME map (incremental mapping: the layers are resident,
-                # the matrices unchanged since the session wrote them)
-                hs.dsm_process(dsm.settings, h_pts)
-                t3h = time.perf_counter()
-                if F:
-                    hs.ortho_process(ncam, mosaic.settings, poses, h_frames)
-                t4h = time.perf_counter()
-            bytes_up = h_pts.nbytes + (sum(f.nbytes for f in h_frames) if F else 0)
-            bytes_down = 4.0 * cells * (4 if F else 1)
-            out["pcie_inclusive"] = {
-                "ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
-                "Mcells_per_s": round(cells / (t2h - t0h) / 1e6, 1),
-                "second_pass_ms": round((t4h - t2h) * 1e3, 1),
-                "bytes_up": bytes_up, "bytes_down": bytes_down,
-                "link_floor_ms": round((bytes_up + bytes_down) / 56e9 * 1e3, 1),
-                "dsm_mode": args.dsm_mode,
-                "note": "amhip_session_dsm_process + amhip_session_ortho_backward_process on pageable "
-                        "host buffers (the drop-in classes' route): cloud + frames up, the matrices "
-                        "that changed down (elevation, elevation_angle, observation_index, ortho); "
-                        "initial-state matrices are recognised by content and not uploaded; "
-                        "link_floor_ms = those bytes at the 56 GB/s this host moves one way at a time "
-                        "(H2D and D2H of one synchronous call cannot overlap)"}
+            out["pcie_inclusive"] = session_route(args, A, st, (1, 1), [local_rank], dsm.settings, ncam,
+                                                  mosaic.settings if F else None, h_pts, poses, h_frames,
+                                                  cells, res, (ox, oy))
+            out["pcie_inclusive"]["route"] = "session (--route session at N = 1 is this object)"
+        if world > 1 and args.route != "ranks" and not batch:
+            out["session_route"] = session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev,
+                                                     wl, fixed, pts_per_rank, ox, oy, Lx, Ly, res, L, dsm,
+                                                     ncam, mosaic, F, ch, rows_all * cols_all)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=host_pg) if host_pg is not None else dist.barrier()
         dist.destroy_process_group()
 
 

@@ -96,3 +96,58 @@ def test_device_buffer_exchange_over_rccl_when_the_node_has_two_gpus():
     assert r["backend"] == "nccl" and r["world_size_reported"] == n and r["distinct_devices"] == n
     assert d["preflight"]["pass"] and d["verify"]["pass"], (d["preflight"], d["verify"])
     assert "REHEARSAL" not in d["data"]
+
+
+def _run_plain(nproc, workload, extra=(), one_gpu=True):
+    """`python bench.py --gpus N ...` WITHOUT a launcher -- the shape of the driver's command."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if one_gpu:
+        env["AMHIP_BENCH_ONE_GPU"] = "1"
+    else:
+        env.pop("AMHIP_BENCH_ONE_GPU", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--workload", workload,
+           "--steps", "2", "--warmup", "1"] + list(extra)
+    return subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          universal_newlines=True, timeout=600)
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks_itself():
+    """(VERDICT r3 missing #1) `python bench.py --gpus 2` used to read WORLD_SIZE (unset -> 1) and
+    print an n_gpus: 1 line.  It now re-executes itself under torch.distributed.run."""
+    r = _run_plain(2, "small", ["--verify"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"]["world_size_reported"] == 2
+    assert d["preflight"]["pass"] and d["verify"]["pass"]
+    # the drop-in's own multi-device route (one host process, amhip_session), timed beside it
+    s = d["session_route"]
+    assert "error" not in s, s
+    if "skipped" not in s:
+        assert s["windows"] == 2 and s["ms"] > 0 and s["points"] > 1_000_000
+
+
+def test_gpus_n_refuses_to_run_on_fewer_devices():
+    import torch
+    nd = torch.cuda.device_count()
+    r = _run_plain(nd + 1, "small", one_gpu=False)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_one_gpu_session_route_is_the_pcie_inclusive_object():
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "2",
+           "--warmup", "1", "--route", "session", "--no-cpu-baseline", "--no-second-mode",
+           "--no-rough-terrain"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       universal_newlines=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["pcie_inclusive"]["windows"] == 1 and d["pcie_inclusive"]["ms"] > 0
+    assert d["config"]["dsm_mode"].startswith("AMHIP_DSM_EXACT") and d["dtype"] == "f64"

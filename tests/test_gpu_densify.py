@@ -28,7 +28,11 @@ def test_densify_matches_oracle_bitwise_in_raster_order(h, w, seed):
     import torch
     import aerial_mapper_amd as A
     disp, img, K, b, R, t = _case(h, w, seed)
-    want_p, want_i = O.densify(disp, img, K, b, R, t)
+    # directly against the reference's own densifier.cpp (compiled unchanged over oracle/refkit)
+    # where it was built, and against the restatement
+    want_p, want_i = O.densify(disp, img, K, b, R, t, which="loops" if O.have_loops() else "port")
+    port_p, port_i = O.densify(disp, img, K, b, R, t)
+    assert np.array_equal(port_p.view(np.uint64), want_p.view(np.uint64)) and np.array_equal(port_i, want_i)
     with A.AerialGridMap(A.GridMapSettings(0, 0, 8, 8, 1.0)) as m:
         got_p, got_i = A.densify(m, torch.from_numpy(disp).cuda(), torch.from_numpy(img).cuda(),
                                  K, b, R, t)

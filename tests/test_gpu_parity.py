@@ -25,9 +25,9 @@ def _A():
 
 
 # Every DSM test runs in both arithmetic modes of the gather (amhip_ctx_set_dsm_precision):
-# "fast" (default: single precision under exact guards) and "exact" (FP64 everywhere).  The bar
-# is the same -- identical NaN pattern, heights within 1e-4 m -- only the share of
-# bit-identical floats differs.
+# "exact" (the library's default: FP64 everywhere, the reference's floats) and "fast" (opt-in:
+# single precision under exact guards).  The bar is the same -- identical NaN pattern, heights
+# within 1e-4 m -- only the share of bit-identical floats differs.
 _EXACT = False
 
 

@@ -200,12 +200,17 @@ def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
     layout = tiling.TileLayout(g.rows, g.cols, tiles[0], tiles[1])
     world = layout.world
     cx, cy = tiling.cell_coords(pts, g)
-    # (points beyond the map border have no owner in a tiled run)
+    # The cloud overhangs the map by 3 m on every side.  The reference's kd-tree -- and the
+    # single-GPU path -- use those points for the border cells; in a tiled run the border
+    # windows own them (owner_mask(..., layout)): the full-map DSM below sees the WHOLE cloud.
     inside_any = np.zeros(npts, bool)
     for r in range(world):
-        inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
+        mk = tiling.owner_mask(cx, cy, layout.window(r), layout)
+        assert not (inside_any & mk).any()          # exactly one owner each
+        inside_any |= mk
+    assert inside_any.all() and (cx < -0.5).any() and (cy > g.cols - 0.5).any()
     with A.AerialGridMap(st) as m:
-        A.Dsm(A.DsmSettings(), m).process(np.ascontiguousarray(pts[inside_any]), m)
+        A.Dsm(A.DsmSettings(), m).process(np.ascontiguousarray(pts), m)
         full = m.get("elevation")
     cap = tiling.halo_strip_rows(npts / ((lx + 6) * (ly + 6)), max(lx, ly), 1, res, slack=2.0)
     comm = _ThreadComm(world)
@@ -214,7 +219,7 @@ def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
     def run(rank):
         try:
             win = layout.window(rank)
-            own = pts[tiling.owner_mask(cx, cy, win)]
+            own = pts[tiling.owner_mask(cx, cy, win, layout)]
             n = own.shape[0]
             buf = torch.full((n + world * cap, 3), 7.0, dtype=torch.float64, device="cuda")
             buf[:n] = torch.from_numpy(np.ascontiguousarray(own)).cuda()
@@ -244,8 +249,8 @@ def test_tiled_dsm_selects_the_halo_in_its_binning_pass(npts, lx, ly, tiles):
     for rank in range(world):
         (i0, j0, r, c), elev, got, sent, select_launches = out[rank]
         win = layout.window(rank)
-        want = pts[tiling.in_window(cx, cy, win, margin / res) & inside_any &
-                   ~tiling.owner_mask(cx, cy, win)]
+        want = pts[tiling.in_window(cx, cy, win, margin / res) &
+                   ~tiling.owner_mask(cx, cy, win, layout)]
         assert want.shape[0] > 0
         assert got.shape == want.shape and np.array_equal(key(got), key(want))
         sent_total += sent

@@ -39,7 +39,8 @@ def _worker(rank, world, port, tiles, assume_owned, via_host, ret):
         cloud = synth.make_points(60000, 90.0, 77)  # spills over the map border
         cx, cy = tiling.cell_coords(cloud, g)
         if assume_owned:
-            mine = cloud[tiling.owner_mask(cx, cy, layout.window(rank))]
+            # (border windows own the points beyond the map's border: owner_mask(..., layout))
+            mine = cloud[tiling.owner_mask(cx, cy, layout.window(rank), layout)]
         else:
             mine = cloud[rank::world]  # partitioned by source, not by tile
         got = tiling.route_points(torch.from_numpy(np.ascontiguousarray(mine)), g, layout, rank,
@@ -48,19 +49,18 @@ def _worker(rank, world, port, tiles, assume_owned, via_host, ret):
         margin = tiling.halo_margin(1, g.resolution)
         want_mask = tiling.in_window(cx, cy, layout.window(rank), margin / g.resolution)
         if assume_owned:
-            # points outside every window (beyond the map) have no owner and are
-            # only needed if they fall inside a grown window: they are dropped
-            # by the owned partition, exactly like a pre-partitioned cloud
-            inside_any = np.zeros(len(cloud), bool)
-            for r in range(world):
-                inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
-            want_mask &= inside_any
+            # a pre-partitioned cloud keeps ALL of a rank's owned points, including the off-map
+            # ones beyond its grown window (the binning drops those later)
+            want_mask |= tiling.owner_mask(cx, cy, layout.window(rank), layout)
+            owners = sum(tiling.owner_mask(cx, cy, layout.window(r), layout).astype(int) for r in range(world))
+            assert (owners == 1).all() and ((cx < -0.5) | (cy < -0.5)).any()
         want = cloud[want_mask]
         key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
         same_set = got.shape == want.shape and np.array_equal(key(got), key(want))
         # exactness of tiling: DSM of the routed subset == DSM of the whole cloud
         # on this window's cells (oracle, full-map geometry)
-        full = OO.dsm_process(cloud if not assume_owned else cloud[inside_any], g)[1]
+        # (the WHOLE cloud, off-map points included: the reference's kd-tree keeps them all)
+        full = OO.dsm_process(cloud, g)[1]
         part = OO.dsm_process(got, g)[1]
         i0, j0, r, c = layout.window(rank)
         a, b = full[j0:j0 + c, i0:i0 + r], part[j0:j0 + c, i0:i0 + r]
@@ -139,10 +139,7 @@ def _worker_neighbours(rank, world, port, tiles, ret):
         layout = tiling.TileLayout(g.rows, g.cols, tiles[0], tiles[1])
         cloud = synth.make_points(70000, 100.0, 78)
         cx, cy = tiling.cell_coords(cloud, g)
-        inside_any = np.zeros(len(cloud), bool)
-        for r in range(world):
-            inside_any |= tiling.owner_mask(cx, cy, layout.window(r))
-        own_mask = tiling.owner_mask(cx, cy, layout.window(rank))
+        own_mask = tiling.owner_mask(cx, cy, layout.window(rank), layout)
         margin = tiling.halo_margin(1, g.resolution)
         mc = margin / g.resolution
         nbrs = tiling.neighbours(layout, rank, margin, g.resolution)
@@ -157,12 +154,12 @@ def _worker_neighbours(rank, world, port, tiles, ret):
         tiling.TorchComm().exchange_rows(recv, torch.from_numpy(send[:len(nbrs) * cap]), splits, splits)
         got = recv.numpy()
         got = got[~np.isnan(got[:, 0])]
-        want = cloud[tiling.in_window(cx, cy, layout.window(rank), mc) & inside_any & ~own_mask]
+        want = cloud[tiling.in_window(cx, cy, layout.window(rank), mc) & ~own_mask]
         key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
         # a rank that is NOT a neighbour holds nothing this window needs
         for q in range(world):
             if q != rank and q not in nbrs:
-                stray = tiling.owner_mask(cx, cy, layout.window(q)) & \
+                stray = tiling.owner_mask(cx, cy, layout.window(q), layout) & \
                     tiling.in_window(cx, cy, layout.window(rank), mc)
                 assert not stray.any()
         ret[rank] = (got.shape == want.shape and np.array_equal(key(got), key(want)), len(nbrs),

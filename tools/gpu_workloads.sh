@@ -1,5 +1,5 @@
 #!/bin/bash
-# The other bench lines quoted in DESIGN.md, one GPU call: FP64 mode, cfg2, colour, UTM origin, cfg4 / cfg5 at N = 1.
+# The other bench lines quoted in DESIGN.md, one GPU call: single-precision mode, cfg2 in both modes, colour, UTM origin, cfg4 / cfg5 at N = 1.
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out"
 run() { # name, env, args...
@@ -14,9 +14,10 @@ except Exception as e:
     print("$name failed", e)
 P
 }
-run exact AMHIP_DSM_EXACT=1 --steps 10 --warmup 3
-run cfg2 A=1 --steps 10 --warmup 3 --workload cfg2
-run cfg2_exact AMHIP_DSM_EXACT=1 --steps 10 --warmup 3 --workload cfg2
+# (bench.py's --dsm-mode decides the arithmetic, not the environment: default exact = FP64)
+run fast A=1 --steps 10 --warmup 3 --dsm-mode fast --no-second-mode --no-rough-terrain
+run cfg2 A=1 --steps 10 --warmup 3 --workload cfg2 --no-second-mode --no-rough-terrain
+run cfg2_fast A=1 --steps 10 --warmup 3 --workload cfg2 --dsm-mode fast --no-second-mode --no-rough-terrain
 run colored A=1 --steps 10 --warmup 3 --colored
 run utm A=1 --steps 10 --warmup 3 --map-origin 464980.25,5272690.5
 run cfg4 A=1 --steps 5 --warmup 2 --workload cfg4

@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--sq", nargs="*", help="rocpd databases of SQ / GRBM counter passes")
     ap.add_argument("--sq-json", help="write the per-kernel averages of the --sq passes")
     ap.add_argument("--tag", default="")
+    ap.add_argument("--dsm-mode", default=None, choices=["exact", "fast"],
+                    help="arithmetic mode of the profiled command: stored in the JSON summaries, bench.py "
+                         "only reads a summary whose mode is the one it runs in")
     a = ap.parse_args()
     if a.sq:
         import json
@@ -72,7 +75,7 @@ def main():
         text = {"_comment": "rocprofv3 PMC SQ / GRBM counters, average per launch summed over XCDs / SEs, "
                             "cfg3, %s build (python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                             "--no-host-path; separate --pmc passes with --kernel-trace only). SQ_* cycle "
-                            "counters tick every 4 clocks." % a.tag, "kernels": out}
+                            "counters tick every 4 clocks." % a.tag, "dsm_mode": a.dsm_mode, "kernels": out}
         if a.sq_json:
             json.dump(text, open(a.sq_json, "w"), indent=1)
         for k, v in out.items():
@@ -107,6 +110,7 @@ def main():
         import json
         slot = lambda k: ("k_dsm_gather" if k.startswith("k_dsm_gather") else
                           "k_dsm_p3_scatter" if k.startswith("k_dsm_p3_scatter") else
+                          "k_dsm_p3_place" if k.startswith("k_dsm_p3_place") else
                           "k_dsm_p3_count" if k.startswith(("k_dsm_p3_count", "k_dsm_p3_reduce", "k_dsm_p3_scan")) else
                           "k_ortho_backward" if k.startswith("k_ortho_backward") else k)
         fetch, write = pmc_rows(a.fetch, "FETCH_SIZE"), pmc_rows(a.write, "WRITE_SIZE")
@@ -136,7 +140,7 @@ def main():
                                "written -> WRITE 400.0 MB, k_scan_partials 100.4 MB read -> FETCH 50.2 MB). bench.py "
                                "copies `bytes` of the dominant kernel into roofline.traffic when the workload matches. "
                                + a.note,
-                   "workload": a.workload, "kernels": out}, open(a.traffic_json, "w"), indent=1)
+                   "workload": a.workload, "dsm_mode": a.dsm_mode, "kernels": out}, open(a.traffic_json, "w"), indent=1)
     text = "\n".join(lines)
     if a.out:
         open(a.out, "w").write(text + "\n")
