@@ -205,6 +205,10 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.j_off = c.win_j0;
   p.sub_x = center_northing;  // dsm.cc:42
   p.sub_y = center_easting;   // dsm.cc:43
+  {
+    static const bool canon_all = std::getenv("AMHIP_DSM_CANON_ALL") != nullptr;
+    p.canon_all = canon_all ? 1 : 0;
+  }
 
   // Squared search radii in the order dsm.cc:127-144 tries them: the initial
   // search with T = R, then lambda*R for lambda = 1, 1.1, 1.1^2, ... where

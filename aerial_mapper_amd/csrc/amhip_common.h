@@ -88,6 +88,7 @@ struct DsmParams {
   float fx_denmax;            // a hit nearer than fx_theta cells makes the weight sum exceed this
   float fx_epsw;              // bound on the relative error of one weight
   unsigned lds_bytes_f32;
+  int canon_all;              // tests: every FP64 quotient goes through canonical_search (amhip_dsm.hip)
 };
 
 // The binned cloud as the gather sees it (amhip_dsm.hip: pts_x / pts_y / pts_z; filled by

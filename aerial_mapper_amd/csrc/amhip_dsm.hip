@@ -82,7 +82,35 @@ struct Accum {
   unsigned cnt;
   bool exact;
   double exact_z;  // value of (one of) the point(s) with d2 == 0
+  double zmax;     // max |z| over the hits (round_is_certain's error bound)
 };
+
+// ---------------------------------------------------------------------------
+// Run-to-run reproducibility of the stored floats (round 4)
+// ---------------------------------------------------------------------------
+// The order in which a cell's neighbours are summed is not fixed: the binning's atomics leave
+// the points of a bin -- and the staging's LDS atomics the points of a cell -- in whatever order
+// the hardware served them.  The double sums then differ in their last bits from run to run, and
+// a quotient that lies on a float rounding boundary rounds either way (observed: 1 cell in 1e8).
+// The reference's kd-tree order is fixed (nanoflann.hpp:929-946), its floats are the same every
+// run.  So are these, without sorting anything: every routine bounds the distance between its
+// quotient and the EXACT inverse-distance average of the same doubles,
+//     |h - h_exact| <= (2 n + 3) 2^-53 max|z|      (a term passes n + 1 roundings on its way into
+//                                                   either sum; the weights are all positive),
+// -- (4 n + 8) 2^-53 max|z| is used: it also covers canonical_search()'s own 2 x 2^-53 --
+// and stores (float)h only when every value within that distance rounds to the same float.
+// The rare cell that fails the test (a few per 1e8) is redone by canonical_search(): the
+// reference's own terms fl(z/d2) and fl(1/d2) -- true divisions -- summed in double-double,
+// where the order of the additions does not reach the 53rd bit, let alone the 24th.  Any two
+// runs therefore store the same float in every cell.
+__device__ __forceinline__ bool round_is_certain(double h, double err) {
+  return (float)(h - err) == (float)(h + err);
+}
+// (p.canon_all -- AMHIP_DSM_CANON_ALL=1, tests: every quotient counts as uncertain, so every cell
+// with a hit is stored by canonical_search())
+__device__ __forceinline__ double idw_err_bound(const DsmParams& p, unsigned n, double zmax) {
+  return p.canon_all ? __builtin_huge_val() : ((double)(4u * n + 8u) * 0x1p-53) * zmax;
+}
 
 // One IDW term.  1/d2 through v_rcp_f64 + two Newton steps (relative error
 // ~1e-16; the accumulation order already differs from the kd-tree's, the
@@ -101,7 +129,7 @@ __device__ __forceinline__ void idw_add(double d2, double z, double* num,
 // Visit every binned point that can lie within the window of half-width w
 // cells around cell (i, j).  MODE 0: accumulate IDW over d2 < T.
 // MODE 1: track the minimum d2.
-template <int MODE>
+template <int MODE, bool kCanon = true>
 __device__ __forceinline__ void scan_window(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
                                             const Pts P,
@@ -127,7 +155,9 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
       if (MODE == 0) {
         if (d2 < T) {  // RadiusResultSet::addPoint, strict (nanoflann.hpp:157)
           if (d2 > 0.0) {
-            idw_add(d2, pts_z(P, (size_t)k), &acc->num, &acc->den);
+            const double z = pts_z(P, (size_t)k);
+            idw_add(d2, z, &acc->num, &acc->den);
+            if (kCanon) acc->zmax = fmax(acc->zmax, fabs(z));
           } else {
             acc->exact = true;  // dsm.cc:165 CHECK / ortho-from-pcl.cc:91-96
             acc->exact_z = pts_z(P, (size_t)k);
@@ -166,9 +196,76 @@ __device__ __forceinline__ void emit_value(const DsmParams& p, const CellOut& o,
   if (o.mask) o.mask[at] = 1;
 }
 
-// Turns an accumulated search into the cell's value.  true = the cell is done.
-__device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& o, int i, int j,
-                                             const Accum& acc) {
+// s + e == a + b exactly (Knuth)
+__device__ __forceinline__ void two_sum(double a, double b, double* s, double* e) {
+  const double t = a + b;
+  const double bb = t - a;
+  *e = (a - (t - bb)) + (b - bb);
+  *s = t;
+}
+
+// One search (window half-width w cells, squared radius T) of cell (i, j) with at least one hit,
+// in the arithmetic every summation order agrees on (see round_is_certain): the reference's
+// terms z / d2 and 1 / d2 (dsm.cc:166-168, true divisions) summed in double-double, one
+// division of the two sums, stored as float.  One lane per cell on the global bins; a few cells
+// per 1e8 come here.
+__device__ __forceinline__ void canonical_search(const DsmParams& p, const uint32_t* __restrict__ start,
+                                              const Pts P, double qx, double qy, int i, int j, int w,
+                                              double T, const CellOut& o) {
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
+  double nh = 0.0, nl = 0.0, dh = 0.0, dl = 0.0;
+  bool exact = false;
+  double exact_z = 0.0;
+  for (int by = by0; by <= by1; ++by) {
+    const uint32_t* row = start + (size_t)by * p.nbx;
+    const uint32_t e = row[bx1 + 1];
+    for (uint32_t k = row[bx0]; k < e; ++k) {
+      const double dx = qx - pts_x(P, (size_t)k);
+      const double dy = qy - pts_y(P, (size_t)k);
+      double d2 = dx * dx;
+      d2 = d2 + dy * dy;  // L2_Adaptor (nanoflann.hpp:319-322)
+      if (!(d2 < T)) continue;
+      const double z = pts_z(P, (size_t)k);
+      if (!(d2 > 0.0)) {
+        exact = true;
+        exact_z = z;
+        continue;
+      }
+      double t, err;
+      two_sum(nh, z / d2, &t, &err);
+      nh = t;
+      nl += err;
+      two_sum(dh, 1.0 / d2, &t, &err);
+      dh = t;
+      dl += err;
+    }
+  }
+  if (exact) {
+    if (p.pcl_mode)
+      emit_value(p, o, i, j, exact_z);       // ortho-from-pcl.cc:91-96 perfect match
+    else {
+      atomicOr(o.dev_err, kDevErrExactHit);  // dsm.cc:165 CHECK(distances[i] > 0.0)
+      leave_untouched(p, o, i, j);
+    }
+    return;
+  }
+  if (!(dh > 0.0)) {  // (never: the caller saw hits)
+    leave_untouched(p, o, i, j);
+    return;
+  }
+  // (nh + nl) / (dh + dl): quotient of the leading parts, corrected by the exact remainder
+  const double q = nh / dh;
+  const double r = (fma(-q, dh, nh) + nl) - q * dl;
+  emit_value(p, o, i, j, q + r / dh);
+}
+
+// Turns an accumulated search into the cell's value.  0: no hit (the cell is not done), 1: done,
+// 2: the quotient is too close to a float rounding boundary to be the same in every summation
+// order -- the caller redoes that search with canonical_search().
+template <bool kCanon = true>
+__device__ __forceinline__ int finish_accum(const DsmParams& p, const CellOut& o, int i, int j,
+                                            const Accum& acc) {
   if (acc.exact) {
     if (p.pcl_mode)
       emit_value(p, o, i, j, acc.exact_z);  // ortho-from-pcl.cc:91-96 perfect match
@@ -176,13 +273,15 @@ __device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& 
       atomicOr(o.dev_err, kDevErrExactHit);  // dsm.cc:165 CHECK(distances[i] > 0.0)
       leave_untouched(p, o, i, j);           // (the reference aborts; never uninitialised memory)
     }
-    return true;
+    return 1;
   }
   if (acc.cnt > 0) {
-    emit_value(p, o, i, j, acc.num / acc.den);
-    return true;
+    const double h = acc.num / acc.den;
+    if (kCanon && !round_is_certain(h, idw_err_bound(p, acc.cnt, acc.zmax))) return 2;
+    emit_value(p, o, i, j, h);
+    return 1;
   }
-  return false;
+  return 0;
 }
 
 // Expanding-radius fallback for a cell whose first search (T[0]) was empty
@@ -190,13 +289,16 @@ __device__ __forceinline__ bool finish_accum(const DsmParams& p, const CellOut& 
 // returns something.  Equivalent: find the nearest point within the LAST
 // radius, pick the first level whose threshold exceeds its d2, gather with
 // that threshold.  Works on the global bin structure.
+// kCanon = false (the single-precision mode's kernels: their floats move with the summation
+// order anyway): an ambiguous quotient is stored as it is, no canonical_search in the kernel
+template <bool kCanon = true>
 __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
                                                      const uint32_t* __restrict__ start,
                                                      const Pts P, int i,
                                                      int j, double qx, double qy,
                                                      const CellOut& o) {
   if (p.nlevels <= 1) return false;
-  Accum acc = {0.0, 0.0, 0u, false, 0.0};
+  Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
   const int last = p.nlevels - 1;
   double dmin = __builtin_huge_val();
   scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
@@ -208,8 +310,10 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
     }
   }
   if (level < 0) return false;  // nothing within the last radius: cell untouched
-  scan_window<0>(p, start, P, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
-  return finish_accum(p, o, i, j, acc);
+  scan_window<0, kCanon>(p, start, P, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
+  const int fin = finish_accum<kCanon>(p, o, i, j, acc);
+  if (kCanon && fin == 2) canonical_search(p, start, P, qx, qy, i, j, p.w[level], p.T[level], o);
+  return fin != 0;
 }
 
 // ---- OPTIONAL capped mode (amhip_ctx_set_dsm_knn; not a reference code path) ----------
@@ -274,7 +378,7 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
   for (int q = 0; q < kMaxKnn; ++q) s.d2[q] = s.z[q] = 0.0;
   knn_scan(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &s);
   if (s.n == 0 && p.nlevels > 1) {  // the ladder of dsm.cc:133-144, as in cell_fallback_global
-    Accum acc = {0.0, 0.0, 0u, false, 0.0};
+    Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
     const int last = p.nlevels - 1;
     double dmin = __builtin_huge_val();
     scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
@@ -307,6 +411,7 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
 }
 
 // Whole cell through the global bins (first level + fallback).
+template <bool kCanon = true>
 __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
                                             const Pts P, int i, int j,
@@ -315,11 +420,13 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
-  Accum acc = {0.0, 0.0, 0u, false, 0.0};
+  Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
   double dmin = 0.0;
-  scan_window<0>(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
-  bool done = finish_accum(p, o, i, j, acc);
-  if (!done) done = cell_fallback_global(p, start, P, i, j, qx, qy, o);
+  scan_window<0, kCanon>(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
+  const int fin = finish_accum<kCanon>(p, o, i, j, acc);
+  if (kCanon && fin == 2) canonical_search(p, start, P, qx, qy, i, j, p.w[0], p.T[0], o);
+  bool done = fin != 0;
+  if (!done) done = cell_fallback_global<kCanon>(p, start, P, i, j, qx, qy, o);
   if (!done) {
     leave_untouched(p, o, i, j);
     if (o.unfilled) atomicAdd(o.unfilled, 1u);
@@ -361,9 +468,12 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
 #pragma unroll
   for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0;
   unsigned exact = 0;  // bit c: some neighbour of cell c at distance 0
+  double zmax = 0.0;   // max |z| over the lane's candidates; ncand: candidates of the wave
+  unsigned ncand = 0;
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
+    ncand += e0 - s0;
     // (the next candidate is on its way while this one is worked on: ~160 FP64 instructions per
     // candidate against a memory round trip, three waves per SIMD to cover it)
     double nx = 0.0, ny = 0.0, nz = 0.0;
@@ -379,6 +489,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
         ny = pts_y(P, (size_t)k + 64);
         nz = pts_z(P, (size_t)k + 64);
       }
+      zmax = fmax(zmax, fabs(pz));
       double dx2[4], dy2[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -405,7 +516,10 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     }
   }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) exact |= __shfl_xor(exact, d, 64);
+  for (int d = 32; d > 0; d >>= 1) {
+    exact |= __shfl_xor(exact, d, 64);
+    zmax = fmax(zmax, __shfl_xor(zmax, d, 64));
+  }
   // Butterfly with halving: 32 partial sums per lane (16 x num, 16 x den) -> after
   // the exchange over lane bit 5 a lane keeps 16 of them, then 8, 4, 2, 1; the
   // last exchange over bit 0 completes the sums.  Lane l ends with the total of
@@ -440,7 +554,12 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     cell_global(p, start, P, i, j, o);
     return;
   }
-  emit_value(p, o, i, j, my_num / my_den);
+  const double hq = my_num / my_den;
+  if (round_is_certain(hq, idw_err_bound(p, ncand, zmax)))
+    emit_value(p, o, i, j, hq);
+  else  // (see round_is_certain: the order-independent arithmetic, a few cells per 1e8)
+    canonical_search(p, start, P, p.base_x + p.res * (-(double)(i + p.i_off)),
+                     p.base_y + p.res * (-(double)(j + p.j_off)), i, j, w, T, o);
 }
 
 // Pure global-memory gather: used when the first-level window is too wide for
@@ -683,7 +802,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   uint32_t* s_rowg = s_off + p.lds_cells + 1;        // global start of a region bin-row
   uint32_t* s_rowp = s_rowg + kMaxRegionRows;        // prefix of the row lengths (+1)
   uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;    // block-scan scratch
-  uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext
+  uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext, [3] max |z| (f32 bits)
   uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_ctl + 4);  // kTileI*kTileJ entries
 
   const int tid = threadIdx.x;
@@ -761,6 +880,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     if (lane == 0) {
       s_rowp[0] = 0;
       s_ctl[1] = 0;
+      s_ctl[3] = 0;
     }
   }
   __syncthreads();
@@ -835,6 +955,17 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       pslot[k] = (cell << 13) | atomicAdd(&s_off[cell], 1u);
     }
   }
+  {
+    // max |z| of the staged points, as a float rounded UP (round_is_certain's error bound is
+    // per tile: one LDS atomic per wave instead of an FP64 max per hit)
+    float zm = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxK; ++k)
+      if (tid + k * NT < np) zm = fmaxf(zm, (float)fabs(ppz[k]));
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) zm = fmaxf(zm, __shfl_xor(zm, d, 64));
+    if (lane == 0) atomicMax(&s_ctl[3], __float_as_uint(zm * 1.0000002f));
+  }
   __syncthreads();
   {
     // exclusive scan of the counters, in place: a thread owns consecutive whole quads, a wave
@@ -878,6 +1009,8 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     }
   }
   __syncthreads();
+  // (>= every |z| in the image: exact as a double, rounded up as a float)
+  const double zmax_tile = (double)__uint_as_float(s_ctl[3]);
 
   // ---- gather: lane = row index i; the lane's cells are taken two at a time
   // (columns j, j+1): every candidate read from LDS is tested against both,
@@ -904,6 +1037,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       // d2 == 0 (dsm.cc:165 CHECK(distances[i] > 0.0)).  One division per cell.
       double NA = 0.0, DA = 0.0, PA = 1.0, NB = 0.0, DB = 0.0, PB = 1.0;
       bool suspectA = false, suspectB = false;
+      unsigned ncand = 0;  // candidates tested (>= hits of either cell): round_is_certain's n
       // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B), one row
       // pair = one contiguous span per trip (lanes wait for each other per
       // trip, and the spread of a two-row candidate count is relatively smaller).
@@ -922,6 +1056,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
         const uint32_t kb = orow[-2 * w];
         const uint32_t ke = orow[2 * w + 2];
         orow += RW2;
+        ncand += ke - kb;
         auto candidate = [&](uint32_t k) __attribute__((always_inline)) {
           const double2 xy = s_xy[k];
           const double z = s_z[k];
@@ -1004,18 +1139,23 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
         const double Nn = h ? NB : NA, Dd = h ? DB : DA, Pp = h ? PB : PA;
         const bool suspect = h ? suspectB : suspectA;
         const int jj = jA + h;
-        int queue = 0;  // 1: no first-level neighbour (ladder), 2: redo the whole cell
+        int queue = 0;  // 1: no first-level neighbour (ladder), 2: redo the whole cell,
+                        // 3: the quotient sits on a float rounding boundary (canonical_search)
         if (Pp == 0.0 || suspect || !(Dd < 0x1p+1000) || !(fabs(Nn) < 0x1p+1000)) {
           queue = 2;
         } else if (Dd > 0.0) {
-          emit_value(p, o, i, jj, Nn / Dd);
+          const double hq = Nn / Dd;
+          if (round_is_certain(hq, idw_err_bound(p, ncand, zmax_tile)))
+            emit_value(p, o, i, jj, hq);
+          else
+            queue = 3;
         } else {
           queue = 1;
         }
         if (queue) {
           const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
           s_flag[slot] = (uint16_t)(((wid * kCellsPerLane + c + h) * kTileI + lane) |
-                                    (queue == 2 ? 0x8000 : 0));
+                                    (queue == 2 ? 0x8000 : (queue == 3 ? 0x4000 : 0)));
         }
       }
     }
@@ -1026,11 +1166,15 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   // OrthoFromPcl the full global routine (several coincident exact hits) ------
   const int nflag = (int)s_ctl[1];
   for (int f = tid; f < nflag; f += NT) {
-    const int code = s_flag[f] & 0x7FFF;
+    const int code = s_flag[f] & 0x3FFF;
     const bool redo = (s_flag[f] & 0x8000) != 0;
+    const bool canon = (s_flag[f] & 0x4000) != 0;
     const int fi = i0 + (code % kTileI);
     const int fj = j0 + (code / kTileI);
-    if (p.pcl_mode || redo) {
+    if (canon) {
+      canonical_search(p, start, P, p.base_x + p.res * (-(double)(fi + p.i_off)),
+                       p.base_y + p.res * (-(double)(fj + p.j_off)), fi, fj, p.w[0], p.T[0], o);
+    } else if (p.pcl_mode || redo) {
       cell_global(p, start, P, fi, fj, o);
     } else {
       const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
@@ -1184,7 +1328,7 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   if (lane != 0) return;
   if (exact || !(den > 0.0)) {
     // exact hit (dsm.cc:165 CHECK) or an empty first search (the ladder): scalar routine
-    cell_global(p, start, P, i, j, o);
+    cell_global<false>(p, start, P, i, j, o);
     return;
   }
   emit_value(p, o, i, j, num / den);
@@ -1296,7 +1440,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     // (cannot happen for the class this launch serves; kept for safety) FP64 global path
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-      if (i <= i_hi && j <= j_hi) cell_global(p, start, P, i, j, o);
+      if (i <= i_hi && j <= j_hi) cell_global<false>(p, start, P, i, j, o);
     }
     return;
   }
@@ -1581,7 +1725,7 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     const int fj = j0 + (code / kTileI);
     const double fqx = p.base_x + p.res * (-(double)(fi + p.i_off));
     const double fqy = p.base_y + p.res * (-(double)(fj + p.j_off));
-    const bool done = cell_fallback_global(p, start, P, fi, fj, fqx, fqy, o);
+    const bool done = cell_fallback_global<false>(p, start, P, fi, fj, fqx, fqy, o);
     if (!done) {
       leave_untouched(p, o, fi, fj);
       if (o.unfilled) atomicAdd(o.unfilled, 1u);

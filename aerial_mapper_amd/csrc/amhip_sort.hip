@@ -177,6 +177,8 @@ constexpr int kP3PlacePer = kP3PlaceMaxCap / kP3PlaceThreads;
 constexpr int kP3BigThreads = 1024;
 constexpr int kP3BigPer = 6;
 constexpr int kP3BigCap = kP3BigThreads * kP3BigPer;  // 6144 points = 147 KB of LDS
+constexpr int kRecWords = 5;  // 20-byte sort records of the single-precision mode (below)
+constexpr size_t kLdsMaxBytes = 160 * 1024 - 512;  // per workgroup on gfx950 (160 KB per CU), a margin kept
 
 __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
                                         int* k2) {
@@ -408,7 +410,8 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
       if (q < iters) {
         // sub-partitions too full for k_dsm_p3_place's registers but not for a whole
         // CU's LDS (denser parts of a non-uniform cloud): k_dsm_p3_place_big's list
-        if (v[q] > cap_small && v[q] <= cap_big)
+        // (no upper bound: beyond a CU's LDS the big kernel places in several rounds)
+        if (v[q] > cap_small)
           big_list[1 + atomicAdd(&big_list[0], 1u)] = (uint32_t)(w0 + q * 64 + lane);
         const unsigned incl = wave_incl_scan(v[q], lane);
         v[q] = run + incl - v[q];
@@ -713,6 +716,157 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
   for (uint32_t e = tid; e < ne; e += THREADS) out[e] = s_pts[e];
 }
 
+
+// ---------------------------------------------------------------------------
+// Pass 3 for sub-partitions beyond one LDS image (contexts of more than ~130 M points: the
+// plan's <= 32 K sub-partitions then hold more than kP3BigCap points each; also the densest
+// parts of clustered clouds).  Until round 4 such a sub-partition was placed DIRECTLY: a second
+// read and one scattered 24-byte store per point through LDS cursors -- 11 of the 45 ms of
+// BASELINE configs[3] on one GPU.  Now: one read for the bins' histogram (-> bin_start), then
+// ROUNDS: the next run of consecutive bins that fits the LDS image (chosen from the exact
+// counts: never an overflow) is collected from a re-read of the sub-partition -- it sits in the
+// L2 by then --, counting-sorted in LDS and written as ONE contiguous coalesced range.  A
+// single bin larger than the image (hundreds of points per cell) is placed directly.
+// kRec: 20-byte records in, 16-byte records + rows out (place_records' formats).
+// ---------------------------------------------------------------------------
+template <int THREADS, bool kRec>
+__device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, const DsmParams& p, int cap,
+                                             const uint32_t* __restrict__ start2,
+                                             uint32_t* __restrict__ bin_start, double* __restrict__ sorted,
+                                             uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
+                                             uint2* __restrict__ bin_z, int sp) {
+  extern __shared__ double s_pts_raw[];
+  constexpr int kWordsPer = kRec ? 5 : 6;
+  uint32_t* s_words = reinterpret_cast<uint32_t*>(s_pts_raw);          // kWordsPer * cap
+  uint32_t* s_bins = s_words + (size_t)kWordsPer * cap;                 // p3_w + 1: starts (+ total)
+  uint32_t* s_cur = s_bins + p.p3_w + 1;                                // p3_w: cursors of the round
+  uint32_t* s_scan = s_cur + p.p3_w;                                    // 24 (+ [20..22] round control)
+  uint32_t* s_zlo = s_scan + 24;                                        // p3_w (bin_z only)
+  uint32_t* s_zhi = s_zlo + p.p3_w;                                     // p3_w
+  const double* srcd = reinterpret_cast<const double*>(src_v);
+  const uint32_t* srcw = reinterpret_cast<const uint32_t*>(src_v);
+  const int tid = threadIdx.x;
+  const int k1 = sp / p.p3_n2, k2 = sp - k1 * p.p3_n2;
+  const int rr = k2 / p.p3_c;
+  const int row = k1 * p.p3_r1 + rr;
+  const int bx0 = (k2 - rr * p.p3_c) * p.p3_w;
+  const int nbw = min(p.p3_w, p.nbx - bx0);
+  if (row >= p.nby || nbw <= 0) return;
+  const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  auto zkey = [](uint32_t fbits) { return (fbits >> 31) ? ~fbits : (fbits | 0x80000000u); };
+  for (int k = tid; k <= nbw; k += THREADS) s_bins[k] = 0;
+  if (bin_z)
+    for (int k = tid; k < nbw; k += THREADS) {
+      s_zlo[k] = 0xFFFFFFFFu;
+      s_zhi[k] = 0u;
+    }
+  __syncthreads();
+  // the bin of sorted point idx
+  auto bin_of = [&](uint32_t idx) -> int {
+    if (kRec) return div_by((int)(srcw[(size_t)kRecWords * idx] & 0xFFFFu), p.B, p.mul_B) - bx0;
+    int bx, by;
+    point_bin_xy(p, srcd[3 * (size_t)idx + 0], srcd[3 * (size_t)idx + 1], &bx, &by);
+    return bx - bx0;
+  };
+  // ---- histogram (first read) ----
+  for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+    const int b = bin_of(idx);
+    atomicAdd(&s_bins[b], 1u);
+    if (bin_z) {
+      const uint32_t zk = kRec ? zkey(srcw[(size_t)kRecWords * idx + 3]) : place_zkey(srcd[3 * (size_t)idx + 2]);
+      atomicMin(&s_zlo[b], zk);
+      atomicMax(&s_zhi[b], zk);
+    }
+  }
+  __syncthreads();
+  {
+    const int per = (nbw + THREADS - 1) / THREADS;
+    const int lo = tid * per;
+    const int hi = min(lo + per, nbw);
+    unsigned sum = 0;
+    for (int k = lo; k < hi; ++k) sum += s_bins[k];
+    unsigned total;
+    unsigned run = block_excl_scan<THREADS>(sum, &total, s_scan);
+    for (int k = lo; k < hi; ++k) {
+      const unsigned t = s_bins[k];
+      s_bins[k] = run;
+      run += t;
+    }
+    if (tid == 0) s_bins[nbw] = total;
+  }
+  __syncthreads();
+  {
+    uint32_t* out_start = bin_start + (size_t)row * p.nbx + bx0;
+    for (int k = tid; k < nbw; k += THREADS) out_start[k] = g0 + s_bins[k];
+    if (bin_z) {
+      uint2* zrow = bin_z + (size_t)row * p.nbx + bx0;
+      for (int k = tid; k < nbw; k += THREADS) zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
+    }
+  }
+  // ---- rounds ----
+  int lo_bin = 0;
+  while (lo_bin < nbw) {
+    // the longest run of bins [lo_bin, hi_bin) with at most cap points (binary search on the
+    // starts, every thread the same); a bin larger than cap forms a run of its own (direct)
+    const uint32_t base = s_bins[lo_bin];
+    int a = lo_bin, b = nbw;  // s_bins[a] - base <= cap always; find the largest such index
+    while (b - a > 0) {
+      const int mid = (a + b + 1) >> 1;
+      if (s_bins[mid] - base <= (uint32_t)cap) a = mid; else b = mid - 1;
+    }
+    const bool direct = a == lo_bin;
+    const int hi_bin = direct ? lo_bin + 1 : a;
+    const uint32_t cnt = s_bins[hi_bin] - base;
+    for (int k = lo_bin + tid; k < hi_bin; k += THREADS) s_cur[k] = s_bins[k];
+    __syncthreads();
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+      const int bb = bin_of(idx);
+      if (bb < lo_bin || bb >= hi_bin) continue;
+      const uint32_t q = atomicAdd(&s_cur[bb], 1u);
+      if (kRec) {
+        uint32_t v[kRecWords];
+#pragma unroll
+        for (int t = 0; t < kRecWords; ++t) v[t] = srcw[(size_t)kRecWords * idx + t];
+        if (direct) {
+          rec16[(size_t)g0 + q] = make_uint4(v[0], v[1], v[2], v[3]);
+          sidx[(size_t)g0 + q] = v[4];
+        } else {
+#pragma unroll
+          for (int t = 0; t < kRecWords; ++t) s_words[(size_t)kRecWords * (q - base) + t] = v[t];
+        }
+      } else {
+        const double x = srcd[3 * (size_t)idx + 0], y = srcd[3 * (size_t)idx + 1], z = srcd[3 * (size_t)idx + 2];
+        if (direct) {
+          double* o = sorted + 3 * ((size_t)g0 + q);
+          o[0] = x;
+          o[1] = y;
+          o[2] = z;
+        } else {
+          double* o = s_pts_raw + 3 * (size_t)(q - base);
+          o[0] = x;
+          o[1] = y;
+          o[2] = z;
+        }
+      }
+    }
+    __syncthreads();
+    if (!direct) {
+      if (kRec) {
+        for (uint32_t q = tid; q < cnt; q += THREADS) {
+          const uint32_t* r = s_words + (size_t)kRecWords * q;
+          rec16[(size_t)g0 + base + q] = make_uint4(r[0], r[1], r[2], r[3]);
+          sidx[(size_t)g0 + base + q] = r[4];
+        }
+      } else {
+        double* out = sorted + 3 * ((size_t)g0 + base);
+        for (uint32_t e = tid; e < 3u * cnt; e += THREADS) out[e] = s_pts_raw[e];
+      }
+    }
+    __syncthreads();
+    lo_bin = hi_bin;
+  }
+}
+
 // cap points in LDS, <= kP3PlacePer per thread in registers; fuller
 // sub-partitions are left to k_dsm_p3_place_big (skip_lo < count <= skip_hi) or,
 // beyond a CU's LDS, placed directly with a second read.
@@ -731,11 +885,16 @@ __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                    double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
-                   uint2* __restrict__ bin_z) {
+                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-    place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted,
-                                                 (int)big_list[1 + k], 0u, 0u, bin_z);
+    const int sp = (int)big_list[1 + k];
+    if (start2[sp + 1] - start2[sp] > rounds_above)
+      place_rounds<kP3BigThreads, false>(src, p, cap_rounds, start2, bin_start, sorted, nullptr, nullptr,
+                                         bin_z, sp);
+    else
+      place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted, sp, 0u,
+                                                   0u, bin_z);
     __syncthreads();
   }
 }
@@ -756,7 +915,6 @@ k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
 // routines that redo a cell or a tile in the reference's doubles use to fetch them from the
 // untouched cloud).  ~0.3 ms less sort and ~0.1 ms less staging per 50 M points.
 // The reference's doubles are NOT lost: they stay where the caller put them.
-constexpr int kRecWords = 5;
 // (20-byte records: 3072 points per scatter workgroup fit the LDS budget of two workgroups per
 // CU that 2560 24-byte points use -- longer runs)
 constexpr int kRecPerThread = 6;
@@ -1101,11 +1259,17 @@ __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_rec_big(const uint32_t* __restrict__ src, DsmParams p,
                        const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                        uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
-                       uint2* __restrict__ bin_z, const uint32_t* __restrict__ big_list) {
+                       uint2* __restrict__ bin_z, const uint32_t* __restrict__ big_list, int cap_rounds,
+                       unsigned rounds_above) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
-    place_records<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, rec16, sidx, bin_z,
-                                            (int)big_list[1 + k], 0u, 0u);
+    const int sp = (int)big_list[1 + k];
+    if (start2[sp + 1] - start2[sp] > rounds_above)
+      place_rounds<kP3BigThreads, true>(src, p, cap_rounds, start2, bin_start, nullptr, rec16, sidx, bin_z,
+                                        sp);
+    else
+      place_records<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, rec16, sidx, bin_z, sp,
+                                              0u, 0u);
     __syncthreads();
   }
 }
@@ -1266,6 +1430,17 @@ k_range_reduce(const double* __restrict__ part, size_t nparts,
   }
 }
 
+// AMHIP_P3_ROUNDS_CAP=n (tests): sub-partitions above n points are placed in rounds over an
+// image of n points -- exercises place_rounds (and its one-bin-beyond-the-image direct case)
+// on clouds of test size; normally only contexts beyond ~130 M points get there
+static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above) {
+  static const int knob = getenv("AMHIP_P3_ROUNDS_CAP") ? atoi(getenv("AMHIP_P3_ROUNDS_CAP")) : 0;
+  if (knob >= 16 && knob < *cap_rounds) {
+    *cap_rounds = knob;
+    *rounds_above = (unsigned)knob;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
@@ -1407,12 +1582,19 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_dsm_p3_place_rec, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                            c->stream, c->rec_b, p, p.p3_cap, start2, c->bin_start, rec16, c->sidx, bin_z,
-                           (unsigned)p.p3_cap, (unsigned)kP3BigCap);
-        const size_t lds_big = (size_t)kP3BigCap * kRecWords * 4 + (3 * (size_t)p.p3_w + 32) * sizeof(uint32_t);
+                           (unsigned)p.p3_cap, 0xFFFFFFFFu);
+        // (sub-partitions beyond one image: rounds over an image of cap_rounds points next to
+        // the rounds' tables -- place_rounds)
+        const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
+        int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / (kRecWords * 4));
+        unsigned rounds_above = kP3BigCap;
+        p3_rounds_knob(&cap_rounds, &rounds_above);
+        const size_t lds_big = std::max((size_t)kP3BigCap * kRecWords * 4 + (3 * (size_t)p.p3_w + 32) * sizeof(uint32_t),
+                                        (size_t)cap_rounds * kRecWords * 4 + tables);
         AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_rec_big),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         hipLaunchKernelGGL(k_dsm_p3_place_rec_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                           c->rec_b, p, start2, c->bin_start, rec16, c->sidx, bin_z, big_list);
+                           c->rec_b, p, start2, c->bin_start, rec16, c->sidx, bin_z, big_list, cap_rounds, rounds_above);
         AMHIP_TRY(hipGetLastError());
         c->bin_z_valid = true;
         c->pts = PtsView{nullptr, rec16, c->sidx, dev_xyz, c->zref, p.sub_x, p.sub_y};
@@ -1450,12 +1632,17 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         (unsigned)p.p3_cap, (unsigned)kP3BigCap, bin_z);
-      const size_t lds_big = (size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds;
+                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z);
+      const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
+      int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
+      unsigned rounds_above = kP3BigCap;
+      p3_rounds_knob(&cap_rounds, &rounds_above);
+      const size_t lds_big = std::max((size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds,
+                                      (size_t)cap_rounds * 24 + tables);
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z);
+                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }

@@ -54,7 +54,7 @@ BUDGETS = [
     ("k_dsm_gather_f32_listILi512ELi16ELi4096E", 4, 0),
     ("k_dsm_gather_f32_wideILi512ELi16ELi7680E", 2, 0),
     ("18k_dsm_gather_denseILb0E", 3, 0),
-    ("18k_dsm_gather_denseILb1E", 3, 24),                 # (spills outside the candidate loop: DESIGN 4.2)
+    ("18k_dsm_gather_denseILb1E", 3, 26),                 # (cold spills, all outside the candidate loop: DESIGN 4.2)
 ]
 
 
