@@ -824,7 +824,7 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
       e = hipMalloc(reinterpret_cast<void**>(&c->layers[l]), c->cells * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_err), 4 * sizeof(unsigned));
     if (e == hipSuccess)
-      e = hipMalloc(reinterpret_cast<void**>(&c->dev_zrange), 2 * sizeof(unsigned long long));
+      e = hipMalloc(reinterpret_cast<void**>(&c->dev_zrange), 4 * sizeof(unsigned long long));  // [2], [3]: the last DSM call's own range
     if (e == hipSuccess)
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_err), sizeof(unsigned), 0);
     if (e == hipSuccess) {

@@ -82,7 +82,6 @@ struct Accum {
   unsigned cnt;
   bool exact;
   double exact_z;  // value of (one of) the point(s) with d2 == 0
-  double zmax;     // max |z| over the hits (round_is_certain's error bound)
 };
 
 // ---------------------------------------------------------------------------
@@ -96,7 +95,9 @@ struct Accum {
 // run.  So are these, without sorting anything: every routine bounds the distance between its
 // quotient and the EXACT inverse-distance average of the same doubles,
 //     |h - h_exact| <= (2 n + 3) 2^-53 max|z|      (a term passes n + 1 roundings on its way into
-//                                                   either sum; the weights are all positive),
+//                                                   either sum; the weights are all positive;
+//                                                   max|z| over the CALL's binned points: the
+//                                                   sort leaves their range, call_zmax()),
 // -- (4 n + 8) 2^-53 max|z| is used: it also covers canonical_search()'s own 2 x 2^-53 --
 // and stores (float)h only when every value within that distance rounds to the same float.
 // The rare cell that fails the test (a few per 1e8) is redone by canonical_search(): the
@@ -129,7 +130,7 @@ __device__ __forceinline__ void idw_add(double d2, double z, double* num,
 // Visit every binned point that can lie within the window of half-width w
 // cells around cell (i, j).  MODE 0: accumulate IDW over d2 < T.
 // MODE 1: track the minimum d2.
-template <int MODE, bool kCanon = true>
+template <int MODE>
 __device__ __forceinline__ void scan_window(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
                                             const Pts P,
@@ -155,9 +156,7 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
       if (MODE == 0) {
         if (d2 < T) {  // RadiusResultSet::addPoint, strict (nanoflann.hpp:157)
           if (d2 > 0.0) {
-            const double z = pts_z(P, (size_t)k);
-            idw_add(d2, z, &acc->num, &acc->den);
-            if (kCanon) acc->zmax = fmax(acc->zmax, fabs(z));
+            idw_add(d2, pts_z(P, (size_t)k), &acc->num, &acc->den);
           } else {
             acc->exact = true;  // dsm.cc:165 CHECK / ortho-from-pcl.cc:91-96
             acc->exact_z = pts_z(P, (size_t)k);
@@ -182,7 +181,16 @@ struct CellOut {
   // value gets the initial value written instead of being left untouched.
   int fill_untouched;
   float init_value;
+  // [min, max] (ordered keys) of the heights / values of the points this call binned: the sort's
+  // first scatter pass leaves them (c->dev_zrange + 2).  max |z| of round_is_certain's bound.
+  const unsigned long long* __restrict__ zcall;
 };
+
+// max |z| over the call's binned points (0 for an empty call); wave-uniform, two cached loads
+__device__ __forceinline__ double call_zmax(const CellOut& o) {
+  const double lo = from_ordered_key(o.zcall[0]), hi = from_ordered_key(o.zcall[1]);
+  return lo <= hi ? fmax(fabs(lo), fabs(hi)) : 0.0;
+}
 
 __device__ __forceinline__ void leave_untouched(const DsmParams& p, const CellOut& o, int i,
                                                 int j) {
@@ -277,7 +285,7 @@ __device__ __forceinline__ int finish_accum(const DsmParams& p, const CellOut& o
   }
   if (acc.cnt > 0) {
     const double h = acc.num / acc.den;
-    if (kCanon && !round_is_certain(h, idw_err_bound(p, acc.cnt, acc.zmax))) return 2;
+    if (kCanon && !round_is_certain(h, idw_err_bound(p, acc.cnt, call_zmax(o)))) return 2;
     emit_value(p, o, i, j, h);
     return 1;
   }
@@ -298,7 +306,7 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
                                                      int j, double qx, double qy,
                                                      const CellOut& o) {
   if (p.nlevels <= 1) return false;
-  Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
+  Accum acc = {0.0, 0.0, 0u, false, 0.0};
   const int last = p.nlevels - 1;
   double dmin = __builtin_huge_val();
   scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
@@ -310,7 +318,7 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
     }
   }
   if (level < 0) return false;  // nothing within the last radius: cell untouched
-  scan_window<0, kCanon>(p, start, P, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
+  scan_window<0>(p, start, P, qx, qy, i, j, p.w[level], p.T[level], &acc, &dmin);
   const int fin = finish_accum<kCanon>(p, o, i, j, acc);
   if (kCanon && fin == 2) canonical_search(p, start, P, qx, qy, i, j, p.w[level], p.T[level], o);
   return fin != 0;
@@ -378,7 +386,7 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
   for (int q = 0; q < kMaxKnn; ++q) s.d2[q] = s.z[q] = 0.0;
   knn_scan(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &s);
   if (s.n == 0 && p.nlevels > 1) {  // the ladder of dsm.cc:133-144, as in cell_fallback_global
-    Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
+    Accum acc = {0.0, 0.0, 0u, false, 0.0};
     const int last = p.nlevels - 1;
     double dmin = __builtin_huge_val();
     scan_window<1>(p, start, P, qx, qy, i, j, p.w[last], 0.0, &acc, &dmin);
@@ -420,9 +428,9 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
-  Accum acc = {0.0, 0.0, 0u, false, 0.0, 0.0};
+  Accum acc = {0.0, 0.0, 0u, false, 0.0};
   double dmin = 0.0;
-  scan_window<0, kCanon>(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
+  scan_window<0>(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &acc, &dmin);
   const int fin = finish_accum<kCanon>(p, o, i, j, acc);
   if (kCanon && fin == 2) canonical_search(p, start, P, qx, qy, i, j, p.w[0], p.T[0], o);
   bool done = fin != 0;
@@ -468,8 +476,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
 #pragma unroll
   for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0;
   unsigned exact = 0;  // bit c: some neighbour of cell c at distance 0
-  double zmax = 0.0;   // max |z| over the lane's candidates; ncand: candidates of the wave
-  unsigned ncand = 0;
+  unsigned ncand = 0;  // candidates of the wave (round_is_certain's n)
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s0 = row[bx0], e0 = row[bx1 + 1];
@@ -489,7 +496,6 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
         ny = pts_y(P, (size_t)k + 64);
         nz = pts_z(P, (size_t)k + 64);
       }
-      zmax = fmax(zmax, fabs(pz));
       double dx2[4], dy2[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -516,10 +522,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     }
   }
 #pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    exact |= __shfl_xor(exact, d, 64);
-    zmax = fmax(zmax, __shfl_xor(zmax, d, 64));
-  }
+  for (int d = 32; d > 0; d >>= 1) exact |= __shfl_xor(exact, d, 64);
   // Butterfly with halving: 32 partial sums per lane (16 x num, 16 x den) -> after
   // the exchange over lane bit 5 a lane keeps 16 of them, then 8, 4, 2, 1; the
   // last exchange over bit 0 completes the sums.  Lane l ends with the total of
@@ -555,7 +558,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     return;
   }
   const double hq = my_num / my_den;
-  if (round_is_certain(hq, idw_err_bound(p, ncand, zmax)))
+  if (round_is_certain(hq, idw_err_bound(p, ncand, call_zmax(o))))
     emit_value(p, o, i, j, hq);
   else  // (see round_is_certain: the order-independent arithmetic, a few cells per 1e8)
     canonical_search(p, start, P, p.base_x + p.res * (-(double)(i + p.i_off)),
@@ -802,7 +805,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   uint32_t* s_rowg = s_off + p.lds_cells + 1;        // global start of a region bin-row
   uint32_t* s_rowp = s_rowg + kMaxRegionRows;        // prefix of the row lengths (+1)
   uint32_t* s_scan = s_rowp + kMaxRegionRows + 1;    // block-scan scratch
-  uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext, [3] max |z| (f32 bits)
+  uint32_t* s_ctl = s_scan + 24;                     // [0] np, [1] nflag, [2] np_ext
   uint16_t* s_flag = reinterpret_cast<uint16_t*>(s_ctl + 4);  // kTileI*kTileJ entries
 
   const int tid = threadIdx.x;
@@ -880,7 +883,6 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     if (lane == 0) {
       s_rowp[0] = 0;
       s_ctl[1] = 0;
-      s_ctl[3] = 0;
     }
   }
   __syncthreads();
@@ -955,17 +957,6 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       pslot[k] = (cell << 13) | atomicAdd(&s_off[cell], 1u);
     }
   }
-  {
-    // max |z| of the staged points, as a float rounded UP (round_is_certain's error bound is
-    // per tile: one LDS atomic per wave instead of an FP64 max per hit)
-    float zm = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kMaxK; ++k)
-      if (tid + k * NT < np) zm = fmaxf(zm, (float)fabs(ppz[k]));
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) zm = fmaxf(zm, __shfl_xor(zm, d, 64));
-    if (lane == 0) atomicMax(&s_ctl[3], __float_as_uint(zm * 1.0000002f));
-  }
   __syncthreads();
   {
     // exclusive scan of the counters, in place: a thread owns consecutive whole quads, a wave
@@ -1009,8 +1000,14 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     }
   }
   __syncthreads();
-  // (>= every |z| in the image: exact as a double, rounded up as a float)
-  const double zmax_tile = (double)__uint_as_float(s_ctl[3]);
+  // (max |z| of the call's points: round_is_certain's bound, loaded here, used after the loop.
+  // The bound's n is the lane's own candidate count: a tile-wide n -- the image's 860 points,
+  // a wave-uniform bound in scalar registers -- sends 1000 cells per 1e8 to the redo instead of
+  // 60, and a redo is a serial walk of global memory as long as a whole tile: measured slower.)
+  // err = (4 n + 8) 2^-53 max|z| as ONE fma per cell pair: c1 n + c0 (wave-uniform constants;
+  // AMHIP_DSM_CANON_ALL makes them infinite)
+  const double zmax_tile = p.canon_all ? __builtin_huge_val() : call_zmax(o);
+  const double err_c1 = 0x1p-51 * zmax_tile, err_c0 = 0x1p-50 * zmax_tile;
 
   // ---- gather: lane = row index i; the lane's cells are taken two at a time
   // (columns j, j+1): every candidate read from LDS is tested against both,
@@ -1133,6 +1130,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       // routine, which weights with reciprocals and tracks exact hits
       // explicitly: DSM -> CHECK failure (dsm.cc:165), OrthoFromPcl -> that
       // point's value (ortho-from-pcl.cc:91-96).
+      const double err_pair = fma((double)ncand, err_c1, err_c0);  // (both cells saw the same candidates)
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         if (h == 1 && !haveB) break;
@@ -1145,10 +1143,15 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           queue = 2;
         } else if (Dd > 0.0) {
           const double hq = Nn / Dd;
-          if (round_is_certain(hq, idw_err_bound(p, ncand, zmax_tile)))
-            emit_value(p, o, i, jj, hq);
-          else
+          // (round_is_certain, with its lower float stored: the same value as (float)hq then)
+          const float f_lo = (float)(hq - err_pair), f_hi = (float)(hq + err_pair);
+          if (f_lo == f_hi) {
+            const size_t at = (size_t)i + (size_t)jj * (size_t)p.rows;
+            o.layer[at] = f_lo;
+            if (o.mask) o.mask[at] = 1;
+          } else {
             queue = 3;
+          }
         } else {
           queue = 1;
         }
@@ -2009,7 +2012,8 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
             const DsmParams& p, float* out, unsigned char* mask, unsigned* unfilled,
             bool fill_untouched, float init_value, unsigned long long* zrange,
             const SortSplit* split) {
-  const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value};
+  const CellOut cell_out = {out, mask, unfilled, c->dev_err, fill_untouched ? 1 : 0, init_value,
+                            c->dev_zrange + 2};
   // any other sort on this context overwrites the histogram rows a pending
   // amhip_dsm_tiled_begin_dev left behind: its finish call then fails instead of mis-binning
   if (!split) c->tiled_pending = false;

@@ -178,6 +178,10 @@ constexpr int kP3BigThreads = 1024;
 constexpr int kP3BigPer = 6;
 constexpr int kP3BigCap = kP3BigThreads * kP3BigPer;  // 6144 points = 147 KB of LDS
 constexpr int kRecWords = 5;  // 20-byte sort records of the single-precision mode (below)
+// points a thread of the big placement kernel keeps in registers across the rounds of a
+// sub-partition beyond one LDS image (place_rounds): 14 x 24 bytes / 16 x 20 bytes
+constexpr int kP3RoundsPer = 14;
+constexpr int kP3RoundsPerRec = 16;
 constexpr size_t kLdsMaxBytes = 160 * 1024 - 512;  // per workgroup on gfx950 (160 KB per CU), a margin kept
 
 __device__ __forceinline__ bool p3_keys(const DsmParams& p, double px, double py, int* k1,
@@ -729,18 +733,22 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
 // single bin larger than the image (hundreds of points per cell) is placed directly.
 // kRec: 20-byte records in, 16-byte records + rows out (place_records' formats).
 // ---------------------------------------------------------------------------
-template <int THREADS, bool kRec>
+template <int THREADS, bool kRec, int PER>
 __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, const DsmParams& p, int cap,
                                              const uint32_t* __restrict__ start2,
                                              uint32_t* __restrict__ bin_start, double* __restrict__ sorted,
                                              uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
                                              uint2* __restrict__ bin_z, int sp) {
+  // PER > 0: the sub-partition holds at most THREADS * PER points and a thread keeps its PER of
+  // them in REGISTERS from the one read to the last round (configs[3] on one GPU: 13.3 K points
+  // per sub-partition, 14 per thread); PER == 0: any size, every round re-reads it (from the L2).
   extern __shared__ double s_pts_raw[];
   constexpr int kWordsPer = kRec ? 5 : 6;
+  constexpr int kRegs = PER > 0 ? PER : 1;
   uint32_t* s_words = reinterpret_cast<uint32_t*>(s_pts_raw);          // kWordsPer * cap
   uint32_t* s_bins = s_words + (size_t)kWordsPer * cap;                 // p3_w + 1: starts (+ total)
   uint32_t* s_cur = s_bins + p.p3_w + 1;                                // p3_w: cursors of the round
-  uint32_t* s_scan = s_cur + p.p3_w;                                    // 24 (+ [20..22] round control)
+  uint32_t* s_scan = s_cur + p.p3_w;                                    // 24
   uint32_t* s_zlo = s_scan + 24;                                        // p3_w (bin_z only)
   uint32_t* s_zhi = s_zlo + p.p3_w;                                     // p3_w
   const double* srcd = reinterpret_cast<const double*>(src_v);
@@ -761,21 +769,63 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
       s_zhi[k] = 0u;
     }
   __syncthreads();
-  // the bin of sorted point idx
+  // the bin of sorted point idx (PER == 0)
   auto bin_of = [&](uint32_t idx) -> int {
     if (kRec) return div_by((int)(srcw[(size_t)kRecWords * idx] & 0xFFFFu), p.B, p.mul_B) - bx0;
     int bx, by;
     point_bin_xy(p, srcd[3 * (size_t)idx + 0], srcd[3 * (size_t)idx + 1], &bx, &by);
     return bx - bx0;
   };
-  // ---- histogram (first read) ----
-  for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
-    const int b = bin_of(idx);
-    atomicAdd(&s_bins[b], 1u);
-    if (bin_z) {
-      const uint32_t zk = kRec ? zkey(srcw[(size_t)kRecWords * idx + 3]) : place_zkey(srcd[3 * (size_t)idx + 2]);
-      atomicMin(&s_zlo[b], zk);
-      atomicMax(&s_zhi[b], zk);
+  // register-resident points (PER > 0): all loads first, branch-free (rows past the end re-read
+  // the last row and get bin -1)
+  double rx[kRegs], ry[kRegs], rz[kRegs];
+  uint32_t rw[kRegs][kRecWords];
+  int rb[kRegs];
+  if (PER > 0) {
+    if (g1 > g0) {
+#pragma unroll
+      for (int k = 0; k < kRegs; ++k) {
+        const size_t ld = min(g0 + tid + (uint32_t)k * THREADS, g1 - 1);
+        if (kRec) {
+#pragma unroll
+          for (int t = 0; t < kRecWords; ++t) rw[k][t] = srcw[(size_t)kRecWords * ld + t];
+        } else {
+          rx[k] = srcd[3 * ld + 0];
+          ry[k] = srcd[3 * ld + 1];
+          rz[k] = srcd[3 * ld + 2];
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRegs; ++k) {
+      const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
+      rb[k] = -1;
+      if (idx < g1) {
+        if (kRec) {
+          rb[k] = div_by((int)(rw[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
+        } else {
+          int bx, by;
+          point_bin_xy(p, rx[k], ry[k], &bx, &by);
+          rb[k] = bx - bx0;
+        }
+        atomicAdd(&s_bins[rb[k]], 1u);
+        if (bin_z) {
+          const uint32_t zk = kRec ? zkey(rw[k][3]) : place_zkey(rz[k]);
+          atomicMin(&s_zlo[rb[k]], zk);
+          atomicMax(&s_zhi[rb[k]], zk);
+        }
+      }
+    }
+  } else {
+    // ---- histogram (first read) ----
+    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+      const int b = bin_of(idx);
+      atomicAdd(&s_bins[b], 1u);
+      if (bin_z) {
+        const uint32_t zk = kRec ? zkey(srcw[(size_t)kRecWords * idx + 3]) : place_zkey(srcd[3 * (size_t)idx + 2]);
+        atomicMin(&s_zlo[b], zk);
+        atomicMax(&s_zhi[b], zk);
+      }
     }
   }
   __syncthreads();
@@ -803,6 +853,23 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
       for (int k = tid; k < nbw; k += THREADS) zrow[k] = make_uint2(s_zlo[k], s_zhi[k]);
     }
   }
+  // one point of the round: to its slot of the LDS image, or (a bin beyond the image) to memory
+  auto put = [&](bool direct, uint32_t q, uint32_t base, const uint32_t* v, double x, double y, double z) {
+    if (kRec) {
+      if (direct) {
+        rec16[(size_t)g0 + q] = make_uint4(v[0], v[1], v[2], v[3]);
+        sidx[(size_t)g0 + q] = v[4];
+      } else {
+#pragma unroll
+        for (int t = 0; t < kRecWords; ++t) s_words[(size_t)kRecWords * (q - base) + t] = v[t];
+      }
+    } else {
+      double* o = direct ? sorted + 3 * ((size_t)g0 + q) : s_pts_raw + 3 * (size_t)(q - base);
+      o[0] = x;
+      o[1] = y;
+      o[2] = z;
+    }
+  };
   // ---- rounds ----
   int lo_bin = 0;
   while (lo_bin < nbw) {
@@ -819,34 +886,30 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
     const uint32_t cnt = s_bins[hi_bin] - base;
     for (int k = lo_bin + tid; k < hi_bin; k += THREADS) s_cur[k] = s_bins[k];
     __syncthreads();
-    for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
-      const int bb = bin_of(idx);
-      if (bb < lo_bin || bb >= hi_bin) continue;
-      const uint32_t q = atomicAdd(&s_cur[bb], 1u);
-      if (kRec) {
-        uint32_t v[kRecWords];
+    if (PER > 0) {
 #pragma unroll
-        for (int t = 0; t < kRecWords; ++t) v[t] = srcw[(size_t)kRecWords * idx + t];
-        if (direct) {
-          rec16[(size_t)g0 + q] = make_uint4(v[0], v[1], v[2], v[3]);
-          sidx[(size_t)g0 + q] = v[4];
-        } else {
+      for (int k = 0; k < kRegs; ++k) {
+        if (rb[k] >= lo_bin && rb[k] < hi_bin) {
+          const uint32_t q = atomicAdd(&s_cur[rb[k]], 1u);
+          put(direct, q, base, rw[k], rx[k], ry[k], rz[k]);
+        }
+      }
+    } else {
+      for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
+        const int bb = bin_of(idx);
+        if (bb < lo_bin || bb >= hi_bin) continue;
+        const uint32_t q = atomicAdd(&s_cur[bb], 1u);
+        uint32_t v[kRecWords] = {0u, 0u, 0u, 0u, 0u};
+        double x = 0.0, y = 0.0, z = 0.0;
+        if (kRec) {
 #pragma unroll
-          for (int t = 0; t < kRecWords; ++t) s_words[(size_t)kRecWords * (q - base) + t] = v[t];
-        }
-      } else {
-        const double x = srcd[3 * (size_t)idx + 0], y = srcd[3 * (size_t)idx + 1], z = srcd[3 * (size_t)idx + 2];
-        if (direct) {
-          double* o = sorted + 3 * ((size_t)g0 + q);
-          o[0] = x;
-          o[1] = y;
-          o[2] = z;
+          for (int t = 0; t < kRecWords; ++t) v[t] = srcw[(size_t)kRecWords * idx + t];
         } else {
-          double* o = s_pts_raw + 3 * (size_t)(q - base);
-          o[0] = x;
-          o[1] = y;
-          o[2] = z;
+          x = srcd[3 * (size_t)idx + 0];
+          y = srcd[3 * (size_t)idx + 1];
+          z = srcd[3 * (size_t)idx + 2];
         }
+        put(direct, q, base, v, x, y, z);
       }
     }
     __syncthreads();
@@ -885,13 +948,17 @@ __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                    double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
-                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above) {
+                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     const int sp = (int)big_list[1 + k];
-    if (start2[sp + 1] - start2[sp] > rounds_above)
-      place_rounds<kP3BigThreads, false>(src, p, cap_rounds, start2, bin_start, sorted, nullptr, nullptr,
-                                         bin_z, sp);
+    const uint32_t cnt = start2[sp + 1] - start2[sp];
+    if (cnt > rounds_above && cnt <= min(reg_max, (unsigned)(kP3BigThreads * kP3RoundsPer)))
+      place_rounds<kP3BigThreads, false, kP3RoundsPer>(src, p, cap_rounds, start2, bin_start, sorted, nullptr,
+                                                       nullptr, bin_z, sp);
+    else if (cnt > rounds_above)
+      place_rounds<kP3BigThreads, false, 0>(src, p, cap_rounds, start2, bin_start, sorted, nullptr, nullptr,
+                                            bin_z, sp);
     else
       place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted, sp, 0u,
                                                    0u, bin_z);
@@ -1260,13 +1327,17 @@ k_dsm_p3_place_rec_big(const uint32_t* __restrict__ src, DsmParams p,
                        const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                        uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
                        uint2* __restrict__ bin_z, const uint32_t* __restrict__ big_list, int cap_rounds,
-                       unsigned rounds_above) {
+                       unsigned rounds_above, unsigned reg_max) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     const int sp = (int)big_list[1 + k];
-    if (start2[sp + 1] - start2[sp] > rounds_above)
-      place_rounds<kP3BigThreads, true>(src, p, cap_rounds, start2, bin_start, nullptr, rec16, sidx, bin_z,
-                                        sp);
+    const uint32_t cnt = start2[sp + 1] - start2[sp];
+    if (cnt > rounds_above && cnt <= min(reg_max, (unsigned)(kP3BigThreads * kP3RoundsPerRec)))
+      place_rounds<kP3BigThreads, true, kP3RoundsPerRec>(src, p, cap_rounds, start2, bin_start, nullptr, rec16,
+                                                         sidx, bin_z, sp);
+    else if (cnt > rounds_above)
+      place_rounds<kP3BigThreads, true, 0>(src, p, cap_rounds, start2, bin_start, nullptr, rec16, sidx, bin_z,
+                                           sp);
     else
       place_records<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, rec16, sidx, bin_z, sp,
                                               0u, 0u);
@@ -1397,9 +1468,17 @@ k_scan_final(uint32_t* __restrict__ data, size_t n,
 
 
 // fold the scatter waves' [min z, max z] partials into the context's range
+// (one thread) the call's own range starts empty
+__global__ void k_range_reset(unsigned long long* __restrict__ call_range) {
+  call_range[0] = kOrderedPlusInf;
+  call_range[1] = kOrderedMinusInf;
+}
+
+// range (may be null): the context's running range since the last reset (the mosaic's coarse
+// cull); call_range: this DSM call's own (the gather's rounding guard: max |z|, amhip_dsm.hip)
 __global__ void __launch_bounds__(1024)
 k_range_reduce(const double* __restrict__ part, size_t nparts,
-               unsigned long long* __restrict__ range) {
+               unsigned long long* __restrict__ range, unsigned long long* __restrict__ call_range) {
   __shared__ double s_pair[2 * 16];
   double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
   const size_t stride = (size_t)gridDim.x * 1024;  // (a handful of workgroups: few atomics)
@@ -1424,8 +1503,12 @@ k_range_reduce(const double* __restrict__ part, size_t nparts,
       hi = fmax(hi, s_pair[2 * w + 1]);
     }
     if (lo <= hi) {
-      atomicMin(&range[0], ordered_key(lo));
-      atomicMax(&range[1], ordered_key(hi));
+      if (range) {
+        atomicMin(&range[0], ordered_key(lo));
+        atomicMax(&range[1], ordered_key(hi));
+      }
+      atomicMin(&call_range[0], ordered_key(lo));
+      atomicMax(&call_range[1], ordered_key(hi));
     }
   }
 }
@@ -1433,12 +1516,16 @@ k_range_reduce(const double* __restrict__ part, size_t nparts,
 // AMHIP_P3_ROUNDS_CAP=n (tests): sub-partitions above n points are placed in rounds over an
 // image of n points -- exercises place_rounds (and its one-bin-beyond-the-image direct case)
 // on clouds of test size; normally only contexts beyond ~130 M points get there
-static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above) {
+// AMHIP_P3_ROUNDS_REREAD=1: the rounds re-read the sub-partition instead of keeping it in registers
+// (the path of sub-partitions beyond 14 K points)
+static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* reg_max) {
   static const int knob = getenv("AMHIP_P3_ROUNDS_CAP") ? atoi(getenv("AMHIP_P3_ROUNDS_CAP")) : 0;
+  static const bool reread = getenv("AMHIP_P3_ROUNDS_REREAD") != nullptr;
   if (knob >= 16 && knob < *cap_rounds) {
     *cap_rounds = knob;
     *rounds_above = (unsigned)knob;
   }
+  if (reread) *reg_max = 0u;
 }
 
 // ---------------------------------------------------------------------------
@@ -1449,13 +1536,16 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   // [min z, max z] of the binned points (for the mosaic's coarse cull): every
   // workgroup of the first scatter pass -- it loads z anyway -- writes a
   // partial, k_range_reduce folds them into *zrange
+  // (always: the call's own range -- c->dev_zrange[2], [3] -- bounds max |z| for the gather's
+  // rounding guard; `zrange`, the running range, may be null)
   double* zpart = nullptr;
-  if (zrange) {
+  {
     const size_t max_waves = 8 * std::max<size_t>((n + 2047) / 2048 + 1, 256 * 16);
     const int rc = ensure_capacity(&c->zpart, &c->zpart_cap, 2 * max_waves + 16);
     if (rc) return rc;
     zpart = c->zpart;
   }
+  unsigned long long* const call_range = c->dev_zrange + 2;
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   {
@@ -1565,8 +1655,9 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                            c->stream, dev_xyz, (const uint32_t*)nullptr, n, p, c->zref, start1, blk2,
                            cursor1, c->rec_a, zpart);
         if (zpart)
+          { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
           hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
-                             (size_t)g1 * (kP3Threads / 64), zrange);
+                             (size_t)g1 * (kP3Threads / 64), zrange, call_range); }
         hipLaunchKernelGGL(k_dsm_p3_scatter_rec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
                            lds, c->stream, (const double*)nullptr, c->rec_a, n, p, c->zref, start1, blk2,
                            cursor2, c->rec_b, (double*)nullptr);
@@ -1587,14 +1678,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         // the rounds' tables -- place_rounds)
         const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
         int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / (kRecWords * 4));
-        unsigned rounds_above = kP3BigCap;
-        p3_rounds_knob(&cap_rounds, &rounds_above);
+        unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
+        p3_rounds_knob(&cap_rounds, &rounds_above, &reg_max);
         const size_t lds_big = std::max((size_t)kP3BigCap * kRecWords * 4 + (3 * (size_t)p.p3_w + 32) * sizeof(uint32_t),
                                         (size_t)cap_rounds * kRecWords * 4 + tables);
         AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_rec_big),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
         hipLaunchKernelGGL(k_dsm_p3_place_rec_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                           c->rec_b, p, start2, c->bin_start, rec16, c->sidx, bin_z, big_list, cap_rounds, rounds_above);
+                           c->rec_b, p, start2, c->bin_start, rec16, c->sidx, bin_z, big_list, cap_rounds, rounds_above, reg_max);
         AMHIP_TRY(hipGetLastError());
         c->bin_z_valid = true;
         c->pts = PtsView{nullptr, rec16, c->sidx, dev_xyz, c->zref, p.sub_x, p.sub_y};
@@ -1613,8 +1704,9 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted,
                          zpart);
       if (zpart)
-        hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
-                           (size_t)g1 * (kP3Threads / 64), zrange);
+        { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
+          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
+                           (size_t)g1 * (kP3Threads / 64), zrange, call_range); }
       hipLaunchKernelGGL(k_dsm_p3_scatter<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
                          lds, c->stream, c->sorted, (const int32_t*)nullptr, n, p, start1, blk2,
                          cursor2, c->tmp_points, (double*)nullptr);
@@ -1635,14 +1727,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
-      unsigned rounds_above = kP3BigCap;
-      p3_rounds_knob(&cap_rounds, &rounds_above);
+      unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
+      p3_rounds_knob(&cap_rounds, &rounds_above, &reg_max);
       const size_t lds_big = std::max((size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds,
                                       (size_t)cap_rounds * 24 + tables);
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above);
+                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }
@@ -1694,8 +1786,9 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         c->pts = PtsView{c->sorted, reinterpret_cast<const uint4*>(c->rec16), c->sidx, dev_xyz, c->zref,
                          p.sub_x, p.sub_y};
       if (zpart)
-        hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
-                           (size_t)grid_pts * 4, zrange);
+        { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
+          hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
+                           (size_t)grid_pts * 4, zrange, call_range); }
       AMHIP_TRY(hipGetLastError());
     }
   }

@@ -416,7 +416,9 @@ def test_dsm_dense_clouds_take_the_wave_per_cell_path(dens):
     # sub-partitions beyond one LDS image (contexts of > 130 M points; here forced at test size):
     # placed in rounds, a single over-full bin directly -- k_dsm_p3_place(_rec)_big / place_rounds
     {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96"},
-], ids=["one-level", "three-pass", "three-pass-many-blocks", "three-pass-rounds"])
+    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96",
+     "AMHIP_P3_ROUNDS_REREAD": "1"},
+], ids=["one-level", "three-pass", "three-pass-many-blocks", "three-pass-rounds", "three-pass-rounds-reread"])
 def test_dsm_every_sort_path_matches(knobs):
     # The binning sort has two implementations (one-level counting sort for
     # clouds below 2^20 points, three-pass partition sort for large clouds; round 1's
