@@ -186,6 +186,34 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
   *by = g.pos_y + off_y;
 }
 
+// The opt-in single-precision mode protects itself on rough terrain.  A
+// tile whose height range leaves no room under the error bound is done by the FP64 kernel, which
+// in that mode stages its points from the caller's UNSORTED cloud through the records' row
+// indices (24 of every 64 bytes it touches); beyond about half the tiles that costs more than the
+// records save in the sort.  The context knows the previous call's share (the pinned mirror of
+// its tile counters, never waited for -- a value one or two calls late is as good): above one
+// half, this call and the next 15 run the FP64 pipeline outright (sorted doubles), then the
+// single-precision pipeline is tried once more.  Results: FP64 is the stricter arithmetic, every
+// bar of the single-precision mode holds.  AMHIP_DSM_NO_ROUGH_SWITCH=1 disables the switch.
+static void dsm_rough_policy(Ctx* c) {
+  const bool off = std::getenv("AMHIP_DSM_NO_ROUGH_SWITCH") != nullptr;  // (read per call: tests toggle it)
+  c->dsm_exact_now = 0;
+  if (c->dsm_exact || c->dsm_knn || off) return;
+  if (c->rough_hold > 0) {
+    --c->rough_hold;
+    c->dsm_exact_now = 1;
+    return;
+  }
+  if (c->last_call_f32 && c->last_ntiles > 0 && c->host_tile_stats) {
+    const volatile unsigned* hs = c->host_tile_stats;
+    const double rejected = (double)hs[4] + (double)hs[5] + (double)hs[6] + (double)hs[7];
+    if (rejected * 2.0 > (double)c->last_ntiles) {
+      c->rough_hold = 15;
+      c->dsm_exact_now = 1;
+    }
+  }
+}
+
 // mode 0: dsm::Dsm ladder.  mode 1: ortho::OrthoFromPcl, one search with the
 // squared radius `radius_sq * pcl_lambda` (pcl_lambda = 1 for the first search,
 // 10, 100, ... for the adaptive retries, ortho-from-pcl.cc:63-71).
@@ -332,7 +360,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     };
     // (single-precision mode: 16-byte records, so 4096 points still leave two workgroups per
     // CU -- clouds of ~1.2 .. 2.2 points per cell keep the one-workgroup-per-tile launch)
-    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_knn && rec_fits;
+    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_exact_now && !c.dsm_knn && rec_fits;
     if (need(16) <= 1024.0) {
       kTileJ = 16;
       cap = 1024;
@@ -396,7 +424,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.knn_k = mode == 0 ? c.dsm_knn : 0;
   if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
   p.fx_ok = 0;
-  if (p.lds_ok && mode == 0 && !c.dsm_exact && rec_fits) {
+  if (p.lds_ok && mode == 0 && !c.dsm_exact && !c.dsm_exact_now && rec_fits) {
     int S = 28;
     while (((long long)(w0 + 2) << S) >= (1LL << 31)) --S;
     const double scale2 = std::ldexp(1.0, 2 * S);
@@ -1036,6 +1064,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
   int rc = use_device(c);
   if (rc) return rc;
   DsmParams p;
+  dsm_rough_policy(c);
   if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n)))
     return rc;
   // a logically-initial elevation layer is filled by the gather itself
@@ -1279,6 +1308,7 @@ int amhip_dsm_tiled_begin_dev(amhip_ctx* h, const double* dev_xyz, size_t n_owne
   sp.halo_out = dev_out;
   sp.halo_counts = reinterpret_cast<unsigned long long*>(dev_counts);
   DsmParams p;
+  dsm_rough_policy(c);
   if ((rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, &p, 0, 1, n_total)))
     return rc;
   if ((rc = dsm_run(c, dev_xyz, nullptr, n_total, p, nullptr, nullptr, nullptr, false, 0.0f,

@@ -193,6 +193,12 @@ struct Ctx {
   hipStream_t stream = nullptr;
   size_t cells = 0;
   int dsm_exact = 0;          // amhip_ctx_set_dsm_precision
+  // single-precision mode on rough terrain (amhip_api.hip: dsm_rough_policy): when a call filed
+  // more than half of its tiles for the FP64 kernel, the next calls run the FP64 pipeline
+  // outright (sorted doubles instead of records + the caller's unsorted cloud)
+  int dsm_exact_now = 0;      // this call
+  int rough_hold = 0;         // calls left before the single-precision pipeline is tried again
+  bool last_call_f32 = false; // the last DSM call ran the record pipeline with bin ranges
   int dsm_knn = 0;            // amhip_ctx_set_dsm_knn
 
   float* layers[AMHIP_NUM_LAYERS] = {nullptr, nullptr, nullptr,

@@ -2027,6 +2027,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     const PtsView pts_view = c->pts;   // what dsm_sort left: doubles, records or both
     const int64_t prev_ntiles = c->last_ntiles;
     c->last_ntiles = 0;
+    c->last_call_f32 = false;
     if (p.lds_ok) {
       const unsigned ntiles = (unsigned)p.tiles_i * (unsigned)p.tiles_j;
       c->last_ntiles = ntiles;
@@ -2086,6 +2087,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // list 6 beyond its largest image
       const bool rej_own = cap0 <= 2048 || ((long)cap0 + 2) * 24 + fixed_bytes <= 150 * 1024;
       const uint2* bin_z = (f32 && c->bin_z_valid) ? reinterpret_cast<const uint2*>(c->bin_z) : nullptr;
+      c->last_call_f32 = bin_z != nullptr;  // (its tile counters say how rough the scene is)
       // Rough scenes: when the PREVIOUS call on this context pre-classified more than a tenth
       // of its tiles for the FP64 kernel, that kernel is launched densely over the tiles (one
       // workgroup each, filtering on occ) instead of walking a list of tens of thousands with a

@@ -266,6 +266,9 @@ def test_rough_scene_second_call_takes_the_dense_fp64_launch(monkeypatch):
     sc.points[rough, 2] += rng.uniform(-30.0, 30.0, int(rough.sum()))
     want = _oracle(sc)
     monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    # (this test is about the two launch forms of the single-precision pipeline: keep the context
+    # from leaving that pipeline altogether, test_rough_scene_switches_to_the_fp64_pipeline)
+    monkeypatch.setenv("AMHIP_DSM_NO_ROUGH_SWITCH", "1")
     g = sc.grid
     with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
         m.set_dsm_precision(False)
@@ -332,3 +335,45 @@ def test_maps_longer_than_the_records_cell_field_fall_back_to_fp64():
     fast, exact = _run(sc, False), _run(sc, True)
     assert np.array_equal(fast.view(np.uint32), exact.view(np.uint32))
     _check(fast, _oracle(sc))
+
+
+def test_rough_scene_switches_to_the_fp64_pipeline(monkeypatch):
+    """ the opt-in mode protects itself: when a call filed more than half of
+    its tiles for the FP64 kernel, the following calls on the context run the FP64 pipeline
+    outright (sorted doubles; the records' FP64 redo would stage from the unsorted cloud), and the
+    single-precision pipeline is tried again after 15 calls.  A smooth scene never switches."""
+    import aerial_mapper_amd as A
+    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    monkeypatch.delenv("AMHIP_DSM_NO_ROUGH_SWITCH", raising=False)
+    sc = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=315)
+    rng = np.random.default_rng(12)
+    rough_pts = sc.points.copy()
+    rough_pts[:, 2] += rng.uniform(-30.0, 30.0, rough_pts.shape[0])          # every tile is rough
+    rc, want_rough, _ = O.dsm_process(rough_pts, sc.grid, 1, 0.0, 0.0)
+    assert rc == O.OK
+    want_smooth = _oracle(sc)
+    g = sc.grid
+    with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
+        m.set_dsm_precision(False)
+        dsm = A.Dsm(A.DsmSettings(1), m)
+        fp64_tiles, fracs = [], []
+        for k in range(20):
+            m.reset()
+            dsm.process(rough_pts, m)          # (sync=True: the tile counters are back before the next call)
+            st = m.dsm_gather_stats()
+            fp64_tiles.append(st["f32_to_fp64"] + st["f32_to_fp64_beyond"])
+            frac, _ = _check(m.get("elevation"), want_rough)
+            fracs.append(frac)
+        # call 0 is the single-precision pipeline (it finds the scene rough), calls 1 .. 16 the FP64
+        # pipeline (no tile is "sent" anywhere: the counters are zero), call 17 tries again
+        assert fp64_tiles[0] > 0.5 * st["tiles"]
+        assert all(v == 0 for v in fp64_tiles[1:17]), fp64_tiles
+        assert fp64_tiles[17] == fp64_tiles[0] and fp64_tiles[18] == 0
+        assert min(fracs[1:17]) >= 0.9999                # the FP64 arithmetic: the reference's floats
+        # a smooth scene afterwards: the hold runs out, then the single-precision pipeline stays
+        for k in range(20):
+            m.reset()
+            dsm.process(sc.points, m)
+        st = m.dsm_gather_stats()
+        frac, _ = _check(m.get("elevation"), want_smooth)
+        assert st["f32_to_fp64"] == 0 and frac < 0.99999   # (f32 sums: a float spacing here and there)
