@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(ROOT, "build", "hip_obj")
 
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
                "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip"]
-HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
+HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box
 # test, pixel rounding, best-view comparison) must see the same doubles as the
