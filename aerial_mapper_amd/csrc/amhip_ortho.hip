@@ -345,6 +345,47 @@ __device__ __forceinline__ void write_cell(const OrthoParams& p, const uint8_t* 
              accepted, read_pixel(p, frames, frame, kp_x, kp_y));
 }
 
+// Deferred write-back of the margin-guarded fold (round 4).  A slab's pixel reads -- single bytes
+// gathered from 2 MB frames, the longest latency of the kernel -- used to be issued and awaited
+// at the end of the slab, with four waves per SIMD to cover them.  Now they are ISSUED at the end
+// of slab s, the rest of what the stores need is parked in LDS (angle, frame, count: 8 bytes per
+// cell), and the stores happen after slab s + 1's arithmetic: by then the bytes have arrived.
+// Two registers per lane stay live (six with colour) instead of a memory round trip per slab.
+template <int kCells>
+struct SlabCarry {
+  unsigned raw[kCells][3];  // the pixel bytes as loaded (gray: [0]; colour: B, G, R)
+  int js;                   // first column of the parked slab; -1: nothing parked
+};
+// meta word: what (2 bits) << 30 | accepted (14) << 16 | frame (16)
+constexpr unsigned kParkFrameMax = 0xFFFFu, kParkAcceptMax = 0x3FFFu;
+
+template <int kCells>
+__device__ __forceinline__ void slab_commit(const OrthoParams& p, const SlabCarry<kCells>& carry,
+                                            const float* s_park_angle, const unsigned* s_park_meta,
+                                            float* __restrict__ elevation_angle,
+                                            float* __restrict__ observation_index,
+                                            float* __restrict__ num_observations,
+                                            float* __restrict__ out_layer, int i) {
+  if (carry.js < 0) return;  // (block-uniform)
+  const int wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int c = 0; c < kCells; ++c) {
+    const int j = carry.js + wid + c * (kOrthoThreads / 64);
+    const unsigned meta = s_park_meta[c * kOrthoThreads + threadIdx.x];
+    const unsigned what = meta >> 30;
+    if (what == (unsigned)kFoldNone) {
+      if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+    } else if (what == (unsigned)kFoldDone) {
+      const float pix = p.colored ? __uint_as_float((carry.raw[c][2] << 16) | (carry.raw[c][1] << 8) |
+                                                    carry.raw[c][0])
+                                  : (float)carry.raw[c][0];
+      store_cell(p, elevation_angle, observation_index, num_observations, out_layer, i, j,
+                 s_park_angle[c * kOrthoThreads + threadIdx.x], (int)(meta & kParkFrameMax),
+                 (int)((meta >> 16) & kParkAcceptMax), pix);
+    }  // (3: no such cell, or a cell the slow path has already written)
+  }
+}
+
 // One slab (64 x kSlab cells, kSlab / 4 per lane) of the block's tile: fold
 // the tile's frame list into the slab's cells and write them back.
 //
@@ -362,17 +403,20 @@ __device__ __forceinline__ void ortho_slab(
     const float* __restrict__ elevation, float* __restrict__ elevation_angle,
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err, int* s_cand, int* s_wave_cnt,
-    double* s_best, const double* s_atan, const V3& centre, double radius, double slack, int i,
-    bool i_ok, int js, bool single, int ncand0) {
+    double* s_best, const double* s_atan, const float* s_elev, float* s_park_angle,
+    unsigned* s_park_meta, SlabCarry<kSlab / (kOrthoThreads / 64)>* carry, const V3& centre,
+    double radius, double slack, int i, bool i_ok, int js, int j0, bool single, int ncand0) {
   constexpr int kCellsPerLane = kSlab / (kOrthoThreads / 64);
   const int wid = threadIdx.x >> 6;
   const double lx = p.base_x + p.res * (-(double)(i + p.i_off));
+  // the tile's elevations were parked in LDS by the range pass (phase A): an LDS round trip per
+  // slab instead of an L2 one (the same wave wrote what it reads: no barrier)
   float elev[kCellsPerLane];
 #pragma unroll
   for (int c = 0; c < kCellsPerLane; ++c) {
     const int j = js + wid + c * (kOrthoThreads / 64);
     float e = __builtin_nanf("");
-    if (i_ok && j < p.cols) e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
+    if (i_ok && j < p.cols) e = s_elev[(j - j0) * kTileI + (threadIdx.x & 63)];
     elev[c] = e;
   }
 
@@ -441,7 +485,7 @@ __device__ __forceinline__ void ortho_slab(
     // the stores.
     int pending = 0;  // 2 bits per cell: kFoldFinish / kFoldRedo
     int what[kCellsPerLane], ku[kCellsPerLane], kv[kCellsPerLane];
-    float angle[kCellsPerLane], pix[kCellsPerLane];
+    float angle[kCellsPerLane];
 #pragma unroll
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int j = js + wid + c * (kOrthoThreads / 64);
@@ -455,6 +499,8 @@ __device__ __forceinline__ void ortho_slab(
     // without a settled winner reads pixel (0, 0) of frame 0 and drops it)
     // (and the colour / gray branch OUTSIDE the loop over the cells: inside, the compiler waits
     // for one cell's pixel before it asks for the next)
+    SlabCarry<kCellsPerLane> mine;
+    mine.js = js;
     {
       const uint8_t* px[kCellsPerLane];
 #pragma unroll
@@ -464,38 +510,45 @@ __device__ __forceinline__ void ortho_slab(
                 (size_t)(done ? kv[c] : 0) * p.row_step + (size_t)(done ? ku[c] : 0) * (p.colored ? 3u : 1u);
       }
       if (p.colored) {
-        // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B (read_pixel)
-        unsigned b0[kCellsPerLane], b1[kCellsPerLane], b2[kCellsPerLane];
+        // cv::Vec3b = (B, G, R); colorVectorToValue packs R<<16 | G<<8 | B (slab_commit)
 #pragma unroll
         for (int c = 0; c < kCellsPerLane; ++c) {
-          b0[c] = px[c][0];
-          b1[c] = px[c][1];
-          b2[c] = px[c][2];
+          mine.raw[c][0] = px[c][0];
+          mine.raw[c][1] = px[c][1];
+          mine.raw[c][2] = px[c][2];
         }
-#pragma unroll
-        for (int c = 0; c < kCellsPerLane; ++c)
-          pix[c] = __uint_as_float((b2[c] << 16) | (b1[c] << 8) | b0[c]);
       } else {
-        unsigned g[kCellsPerLane];
 #pragma unroll
-        for (int c = 0; c < kCellsPerLane; ++c) g[c] = px[c][0];
-#pragma unroll
-        for (int c = 0; c < kCellsPerLane; ++c) pix[c] = (float)g[c];
+        for (int c = 0; c < kCellsPerLane; ++c) {
+          mine.raw[c][0] = px[c][0];
+          mine.raw[c][1] = mine.raw[c][2] = 0u;
+        }
       }
     }
+    // the PREVIOUS slab's stores, while this slab's bytes are on their way (slab_commit reads
+    // the parked words before they are overwritten below; same thread: no barrier)
+    slab_commit<kCellsPerLane>(p, *carry, s_park_angle, s_park_meta, elevation_angle, observation_index,
+                               num_observations, out_layer, i);
+    const bool parkable = p.num_frames <= (int)kParkFrameMax;
 #pragma unroll
     for (int c = 0; c < kCellsPerLane; ++c) {
-      const int j = js + wid + c * (kOrthoThreads / 64);
+      unsigned code = 3u;  // nothing to do at commit time
       if (what[c] == kFoldNone) {
-        if (p.virt_out) write_initial(p, elevation_angle, observation_index, out_layer, i, j);
+        code = (unsigned)kFoldNone;
       } else if (what[c] == kFoldDone) {
-        store_cell(p, elevation_angle, observation_index, num_observations, out_layer, i, j,
-                   angle[c], st[c].best_f, st[c].accepted, pix[c]);
-      } else if (what[c] > 0) {
-        pending |= what[c] << (2 * c);
-        // (what slow_finish needs survives in two registers per cell)
+        if (parkable && st[c].accepted <= (int)kParkAcceptMax) {
+          code = (unsigned)kFoldDone;
+        } else {  // (more frames than the packed word holds: finish this cell the slow way)
+          what[c] = kFoldFinish;
+        }
       }
+      if (what[c] > 0 && what[c] != kFoldDone) pending |= what[c] << (2 * c);
+      s_park_angle[c * kOrthoThreads + threadIdx.x] = angle[c];
+      s_park_meta[c * kOrthoThreads + threadIdx.x] =
+          (code << 30) | (((unsigned)st[c].accepted & kParkAcceptMax) << 16) |
+          ((unsigned)max(st[c].best_f, 0) & kParkFrameMax);
     }
+    *carry = mine;
     // ---- pass 2 (rare): the reference's arithmetic -------------------------------
     if (pending) {
       const bool whole_list = single;  // else: every frame, like the reference itself
@@ -660,7 +713,7 @@ __device__ __forceinline__ void ortho_backward_tile(
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
     const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt,
-    double* s_best, double* s_atan) {
+    double* s_best, double* s_atan, float* s_elev, float* s_park_angle, unsigned* s_park_meta) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
   const int i = blockIdx.x * kTileI + lane;
@@ -707,6 +760,7 @@ __device__ __forceinline__ void ortho_backward_tile(
     if (i_ok) {
       for (int j = j0 + wid; j <= j_hi; j += kOrthoThreads / 64) {
         const float e = elevation[(size_t)i + (size_t)j * (size_t)p.rows];
+        s_elev[(j - j0) * kTileI + lane] = e;  // (the slab that folds row j is this wave's: j = js + wid + 4 c)
         if (e == e) {  // NaN elevation can never be visible
           zmin = fminf(zmin, e);
           zmax = fmaxf(zmax, e);
@@ -758,17 +812,24 @@ __device__ __forceinline__ void ortho_backward_tile(
                                  s_cand, s_wave_cnt, s_best);
   const bool single = ncand0 >= 0;
   if (!single) ncand0 = 0;
+  SlabCarry<kSlab / (kOrthoThreads / 64)> carry;  // (fast path: the previous slab's parked write-back)
+  carry.js = -1;
   if constexpr (kTileJ == kSlab) {
     ortho_slab<kFast, kSlab>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
-                      num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
-                      ucentre, uradius, uslack, i, i_ok, j0, single, ncand0);
+                      num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan, s_elev,
+                      s_park_angle, s_park_meta, &carry, ucentre, uradius, uslack, i, i_ok, j0, j0, single,
+                      ncand0);
   } else {
 #pragma unroll 1
     for (int js = j0; js <= j_hi; js += kSlab)
       ortho_slab<kFast, kSlab>(p, poses, fast_tab, frames, elevation, elevation_angle, observation_index,
-                        num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan,
-                        ucentre, uradius, uslack, i, i_ok, js, single, ncand0);
+                        num_observations, out_layer, dev_err, s_cand, s_wave_cnt, s_best, s_atan, s_elev,
+                        s_park_angle, s_park_meta, &carry, ucentre, uradius, uslack, i, i_ok, js, j0, single,
+                        ncand0);
   }
+  if constexpr (kFast)  // the last slab's stores
+    slab_commit<kSlab / (kOrthoThreads / 64)>(p, carry, s_park_angle, s_park_meta, elevation_angle,
+                                              observation_index, num_observations, out_layer, i);
 }
 
 #define AMHIP_ORTHO_KERNEL_ARGS                                                              \
@@ -783,9 +844,13 @@ __device__ __forceinline__ void ortho_backward_tile(
   __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
   __shared__ double s_best[kOrthoThreads / 64];                                              \
   __shared__ double s_atan[kAtanTabSize];                                                    \
+  __shared__ float s_elev[kTileI * kTileJ];                                                  \
+  __shared__ float s_park_angle[kOrthoThreads * ((SLAB) / (kOrthoThreads / 64))];            \
+  __shared__ unsigned s_park_meta[kOrthoThreads * ((SLAB) / (kOrthoThreads / 64))];          \
   ortho_backward_tile<FAST, SLAB>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
                             observation_index, num_observations, out_layer, dev_err, zrange, \
-                            s_red, s_cand, s_wave_cnt, s_best, s_atan);
+                            s_red, s_cand, s_wave_cnt, s_best, s_atan, s_elev, s_park_angle, \
+                            s_park_meta);
 
 // every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
