@@ -84,6 +84,13 @@ run("wave_per_block", sc)
 sc2 = S.Scene(90.0, 70.0, 0.5, 30000, seed=46)
 sc2.points[:, 2] -= 400.0        # heights of both signs: the sums cancel
 run("mixed_signs_r2", sc2, radius=2)
+# OrthoFromPcl: the same gather on intensities (values mode), written to the ortho layer
+sc3 = S.Scene(120.0, 90.0, 0.5, 60000, seed=47)
+inten = (np.arange(sc3.points.shape[0]) * 7919 % 251).astype(np.int32)
+g = sc3.grid
+with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
+    A.OrthoFromPcl(A.OrthoFromPclSettings()).process(sc3.points, inten, m)
+    out["from_pcl_intensities"] = m.get("ortho")
 """
 
 
@@ -101,7 +108,7 @@ def _child(env_extra, tmp_path, tag):
 def test_canonical_arithmetic_in_every_cell_gives_the_same_floats(tmp_path):
     normal = _child({}, tmp_path, "normal")
     canon = _child({"AMHIP_DSM_CANON_ALL": "1"}, tmp_path, "canon")
-    assert sorted(normal) == sorted(canon) and len(normal) == 5
+    assert sorted(normal) == sorted(canon) and len(normal) == 6
     for name in normal:
         a, b = normal[name], canon[name]
         assert np.array_equal(np.isnan(a), np.isnan(b)), name
