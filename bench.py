@@ -109,6 +109,7 @@ def parse():
                          "main-ortho-backward-grid.cc:128-141) -- reported as `session_route` (N = 1: "
                          "`pcie_inclusive`, the same thing), never as value.  auto (default): the same "
                          "when the host has the memory for the whole map's matrices; ranks: never")
+    ap.add_argument("--session-child", type=int, default=0, help=argparse.SUPPRESS)   # (internal: see session_route_all)
     ap.add_argument("--map-origin", default="0,0",
                     help="easting,northing of the map centre (default 0,0; e.g. 464980.25,5272690.5 "
                          "puts the same workload at UTM magnitudes)")
@@ -434,7 +435,7 @@ def session_route(args, A, st, tiles, devices, dsm_settings, ncam, mosaic_settin
 
 
 def session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev, wl, fixed, pts_per_rank,
-                      ox, oy, Lx, Ly, res, L, dsm, ncam, mosaic, F, ch, cells_total):
+                      ox, oy, Lx, Ly, res, L, dsm_settings, ncam, mosaic_settings, F, ch, cells_total):
     """N > 1, rank 0 while the other ranks wait on the host: the WHOLE map (every rank's points,
     regenerated here with the ranks' seeds; every rank's frames) through one amhip_session with
     one window per device.  Skipped, with the reason, when the host lacks the memory."""
@@ -476,8 +477,8 @@ def session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev, w
         h_pts = np.concatenate(parts, 0)
         del parts
         devices = [0] * world if one_gpu else list(range(world))
-        res_out = session_route(args, A, st, (layout.tiles_i, layout.tiles_j), devices, dsm.settings, ncam,
-                                mosaic.settings if F else None, h_pts,
+        res_out = session_route(args, A, st, (layout.tiles_i, layout.tiles_j), devices, dsm_settings, ncam,
+                                mosaic_settings if F else None, h_pts,
                                 np.concatenate(posel, 0) if F else None, framel if F else None,
                                 cells_total, res, (ox, oy))
         res_out["route"] = ("one host process, amhip_session over %d devices (AERIAL_MAPPER_HIP_DEVICES): what "
@@ -536,6 +537,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    if args.session_child:
+        args.gpus = args.session_child
+        os.environ["WORLD_SIZE"] = str(args.session_child)   # (geometry only: no process group is made)
+        os.environ["RANK"] = os.environ["LOCAL_RANK"] = "0"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process
         # per GPU over RCCL) instead of silently timing one.  The reference host is ONE process
@@ -574,7 +579,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     dist = host_pg = None
-    if world > 1:
+    if world > 1 and not args.session_child:
         import torch.distributed as dist
         if one_gpu:
             dist.init_process_group("gloo")
@@ -609,6 +614,18 @@ def main():
         layout = tiling.TileLayout(rows_all, cols_all, world, 1)
         pts_per_rank = wl["points"]
     st = A.GridMapSettings(ox, oy, Lx, Ly, res)
+    if args.session_child:
+        # (internal) the whole map of an N-rank run through ONE amhip_session with one window per
+        # device: prints the `session_route` object and nothing else
+        F = wl["frames"]
+        ch = 3 if args.colored else 1
+        ncam = A.NCamera(wl["f"], wl["f"], (wl["W"] - 1) / 2.0, (wl["H"] - 1) / 2.0, wl["W"], wl["H"]) if F else None
+        res_out = session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev, wl, fixed,
+                                    pts_per_rank, ox, oy, Lx, Ly, res, L, A.DsmSettings(interpolation_radius=1),
+                                    ncam, A.OrthoSettings(colored_ortho=args.colored), F, ch,
+                                    rows_all * cols_all)
+        print(json.dumps(res_out))
+        return
     win = layout.window(rank)
     m = A.AerialGridMap(st, device=local_rank, window=win)
     m.set_stream(stream.cuda_stream)
@@ -968,9 +985,29 @@ def main():
                                                   cells, res, (ox, oy))
             out["pcie_inclusive"]["route"] = "session (--route session at N = 1 is this object)"
         if world > 1 and args.route != "ranks" and not batch:
-            out["session_route"] = session_route_all(args, A, synth, tiling, st, layout, world, one_gpu, dev,
-                                                     wl, fixed, pts_per_rank, ox, oy, Lx, Ly, res, L, dsm,
-                                                     ncam, mosaic, F, ch, rows_all * cols_all)
+            # In a CHILD process with a time limit: one host process driving all N devices has never
+            # run next to N live ranks on real hardware -- whatever it does (fail, hang), this
+            # line's own numbers are already measured and must be printed.  The ranks wait on the
+            # host meanwhile (gloo), not in an RCCL kernel.
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--session-child", str(world), "--workload",
+                   args.workload, "--dsm-mode", args.dsm_mode, "--route", args.route, "--map-origin",
+                   args.map_origin] + (["--colored"] if args.colored else [])
+            env = dict(os.environ)
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                      "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
+                env.pop(k, None)
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                   universal_newlines=True, timeout=420)
+                lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["session_route"] = json.loads(lines[-1]) if lines else {
+                    "error": "child exit %d: %s" % (r.returncode, r.stderr[-400:])}
+            except subprocess.TimeoutExpired:
+                out["session_route"] = {"error": "the one-process session over %d devices did not finish in "
+                                                 "420 s (killed); the ranks' numbers above are unaffected" % world}
+            except Exception as e:
+                out["session_route"] = {"error": repr(e)}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
