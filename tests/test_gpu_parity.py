@@ -76,7 +76,9 @@ def test_dsm_sparse_1m_grid_with_fallback():
     sc = S.Scene(300.0, 200.0, 1.0, 66000, seed=42)
     got, want = _dsm_both(sc)
     frac = S.assert_dsm_close(got, want)
-    assert frac > (0.99 if _EXACT else 0.5)
+    # measured: 1.0 (FP64) / 0.9971 (single precision: f32 sums + the records' once-more-rounded
+    # height offsets move a float spacing in 3 cells per thousand)
+    assert frac > (0.9999 if _EXACT else 0.99)
 
 
 def test_dsm_dense_quarter_metre():
