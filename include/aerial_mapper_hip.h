@@ -148,8 +148,11 @@ int amhip_ctx_set_stream(amhip_ctx* ctx, void* hip_stream);
  *   AMHIP_DSM_EXACT (DEFAULT since round 3) the FP64 gather everywhere: the reference's doubles
  *                   decide and weigh every pair, only the ORDER of the double sums differs from
  *                   the kd-tree's (1e-16 relative, then rounded to float): bit-identical floats
- *                   in every test so far, deterministic from run to run, and therefore a
- *                   byte-identical mosaic on top of it.  What a drop-in must be by default.
+ *                   in every test so far (one cell in 1e8 follows the kd-tree's own summation
+ *                   order), THE SAME BITS IN EVERY RUN AND FOR EVERY ORDER OF THE CLOUD (since
+ *                   round 4: the rounding of every quotient is guarded, the cells on a float
+ *                   rounding boundary are redone in order-independent double-double sums), and
+ *                   therefore a byte-identical mosaic on top.  What a drop-in must be by default.
  *   AMHIP_DSM_FAST  (opt-in) single-precision distances and weights under exact guards: the
  *                   reference's neighbour sets (any decision within 2e-6 of the radius is taken
  *                   in its own doubles), identical NaN pattern, heights within the contract's
@@ -158,7 +161,9 @@ int amhip_ctx_set_stream(amhip_ctx* ctx, void* hip_stream);
  *                   100 M cells; heights may differ from the reference's by one float spacing
  *                   and from run to run (the f32 sums follow the order the atomics of the
  *                   binning left the points in), so a mosaic on top of them can differ in the
- *                   rare cell whose keypoint sits on a pixel boundary.
+ *                   rare cell whose keypoint sits on a pixel boundary.  A context whose
+ *                   scene is mostly rough (more than half of the tiles without room under the
+ *                   bound) runs the FP64 pipeline by itself for 16 calls at a time.
  * New contexts start in EXACT; the environment variable AMHIP_DSM_FAST=1 makes FAST their
  * default (hosts that cannot be recompiled), AMHIP_DSM_EXACT=1 (round 2's switch) still forces
  * EXACT.  The setters override either.  amhip_session_set_dsm_precision applies to every window
