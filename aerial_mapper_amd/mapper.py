@@ -144,7 +144,11 @@ class AerialGridMap(object):
         return self._lib.amhip_layer_device_ptr(self._h, self._layer_id(layer))
 
     def as_torch(self, layer):
-        """Zero-copy torch view (cols, rows) of a device-resident layer."""
+        """Zero-copy torch view (cols, rows) of a device-resident layer.  The view lives on the
+        map's memory: torch work on it (a clone, a reduction) runs on TORCH's stream and must have
+        finished -- torch.cuda.synchronize() / set_stream(torch's stream) -- before the next call
+        on the map writes the layer (reset(), process()); the map's stream does not wait for
+        torch's readers."""
         import torch
         ptr = self.device_ptr(layer)
         n = self.num_cells
