@@ -663,8 +663,11 @@ int amhip_session_ortho_backward_process(
   }
   // layer order of the context: ORTHO, ELEVATION, ELEVATION_ANGLE, NUM_OBSERVATIONS,
   // OBSERVATION_INDEX, COLORED_ORTHO
-  const float* ins[AMHIP_NUM_LAYERS] = {ortho, elevation, elevation_angle, num_observations,
-                                        observation_index, colored_ortho};
+  // (the mosaic touches ONE of the two output layers -- ortho-backward-grid.cc:186-208 --: the
+  // other matrix is neither summed, uploaded nor downloaded; 400 MB of host hashing per call)
+  const float* ins[AMHIP_NUM_LAYERS] = {colored ? nullptr : ortho, elevation, elevation_angle,
+                                        num_observations, observation_index,
+                                        colored ? colored_ortho : nullptr};
   std::vector<Hash128> hh;
   auto upload_frames = [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
@@ -708,7 +711,8 @@ int amhip_session_ortho_backward_process(
       return r;
     const int lay[5] = {AMHIP_LAYER_ORTHO, AMHIP_LAYER_ELEVATION_ANGLE, AMHIP_LAYER_NUM_OBSERVATIONS,
                         AMHIP_LAYER_OBSERVATION_INDEX, AMHIP_LAYER_COLORED_ORTHO};
-    float* outs[5] = {ortho, elevation_angle, num_observations, observation_index, colored_ortho};
+    float* outs[5] = {colored ? nullptr : ortho, elevation_angle, num_observations, observation_index,
+                      colored ? colored_ortho : nullptr};
     if ((r = sync_out(s, k, lay, outs, 5))) return r;
     return ctx_fetch_status(c);
   });
