@@ -140,3 +140,41 @@ def test_canonical_arithmetic_matches_the_oracle():
         assert rc == O.OK
         frac = S.assert_dsm_close(got[name], want, tol=1e-6)
         assert frac >= 0.9999, (name, frac)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_two_runs_and_a_permuted_cloud_give_the_same_bits(seed):
+    """Random scenes across the gather's routines (LDS tiles of every capacity class, the
+    wave-per-block kernel of dense clouds, the ladder of sparse ones, heights of both signs, radii
+    1 .. 9): the default mode's map is a function of the point SET."""
+    import torch
+    import aerial_mapper_amd as A
+    rng = np.random.default_rng(4100 + seed)
+    res = float(rng.choice([0.2, 0.25, 0.5, 1.0]))
+    rows, cols = int(rng.integers(200, 700)), int(rng.integers(150, 500))
+    lx, ly = rows * res, cols * res
+    dens = float(rng.choice([0.03, 0.3, 0.6, 2.5, 7.0, 14.0]))       # points per cell
+    n = max(1000, min(int(dens * rows * cols), 2_500_000))
+    radius = int(rng.choice([1, 1, 1, 2, 4, 9]))
+    pts = np.empty((n, 3))
+    pts[:, 0] = rng.uniform(-lx / 2 - 2.0, lx / 2 + 2.0, n)
+    pts[:, 1] = rng.uniform(-ly / 2 - 2.0, ly / 2 + 2.0, n)
+    pts[:, 2] = synth.terrain_height(pts[:, 0], pts[:, 1]) + rng.uniform(-1.0, 1.0, n)
+    if seed % 3 == 1:
+        pts[:, 2] -= 400.0                                            # both signs
+    if seed % 4 == 2:
+        pts = pts[np.abs(pts[:, 0]) > 0.05 * lx]                      # a strip without points
+    dev = torch.device("cuda", 0)
+    cloud = torch.from_numpy(np.ascontiguousarray(pts)).to(dev)
+    with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, lx, ly, res)) as m:
+        m.set_dsm_precision(True)
+        dsm = A.Dsm(A.DsmSettings(radius), m)
+        maps = []
+        for k in range(3):
+            src = cloud if k < 2 else cloud[torch.randperm(cloud.shape[0], device=dev)].contiguous()
+            m.reset()
+            dsm.process(src, m)
+            maps.append(m.get("elevation").view(np.uint32).copy())
+    assert (~np.isnan(maps[0].view(np.float32))).any()
+    assert np.array_equal(maps[0], maps[1]), int((maps[0] != maps[1]).sum())
+    assert np.array_equal(maps[0], maps[2]), int((maps[0] != maps[2]).sum())
