@@ -75,13 +75,14 @@ AMHIP_ATAN_HD DD dd_div(const DD& a, const DD& b) {
   return dd_fast_two_sum(q.hi, q.lo);
 }
 
-AMHIP_ATAN_HD double atan_cr(double r) {
+AMHIP_ATAN_HD double atan_cr(double x) {
   constexpr double kTab[kAtanCrSteps + 1][2] = AMHIP_ATAN_CR_TABLE;
   constexpr double kCoeff[9][2] = AMHIP_ATAN_CR_COEFF;
-  if (!(r == r)) return r;                       // NaN
-  if (r < 0.0) return -atan_cr(-r);              // (the callers pass radii; kept total)
-  if (r < 0x1p-27) return r;                     // r - r^3 / 3 rounds to r
-  if (r > 0x1p+60) return kHalfPiHi;             // pi/2 - 1/r rounds to fl(pi/2)
+  if (!(x == x)) return x;                       // NaN
+  const double sign = x < 0.0 ? -1.0 : 1.0;      // (the callers pass radii; kept total: atan is odd)
+  const double r = x < 0.0 ? -x : x;
+  if (r < 0x1p-27) return x;                     // r - r^3 / 3 rounds to r
+  if (r > 0x1p+60) return sign * kHalfPiHi;      // pi/2 - 1/r rounds to fl(pi/2)
   const bool invert = r > 1.0;
   DD t = {r, 0.0};
   if (invert) t = dd_div({1.0, 0.0}, {r, 0.0});
@@ -104,7 +105,7 @@ AMHIP_ATAN_HD double atan_cr(double r) {
   DD a = dd_add(y, corr);
   a = dd_add({kTab[j][0], kTab[j][1]}, a);
   if (invert) a = dd_add({kHalfPiHi, kHalfPiLo}, {-a.hi, -a.lo});
-  return a.hi + a.lo;
+  return sign * (a.hi + a.lo);
 }
 
 // The same value on a fast path (Ziv's strategy): atan as hi + lo with ~76 good bits from plain
