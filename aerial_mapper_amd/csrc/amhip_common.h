@@ -271,6 +271,8 @@ struct Ctx {
   size_t frame_pose_cap = 0;
   uint8_t* stage_frames = nullptr;
   size_t stage_frames_cap = 0;
+  int* ortho_list = nullptr;     // [count (4 ints)] [tiles some frame of a small batch can see]
+  size_t ortho_list_cap = 0;
 
   // amhip_dsm_tiled_begin_dev .. amhip_dsm_tiled_finish_dev
   bool tiled_pending = false;

@@ -713,11 +713,12 @@ __device__ __forceinline__ void ortho_backward_tile(
     float* __restrict__ observation_index, float* __restrict__ num_observations,
     float* __restrict__ out_layer, unsigned* __restrict__ dev_err,
     const unsigned long long* __restrict__ zrange, float* s_red, int* s_cand, int* s_wave_cnt,
-    double* s_best, double* s_atan, float* s_elev, float* s_park_angle, unsigned* s_park_meta) {
+    double* s_best, double* s_atan, float* s_elev, float* s_park_angle, unsigned* s_park_meta,
+    const int tile_x, const int tile_y) {
   const int lane = threadIdx.x & 63;
   const int wid = threadIdx.x >> 6;
-  const int i = blockIdx.x * kTileI + lane;
-  const int j0 = blockIdx.y * kTileJ;
+  const int i = tile_x * kTileI + lane;
+  const int j0 = tile_y * kTileJ;
   const bool i_ok = i < p.rows;
   if constexpr (kFast) {
     // fold_finish()'s atan table (doubles 8 .. 24 behind the frame table) next to the lanes: a
@@ -728,9 +729,9 @@ __device__ __forceinline__ void ortho_backward_tile(
   }
 
   // tile extents (cell centres)
-  const int i_hi = min(blockIdx.x * kTileI + kTileI, p.rows) - 1;
+  const int i_hi = min(tile_x * kTileI + kTileI, p.rows) - 1;
   const int j_hi = min(j0 + kTileJ, p.cols) - 1;
-  const double xa = p.base_x + p.res * (-(double)((int)(blockIdx.x * kTileI) + p.i_off));
+  const double xa = p.base_x + p.res * (-(double)(tile_x * kTileI + p.i_off));
   const double xb = p.base_x + p.res * (-(double)(i_hi + p.i_off));
   const double ya = p.base_y + p.res * (-(double)(j0 + p.j_off));
   const double yb = p.base_y + p.res * (-(double)(j_hi + p.j_off));
@@ -838,7 +839,7 @@ __device__ __forceinline__ void ortho_backward_tile(
       float *__restrict__ elevation_angle, float *__restrict__ observation_index,            \
       float *__restrict__ num_observations, float *__restrict__ out_layer,                   \
       unsigned *__restrict__ dev_err, const unsigned long long *__restrict__ zrange
-#define AMHIP_ORTHO_KERNEL_BODY(FAST, SLAB)                                                      \
+#define AMHIP_ORTHO_KERNEL_LDS(SLAB)                                                           \
   __shared__ float s_red[2 * (kOrthoThreads / 64)];                                          \
   __shared__ int s_cand[kChunk];                                                             \
   __shared__ int s_wave_cnt[kOrthoThreads / 64];                                             \
@@ -846,11 +847,29 @@ __device__ __forceinline__ void ortho_backward_tile(
   __shared__ double s_atan[kAtanTabSize];                                                    \
   __shared__ float s_elev[kTileI * kTileJ];                                                  \
   __shared__ float s_park_angle[kOrthoThreads * ((SLAB) / (kOrthoThreads / 64))];            \
-  __shared__ unsigned s_park_meta[kOrthoThreads * ((SLAB) / (kOrthoThreads / 64))];          \
-  ortho_backward_tile<FAST, SLAB>(p, poses, fast_tab, frames, elevation, elevation_angle,          \
-                            observation_index, num_observations, out_layer, dev_err, zrange, \
-                            s_red, s_cand, s_wave_cnt, s_best, s_atan, s_elev, s_park_angle, \
-                            s_park_meta);
+  __shared__ unsigned s_park_meta[kOrthoThreads * ((SLAB) / (kOrthoThreads / 64))];
+// one workgroup per tile of the map (blockIdx = tile)
+#define AMHIP_ORTHO_KERNEL_BODY(FAST, SLAB)                                                      \
+  AMHIP_ORTHO_KERNEL_LDS(SLAB)                                                               \
+  ortho_backward_tile<FAST, SLAB>(p, poses, fast_tab, frames, elevation, elevation_angle,    \
+                                  observation_index, num_observations, out_layer, dev_err,   \
+                                  zrange, s_red, s_cand, s_wave_cnt, s_best, s_atan, s_elev, \
+                                  s_park_angle, s_park_meta, (int)blockIdx.x, (int)blockIdx.y);
+// a fixed grid walks the list k_ortho_tile_list made of the tiles some frame of the batch can
+// see (kernels of their own: the loop's extra live values would cost the dense kernels registers)
+#define AMHIP_ORTHO_KERNEL_BODY_LIST(FAST, SLAB)                                                 \
+  AMHIP_ORTHO_KERNEL_LDS(SLAB)                                                               \
+  const unsigned count = *tile_count;                                                        \
+  const int ntx = (p.rows + kTileI - 1) / kTileI;                                            \
+  for (unsigned t = blockIdx.x; t < count; t += gridDim.x) {                                 \
+    const int tile = tile_list[t];                                                           \
+    ortho_backward_tile<FAST, SLAB>(p, poses, fast_tab, frames, elevation, elevation_angle,  \
+                                    observation_index, num_observations, out_layer, dev_err, \
+                                    zrange, s_red, s_cand, s_wave_cnt, s_best, s_atan,       \
+                                    s_elev, s_park_angle, s_park_meta, tile % ntx,           \
+                                    tile / ntx);                                             \
+    __syncthreads(); /* the next tile reuses every LDS array */                              \
+  }
 
 // every pair in the reference's arithmetic (distorted cameras, non-unit quaternions)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
@@ -868,6 +887,61 @@ __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per
 k_ortho_backward_fast4(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(true, 8)
 }
+// the same two over a tile list (small batches onto a large map, below)
+__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
+k_ortho_backward_list(AMHIP_ORTHO_KERNEL_ARGS, const int* __restrict__ tile_list,
+                      const unsigned* __restrict__ tile_count) {
+  AMHIP_ORTHO_KERNEL_BODY_LIST(false, 16)
+}
+__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_ortho_backward_fast4_list(AMHIP_ORTHO_KERNEL_ARGS, const int* __restrict__ tile_list,
+                            const unsigned* __restrict__ tile_count) {
+  AMHIP_ORTHO_KERNEL_BODY_LIST(true, 8)
+}
+
+// Small batches onto a large map (incremental mapping: one frame or a 64-frame batch sees a few
+// per cent of a 40 000 x 40 000 map): a dense launch spends its time DISPATCHING workgroups that
+// leave at once (390 K tiles: 0.5 ms of the 1.5 ms of a 64-frame batch, all of the 0.56 ms of a
+// single frame).  One lane per tile asks the dense launch's own first question -- can ANY frame of
+// the batch see the tile's bounding sphere over the range of heights the DSM ever wrote (phase 0
+// of ortho_backward_tile, the same arithmetic) -- and the tiles that pass go onto a list a fixed
+// grid walks.  Only while every layer is materialized: a lazily reset layer has to be written
+// everywhere, which is the dense launch's job.
+__global__ void __launch_bounds__(256)
+k_ortho_tile_list(OrthoParams p, const FramePose* __restrict__ poses,
+                  const unsigned long long* __restrict__ zrange, int* __restrict__ list,
+                  unsigned* __restrict__ count) {
+  const int ntx = (p.rows + kTileI - 1) / kTileI, nty = (p.cols + kTileJ - 1) / kTileJ;
+  const int tile = blockIdx.x * 256 + threadIdx.x;
+  bool any = false;
+  if (tile < ntx * nty) {
+    const int tx = tile % ntx, ty = tile / ntx;
+    const int i_hi = min(tx * kTileI + kTileI, p.rows) - 1;
+    const int j0 = ty * kTileJ, j_hi = min(j0 + kTileJ, p.cols) - 1;
+    const double xa = p.base_x + p.res * (-(double)(tx * kTileI + p.i_off));
+    const double xb = p.base_x + p.res * (-(double)(i_hi + p.i_off));
+    const double ya = p.base_y + p.res * (-(double)(j0 + p.j_off));
+    const double yb = p.base_y + p.res * (-(double)(j_hi + p.j_off));
+    const double hx = 0.5 * fabs(xa - xb), hy = 0.5 * fabs(ya - yb);
+    const double glo = from_ordered_key(zrange[0]), ghi = from_ordered_key(zrange[1]);
+    if (glo <= ghi) {
+      const double ghz = 0.5 * (ghi - glo) * (1.0 + 1e-6) + 1e-3;  // float-rounded heights
+      const V3 gc = {0.5 * (xa + xb), 0.5 * (ya + yb), 0.5 * (glo + ghi)};
+      const double gr = (sqrt(hx * hx + hy * hy + ghz * ghz) * (1.0 + 1e-9) + 1e-6) * p.radius_scale;
+      for (int f = 0; f < p.num_frames && !any; ++f) any = frame_may_see(p, poses[f], gc, gr);
+    }
+  }
+  // (one returning atomic per wave)
+  const unsigned long long m = __ballot(any);
+  if (m) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (any) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = tile;
+  }
+}
 
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
               const uint8_t* dev_frames) {
@@ -880,6 +954,31 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   const int fast_waves = fw ? std::atoi(fw) : 4;
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
+  // small batch, big map, the output layers materialized: only the tiles some frame can see
+  // (AMHIP_ORTHO_NO_TILE_LIST=1: the dense launch -- A-B and tests).  num_observations may stay
+  // lazily initial: the kernels neither read nor write it then.
+  const size_t ntiles = (size_t)grid.x * (size_t)grid.y;
+  // (from 16 K tiles: below, dispatching every tile costs less than the list's extra launch)
+  if (p.coarse && !p.virt_out && ntiles >= 16384 && !std::getenv("AMHIP_ORTHO_NO_TILE_LIST")) {
+    int rc;
+    if ((rc = ensure_capacity(&c->ortho_list, &c->ortho_list_cap, ntiles + 16))) return rc;
+    unsigned* cnt = reinterpret_cast<unsigned*>(c->ortho_list);
+    AMHIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_ortho_tile_list, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream,
+                       p, dev_poses, c->dev_zrange, c->ortho_list + 4, cnt);
+    OrthoParams q = p;
+    q.coarse = 0;  // (the list kernel asked the question already)
+    const dim3 lgrid((unsigned)std::min<size_t>(ntiles, 256 * 16));
+    hipLaunchKernelGGL(p.fast ? k_ortho_backward_fast4_list : k_ortho_backward_list, lgrid,
+                       dim3(kOrthoThreads), 0, c->stream, q, dev_poses, dev_fast, dev_frames,
+                       c->layers[AMHIP_LAYER_ELEVATION], c->layers[AMHIP_LAYER_ELEVATION_ANGLE],
+                       c->layers[AMHIP_LAYER_OBSERVATION_INDEX],
+                       c->layers[AMHIP_LAYER_NUM_OBSERVATIONS], out, c->dev_err,
+                       (const unsigned long long*)nullptr, (const int*)(c->ortho_list + 4),
+                       (const unsigned*)cnt);
+    AMHIP_TRY(hipGetLastError());
+    return AMHIP_OK;
+  }
   hipLaunchKernelGGL(kernel, grid, dim3(kOrthoThreads), 0, c->stream,
                      p, dev_poses, dev_fast, dev_frames,
                      c->layers[AMHIP_LAYER_ELEVATION],

@@ -219,3 +219,52 @@ def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(monkeypatch, 
     assert (~np.isnan(want["observation_index"])).mean() > 0.5
     for name in ("rect", "pruned"):
         S.assert_layers_equal(results[name], want, LAYERS)
+
+
+def test_small_batches_onto_a_large_map_walk_a_tile_list(monkeypatch):
+    """Round 4: a small batch (<= 64 frames) onto a map of >= 16 384 mosaic tiles with materialized
+    layers does not dispatch a workgroup per tile: one lane per tile asks the dense launch's own first
+    question (can any frame see the tile's bounding sphere?) and a fixed grid walks the list
+    (k_ortho_tile_list / k_ortho_backward_fast4_list).  Same layers, bit for bit, as the dense launch
+    (AMHIP_ORTHO_NO_TILE_LIST=1), which the oracle tests hold to the reference."""
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import synth
+    side, res = 8320, 1.0                       # 130 x 130 tiles of 64 x 64 cells
+    L = side * res
+    dev = torch.device("cuda", 0)
+    pts = synth.make_points_torch(24_000_000, L / 2.0 + 3.0, 91, dev)
+    W, H, F = 320, 240, 40
+    frames = synth.make_frames_torch(F, H, W, 1, 92, dev)
+    poses = synth.make_lawnmower_poses(F, L / 5.0, 400.0 + 600.0, 92, tilt_deg=6.0)
+    ncam = A.NCamera(300.0, 300.0, (W - 1) / 2.0, (H - 1) / 2.0, W, H)
+    names = ("elevation_angle", "observation_index", "ortho", "num_observations")
+
+    def run(dense):
+        if dense:
+            monkeypatch.setenv("AMHIP_ORTHO_NO_TILE_LIST", "1")
+        else:
+            monkeypatch.delenv("AMHIP_ORTHO_NO_TILE_LIST", raising=False)
+        with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, res)) as m:
+            A.Dsm(A.DsmSettings(), m).process(pts, m)
+            mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
+            mosaic.process(poses[:8], frames[:8], m)        # (lazily reset layers: the dense launch either way)
+            mosaic.process(poses[8:24], frames[8:24], m)    # a batch
+            for k in range(24, F):                          # single frames
+                mosaic.process(poses[k:k + 1], frames[k:k + 1], m)
+            times = None
+            m.enable_timing(True)
+            m.timing_reset()
+            mosaic.process(poses[30:31], frames[30:31], m)
+            times = m.kernel_times()["k_ortho_backward"][0]
+            return {n: m.get(n) for n in names}, times
+
+    listed, t_list = run(False)
+    dense, t_dense = run(True)
+    seen = ~np.isnan(listed["observation_index"])
+    assert 0.002 < seen.mean() < 0.9
+    for n in names:
+        a, b = listed[n], dense[n]
+        eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert eq.all(), (n, int((~eq).sum()))
+    assert t_list < t_dense                                   # (one frame: a few tiles instead of 16 900 workgroups)
