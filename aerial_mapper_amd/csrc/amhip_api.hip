@@ -214,13 +214,63 @@ static void dsm_rough_policy(Ctx* c) {
   }
 }
 
+// A SMALL cloud onto a LARGE resident map (the incremental demo: one stereo pair's 360 K points
+// per call onto a map of 1e8 .. 1.6e9 cells, main-ortho-backward-grid-incremental.cc:143-157).
+// Binned over the context's whole window the call costs O(map): a 400 MB memset and scan of the
+// bin table of a 40 000 x 40 000 map, an occupancy pre-pass over its 1.5 M gather tiles -- 0.75 ms
+// for 0.05 ms of work.  Instead: the bounding box of the points the binning would accept (one
+// pass over the cloud, five integers back to the host: the one synchronisation of such a call),
+// grown by the last fallback radius -- no cell outside it can receive a value -- becomes the
+// window of THIS call; the kernels run unchanged on it and write into the full layer
+// (DsmParams::out_*).  Only while the layer is materialized (a lazily reset layer has to be
+// written everywhere).  AMHIP_DSM_NO_SUBWINDOW=1: never.
+// Returns 1: *p_sub is the call's parameter set; 0: run on the whole window; 2: no point near the
+// window, nothing to do; < 0: error.
+static int make_dsm_params(const Ctx& c, int radius_sq, double center_easting, double center_northing,
+                           DsmParams* out, int mode, int pcl_lambda, size_t num_points);
+static int dsm_subwindow(Ctx* c, const double* dev_xyz, size_t n, int radius_sq, double center_easting,
+                         double center_northing, const DsmParams& p_full, DsmParams* p_sub) {
+  if (n > (1u << 20) || c->cells < (size_t)(4u << 20) || !c->dev_bbox || !c->host_bbox ||
+      std::getenv("AMHIP_DSM_NO_SUBWINDOW"))
+    return 0;
+  int rc;
+  if ((rc = dsm_bbox_run(c, dev_xyz, n, p_full, c->dev_bbox))) return -rc;
+  if (hipMemcpyAsync(c->host_bbox, c->dev_bbox, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess)
+    return -hip_fail(hipGetLastError(), "bounding box of the cloud", __FILE__, __LINE__);
+  const int* b = c->host_bbox;
+  if (b[4] == 0) return 2;
+  const int grow = p_full.w[p_full.nlevels - 1] + 2;   // last radius of the ladder, in cells (+ slack)
+  const int i_lo = std::max(0, b[0] - grow), i_hi = std::min(p_full.rows - 1, b[1] + grow);
+  const int j_lo = std::max(0, b[2] - grow), j_hi = std::min(p_full.cols - 1, b[3] + grow);
+  if (i_lo > i_hi || j_lo > j_hi) return 2;             // (every binned point lies beyond the border by more than the radius)
+  const size_t sub = (size_t)(i_hi - i_lo + 1) * (size_t)(j_hi - j_lo + 1);
+  if (sub * 4 > c->cells) return 0;                     // not small against the map: nothing to win
+  // the same context, seen through the sub-window
+  const int wi0 = c->win_i0, wj0 = c->win_j0, wr = c->win_rows, wc = c->win_cols;
+  c->win_i0 = wi0 + i_lo;
+  c->win_j0 = wj0 + j_lo;
+  c->win_rows = i_hi - i_lo + 1;
+  c->win_cols = j_hi - j_lo + 1;
+  rc = make_dsm_params(*c, radius_sq, center_easting, center_northing, p_sub, 0, 1, n);
+  c->win_i0 = wi0;
+  c->win_j0 = wj0;
+  c->win_rows = wr;
+  c->win_cols = wc;
+  if (rc) return -rc;
+  p_sub->out_i0 = i_lo;
+  p_sub->out_j0 = j_lo;
+  p_sub->out_pitch = wr;
+  return 1;
+}
+
 // mode 0: dsm::Dsm ladder.  mode 1: ortho::OrthoFromPcl, one search with the
 // squared radius `radius_sq * pcl_lambda` (pcl_lambda = 1 for the first search,
 // 10, 100, ... for the adaptive retries, ortho-from-pcl.cc:63-71).
 static int make_dsm_params(const Ctx& c, int radius_sq,
                            double center_easting, double center_northing,
-                           DsmParams* out, int mode = 0, int pcl_lambda = 1,
-                           size_t num_points = 0) {
+                           DsmParams* out, int mode, int pcl_lambda,
+                           size_t num_points) {
   const amhip_grid_desc& g = c.grid;
   DsmParams p;
   std::memset(&p, 0, sizeof(p));
@@ -450,6 +500,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     p.lds_bytes_f32 = static_cast<unsigned>((bytes + 15) & ~size_t(15));
     p.fx_ok = 1;
   }
+  p.out_i0 = p.out_j0 = 0;
+  p.out_pitch = p.rows;
   *out = p;
   return AMHIP_OK;
 }
@@ -859,6 +911,8 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_tile_stats), 8 * sizeof(unsigned), 0);
       if (e == hipSuccess) std::memset(c->host_tile_stats, 0, 8 * sizeof(unsigned));
     }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_bbox), 8 * sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->host_bbox), 8 * sizeof(int), 0);
     if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
     if (e != hipSuccess) {
       rc = hip_fail(e, "context allocation", __FILE__, __LINE__);
@@ -888,12 +942,13 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->dev_bbox, c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->host_err) (void)hipHostFree(c->host_err);
   if (c->host_tile_stats) (void)hipHostFree(c->host_tile_stats);
+  if (c->host_bbox) (void)hipHostFree(c->host_bbox);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
 }
@@ -1073,6 +1128,13 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
     c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
   else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
     return rc;
+  if (!fused_fill) {  // a small cloud onto a large materialized map: its bounding box is the window
+    DsmParams ps;
+    const int sw = dsm_subwindow(c, dev_xyz, n, radius_sq, center_easting, center_northing, p, &ps);
+    if (sw < 0) return -sw;
+    if (sw == 2) return AMHIP_OK;  // (no point within the last radius of any cell: every cell stays)
+    if (sw == 1) p = ps;
+  }
   return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr,
                  fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION),
                  c->zrange_valid ? c->dev_zrange : nullptr);

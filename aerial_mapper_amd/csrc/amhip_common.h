@@ -89,6 +89,11 @@ struct DsmParams {
   float fx_epsw;              // bound on the relative error of one weight
   unsigned lds_bytes_f32;
   int canon_all;              // tests: every FP64 quotient goes through canonical_search (amhip_dsm.hip)
+  // Where cell (i, j) of THIS call's window lives in the layer it writes: out_i0 + i + (out_j0 + j)
+  // * out_pitch.  A call on the context's whole window: 0, 0, rows.  A small cloud onto a large map
+  // runs on a SUB-window around the cloud's bounding box (amhip_api.hip: dsm_subwindow) and
+  // writes into the full layer.
+  int out_i0, out_j0, out_pitch;
 };
 
 // The binned cloud as the gather sees it (amhip_dsm.hip: pts_x / pts_y / pts_z; filled by
@@ -271,6 +276,8 @@ struct Ctx {
   size_t frame_pose_cap = 0;
   uint8_t* stage_frames = nullptr;
   size_t stage_frames_cap = 0;
+  int* dev_bbox = nullptr;       // k_dsm_bbox: [min i, max i, min j, max j, count] of a small cloud
+  int* host_bbox = nullptr;      // pinned mirror
   int* ortho_list = nullptr;     // [count (4 ints)] [tiles some frame of a small batch can see]
   size_t ortho_list_cap = 0;
 
@@ -331,6 +338,9 @@ int densify_run(Ctx* c, const DensifyParams& p, const float* dev_disparity,
 // multi-GPU halo selection
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
                     double* dev_out, unsigned long long* dev_counts);
+// cells (of p's window, point_bin's arithmetic) the points of a cloud fall into: dev_bbox5 =
+// [min i, max i, min j, max j, points inside the binned area] (amhip_sort.hip)
+int dsm_bbox_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p, int* dev_bbox5);
 // geometry of a selection for `nd` destination windows (amhip_api.hip); off / cap_d are set to
 // the equal-split layout (d * cap_per_dest, cap_per_dest)
 int make_halo_params(const Ctx& c, double center_easting, double center_northing,

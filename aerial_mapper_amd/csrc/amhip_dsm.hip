@@ -192,14 +192,19 @@ __device__ __forceinline__ double call_zmax(const CellOut& o) {
   return lo <= hi ? fmax(fabs(lo), fabs(hi)) : 0.0;
 }
 
+// cell (i, j) of the call's window in the layer (and mask) it writes: DsmParams::out_*
+__device__ __forceinline__ size_t cell_at(const DsmParams& p, int i, int j) {
+  return (size_t)(p.out_i0 + i) + (size_t)(p.out_j0 + j) * (size_t)p.out_pitch;
+}
+
 __device__ __forceinline__ void leave_untouched(const DsmParams& p, const CellOut& o, int i,
                                                 int j) {
-  if (o.fill_untouched) o.layer[(size_t)i + (size_t)j * (size_t)p.rows] = o.init_value;
+  if (o.fill_untouched) o.layer[cell_at(p, i, j)] = o.init_value;
 }
 
 __device__ __forceinline__ void emit_value(const DsmParams& p, const CellOut& o, int i, int j,
                                            double v) {
-  const size_t at = (size_t)i + (size_t)j * (size_t)p.rows;
+  const size_t at = cell_at(p, i, j);
   o.layer[at] = (float)v;
   if (o.mask) o.mask[at] = 1;
 }
@@ -424,7 +429,7 @@ __device__ __forceinline__ void cell_global(const DsmParams& p,
                                             const uint32_t* __restrict__ start,
                                             const Pts P, int i, int j,
                                             const CellOut& o) {
-  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  if (p.only_unfilled && o.mask[cell_at(p, i, j)]) return;
   // grid_map_core getPosition (oracle/amo_compat.h cell_position)
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
@@ -550,7 +555,7 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
   const int a = cidx & 3, bq = cidx >> 2;
   if (lane >= 32 || (lane & 1) || bi0 + a > bi1 || bj0 + bq > bj1) return;
   const int i = bi0 + a, j = bj0 + bq;
-  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  if (p.only_unfilled && o.mask[cell_at(p, i, j)]) return;
   if (((exact >> cidx) & 1u) || !(my_den > 0.0)) {
     // exact hit (CHECK failure / OrthoFromPcl's perfect match, which depends on
     // the scan order) or an empty first search (the ladder): the scalar routine
@@ -585,7 +590,7 @@ k_dsm_gather_knn(DsmParams p, const uint32_t* __restrict__ start,
   const int i = blockIdx.x * 64 + (threadIdx.x & 63);
   const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (i >= p.rows || j >= p.cols) return;
-  if (p.only_unfilled && o.mask[(size_t)i + (size_t)j * (size_t)p.rows]) return;
+  if (p.only_unfilled && o.mask[cell_at(p, i, j)]) return;
   cell_global_knn(p, start, P, i, j, o);
 }
 
@@ -1146,7 +1151,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           // (round_is_certain, with its lower float stored: the same value as (float)hq then)
           const float f_lo = (float)(hq - err_pair), f_hi = (float)(hq + err_pair);
           if (f_lo == f_hi) {
-            const size_t at = (size_t)i + (size_t)jj * (size_t)p.rows;
+            const size_t at = cell_at(p, i, jj);
             o.layer[at] = f_lo;
             if (o.mask) o.mask[at] = 1;
           } else {

@@ -1377,6 +1377,87 @@ int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& h
 }
 
 // ---------------------------------------------------------------------------
+// bounding box, in cells of p's window, of the points point_bin() would bin (small clouds onto
+// large maps: the call then runs on a sub-window, amhip_api.hip)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_dsm_bbox(const double* __restrict__ xyz, size_t n, DsmParams p, int* __restrict__ out5) {
+  int lo_i = 0x7FFFFFFF, hi_i = -0x7FFFFFFF, lo_j = 0x7FFFFFFF, hi_j = -0x7FFFFFFF;
+  unsigned cnt = 0;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < n; idx += stride) {
+    const double px = xyz[3 * idx + 0] - p.sub_x;  // dsm.cc:42
+    const double py = xyz[3 * idx + 1] - p.sub_y;  // dsm.cc:43
+    // (point_bin's own test and rounding)
+    const double cx = (p.base_x - px) * p.inv_res - (double)p.i_off;
+    const double cy = (p.base_y - py) * p.inv_res - (double)p.j_off;
+    const double lo = -(double)p.M - 0.5;
+    const double hx = (double)(p.rows + p.M) - 0.5;
+    const double hy = (double)(p.cols + p.M) - 0.5;
+    if (!(cx >= lo && cx < hx && cy >= lo && cy < hy)) continue;
+    const int ix = (int)floor(cx + 0.5), iy = (int)floor(cy + 0.5);
+    lo_i = min(lo_i, ix);
+    hi_i = max(hi_i, ix);
+    lo_j = min(lo_j, iy);
+    hi_j = max(hi_j, iy);
+    ++cnt;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    lo_i = min(lo_i, __shfl_xor(lo_i, d, 64));
+    hi_i = max(hi_i, __shfl_xor(hi_i, d, 64));
+    lo_j = min(lo_j, __shfl_xor(lo_j, d, 64));
+    hi_j = max(hi_j, __shfl_xor(hi_j, d, 64));
+    cnt += __shfl_xor(cnt, d, 64);
+  }
+  // (one set of atomics per WORKGROUP, a hundred workgroups: thousands of atomics on the same five
+  // words serialise in the L2 -- 0.26 ms for a 360 K-point cloud when every wave sent its own)
+  __shared__ int s_box[4][5];
+  if ((threadIdx.x & 63) == 0) {
+    int* w = s_box[threadIdx.x >> 6];
+    w[0] = lo_i;
+    w[1] = hi_i;
+    w[2] = lo_j;
+    w[3] = hi_j;
+    w[4] = (int)cnt;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (int k = 0; k < 4; ++k) {
+      lo_i = min(lo_i, s_box[k][0]);
+      hi_i = max(hi_i, s_box[k][1]);
+      lo_j = min(lo_j, s_box[k][2]);
+      hi_j = max(hi_j, s_box[k][3]);
+      total += (unsigned)s_box[k][4];
+    }
+    if (total) {
+      atomicMin(&out5[0], lo_i);
+      atomicMax(&out5[1], hi_i);
+      atomicMin(&out5[2], lo_j);
+      atomicMax(&out5[3], hi_j);
+      atomicAdd(reinterpret_cast<unsigned*>(&out5[4]), total);
+    }
+  }
+}
+__global__ void k_dsm_bbox_reset(int* __restrict__ out5) {
+  out5[0] = 0x7FFFFFFF;
+  out5[1] = -0x7FFFFFFF;
+  out5[2] = 0x7FFFFFFF;
+  out5[3] = -0x7FFFFFFF;
+  out5[4] = 0;
+}
+
+int dsm_bbox_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p, int* dev_bbox5) {
+  ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
+  hipLaunchKernelGGL(k_dsm_bbox_reset, dim3(1), dim3(1), 0, c->stream, dev_bbox5);
+  size_t grid = std::min<size_t>((n + 2047) / 2048, 128);
+  hipLaunchKernelGGL(k_dsm_bbox, dim3((unsigned)grid), dim3(256), 0, c->stream, dev_xyz, n, p, dev_bbox5);
+  AMHIP_TRY(hipGetLastError());
+  return AMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
 // exclusive scan of a u32 array, in place (3 launches)
 // ---------------------------------------------------------------------------
 constexpr int kScanT = 256;

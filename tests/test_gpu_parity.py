@@ -817,3 +817,50 @@ def test_ortho_coarse_cull_with_the_tracked_height_range():
             assert (~np.isnan(layers["observation_index"])).mean() > 0.3
             assert np.nanmax(layers["elevation"]) > 460.0
             m.reset()
+
+
+def test_dsm_small_cloud_on_a_large_map_runs_on_its_bounding_box(monkeypatch):
+    """Round 4: a cloud of < 2^20 points onto a materialized map of >= 4 M cells is binned and
+    gathered on a SUB-window around its bounding box (amhip_api.hip: dsm_subwindow), writing into
+    the full layer -- the incremental demo's call per stereo pair.  Same heights as the whole-window
+    call (AMHIP_DSM_NO_SUBWINDOW=1) in both modes, cells outside the box untouched, clouds across
+    the map's corner and wholly beyond its border included; against the oracle on the whole map."""
+    A = _A()
+    rows, cols, res = 2304, 2048, 0.5                      # 4.7 M cells
+    lx, ly = rows * res, cols * res
+    g = O.make_grid(lx, ly, res, 100.0, -50.0)
+    st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
+    rng = np.random.default_rng(77)
+    centres = [(-300.0, 200.0),                                            # inside the map
+               (g.pos_x + lx / 2 - 10.0, g.pos_y - ly / 2 + 12.0),         # across a corner
+               (g.pos_x - lx / 2 - 40.0, 0.0)]                             # wholly outside, beyond the radius
+    clouds = [np.c_[rng.uniform(cx - 40.0, cx + 40.0, 60000), rng.uniform(cy - 25.0, cy + 25.0, 60000),
+                    400.0 + rng.uniform(-1.0, 1.0, 60000)] for cx, cy in centres]
+    clouds[2][:, 0] = rng.uniform(g.pos_x - lx / 2 - 60.0, g.pos_x - lx / 2 - 20.0, 60000)
+    base = rng.uniform(300.0, 310.0, (cols, rows)).astype(np.float32)
+    want = base.copy()                                     # the oracle: earlier content where no point reaches
+    for pts in clouds:
+        rc, want, _ = O.dsm_process(pts, g, 1, 0.0, 0.0, elevation=want)
+        assert rc == O.OK
+    for exact in (True, False):
+        outs = {}
+        for sub in (True, False):
+            if sub:
+                monkeypatch.delenv("AMHIP_DSM_NO_SUBWINDOW", raising=False)
+            else:
+                monkeypatch.setenv("AMHIP_DSM_NO_SUBWINDOW", "1")
+            with A.AerialGridMap(st) as m:
+                m.set_dsm_precision(exact)
+                m.set("elevation", base)                   # a materialized layer with earlier content
+                dsm = A.Dsm(A.DsmSettings(), m)
+                for pts in clouds:
+                    dsm.process(pts, m)
+                outs[sub] = m.get("elevation")
+        a, b = outs[True], outs[False]
+        if exact:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        else:
+            assert np.abs(a.astype(np.float64) - b).max() <= 1e-4
+        changed = a != base
+        assert 0.001 < changed.mean() < 0.05                # two patches of 80 x 50 m on a 1152 x 1024 m map
+        S.assert_dsm_close(a, want, tol=1e-6 if exact else 1e-4)
