@@ -1044,6 +1044,27 @@ static void overwrite(Ctx* c, int layer) {
 
 namespace amhip {
 int ctx_use_device(Ctx* c) { return use_device(c); }
+int ctx_last_dirty(Ctx* c, int rect[4]) {
+  if (c->dirty_on_device) {
+    // (k_ortho_tile_list left [min tx, max tx, min ty, max ty] of the listed tiles behind the count)
+    if (!c->ortho_list || !c->host_bbox) return arg_fail("no tile list");
+    AMHIP_TRY(hipMemcpyAsync(c->host_bbox, c->ortho_list, 8 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    const int* b = c->host_bbox;
+    if (b[0] == 0 || b[4] > b[5] || b[6] > b[7]) {
+      c->dirty[0] = c->dirty[1] = c->dirty[2] = c->dirty[3] = 0;
+    } else {
+      const int i0 = b[4] * 64, j0 = b[6] * 64;   // (the mosaic's tiles: 64 x 64 cells)
+      c->dirty[0] = i0;
+      c->dirty[1] = j0;
+      c->dirty[2] = std::min(c->win_rows, (b[5] + 1) * 64) - i0;
+      c->dirty[3] = std::min(c->win_cols, (b[7] + 1) * 64) - j0;
+    }
+    c->dirty_on_device = false;
+  }
+  for (int k = 0; k < 4; ++k) rect[k] = c->dirty[k];
+  return AMHIP_OK;
+}
 int ctx_materialize(Ctx* c, int layer) { return materialize(c, layer); }
 void ctx_overwrite(Ctx* c, int layer) { overwrite(c, layer); }
 int ctx_fetch_status(Ctx* c) { return fetch_status(c); }
@@ -1128,12 +1149,25 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
     c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
   else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
     return rc;
+  c->dirty_on_device = false;
+  c->dirty[0] = c->dirty[1] = 0;
+  c->dirty[2] = c->win_rows;
+  c->dirty[3] = c->win_cols;
   if (!fused_fill) {  // a small cloud onto a large materialized map: its bounding box is the window
     DsmParams ps;
     const int sw = dsm_subwindow(c, dev_xyz, n, radius_sq, center_easting, center_northing, p, &ps);
     if (sw < 0) return -sw;
-    if (sw == 2) return AMHIP_OK;  // (no point within the last radius of any cell: every cell stays)
-    if (sw == 1) p = ps;
+    if (sw == 2) {  // (no point within the last radius of any cell: every cell stays)
+      c->dirty[2] = c->dirty[3] = 0;
+      return AMHIP_OK;
+    }
+    if (sw == 1) {
+      p = ps;
+      c->dirty[0] = ps.out_i0;
+      c->dirty[1] = ps.out_j0;
+      c->dirty[2] = ps.rows;
+      c->dirty[3] = ps.cols;
+    }
   }
   return dsm_run(c, dev_xyz, nullptr, n, p, c->layers[AMHIP_LAYER_ELEVATION], nullptr, nullptr,
                  fused_fill, layer_init_value(AMHIP_LAYER_ELEVATION),

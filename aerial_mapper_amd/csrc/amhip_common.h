@@ -276,6 +276,12 @@ struct Ctx {
   size_t frame_pose_cap = 0;
   uint8_t* stage_frames = nullptr;
   size_t stage_frames_cap = 0;
+  // The cells of the window the LAST DSM / mosaic call can have written (window coordinates):
+  // the whole window, the sub-window of a small cloud, or the bounding box of the mosaic's tile
+  // list (then still on the device: dirty_on_device, read back by ctx_last_dirty()).  What the
+  // session downloads after the call (amhip_session.hip) instead of whole layers.
+  int dirty[4] = {0, 0, 0, 0};   // i0, j0, rows, cols
+  bool dirty_on_device = false;
   int* dev_bbox = nullptr;       // k_dsm_bbox: [min i, max i, min j, max j, count] of a small cloud
   int* host_bbox = nullptr;      // pinned mirror
   int* ortho_list = nullptr;     // [count (4 ints)] [tiles some frame of a small batch can see]
@@ -363,6 +369,9 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
               const uint8_t* dev_frames);
 
 // context internals shared with amhip_session.hip (defined in amhip_api.hip)
+// i0, j0, rows, cols (window coordinates) of what the last DSM / mosaic call can have written;
+// synchronises the stream when the box is still on the device.  rows == 0: nothing.
+int ctx_last_dirty(Ctx* c, int rect[4]);
 int ctx_use_device(Ctx* c);
 int ctx_materialize(Ctx* c, int layer);      // lazy-initial -> filled
 void ctx_overwrite(Ctx* c, int layer);       // about to be fully overwritten from outside

@@ -940,7 +940,32 @@ k_ortho_tile_list(OrthoParams p, const FramePose* __restrict__ poses,
     if (lane == leader) base = atomicAdd(count, (unsigned)__popcll(m));
     base = __shfl(base, leader, 64);
     if (any) list[base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))] = tile;
+    // the listed tiles' bounding box (what the call can write: the session downloads only that):
+    // ints 4 .. 7 behind the count = min tx, max tx, min ty, max ty
+    int tx_lo = any ? tile % ntx : 0x7FFFFFFF, tx_hi = any ? tile % ntx : -1;
+    int ty_lo = any ? tile / ntx : 0x7FFFFFFF, ty_hi = any ? tile / ntx : -1;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      tx_lo = min(tx_lo, __shfl_xor(tx_lo, d, 64));
+      tx_hi = max(tx_hi, __shfl_xor(tx_hi, d, 64));
+      ty_lo = min(ty_lo, __shfl_xor(ty_lo, d, 64));
+      ty_hi = max(ty_hi, __shfl_xor(ty_hi, d, 64));
+    }
+    if (lane == leader) {
+      int* box = reinterpret_cast<int*>(count) + 4;
+      atomicMin(&box[0], tx_lo);
+      atomicMax(&box[1], tx_hi);
+      atomicMin(&box[2], ty_lo);
+      atomicMax(&box[3], ty_hi);
+    }
   }
+}
+__global__ void k_ortho_tile_list_reset(int* __restrict__ hdr) {
+  hdr[0] = 0;
+  hdr[4] = 0x7FFFFFFF;
+  hdr[5] = -1;
+  hdr[6] = 0x7FFFFFFF;
+  hdr[7] = -1;
 }
 
 int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const FrameFast* dev_fast,
@@ -954,6 +979,10 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   const int fast_waves = fw ? std::atoi(fw) : 4;
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
+  c->dirty_on_device = false;  // (a dense launch can write anywhere in the window)
+  c->dirty[0] = c->dirty[1] = 0;
+  c->dirty[2] = c->win_rows;
+  c->dirty[3] = c->win_cols;
   // small batch, big map, the output layers materialized: only the tiles some frame can see
   // (AMHIP_ORTHO_NO_TILE_LIST=1: the dense launch -- A-B and tests).  num_observations may stay
   // lazily initial: the kernels neither read nor write it then.
@@ -963,9 +992,10 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
     int rc;
     if ((rc = ensure_capacity(&c->ortho_list, &c->ortho_list_cap, ntiles + 16))) return rc;
     unsigned* cnt = reinterpret_cast<unsigned*>(c->ortho_list);
-    AMHIP_TRY(hipMemsetAsync(cnt, 0, sizeof(unsigned), c->stream));
+    hipLaunchKernelGGL(k_ortho_tile_list_reset, dim3(1), dim3(1), 0, c->stream, c->ortho_list);
     hipLaunchKernelGGL(k_ortho_tile_list, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, c->stream,
-                       p, dev_poses, c->dev_zrange, c->ortho_list + 4, cnt);
+                       p, dev_poses, c->dev_zrange, c->ortho_list + 8, cnt);
+    c->dirty_on_device = true;  // (ctx_last_dirty reads the listed tiles' box back on demand)
     OrthoParams q = p;
     q.coarse = 0;  // (the list kernel asked the question already)
     const dim3 lgrid((unsigned)std::min<size_t>(ntiles, 256 * 16));
@@ -974,7 +1004,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
                        c->layers[AMHIP_LAYER_ELEVATION], c->layers[AMHIP_LAYER_ELEVATION_ANGLE],
                        c->layers[AMHIP_LAYER_OBSERVATION_INDEX],
                        c->layers[AMHIP_LAYER_NUM_OBSERVATIONS], out, c->dev_err,
-                       (const unsigned long long*)nullptr, (const int*)(c->ortho_list + 4),
+                       (const unsigned long long*)nullptr, (const int*)(c->ortho_list + 8),
                        (const unsigned*)cnt);
     AMHIP_TRY(hipGetLastError());
     return AMHIP_OK;

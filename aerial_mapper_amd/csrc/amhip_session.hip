@@ -22,7 +22,12 @@
 //                of an upload; anything else is uploaded.  Outputs the kernels did not change
 //                (num_observations: `+= itself`, ortho-backward-grid.cc:183) are not downloaded.
 //                AMHIP_SESSION_ALWAYS_COPY=1: every matrix up and down, like round 1.
+#include <sched.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -75,7 +80,29 @@ struct Session {
   std::vector<double*> cloud;
   std::vector<size_t> cloud_cap;               // doubles
   std::vector<unsigned long long*> dev_hash;   // device scratch: two u64 per layer
+  std::vector<float*> pin;                     // pinned host staging of partial downloads
+  std::vector<size_t> pin_cap;                 // floats
+  bool verify_partial = false;                 // AMHIP_SESSION_VERIFY_PARTIAL: re-sum the host matrix
+  std::atomic<unsigned long long> up_bytes{0}, down_bytes{0};  // layer traffic (amhip_session_transfer_stats)
   int W() const { return (int)ctx.size(); }
+};
+
+// AMHIP_SESSION_TRACE=1: wall time of every phase of a call on stderr (where does a host-matrix
+// call spend its time: content sums, uploads, kernels, downloads?)
+struct PhaseClock {
+  bool on;
+  const char* call;
+  std::chrono::steady_clock::time_point t0;
+  explicit PhaseClock(const char* name)
+      : on(std::getenv("AMHIP_SESSION_TRACE") != nullptr), call(name), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* phase, hipStream_t wait_for = nullptr, bool wait = false) {
+    if (!on) return;
+    if (wait) (void)hipStreamSynchronize(wait_for);
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[amhip session] %s: %-28s %8.3f ms\n", call, phase,
+                 std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
 };
 
 // ---- content sums ------------------------------------------------------------------
@@ -123,17 +150,80 @@ k_layer_hash(const float* __restrict__ layer, float constant, int rows, int cols
   }
 }
 
+// CPUs this process may keep busy: hardware threads, capped by its affinity mask and by a cgroup
+// CPU quota (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1).  *quota_cpus: the quota
+// alone (0: none).  A GPU box's pod runs under such a quota: 256 hardware threads, 16 CPUs' worth of
+// time per 100 ms (tools/ubench/host_sum_bench.cc: 128 summing threads run 12 ms at 200 GB/s,
+// then the whole process is frozen until the period ends).
+static int usable_cpus(double* quota_cpus) {
+  static int cpus = 0;
+  static double quota = 0.0;
+  if (!cpus) {
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 8;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    double q = 0.0;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char a[64] = {0};
+      double period = 0.0;
+      if (std::fscanf(f, "%63s %lf", a, &period) == 2 && period > 0.0 && a[0] >= '0' && a[0] <= '9')
+        q = std::atof(a) / period;
+      std::fclose(f);
+    } else {
+      double qu = -1.0, period = 0.0;
+      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(g, "%lf", &qu) != 1) qu = -1.0;
+        std::fclose(g);
+      }
+      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(g, "%lf", &period) != 1) period = 0.0;
+        std::fclose(g);
+      }
+      if (qu > 0.0 && period > 0.0) q = qu / period;
+    }
+    quota = q;
+    if (q > 0.0) n = std::min(n, std::max(1, (int)std::ceil(q)));
+    cpus = n;
+  }
+  if (quota_cpus) *quota_cpus = quota;
+  return cpus;
+}
+
+// threads for a pass of host threads over `bytes` of matrices
+static int host_threads(size_t bytes) {
+  if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) return std::max(1, std::atoi(e));
+  unsigned hw = std::thread::hardware_concurrency();
+  // (the non-linear mix costs three multiplies per cell: 128 threads keep the six matrices of a
+  // mosaic call -- 2.4 GB at cfg3 -- near the host's memory bandwidth)
+  int T = (int)std::min<unsigned>(hw ? hw : 8u, 128u);
+  double quota = 0.0;
+  const int cpus = usable_cpus(&quota);
+  if (quota > 0.0 && quota < (double)T) {
+    // under a CPU quota: a short pass may burst over four times the quota's CPUs (64 threads draw
+    // 175 GB/s; more only burn the period's allowance in memory stalls); a pass worth more than
+    // ~ 60 % of one period's allowance (100 ms x quota; a thread sums ~ 4.5 GB/s) would get the
+    // process frozen mid-way: one thread per CPU of the quota, steadily.  Measured on the pool's
+    // boxes (quota 16): cfg3's six matrices 75 - 82 ms per first pass whatever the burst width
+    // (32 .. 128), 100 ms at 16 threads; the five 1.6 GB matrices of a 20 000^2 map 180 ms at
+    // 128 threads, 150 ms at 16.
+    const double cpu_seconds = (double)bytes / 4.5e9;
+    T = cpu_seconds <= 0.06 * quota ? std::min(T, 4 * cpus) : cpus;
+  } else {
+    T = std::min(T, std::max(cpus, 1));
+  }
+  return std::max(1, T);
+}
+
 // per-window sums of `nl` host matrices (column-major, the map's size) with host threads
 static void host_hashes(const Session& s, const float* const* mats, int nl,
                         std::vector<Hash128>* out /* [nl][W] */) {
   const int W = s.W(), R = s.grid.rows, Cc = s.grid.cols;
   out->assign((size_t)nl * W, Hash128());
-  unsigned hw = std::thread::hardware_concurrency();
-  // (the non-linear mix costs three multiplies per cell: 128 threads keep the six matrices of a
-  // mosaic call -- 2.4 GB at cfg3 -- near the host's memory bandwidth)
-  int T = (int)std::min<unsigned>(hw ? hw : 8u, 128u);
-  if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) T = std::max(1, std::atoi(e));
-  T = std::max(1, std::min(T, Cc));
+  size_t bytes = 0;
+  for (int l = 0; l < nl; ++l)
+    if (mats[l]) bytes += (size_t)R * (size_t)Cc * 4;
+  const int T = std::max(1, std::min(host_threads(bytes), Cc));
   std::vector<std::vector<Hash128>> part(T, std::vector<Hash128>((size_t)nl * W));
   auto work = [&](int t) {
     const int c0 = (int)((long long)Cc * t / T), c1 = (int)((long long)Cc * (t + 1) / T);
@@ -214,6 +304,7 @@ static int sync_in(Session& s, int k, int layer, const float* host, const Hash12
     st.device_valid = false;
     ctx_overwrite(c, layer);
     AMHIP_TRY(copy_window(c->layers[layer], map_at(host, s, w), s, w, false, c->stream));
+    s.up_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
   }
   st.device = host_hash;
   // (a layer the next kernel writes is unknown until sync_out has summed it again)
@@ -221,14 +312,49 @@ static int sync_in(Session& s, int k, int layer, const float* host, const Hash12
   return AMHIP_OK;
 }
 
-// window layers -> host matrices where the device content differs from what the host holds
-static int sync_out(Session& s, int k, const int* layers, float* const* hosts, int nl) {
+// columns [0, cols) of a packed rows x cols block -> the map-shaped host matrix at (i, j)
+static void unpack_block(const float* packed, float* host, const Session& s, int i, int j, int rows,
+                         int cols) {
+  const size_t bytes = (size_t)rows * (size_t)cols * 4;
+  const int T = bytes < (8u << 20) ? 1 : std::min(16, cols);
+  auto work = [&](int t) {
+    const int c0 = (int)((long long)cols * t / T), c1 = (int)((long long)cols * (t + 1) / T);
+    for (int q = c0; q < c1; ++q)
+      std::memcpy(host + (size_t)i + (size_t)(j + q) * (size_t)s.grid.rows, packed + (size_t)q * rows,
+                  (size_t)rows * 4);
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
+}
+
+// window layers -> host matrices where the device content differs from what the host holds.
+// dirty_ok: the call before was a DSM / backward-mosaic call, whose context knows which cells of
+// the window it can have written (ctx_last_dirty): a small cloud's sub-window, the bounding box of
+// a small batch's tile list.  A host matrix that equalled the device layer BEFORE the call (what
+// sync_in establishes) differs from it only there: that rectangle is downloaded (device -> pinned
+// staging -> the matrix's columns) instead of the window -- the incremental use case on a large
+// map downloads megabytes instead of gigabytes per call.  AMHIP_SESSION_NO_PARTIAL=1: always the
+// whole window (A-B, tests).
+static int sync_out(Session& s, int k, const int* layers, float* const* hosts, int nl,
+                    bool dirty_ok = false) {
+  PhaseClock clock("sync_out");
   Ctx* c = &s.ctx[k]->impl;
   int rc = ctx_use_device(c);
   if (rc) return rc;
   const Win& w = s.win[k];
   Hash128 h[AMHIP_NUM_LAYERS];
   bool run[AMHIP_NUM_LAYERS] = {};
+  int rect[4] = {0, 0, w.rows, w.cols};
+  bool partial = false;
+  if (dirty_ok && !s.always_copy && !std::getenv("AMHIP_SESSION_NO_PARTIAL")) {
+    if ((rc = ctx_last_dirty(c, rect))) return rc;
+    partial = rect[2] > 0 && rect[3] > 0 && rect[0] >= 0 && rect[1] >= 0 &&
+              rect[0] + rect[2] <= w.rows && rect[1] + rect[3] <= w.cols &&
+              2 * (size_t)rect[2] * (size_t)rect[3] <= (size_t)w.rows * (size_t)w.cols;
+  }
+  clock.mark("kernels (wait)", c->stream, true);
   if (!s.always_copy) {
     AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS, c->stream));
     for (int q = 0; q < nl; ++q) {
@@ -251,28 +377,76 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
         h[q].b = got[2 * q + 1];
       }
   }
+  clock.mark("device content sums");
   // A download is asynchronous: until the stream has synchronised without an error the host
   // matrix may be stale or half written, so the layers being downloaded are marked "host
   // unknown" FIRST and "host == device sum" only after the wait (a failed copy must
   // not leave the session believing the host holds h[q] -- the next call would skip it).
   bool copied[AMHIP_NUM_LAYERS] = {};
+  bool packed[AMHIP_NUM_LAYERS] = {};
   bool any = false;
+  const size_t block = (size_t)rect[2] * (size_t)rect[3];
+  if (partial) {  // (staging for every layer of the call, at most 1 GiB: beyond, the plain way)
+    const size_t need = block * (size_t)nl;
+    if (need * 4 > (1ull << 30)) {
+      partial = false;
+    } else if (need > s.pin_cap[k]) {
+      if (s.pin[k]) (void)hipHostFree(s.pin[k]);
+      s.pin[k] = nullptr;
+      s.pin_cap[k] = 0;
+      if (hipHostMalloc(reinterpret_cast<void**>(&s.pin[k]), need * 4, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        s.pin[k] = nullptr;
+        partial = false;
+      } else {
+        s.pin_cap[k] = need;
+      }
+    }
+  }
   for (int q = 0; q < nl; ++q) {
     if (!hosts[q]) continue;
     const int l = layers[q];
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + l];
     const bool host_has_it = !s.always_copy && st.host_known && st.host == h[q];
+    // (the host matrix is what the device layer was before the call)
+    const bool host_is_before = !s.always_copy && st.host_known && st.host == st.device;
     st.device_valid = !s.always_copy;
     st.device = h[q];
     if (!host_has_it) {
       st.host_known = false;
       if ((rc = ctx_materialize(c, l))) return rc;
-      AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
+      if (partial && host_is_before) {
+        AMHIP_TRY(hipMemcpy2DAsync(s.pin[k] + block * (size_t)q, (size_t)rect[2] * 4,
+                                   c->layers[l] + (size_t)rect[0] + (size_t)rect[1] * (size_t)w.rows,
+                                   (size_t)w.rows * 4, (size_t)rect[2] * 4, (size_t)rect[3],
+                                   hipMemcpyDeviceToHost, c->stream));
+        packed[q] = true;
+        s.down_bytes += (unsigned long long)block * 4ull;
+      } else {
+        AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
+        s.down_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
+      }
       copied[q] = true;
       any = true;
     }
   }
   if (any) AMHIP_TRY(hipStreamSynchronize(c->stream));
+  clock.mark("downloads");
+  for (int q = 0; q < nl; ++q)
+    if (packed[q])
+      unpack_block(s.pin[k] + block * (size_t)q, hosts[q], s, w.i0 + rect[0], w.j0 + rect[1], rect[2],
+                   rect[3]);
+  clock.mark("unpack");
+  if (s.verify_partial) {  // (tests: the matrix as a whole must now carry the device's sums)
+    for (int q = 0; q < nl; ++q) {
+      if (!packed[q]) continue;
+      std::vector<Hash128> hv;
+      const float* m[1] = {hosts[q]};
+      host_hashes(s, m, 1, &hv);
+      if (hv[(size_t)k] != h[q])
+        return arg_failure("session: a partial download left the host matrix different from the device layer");
+    }
+  }
   for (int q = 0; q < nl; ++q) {
     if (!hosts[q] || !copied[q]) continue;
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layers[q]];
@@ -338,6 +512,7 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
   s.ti = tiles_i;
   s.tj = tiles_j;
   s.always_copy = std::getenv("AMHIP_SESSION_ALWAYS_COPY") != nullptr;
+  s.verify_partial = std::getenv("AMHIP_SESSION_VERIFY_PARTIAL") != nullptr;
   // window edges on multiples of the gather tile (64 x 32 cells) except at the map border
   auto edges = [](int n, int parts, int align, std::vector<int>* e) {
     e->assign(1, 0);
@@ -411,6 +586,8 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
   s.route_counts.assign(W, nullptr);
   s.cloud.assign(W, nullptr);
   s.cloud_cap.assign(W, 0);
+  s.pin.assign(W, nullptr);
+  s.pin_cap.assign(W, 0);
   // direct device-to-device copies where the hardware allows them (xGMI)
   for (int a = 0; a < W; ++a)
     for (int b = 0; b < W; ++b)
@@ -437,6 +614,7 @@ void amhip_session_destroy(amhip_session* h) {
       if (k < s.route_done.size() && s.route_done[k]) (void)hipEventDestroy(s.route_done[k]);
       if (k < s.cloud.size() && s.cloud[k]) (void)hipFree(s.cloud[k]);
       if (k < s.dev_hash.size() && s.dev_hash[k]) (void)hipFree(s.dev_hash[k]);
+      if (k < s.pin.size() && s.pin[k]) (void)hipHostFree(s.pin[k]);
       amhip_ctx_destroy(s.ctx[k]);
     }
   }
@@ -468,6 +646,14 @@ int amhip_session_set_always_copy(amhip_session* h, int on) {
   return AMHIP_OK;
 }
 
+int amhip_session_transfer_stats(const amhip_session* h, uint64_t* uploaded_bytes,
+                                 uint64_t* downloaded_bytes) {
+  if (!h) return arg_failure("null session");
+  if (uploaded_bytes) *uploaded_bytes = h->impl.up_bytes.load();
+  if (downloaded_bytes) *downloaded_bytes = h->impl.down_bytes.load();
+  return AMHIP_OK;
+}
+
 int amhip_session_set_dsm_precision(amhip_session* h, int mode) {
   if (!h) return arg_failure("null session");
   for (amhip_ctx* c : h->impl.ctx) {
@@ -493,6 +679,7 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   const float* mats[1] = {elevation};
   int rc;
   if (W == 1) {
+    PhaseClock clock("dsm");
     Ctx* c = &s.ctx[0]->impl;
     if ((rc = ctx_use_device(c))) return rc;
     if (n >= 0x7FFFFFFFull) return arg_failure("more than 2^31-1 points");
@@ -505,15 +692,18 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     });
     hipError_t e = hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
                                   hipMemcpyHostToDevice, c->stream);
+    clock.mark("cloud enqueued");
     hasher.join();
+    clock.mark("host content sum");
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cloud)", __FILE__, __LINE__);
     if ((rc = sync_in(s, 0, AMHIP_LAYER_ELEVATION, elevation, hh[0], true))) return rc;
     if ((rc = amhip_dsm_process_dev(s.ctx[0], c->stage_points, n, radius_sq, center_easting,
                                     center_northing)))
       return rc;
+    clock.mark("sync_in + dsm enqueued");
     const int lay[1] = {AMHIP_LAYER_ELEVATION};
     float* outs[1] = {elevation};
-    if ((rc = sync_out(s, 0, lay, outs, 1))) return rc;
+    if ((rc = sync_out(s, 0, lay, outs, 1, true))) return rc;
     return ctx_fetch_status(c);
   }
 
@@ -632,7 +822,7 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     }
     const int lay[1] = {AMHIP_LAYER_ELEVATION};
     float* outs[1] = {elevation};
-    if ((r = sync_out(s, d, lay, outs, 1))) return r;
+    if ((r = sync_out(s, d, lay, outs, 1, total != 0))) return r;  // (no call: no dirty cells on record)
     return ctx_fetch_status(c);
   });
   // (a later call may overwrite route_out[k] while a slower peer still reads it: every window
@@ -685,6 +875,7 @@ int amhip_session_ortho_backward_process(
     return AMHIP_OK;
   };
   // the frames go up while host threads hash the six matrices
+  PhaseClock clock("ortho_backward");
   int rc_up = AMHIP_OK;
   std::string up_msg;
   std::thread uploader([&]() {
@@ -693,7 +884,9 @@ int amhip_session_ortho_backward_process(
   });
   if (!s.always_copy) host_hashes(s, ins, AMHIP_NUM_LAYERS, &hh);
   else hh.assign((size_t)AMHIP_NUM_LAYERS * W, Hash128());
+  clock.mark("host content sums");
   uploader.join();
+  clock.mark("frames enqueued");
   if (rc_up) {
     set_last_error(up_msg);
     return rc_up;
@@ -706,14 +899,16 @@ int amhip_session_ortho_backward_process(
     for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
       if (ins[l] && (r = sync_in(s, k, l, ins[l], hh[(size_t)l * W + k], l != AMHIP_LAYER_ELEVATION)))
         return r;
+    if (k == 0) clock.mark("sync_in");
     if ((r = amhip_ortho_backward_process_dev(s.ctx[k], cam, host_T_G_C, F, c->stage_frames, frame,
                                               row, channels, colored)))
       return r;
+    if (k == 0) clock.mark("mosaic enqueued");
     const int lay[5] = {AMHIP_LAYER_ORTHO, AMHIP_LAYER_ELEVATION_ANGLE, AMHIP_LAYER_NUM_OBSERVATIONS,
                         AMHIP_LAYER_OBSERVATION_INDEX, AMHIP_LAYER_COLORED_ORTHO};
     float* outs[5] = {colored ? nullptr : ortho, elevation_angle, num_observations, observation_index,
                       colored ? colored_ortho : nullptr};
-    if ((r = sync_out(s, k, lay, outs, 5))) return r;
+    if ((r = sync_out(s, k, lay, outs, 5, true))) return r;
     return ctx_fetch_status(c);
   });
 }

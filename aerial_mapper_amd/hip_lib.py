@@ -53,7 +53,7 @@ EXPORTS = [
     "amhip_camera_view_bounds",
     "amhip_session_create", "amhip_session_destroy", "amhip_session_num_windows",
     "amhip_session_context", "amhip_session_window", "amhip_session_set_always_copy",
-    "amhip_session_set_dsm_precision",
+    "amhip_session_set_dsm_precision", "amhip_session_transfer_stats",
     "amhip_session_dsm_process", "amhip_session_ortho_backward_process",
     "amhip_session_ortho_from_pcl_process",
     "amhip_io_parse_point_cloud_text", "amhip_io_download_point_cloud", "amhip_io_free",
@@ -165,6 +165,7 @@ def load():
     lib.amhip_session_window.argtypes = [vp, C.c_int, C.POINTER(C.c_int32)]
     lib.amhip_session_set_always_copy.argtypes = [vp, C.c_int]
     lib.amhip_session_set_dsm_precision.argtypes = [vp, C.c_int]
+    lib.amhip_session_transfer_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.amhip_session_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
     lib.amhip_session_ortho_from_pcl_process.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     lib.amhip_session_ortho_backward_process.argtypes = [

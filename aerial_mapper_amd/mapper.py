@@ -483,6 +483,12 @@ class HostSession(object):
     def set_dsm_precision(self, exact):
         L.check(self._lib.amhip_session_set_dsm_precision(self._h, 1 if exact else 0))
 
+    def transfer_stats(self):
+        """(bytes of layer data uploaded, downloaded) since the session was created."""
+        up, down = C.c_uint64(), C.c_uint64()
+        L.check(self._lib.amhip_session_transfer_stats(self._h, C.byref(up), C.byref(down)))
+        return int(up.value), int(down.value)
+
     def dsm_process(self, dsm_settings, points):
         pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
         s = dsm_settings

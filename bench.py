@@ -166,7 +166,8 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
                              colored=args.colored, which=which, timing=t_mosaic)
         assert rc == 0
         t_ortho = time.time() - t0
-    cores = os.cpu_count() or 1
+    threads = os.cpu_count() or 1
+    cores, quota = usable_cpus()
     if which == "loops":
         # the two process() calls alone; the constructors' one-sample-per-cell tables
         # (dsm.cc:20-34, ortho-backward-grid.cc:22-40) are set-up, reported beside them
@@ -185,13 +186,43 @@ def cpu_baseline(args, wl, map_, pts_dev, frames_dev, poses, ncam, tile_center):
     total = t_dsm + t_ortho
     refs = {"s": s, "elev": elev, "layers": layers, "grid": g, "cam": cam if F else None,
             "frames_host": frames_host if F else None, "which": which}
+    # cores: the CPUs the threads could actually keep busy -- hardware threads capped by the
+    # affinity mask and the pod's cgroup CPU quota (the GPU boxes of this pool: 256 hardware
+    # threads, 16 CPUs' worth of time)
     return refs, {"value": round(s * s / total / 1e6, 4), "unit": "Mcells/s", "cores": cores,
+            "threads": threads, "cpu_quota": quota,
             "kind": "port" if which == "port" else "reference",
             "reference_code": {"loops": "dsm.cc + ortho-backward-grid.cc unchanged (oracle/refkit)",
                                "ref": "vendored nanoflann under restated loops",
                                "port": "none (restated loops, own kd-tree)"}[which],
             "sample": sample,
             "dsm_s": round(t_dsm, 3), "ortho_s": round(t_ortho, 3)}
+
+
+def usable_cpus():
+    """(CPUs this process may keep busy, the cgroup CPU quota in CPUs or None)."""
+    import math
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        a, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if a != "max":
+            quota = float(a) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(math.ceil(quota))))
+    return n, quota
 
 
 def parity_against(refs, args, map_, poses, ncam, F):

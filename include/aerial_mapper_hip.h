@@ -524,9 +524,14 @@ int amhip_rectify_stereo_pair_dev(amhip_ctx* ctx, const double* K, const double*
  * The layers stay resident between calls: whether a host matrix still holds what the devices
  * hold is decided by a 64-bit content sum (host threads on the way in, a kernel on the way out)
  * -- equal: no transfer; the layer's initial constant: a lazy device-side reset; anything
- * else: uploaded.  Outputs the kernels left unchanged are not downloaded.  Results are those
- * of the single-context calls (same kernels; windows reproduce the full map).
- * AMHIP_SESSION_ALWAYS_COPY=1 / amhip_session_set_always_copy: every matrix up and down. */
+ * else: uploaded.  Outputs the kernels left unchanged are not downloaded; of a layer that a call
+ * changed only inside a rectangle it knows (a small cloud's bounding box on a large map, the
+ * tiles a small batch of frames can see: the incremental use case) only that rectangle is
+ * (AMHIP_SESSION_NO_PARTIAL=1: whole windows).  Results are those of the single-context calls
+ * (same kernels; windows reproduce the full map).
+ * AMHIP_SESSION_ALWAYS_COPY=1 / amhip_session_set_always_copy: every matrix up and down.
+ * amhip_session_transfer_stats: bytes of layer data uploaded / downloaded since the session was
+ * created (clouds and frames not counted). */
 typedef struct amhip_session amhip_session;
 int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
                          const int32_t* devices, amhip_session** out);
@@ -536,6 +541,8 @@ amhip_ctx* amhip_session_context(amhip_session* s, int window);
 int amhip_session_window(const amhip_session* s, int window, int32_t* i0_j0_rows_cols);
 int amhip_session_set_always_copy(amhip_session* s, int on);
 int amhip_session_set_dsm_precision(amhip_session* s, int mode);  /* AMHIP_DSM_FAST / _EXACT */
+int amhip_session_transfer_stats(const amhip_session* s, uint64_t* uploaded_bytes,
+                                 uint64_t* downloaded_bytes);
 /* dsm::Dsm::process (dsm.cc:186-201): `elevation` = the GridMap's matrix (map rows x cols,
  * column-major), read and written like the reference does. */
 int amhip_session_dsm_process(amhip_session* s, const double* host_xyz, size_t n, int radius_sq,

@@ -214,3 +214,62 @@ def test_session_on_distinct_devices_when_the_node_has_them():
         hs.ortho_process(_ncam(A, sc), A.OrthoSettings(), sc.poses, sc.frames)
         if np.array_equal(hs.layers["elevation"].view(np.uint32), want["elevation"].view(np.uint32)):
             S.assert_layers_equal(hs.layers, want, ORTHO_LAYERS)
+
+
+def test_session_downloads_only_the_rectangle_a_small_call_wrote(monkeypatch):
+    """Round 4: on a large map the incremental calls -- one stereo pair's cloud (the DSM's
+    sub-window), a few frames (the mosaic's tile list) -- know which rectangle of the window they can
+    have written; a host matrix that equalled the device layer before the call gets that rectangle
+    only (amhip_session.hip: sync_out).  Same matrices, bit for bit, as with whole-window downloads
+    (AMHIP_SESSION_NO_PARTIAL=1); host edits far from the rectangle survive; the traffic counters
+    show the difference.  AMHIP_SESSION_VERIFY_PARTIAL=1: the session re-sums every partially
+    downloaded matrix against the device's content sum."""
+    import torch
+    import aerial_mapper_amd as A
+    from aerial_mapper_amd import synth
+    side, res = 8320, 1.0                           # 130 x 130 mosaic tiles, 69 M cells
+    L = side * res
+    dev = torch.device("cuda", 0)
+    pts = synth.make_points_torch(24_000_000, L / 2.0 + 3.0, 191, dev).cpu().numpy()
+    W, H, F = 320, 240, 14
+    frames = synth.make_frames_torch(F, H, W, 1, 192, dev).cpu().numpy()
+    poses = synth.make_lawnmower_poses(F, L / 5.0, 400.0 + 600.0, 192, tilt_deg=6.0)
+    ncam = A.NCamera(300.0, 300.0, (W - 1) / 2.0, (H - 1) / 2.0, W, H)
+    rng = np.random.default_rng(193)
+    pair = np.c_[rng.uniform(-900.0, -820.0, 60000), rng.uniform(400.0, 450.0, 60000),
+                 float(np.median(pts[:, 2])) + 5.0 + rng.uniform(-1.0, 1.0, 60000)]
+    st = A.GridMapSettings(0.0, 0.0, L, L, res)
+    monkeypatch.setenv("AMHIP_SESSION_VERIFY_PARTIAL", "1")
+
+    def run(partial):
+        if partial:
+            monkeypatch.delenv("AMHIP_SESSION_NO_PARTIAL", raising=False)
+        else:
+            monkeypatch.setenv("AMHIP_SESSION_NO_PARTIAL", "1")
+        down = {}
+        with A.HostSession(st) as hs:
+            hs.dsm_process(A.DsmSettings(1), pts)
+            mosaic = A.OrthoSettings()
+            hs.ortho_process(ncam, mosaic, poses[:8], frames[:8])     # (lazily reset layers: dense, whole window)
+            d0 = hs.transfer_stats()[1]
+            hs.dsm_process(A.DsmSettings(1), pair)                    # the sub-window
+            down["dsm"] = hs.transfer_stats()[1] - d0
+            hs.layers["elevation_angle"][100, 200] = 0.5              # (a host edit far from what follows:
+            hs.layers["ortho"][8000, 17] = 77.0                       #  uploaded, and it must survive)
+            d0 = hs.transfer_stats()[1]
+            for k in range(8, F):                                     # single frames: the tile list
+                hs.ortho_process(ncam, mosaic, poses[k:k + 1], frames[k:k + 1])
+            down["mosaic"] = hs.transfer_stats()[1] - d0
+            return {n: v.copy() for n, v in hs.layers.items()}, down
+
+    part, down_part = run(True)
+    full, down_full = run(False)
+    for n in part:
+        a, b = part[n], full[n]
+        eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+        assert eq.all(), (n, int((~eq).sum()))
+    window = side * side * 4
+    assert down_full["dsm"] == window                                 # one layer, whole
+    assert 0 < down_part["dsm"] < window // 500                       # ~ 85 x 55 cells (+ the ladder's rim)
+    assert down_full["mosaic"] >= 3 * window                          # >= one frame's three layers, whole
+    assert 0 < down_part["mosaic"] < down_full["mosaic"] // 20
