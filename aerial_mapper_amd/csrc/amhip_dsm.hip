@@ -657,6 +657,10 @@ __device__ __forceinline__ int fx_allowed_additions(float zmin_f, float zmax_f, 
   const float room = (0.5f * allowed / S_half - epsw) * 16777216.0f - 3.0f;
   return room > 1.0e6f ? (1 << 20) : (int)room;
 }
+constexpr int kSortTrips = 6;       // gather: windows of up to this many row pairs take their spans longest first
+#ifndef AMHIP_GATHER_PLAIN_TRIPS
+#define AMHIP_GATHER_PLAIN_TRIPS 0  // (1: A-B build with the spans top to bottom)
+#endif
 constexpr int kFxMinAdditions = 48;  // a trip of a dense tile brings up to ~20 candidates; below: FP64
 
 // One lane per gather tile (tile numbering: ti + tj * tiles_i, as in the gather):
@@ -1053,12 +1057,51 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       // sticky anyway.  A d2 itself is never denormal: coordinates are doubles of
       // magnitude >= 1e-3, their differences multiples of ~1e-19.)
       __builtin_amdgcn_s_setreg(kHwRegModeFpDenormF64, 0);
+      // The lanes of a wave wait for each other per trip, and a trip lasts as long as its
+      // busiest lane: 70 iterations per wave for a mean of 41 candidates per lane when every lane
+      // takes its row pairs top to bottom (5 trips at cfg2's density; max over 64 lanes of a
+      // Poisson count, five times).  Every lane therefore takes its spans LONGEST FIRST: the
+      // s-th trip of the wave then meets every lane's s-th longest span, and the sum over s of
+      // the maxima is 60 (simulated; the sums are order-free, the rounding guard below covers
+      // the order).  Spans as (length << 16 | first) in a 6-key sorting network of v_max / v_min
+      // pairs; windows of more than 6 row pairs keep the plain order.
+      uint32_t key0 = 0, key1 = 0, key2 = 0, key3 = 0, key4 = 0, key5 = 0;
+      const bool sorted_trips = w0 < kSortTrips && !AMHIP_GATHER_PLAIN_TRIPS;
+      if (sorted_trips) {
+        auto span = [&](int r) __attribute__((always_inline)) -> uint32_t {
+          if (r > w0) return 0u;
+          const int w = p.wrp[r];
+          const uint32_t kb = orow[r * RW2 - 2 * w];
+          const uint32_t ke = orow[r * RW2 + 2 * w + 2];
+          ncand += ke - kb;
+          return ((ke - kb) << 16) | kb;   // (both below 2^16: the LDS image holds <= 7680 points)
+        };
+        key0 = span(0), key1 = span(1), key2 = span(2), key3 = span(3), key4 = span(4), key5 = span(5);
+        auto cx = [](uint32_t& a, uint32_t& b) __attribute__((always_inline)) {
+          const uint32_t hi = max(a, b), lo = min(a, b);
+          a = hi;
+          b = lo;
+        };
+        // (12 compare-exchanges, 5 layers)
+        cx(key0, key5), cx(key1, key3), cx(key2, key4);
+        cx(key1, key2), cx(key3, key4);
+        cx(key0, key3), cx(key2, key5);
+        cx(key0, key1), cx(key2, key3), cx(key4, key5);
+        cx(key1, key2), cx(key3, key4);
+      }
       for (int r = 0; r <= w0; ++r) {
-        const int w = p.wrp[r];
-        const uint32_t kb = orow[-2 * w];
-        const uint32_t ke = orow[2 * w + 2];
-        orow += RW2;
-        ncand += ke - kb;
+        uint32_t kb, ke;
+        if (sorted_trips) {
+          kb = key0 & 0xFFFFu;
+          ke = kb + (key0 >> 16);
+          key0 = key1, key1 = key2, key2 = key3, key3 = key4, key4 = key5;
+        } else {
+          const int w = p.wrp[r];
+          kb = orow[-2 * w];
+          ke = orow[2 * w + 2];
+          orow += RW2;
+          ncand += ke - kb;
+        }
         auto candidate = [&](uint32_t k) __attribute__((always_inline)) {
           const double2 xy = s_xy[k];
           const double z = s_z[k];
@@ -1605,11 +1648,41 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
       float mA = 0.f, mB = 0.f;                          // largest d2 among the hits
       int nmax = 0;                                      // most candidates of one trip
       const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * RW2 + 2 * ci;
+      // (every lane takes its spans longest first: see gather_tile)
+      uint32_t key0 = 0, key1 = 0, key2 = 0, key3 = 0, key4 = 0, key5 = 0;
+      const bool sorted_trips = w0 < kSortTrips && !AMHIP_GATHER_PLAIN_TRIPS;
+      if (sorted_trips) {
+        auto span = [&](int r) __attribute__((always_inline)) -> uint32_t {
+          if (r > w0) return 0u;
+          const int w = p.wrp[r];
+          const uint32_t kb = orow[r * RW2 - 2 * w];
+          const uint32_t ke = orow[r * RW2 + 2 * w + 2];
+          return ((ke - kb) << 16) | kb;
+        };
+        key0 = span(0), key1 = span(1), key2 = span(2), key3 = span(3), key4 = span(4), key5 = span(5);
+        auto cx = [](uint32_t& a, uint32_t& b) __attribute__((always_inline)) {
+          const uint32_t hi = max(a, b), lo = min(a, b);
+          a = hi;
+          b = lo;
+        };
+        cx(key0, key5), cx(key1, key3), cx(key2, key4);
+        cx(key1, key2), cx(key3, key4);
+        cx(key0, key3), cx(key2, key5);
+        cx(key0, key1), cx(key2, key3), cx(key4, key5);
+        cx(key1, key2), cx(key3, key4);
+      }
       for (int r = 0; r <= w0; ++r) {
-        const int w = p.wrp[r];
-        const uint32_t kb = orow[-2 * w];
-        const uint32_t ke = orow[2 * w + 2];
-        orow += RW2;
+        uint32_t kb, ke;
+        if (sorted_trips) {
+          kb = key0 & 0xFFFFu;
+          ke = kb + (key0 >> 16);
+          key0 = key1, key1 = key2, key2 = key3, key3 = key4, key4 = key5;
+        } else {
+          const int w = p.wrp[r];
+          kb = orow[-2 * w];
+          ke = orow[2 * w + 2];
+          orow += RW2;
+        }
         nmax = max(nmax, (int)(ke - kb));
         float nA = 0.f, dA = 0.f, nB = 0.f, dB = 0.f;  // this trip's sums
         // One candidate = 18 f32-rate VALU instructions for the two cells: exact integer
