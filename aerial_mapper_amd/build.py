@@ -21,8 +21,9 @@ RESOURCES_PATH = os.path.join(LIB_DIR, "kernel_resources.txt")
 OBJ_DIR = os.path.join(ROOT, "build", "hip_obj")
 
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
-               "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip"]
-HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
+               "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip",
+               "amhip_hostsum.cc"]   # (.cc: host-only, the AVX-512 loop of the session's content sums)
+HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", "amhip_content_sum.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box
 # test, pixel rounding, best-view comparison) must see the same doubles as the
@@ -72,9 +73,12 @@ def build_hip(force=False, verbose=False):
 
     def compile_one(job):
         src, obj = job
-        cmd = [_hipcc()] + [f for f in HIPCC_FLAGS if f != "-shared"] + extra + [
-            "-c", "-Rpass-analysis=kernel-resource-usage", "-I" + os.path.join(ROOT, "include"),
-            "-I" + CSRC, "-o", obj, src]
+        host_only = src.endswith(".cc")
+        cmd = [_hipcc()] + [f for f in HIPCC_FLAGS if f != "-shared" and
+                            not (host_only and f.startswith("--offload-arch"))] + extra + [
+            "-c"] + ([] if host_only else ["-Rpass-analysis=kernel-resource-usage"]) + [
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", obj] + (
+            ["-x", "c++"] if host_only else []) + [src]   # (hipcc takes any source for HIP otherwise)
         if verbose:
             print(" ".join(cmd))
         res = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "amhip_common.h"
+#include "amhip_content_sum.h"
 
 namespace amhip {
 
@@ -105,26 +106,7 @@ struct PhaseClock {
   }
 };
 
-// ---- content sums ------------------------------------------------------------------
-// x = mix(bits + K (g + 1)),  a += x,  b += mix2(x);  g = i + j * map rows.  Both mixes are
-// bijections of 64-bit words (xor-shift, odd multiplier), so ONE changed cell always changes
-// both sums; they are not affine in the bits, so no relation d1 w1 + d2 w2 = 0 between two
-// edits cancels in either, let alone in both.  The sums are order-free: host threads and GPU
-// lanes each take any part.
-constexpr unsigned long long kHashK = 0x9E3779B97F4A7C15ull;
-
-__host__ __device__ inline void cell_mix(unsigned bits, unsigned long long g,
-                                         unsigned long long* a, unsigned long long* b) {
-  unsigned long long x = (unsigned long long)bits + kHashK * (g + 1ull);
-  x ^= x >> 29;
-  x *= 0xBF58476D1CE4E5B9ull;
-  x ^= x >> 32;
-  unsigned long long y = x * 0x94D049BB133111EBull;
-  y ^= y >> 31;
-  *a += x;
-  *b += y;
-}
-
+// ---- content sums (amhip_content_sum.h: cell_mix, host_column_sum) ----------------------
 // layer == nullptr: the sums of a window filled with `constant` (no memory is read)
 __global__ void __launch_bounds__(256)
 k_layer_hash(const float* __restrict__ layer, float constant, int rows, int cols, int i0, int j0,
@@ -194,11 +176,14 @@ static int usable_cpus(double* quota_cpus) {
 static int host_threads(size_t bytes) {
   if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) return std::max(1, std::atoi(e));
   unsigned hw = std::thread::hardware_concurrency();
-  // (the non-linear mix costs three multiplies per cell: 128 threads keep the six matrices of a
-  // mosaic call -- 2.4 GB at cfg3 -- near the host's memory bandwidth)
-  int T = (int)std::min<unsigned>(hw ? hw : 8u, 128u);
   double quota = 0.0;
   const int cpus = usable_cpus(&quota);
+  // (the AVX-512 loop sums 33 GB/s per thread on the pool's EPYCs: a few threads per memory
+  // channel group saturate the host's memory, more only burn CPU time in stalls)
+  if (host_sum_is_vectorized()) return std::max(1, std::min(cpus, 32));
+  // (the scalar mix costs three multiplies per cell, 5 GB/s per thread: 128 threads keep the six
+  // matrices of a mosaic call -- 2.4 GB at cfg3 -- near the host's memory bandwidth)
+  int T = (int)std::min<unsigned>(hw ? hw : 8u, 128u);
   if (quota > 0.0 && quota < (double)T) {
     // under a CPU quota: a short pass may burst over four times the quota's CPUs (64 threads draw
     // 175 GB/s; more only burn the period's allowance in memory stalls); a pass worth more than
@@ -238,10 +223,8 @@ static void host_hashes(const Session& s, const float* const* mats, int nl,
         for (int l = 0; l < nl; ++l) {
           if (!mats[l]) continue;
           const unsigned* col = reinterpret_cast<const unsigned*>(mats[l]) + (size_t)j * R;
-          unsigned long long ha = 0, hb = 0;
-          for (int i = ia; i < ib; ++i) cell_mix(col[i], g0 + (unsigned long long)i, &ha, &hb);
-          acc[(size_t)l * W + k].a += ha;
-          acc[(size_t)l * W + k].b += hb;
+          host_column_sum(col + ia, (size_t)(ib - ia), g0 + (unsigned long long)ia,
+                          &acc[(size_t)l * W + k].a, &acc[(size_t)l * W + k].b);
         }
       }
     }
