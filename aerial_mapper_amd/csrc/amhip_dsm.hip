@@ -1068,13 +1068,21 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       uint32_t key0 = 0, key1 = 0, key2 = 0, key3 = 0, key4 = 0, key5 = 0;
       const bool sorted_trips = w0 < kSortTrips && !AMHIP_GATHER_PLAIN_TRIPS;
       if (sorted_trips) {
+        // (branch-free: a row pair beyond the window re-reads the last one and gets length 0, so
+        // that all twelve offsets are in flight before the first wait)
+        uint32_t kb_[kSortTrips], ke_[kSortTrips];
+#pragma unroll
+        for (int r = 0; r < kSortTrips; ++r) {
+          // (static index: the six widths arrive with one scalar load, not one load and wait each)
+          const int rr = min(r, w0);
+          const int w = r <= w0 ? p.wrp[r] : 0;
+          kb_[r] = orow[rr * RW2 - 2 * w];
+          ke_[r] = orow[rr * RW2 + 2 * w + 2];
+        }
         auto span = [&](int r) __attribute__((always_inline)) -> uint32_t {
-          if (r > w0) return 0u;
-          const int w = p.wrp[r];
-          const uint32_t kb = orow[r * RW2 - 2 * w];
-          const uint32_t ke = orow[r * RW2 + 2 * w + 2];
-          ncand += ke - kb;
-          return ((ke - kb) << 16) | kb;   // (both below 2^16: the LDS image holds <= 7680 points)
+          const uint32_t len = r <= w0 ? ke_[r] - kb_[r] : 0u;
+          ncand += len;
+          return (len << 16) | kb_[r];   // (both below 2^16: the LDS image holds <= 7680 points)
         };
         key0 = span(0), key1 = span(1), key2 = span(2), key3 = span(3), key4 = span(4), key5 = span(5);
         auto cx = [](uint32_t& a, uint32_t& b) __attribute__((always_inline)) {
@@ -1652,12 +1660,18 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
       uint32_t key0 = 0, key1 = 0, key2 = 0, key3 = 0, key4 = 0, key5 = 0;
       const bool sorted_trips = w0 < kSortTrips && !AMHIP_GATHER_PLAIN_TRIPS;
       if (sorted_trips) {
+        uint32_t kb_[kSortTrips], ke_[kSortTrips];   // (all twelve offsets in flight: see gather_tile)
+#pragma unroll
+        for (int r = 0; r < kSortTrips; ++r) {
+          // (static index: the six widths arrive with one scalar load, not one load and wait each)
+          const int rr = min(r, w0);
+          const int w = r <= w0 ? p.wrp[r] : 0;
+          kb_[r] = orow[rr * RW2 - 2 * w];
+          ke_[r] = orow[rr * RW2 + 2 * w + 2];
+        }
         auto span = [&](int r) __attribute__((always_inline)) -> uint32_t {
-          if (r > w0) return 0u;
-          const int w = p.wrp[r];
-          const uint32_t kb = orow[r * RW2 - 2 * w];
-          const uint32_t ke = orow[r * RW2 + 2 * w + 2];
-          return ((ke - kb) << 16) | kb;
+          const uint32_t len = r <= w0 ? ke_[r] - kb_[r] : 0u;
+          return (len << 16) | kb_[r];
         };
         key0 = span(0), key1 = span(1), key2 = span(2), key3 = span(3), key4 = span(4), key5 = span(5);
         auto cx = [](uint32_t& a, uint32_t& b) __attribute__((always_inline)) {
