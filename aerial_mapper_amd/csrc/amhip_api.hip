@@ -942,13 +942,14 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->dev_bbox, c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->spec_plan, c->dev_bbox, c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   if (c->host_err) (void)hipHostFree(c->host_err);
   if (c->host_tile_stats) (void)hipHostFree(c->host_tile_stats);
   if (c->host_bbox) (void)hipHostFree(c->host_bbox);
+  if (c->spec_flag_host) (void)hipHostFree(c->spec_flag_host);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
 }
@@ -1688,6 +1689,21 @@ const char* amhip_kernel_name(int kernel) {
     default:
       return "?";
   }
+}
+
+int amhip_ctx_dsm_sort_stats(amhip_ctx* h, int64_t* out4) {
+  if (!h || !out4) return arg_fail("amhip_ctx_dsm_sort_stats: null argument");
+  Ctx* c = &h->impl;
+  if (c->spec_flag_host && c->spec_flag_host[0]) {  // (what spec_wanted would do at the next call)
+    c->spec_flag_host[0] = 0u;
+    c->spec_cooldown = 8;
+    ++c->spec_misses;
+  }
+  out4[0] = (int64_t)c->spec_calls;
+  out4[1] = (int64_t)c->spec_hits_started;
+  out4[2] = (int64_t)c->spec_misses;
+  out4[3] = (int64_t)c->spec_cooldown;
+  return AMHIP_OK;
 }
 
 int amhip_ctx_dsm_gather_stats(amhip_ctx* h, int64_t* out8) {

@@ -255,6 +255,19 @@ struct Ctx {
   size_t tmp_points_cap = 0;
   uint32_t* stripe_ws = nullptr;   // stripe counts / starts / cursors
   size_t stripe_ws_cap = 0;
+  // The speculative sort (amhip_sort.hip, dsm_sort): the regions the previous three-pass call in the
+  // FP64 pipeline on this context planned for its successor from its own exact (k1, k2) counts --
+  // the next call appends into them instead of counting first --, what that call looked like, and
+  // the overflow word of the last speculative call (pinned mirror, never waited for).
+  uint32_t* spec_plan = nullptr;   // two plans (regions + cursors of both passes) + two overflow words
+  size_t spec_plan_cap = 0;
+  int spec_parity = 0;             // which of the two the next call consumes
+  unsigned* spec_flag_host = nullptr;
+  bool spec_valid = false;
+  unsigned long long spec_sig = 0;
+  size_t spec_n = 0;
+  int spec_cooldown = 0;
+  unsigned long long spec_calls = 0, spec_hits_started = 0, spec_misses = 0;  // (three-pass FP64 calls / speculative / overflowed)
   uint8_t* tile_occ = nullptr;         // per gather tile: any point within the last radius
   size_t tile_occ_cap = 0;
   int* tile_list = nullptr;            // sparse gather: [count (4 ints)] [occupied tile ids]

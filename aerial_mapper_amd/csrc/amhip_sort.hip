@@ -296,8 +296,10 @@ template <bool kHalo>
 __global__ void __launch_bounds__(kP3CountThreads)
 k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
                uint32_t* __restrict__ hist_rows, HaloParams hp, double* __restrict__ halo_out,
-               unsigned long long* __restrict__ halo_counts, double* __restrict__ zall) {
+               unsigned long long* __restrict__ halo_counts, double* __restrict__ zall,
+               const uint32_t* __restrict__ gate /* may be null: dsm_sort's speculation */) {
   extern __shared__ uint32_t s_hist[];
+  if (gate && !*gate) return;
   const int nk = p.p3_n1 * p.p3_n2;
   // (kHalo: the staging area follows the histogram, 8-byte aligned)
   HaloStage* const stage = reinterpret_cast<HaloStage*>(s_hist + ((nk + 1) & ~1));
@@ -384,8 +386,17 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
               uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
               uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
-              uint32_t* __restrict__ big_list, unsigned chunk) {
+              uint32_t* __restrict__ big_list, unsigned chunk,
+              const uint32_t* __restrict__ gate /* may be null */,
+              // the speculative sort (dsm_sort): spec_start2 / spec_cursor2 (may be null) -- the
+              // counts are what pass 2 appended to its regions, not cnt[]; plan (may be null) -- the
+              // NEXT call's regions from this call's counts, count + count / 8 + 32 each:
+              // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1], and its overflow word
+              const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
+              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag) {
   __shared__ unsigned lds[1024 / 64 + 1];
+  __shared__ unsigned lds2[1024 / 64 + 1];
+  if (gate && !*gate) return;
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
   unsigned carry = 0;
@@ -403,15 +414,31 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
     const int iters = seg / 64;
     const int w0 = wid * seg;
     unsigned v[kMaxIt];  // the counter, then its exclusive prefix inside the wave's segment
+    unsigned r[kMaxIt];  // the same for the next call's regions (plan)
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
       const int i = w0 + q * 64 + lane;
-      v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
+      if (spec_start2) {
+        const unsigned a = (q < iters && i < nk) ? spec_start2[i] : 0u;
+        const unsigned e = (q < iters && i < nk) ? spec_start2[i + 1] : 0u;
+        const unsigned cu = (q < iters && i < nk) ? spec_cursor2[i] : 0u;
+        v[q] = min(cu, e) - a;
+      } else {
+        v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
+      }
     }
-    unsigned run = 0;  // (wave-uniform)
+    unsigned run = 0;   // (wave-uniform)
+    unsigned run2 = 0;
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
       if (q < iters) {
+        if (plan) {
+          const int i = w0 + q * 64 + lane;
+          const unsigned room = i < nk ? v[q] + (v[q] >> 3) + 32u : 0u;
+          const unsigned incl2 = wave_incl_scan(room, lane);
+          r[q] = run2 + incl2 - room;
+          run2 += __shfl(incl2, 63, 64);
+        }
         // sub-partitions too full for k_dsm_p3_place's registers but not for a whole
         // CU's LDS (denser parts of a non-uniform cloud): k_dsm_p3_place_big's list
         // (no upper bound: beyond a CU's LDS the big kernel places in several rounds)
@@ -422,14 +449,43 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
         run += __shfl(incl, 63, 64);
       }
     }
-    if (lane == 0) lds[wid] = run;
+    if (lane == 0) {
+      lds[wid] = run;
+      lds2[wid] = run2;
+    }
     __syncthreads();
-    unsigned base = 0, total = 0;
+    unsigned base = 0, total = 0, base2 = 0, total2 = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      const unsigned t = lds[w];
+      const unsigned t = lds[w], t2 = lds2[w];
       if (w < wid) base += t;
       total += t;
+      if (w < wid) base2 += t2;
+      total2 += t2;
+    }
+    if (plan) {
+      uint32_t* const pstart2 = plan;
+      uint32_t* const pcur2 = plan + nk + 1;
+      uint32_t* const pstart1 = pcur2 + nk;
+      uint32_t* const pcur1 = pstart1 + n1 + 1;
+#pragma unroll
+      for (int q = 0; q < kMaxIt; ++q) {
+        const int i = w0 + q * 64 + lane;
+        if (q < iters && i < nk) {
+          const unsigned st = base2 + r[q];
+          pstart2[i] = st;
+          pcur2[i] = st;
+          if (i % n2 == 0) {
+            pstart1[i / n2] = st;
+            pcur1[i / n2] = st;
+          }
+        }
+      }
+      if (threadIdx.x == 0) {
+        pstart2[nk] = total2;
+        pstart1[n1] = total2;
+        plan_flag[0] = 0u;
+      }
     }
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
@@ -465,12 +521,20 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
 
 // Passes 1 and 2.  kFirst: chunk of the input cloud, key k1, values/centre
 // handling of the reference; else: chunk of one k1 partition, key k2.
-template <bool kFirst>
-__global__ void __launch_bounds__(kP3Threads)
-k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ values, size_t n,
-                 DsmParams p, const uint32_t* __restrict__ start1,
-                 const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
-                 double* __restrict__ dst, double* __restrict__ zpart) {
+// kSpec (the speculative sort, dsm_sort): the regions come from the previous call's counts plus
+// a margin, `limit[key]` is the end of key's region; a run that does not fit is NOT written and
+// raises *flag -- the exact pipeline then runs behind (k_dsm_p3_scatter_pers).  `end1`: the end of
+// every k1 partition's points in `src` (pass 2; exact pipeline: start1 + 1).  vb: the chunk.
+template <bool kFirst, bool kSpec>
+__device__ __forceinline__ void p3_scatter_body(const unsigned vb, const double* __restrict__ src,
+                                                const int32_t* __restrict__ values, size_t n,
+                                                const DsmParams& p, const uint32_t* __restrict__ start1,
+                                                const uint32_t* __restrict__ end1,
+                                                const uint32_t* __restrict__ blk2,
+                                                uint32_t* __restrict__ cursor,
+                                                const uint32_t* __restrict__ limit,
+                                                uint32_t* __restrict__ flag, double* __restrict__ dst,
+                                                double* __restrict__ zpart) {
   extern __shared__ double s_pts[];                                       // 3 * kP3Chunk
   uint32_t* s_dest = reinterpret_cast<uint32_t*>(s_pts + 3 * kP3Chunk);   // kP3Chunk
   uint32_t* s_cnt = s_dest + kP3Chunk;                                    // kP3MaxKeys
@@ -481,12 +545,12 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
   int nkeys;
   size_t c0, c1;
   if (kFirst) {
-    c0 = (size_t)blockIdx.x * kP3Chunk;
+    c0 = (size_t)vb * kP3Chunk;
     c1 = min(c0 + (size_t)kP3Chunk, n);
     nkeys = p.p3_n1;
   } else {
     const int n1 = p.p3_n1;
-    const uint32_t b = blockIdx.x;
+    const uint32_t b = vb;
     if (b >= blk2[n1]) return;
     int lo = 0, hi = n1;  // blk2[lo] <= b < blk2[hi]
     while (hi - lo > 1) {
@@ -494,9 +558,10 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
       if (blk2[mid] <= b) lo = mid; else hi = mid;
     }
     c0 = (size_t)start1[lo] + (size_t)(b - blk2[lo]) * kP3Chunk;
-    c1 = min(c0 + (size_t)kP3Chunk, (size_t)start1[lo + 1]);
+    c1 = min(c0 + (size_t)kP3Chunk, (size_t)end1[lo]);
     nkeys = p.p3_n2;
     cursor += (size_t)lo * p.p3_n2;
+    if (kSpec) limit += (size_t)lo * p.p3_n2;
   }
   if (tid < kP3MaxKeys) s_cnt[tid] = 0;
   __syncthreads();
@@ -542,11 +607,13 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
     }
   }
   if (kFirst && zpart)
-    range_commit_wave(zlo, zhi, zpart, (size_t)blockIdx.x * (kP3Threads / 64) + (tid >> 6));
+    range_commit_wave(zlo, zhi, zpart, (size_t)vb * (kP3Threads / 64) + (tid >> 6));
   __syncthreads();
   unsigned my_base = 0;  // first slot of key `tid`'s run in the destination
+  unsigned my_count = 0;
   {
     const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
+    my_count = c;
     unsigned total;
     const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
     if (tid < nkeys) {
@@ -569,14 +636,95 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
       s_dest[q] = slot[k];
     }
   }
-  if (tid < nkeys) s_base[tid] = my_base;
+  if (tid < nkeys) {
+    if (kSpec && my_count && (unsigned long long)my_base + my_count > (unsigned long long)limit[tid]) {
+      my_base = 0xFFFFFFFFu;  // (the run does not fit its region: dropped, the exact pipeline follows)
+      *flag = 1u;
+    }
+    s_base[tid] = my_base;
+  }
   __syncthreads();
   const uint32_t ne = 3u * s_scan[23];
   for (uint32_t e = tid; e < ne; e += kP3Threads) {
     const uint32_t q = e / 3u;
     const uint32_t d = s_dest[q];
-    dst[3 * (size_t)(s_base[d >> 13] + (d & 0x1FFFu)) + (e - 3u * q)] = s_pts[e];
+    const uint32_t b = s_base[d >> 13];
+    if (!kSpec || b != 0xFFFFFFFFu) dst[3 * (size_t)(b + (d & 0x1FFFu)) + (e - 3u * q)] = s_pts[e];
   }
+}
+
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ values, size_t n,
+                 DsmParams p, const uint32_t* __restrict__ start1,
+                 const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
+                 double* __restrict__ dst, double* __restrict__ zpart) {
+  p3_scatter_body<kFirst, false>(blockIdx.x, src, values, n, p, start1, start1 + 1, blk2, cursor, nullptr,
+                                 nullptr, dst, zpart);
+}
+
+// the speculative sort's passes (regions from the previous call's counts: dsm_sort)
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter_spec(const double* __restrict__ src, size_t n, DsmParams p,
+                      const uint32_t* __restrict__ start1, const uint32_t* __restrict__ end1,
+                      const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
+                      const uint32_t* __restrict__ limit, uint32_t* __restrict__ flag,
+                      double* __restrict__ dst, double* __restrict__ zpart) {
+  p3_scatter_body<kFirst, true>(blockIdx.x, src, nullptr, n, p, start1, end1, blk2, cursor, limit, flag, dst,
+                                zpart);
+}
+
+// the exact passes BEHIND a speculative sort: a fixed grid that leaves at once unless the
+// speculation overflowed (*gate != 0), and walks the chunks itself if it did (a dense launch of
+// 20 K workgroups that all return costs 0.5 ms; 256 cost 7 us)
+template <bool kFirst>
+__global__ void __launch_bounds__(kP3Threads)
+k_dsm_p3_scatter_pers(const double* __restrict__ src, size_t n, DsmParams p,
+                      const uint32_t* __restrict__ start1, const uint32_t* __restrict__ blk2,
+                      uint32_t* __restrict__ cursor, double* __restrict__ dst,
+                      const uint32_t* __restrict__ gate, unsigned nvb) {
+  if (!*gate) return;
+  for (unsigned vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+    p3_scatter_body<kFirst, false>(vb, src, nullptr, n, p, start1, start1 + 1, blk2, cursor, nullptr, nullptr,
+                                   dst, nullptr);
+    __syncthreads();
+  }
+}
+
+// ---- the speculative sort's small kernel between its passes --------------------------------
+// after pass 1: where every k1 partition's points end, and the chunks of pass 2
+__global__ void __launch_bounds__(1024)
+k_p3_spec_mid(const uint32_t* __restrict__ cstart1, const uint32_t* __restrict__ cursor1, int n1,
+              uint32_t* __restrict__ end1, uint32_t* __restrict__ blk2, unsigned chunk) {
+  __shared__ unsigned lds[1024 / 64 + 1];
+  const int k = threadIdx.x;
+  unsigned nblk = 0;
+  if (k < n1) {
+    const unsigned e = min(cursor1[k], cstart1[k + 1]);
+    end1[k] = e;
+    nblk = (e - cstart1[k] + chunk - 1) / chunk;
+  }
+  unsigned total;
+  const unsigned ex = block_excl_scan<1024>(nblk, &total, lds);
+  if (k < n1) blk2[k] = ex;
+  if (k == 0) blk2[n1] = total;
+}
+
+// (the exact pipeline's small kernels behind a speculative sort: only if it overflowed)
+__global__ void __launch_bounds__(256)
+k_dsm_p3_reduce_gated(const uint32_t* __restrict__ hist_rows, int nrows, int nk, uint32_t* __restrict__ cnt,
+                      const uint32_t* __restrict__ gate) {
+  if (!*gate) return;
+  __shared__ uint32_t s_part[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  uint32_t sum = 0;
+  if (k < nk)
+    for (int r = wid; r < nrows; r += 4) sum += hist_rows[(size_t)r * nk + k];
+  s_part[wid][lane] = sum;
+  __syncthreads();
+  if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
 }
 
 // Pass 3: one workgroup per (k1, k2) sub-partition.
@@ -592,7 +740,8 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
                                                    uint32_t* __restrict__ bin_start,
                                                    double* __restrict__ sorted, int sp,
                                                    unsigned skip_lo, unsigned skip_hi,
-                                                   uint2* __restrict__ bin_z) {
+                                                   uint2* __restrict__ bin_z,
+                                                   const uint32_t* __restrict__ src_start = nullptr) {
   extern __shared__ double s_pts[];                                  // 3 * cap
   uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
   uint32_t* s_scan = s_bins + p.p3_w;                                // 24
@@ -608,6 +757,9 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
     bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
   if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  // (speculative sort: the sub-partition's points lie at src_start[sp] of `src`, their final
+  // place is g0 -- every read below indexes src with FINAL positions)
+  if (src_start) src += 3 * ((long long)src_start[sp] - (long long)g0);
   for (int k = tid; k < nbw; k += THREADS) {
     s_bins[k] = 0;
     if (bin_z) {
@@ -738,7 +890,8 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
                                              const uint32_t* __restrict__ start2,
                                              uint32_t* __restrict__ bin_start, double* __restrict__ sorted,
                                              uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
-                                             uint2* __restrict__ bin_z, int sp) {
+                                             uint2* __restrict__ bin_z, int sp,
+                                             const uint32_t* __restrict__ src_start = nullptr) {
   // PER > 0: the sub-partition holds at most THREADS * PER points and a thread keeps its PER of
   // them in REGISTERS from the one read to the last round (configs[3] on one GPU: 13.3 K points
   // per sub-partition, 14 per thread); PER == 0: any size, every round re-reads it (from the L2).
@@ -761,6 +914,7 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
   const int nbw = min(p.p3_w, p.nbx - bx0);
   if (row >= p.nby || nbw <= 0) return;
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
+  if (!kRec && src_start) srcd += 3 * ((long long)src_start[sp] - (long long)g0);  // (see place_subpartition)
   auto zkey = [](uint32_t fbits) { return (fbits >> 31) ? ~fbits : (fbits | 0x80000000u); };
   for (int k = tid; k <= nbw; k += THREADS) s_bins[k] = 0;
   if (bin_z)
@@ -937,9 +1091,23 @@ __global__ void __launch_bounds__(kP3PlaceThreads)
 k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
                const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
-               uint2* __restrict__ bin_z) {
+               uint2* __restrict__ bin_z, const uint32_t* __restrict__ src_start) {
   place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted,
-                                                   (int)blockIdx.x, skip_lo, skip_hi, bin_z);
+                                                   (int)blockIdx.x, skip_lo, skip_hi, bin_z, src_start);
+}
+
+// (behind a speculative sort: see k_dsm_p3_scatter_pers)
+__global__ void __launch_bounds__(kP3PlaceThreads)
+k_dsm_p3_place_pers(const double* __restrict__ src, DsmParams p, int cap,
+                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
+                    double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
+                    const uint32_t* __restrict__ gate, int nsp) {
+  if (!*gate) return;
+  for (int sp = (int)blockIdx.x; sp < nsp; sp += (int)gridDim.x) {
+    place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted, sp, skip_lo,
+                                                     skip_hi, nullptr);
+    __syncthreads();
+  }
 }
 
 // The same with 1024 threads and a whole CU's LDS (kP3BigCap points), walking
@@ -948,20 +1116,23 @@ __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                    double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
-                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max) {
+                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max,
+                   const uint32_t* __restrict__ src_start /* speculative sort, else null */,
+                   const uint32_t* __restrict__ gate /* the exact pass behind one, else null */) {
+  if (gate && !*gate) return;
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     const int sp = (int)big_list[1 + k];
     const uint32_t cnt = start2[sp + 1] - start2[sp];
     if (cnt > rounds_above && cnt <= min(reg_max, (unsigned)(kP3BigThreads * kP3RoundsPer)))
       place_rounds<kP3BigThreads, false, kP3RoundsPer>(src, p, cap_rounds, start2, bin_start, sorted, nullptr,
-                                                       nullptr, bin_z, sp);
+                                                       nullptr, bin_z, sp, src_start);
     else if (cnt > rounds_above)
       place_rounds<kP3BigThreads, false, 0>(src, p, cap_rounds, start2, bin_start, sorted, nullptr, nullptr,
-                                            bin_z, sp);
+                                            bin_z, sp, src_start);
     else
       place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted, sp, 0u,
-                                                   0u, bin_z);
+                                                   0u, bin_z, src_start);
     __syncthreads();
   }
 }
@@ -1609,9 +1780,43 @@ static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* re
   if (reread) *reg_max = 0u;
 }
 
+// ---- the speculative sort's host side ------------------------------------------------------
+// what the previous call's counts are counts OF: the window's geometry and the sort's plan
+static unsigned long long spec_signature(const DsmParams& p) {
+  unsigned long long h = 1469598103934665603ull;
+  auto mix = [&](const void* v, size_t bytes) {
+    const unsigned char* b = static_cast<const unsigned char*>(v);
+    for (size_t k = 0; k < bytes; ++k) h = (h ^ b[k]) * 1099511628211ull;
+  };
+  const int ints[] = {p.rows, p.cols, p.M, p.B, p.nbx, p.nby, p.i_off, p.j_off, p.p3_r1, p.p3_c,
+                      p.p3_w, p.p3_n1, p.p3_n2, p.p3_cap};
+  const double dbls[] = {p.base_x, p.base_y, p.res, p.inv_res, p.sub_x, p.sub_y};
+  mix(ints, sizeof(ints));
+  mix(dbls, sizeof(dbls));
+  return h ? h : 1ull;
+}
+
+// AMHIP_SORT_NO_SPECULATION=1: always count first
+static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
+  const bool off = getenv("AMHIP_SORT_NO_SPECULATION") != nullptr;  // (read per call: tests flip it)
+  if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
+  if (c->spec_flag_host && c->spec_flag_host[0]) {  // a speculative call overflowed
+    c->spec_flag_host[0] = 0u;
+    c->spec_cooldown = 8;
+    ++c->spec_misses;
+  }
+  if (c->spec_cooldown > 0) {
+    --c->spec_cooldown;
+    return false;
+  }
+  // (more points than the margins can take, or far fewer: count first)
+  return n <= c->spec_n + c->spec_n / 16 + 1024 && 2 * n >= c->spec_n;
+}
+
 // ---------------------------------------------------------------------------
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
+
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split) {
   // [min z, max z] of the binned points (for the mosaic's coarse cull): every
@@ -1629,9 +1834,16 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   unsigned long long* const call_range = c->dev_zrange + 2;
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
+  // the speculative sort (three-pass, FP64 pipeline, plain DSM call): see below
+  static const bool force_one_level_ = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
+  const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split;
+  const unsigned long long sig = spec_mode ? spec_signature(p) : 0ull;
+  const bool spec = spec_mode && spec_wanted(c, n, sig);
+  // (regions of count + count / 8 + 32 over the previous call's counts)
+  const size_t spec_points = spec ? c->spec_n + c->spec_n / 8 + 32 * (size_t)p.p3_n1 * (size_t)p.p3_n2 + 64 : 0;
   {
     int rc;
-    if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * n))) return rc;
+    if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * std::max(n, spec_points)))) return rc;
     if ((rc = ensure_capacity(&c->bin_start, &c->bin_cap, nbins + 4))) return rc;
   }
   c->last_num_bins = (int64_t)nbins;
@@ -1669,11 +1881,11 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       if ((rc = ensure_capacity(&c->rec_a, &c->rec_a_cap, (size_t)kRecWords * n + 16))) return rc;
       if ((rc = ensure_capacity(&c->rec_b, &c->rec_b_cap, (size_t)kRecWords * n + 16))) return rc;
       if ((rc = ensure_capacity(&c->zall, &c->zall_cap, 2 * gcount * (kP3CountThreads / 64) + 16))) return rc;
-    } else if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) {
+    } else if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * std::max(n, spec_points)))) {
       return rc;
     }
     double* const zall = rec ? c->zall : nullptr;
-    const size_t ws_words = gcount * (size_t)nk + 4 * (size_t)nk + 3 * (size_t)n1 + 24;
+    const size_t ws_words = gcount * (size_t)nk + 4 * (size_t)nk + 4 * (size_t)n1 + 64;
     if ((rc = ensure_capacity(&c->stripe_ws, &c->stripe_ws_cap, ws_words))) return rc;
     uint32_t* hist_rows = c->stripe_ws;
     uint32_t* cnt = hist_rows + gcount * (size_t)nk;
@@ -1683,7 +1895,131 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     uint32_t* cursor1 = start1 + n1 + 1;
     uint32_t* blk2 = cursor1 + n1;     // n1 + 1
     uint32_t* big_list = blk2 + n1 + 1;  // [count] + up to nk sub-partition ids
+    uint32_t* end1 = big_list + nk + 1;  // n1 (speculative sort: the ends of pass 1's partitions)
+    // The speculative sort's plans live in a buffer of their own (two of them, used alternately:
+    // a call consumes the plan its predecessor's k_dsm_p3_scan wrote and writes its successor's):
+    // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1] each, then the two overflow words
+    const size_t plan_words = 2 * (size_t)nk + 2 * (size_t)n1 + 4;
+    uint32_t *plan_use = nullptr, *plan_next = nullptr, *flag_use = nullptr, *flag_next = nullptr;
+    if (spec_mode) {
+      uint32_t* const before = c->spec_plan;
+      if ((rc = ensure_capacity(&c->spec_plan, &c->spec_plan_cap, 2 * plan_words + 16))) return rc;
+      if (c->spec_plan != before && spec) return arg_failure("speculative sort: plan buffer moved");  // (cannot happen: the signature holds nk)
+      if (!c->spec_flag_host) {
+        AMHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->spec_flag_host), 4 * sizeof(unsigned), 0));
+        c->spec_flag_host[0] = 0u;
+      }
+      const int use = c->spec_parity & 1, next = use ^ 1;
+      plan_use = c->spec_plan + (size_t)use * plan_words;
+      plan_next = c->spec_plan + (size_t)next * plan_words;
+      flag_use = c->spec_plan + 2 * plan_words + use;
+      flag_next = c->spec_plan + 2 * plan_words + next;
+      ++c->spec_calls;
+    }
+    uint32_t* const cstart2 = plan_use;                                   // nk + 1
+    uint32_t* const cursor2s = plan_use ? plan_use + nk + 1 : nullptr;    // nk
+    uint32_t* const cstart1 = plan_use ? cursor2s + nk : nullptr;         // n1 + 1
+    uint32_t* const cursor1s = plan_use ? cstart1 + n1 + 1 : nullptr;     // n1
+    uint32_t* const spec_flag = flag_use;
+    if (spec) {
+      // ---- the speculative sort -----------------------------------------
+      // No count pass: both scatter passes append into regions sized from the PREVIOUS call's
+      // exact (k1, k2) counts on this context (count + count / 8 + 32 each), a run that does not
+      // fit raises a flag instead of being written; the cursors give this call's exact counts,
+      // k_dsm_p3_scan the final positions, and the placement pass moves every sub-partition from
+      // its region to its place.  Behind it the exact pipeline is launched as FIXED grids that
+      // leave at once unless the flag is up (no device-side launch in HIP; a host wait inside a
+      // DSM call is not on offer): a few hundred workgroups each.  A miss costs the wasted
+      // scatters once; the context then counts first for the next eight calls.  It can only hit
+      // when consecutive calls bring similarly distributed clouds.
+      ++c->spec_hits_started;
+      const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
+      const size_t lds_sc = (size_t)kP3Chunk * 28 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
+      const size_t lds_cnt = (size_t)nk * sizeof(uint32_t);
+      const size_t lds_pl = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
+      const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
+      int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
+      unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
+      p3_rounds_knob(&cap_rounds, &rounds_above, &reg_max);
+      const size_t lds_big = std::max((size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t),
+                                      (size_t)cap_rounds * 24 + tables);
+      const void* kernels_sc[] = {reinterpret_cast<const void*>(k_dsm_p3_scatter_spec<true>),
+                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_spec<false>),
+                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_pers<true>),
+                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_pers<false>)};
+      for (const void* k : kernels_sc)
+        AMHIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cnt));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pl));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_pers),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pl));
+      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+      {
+        ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
+        hipLaunchKernelGGL(k_dsm_p3_scatter_spec<true>, dim3((unsigned)g1), dim3(kP3Threads), lds_sc, c->stream,
+                           dev_xyz, n, p, cstart1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, cursor1s,
+                           cstart1 + 1, spec_flag, c->sorted, zpart);
+        if (zpart) {
+          hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
+          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
+                             (size_t)g1 * (kP3Threads / 64), zrange, call_range);
+        }
+        hipLaunchKernelGGL(k_p3_spec_mid, dim3(1), dim3(1024), 0, c->stream, cstart1, cursor1s, n1, end1, blk2,
+                           (unsigned)kP3Chunk);
+        hipLaunchKernelGGL(k_dsm_p3_scatter_spec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads), lds_sc,
+                           c->stream, c->sorted, n, p, cstart1, end1, blk2, cursor2s, cstart2 + 1, spec_flag,
+                           c->tmp_points, (double*)nullptr);
+      }
+      {
+        ScopedTimer t(c, AMHIP_K_DSM_SCAN);
+        // (this call's exact counts are what pass 2 appended; the same kernel plans the next call)
+        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
+                           start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
+                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next);
+        hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
+                           c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
+                           0xFFFFFFFFu, (uint2*)nullptr, cstart2);
+        hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
+                           c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, (uint2*)nullptr,
+                           cap_rounds, rounds_above, reg_max, cstart2, (const uint32_t*)nullptr);
+      }
+      {
+        // ---- the exact pipeline behind it: leaves at once unless spec_flag is up ----
+        ScopedTimer t(c, AMHIP_K_MISC);
+        const HaloParams no_halo = {};
+        hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds_cnt, c->stream,
+                           dev_xyz, n, p, hist_rows, no_halo, (double*)nullptr, (unsigned long long*)nullptr,
+                           (double*)nullptr, spec_flag);
+        hipLaunchKernelGGL(k_dsm_p3_reduce_gated, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, c->stream,
+                           hist_rows, (int)gcount, nk, cnt, spec_flag);
+        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
+                           start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
+                           (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                           plan_next, flag_next);
+        hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
+                           n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
+        hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
+                           c->sorted, n, p, start1, blk2, cursor2, c->tmp_points, spec_flag,
+                           (unsigned)(g1 + n1));
+        // (every sub-partition, the over-full ones by direct placement: this pass is the rare one)
+        hipLaunchKernelGGL(k_dsm_p3_place_pers, dim3(1024), dim3(kP3PlaceThreads), lds_pl, c->stream,
+                           c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, 0xFFFFFFFFu,
+                           0xFFFFFFFFu, spec_flag, nk);
+        // this call's overflow word for the host's policy (never waited for)
+        AMHIP_TRY(hipMemcpyAsync(c->spec_flag_host, spec_flag, sizeof(unsigned), hipMemcpyDeviceToHost,
+                                 c->stream));
+        AMHIP_TRY(hipGetLastError());
+      }
+      c->spec_n = n;
+      c->spec_parity ^= 1;  // (the plan this call's scan wrote)
+      c->bin_z_valid = false;
+      return AMHIP_OK;
+    }
     {
+
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
       const size_t lds = (size_t)nk * sizeof(uint32_t);
       const size_t lds_halo = (size_t)((nk + 1) & ~1) * sizeof(uint32_t) + sizeof(HaloStage);
@@ -1697,19 +2033,19 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                  sizeof(unsigned long long) * split->hp.nd, c->stream));
         hipLaunchKernelGGL(k_dsm_p3_count<true>, dim3((unsigned)g_a), dim3(kP3CountThreads),
                            lds_halo, c->stream, dev_xyz, n_a, p, hist_rows, split->hp, split->halo_out,
-                           split->halo_counts, zall);
+                           split->halo_counts, zall, (const uint32_t*)nullptr);
         AMHIP_TRY(hipGetLastError());
         return AMHIP_OK;  // amhip_dsm_tiled_finish_dev comes back with phase 2
       }
       if (!split)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz, n_a, p, hist_rows, no_halo, (double*)nullptr,
-                           (unsigned long long*)nullptr, zall);
+                           (unsigned long long*)nullptr, zall, (const uint32_t*)nullptr);
       else if (g_b)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_b), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz + 3 * n_a, n - n_a, p, hist_rows + g_a * (size_t)nk,
                            no_halo, (double*)nullptr, (unsigned long long*)nullptr,
-                           zall ? zall + 2 * g_a * (kP3CountThreads / 64) : nullptr);
+                           zall ? zall + 2 * g_a * (kP3CountThreads / 64) : nullptr, (const uint32_t*)nullptr);
       // (the records' reference height: the middle of the range every count workgroup left --
       // in a tiled call both parts', the second of which may be absent: its rows hold the first
       // call's partials or the initial "empty" pairs)
@@ -1720,8 +2056,15 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
-                         big_list, (unsigned)(rec ? kRecChunk : kP3Chunk));
+                         big_list, (unsigned)(rec ? kRecChunk : kP3Chunk), (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next);
       AMHIP_TRY(hipGetLastError());
+      if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
+        c->spec_valid = true;
+        c->spec_sig = sig;
+        c->spec_n = n;
+        c->spec_parity ^= 1;
+      }
     }
     if (rec) {
       {
@@ -1805,7 +2148,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z);
+                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
       unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
@@ -1815,7 +2158,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max);
+                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }

@@ -227,6 +227,13 @@ class AerialGridMap(object):
         L.check(self._lib.amhip_ctx_dsm_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"points_binned": a.value, "num_bins": b.value, "bin_cells": c.value}
 
+    def dsm_sort_stats(self):
+        """amhip_ctx_dsm_sort_stats: the speculative sort's bookkeeping on this context."""
+        out = (C.c_int64 * 4)()
+        L.check(self._lib.amhip_ctx_dsm_sort_stats(self._h, out))
+        return {"three_pass_calls": int(out[0]), "speculative": int(out[1]), "overflowed": int(out[2]),
+                "counting_calls_left": int(out[3])}
+
     def dsm_gather_stats(self):
         """amhip_ctx_dsm_gather_stats: where the gather tiles of the last DSM call went."""
         out = (C.c_int64 * 8)()

@@ -583,6 +583,16 @@ int amhip_ctx_dsm_stats(amhip_ctx* ctx, int64_t* points_binned,
  * not used. */
 int amhip_ctx_dsm_gather_stats(amhip_ctx* ctx, int64_t* out8);
 
+/* The speculative sort of the FP64 pipeline (clouds of >= 2^20 points; no reference counterpart:
+ * dsm.cc:36-52 builds a kd-tree): a call whose context saw a three-pass DSM call before sizes its
+ * sort regions from THAT call's exact counts instead of counting first, with the counting
+ * pipeline behind it for the case that a region overflows (same result either way; a miss is
+ * followed by eight counting calls).  out4 = three-pass FP64 calls so far, how many of them
+ * started speculatively, how many of those overflowed (as far as their overflow words have
+ * arrived: synchronise first for an exact figure), counting calls left before the next attempt.
+ * AMHIP_SORT_NO_SPECULATION=1: always count first. */
+int amhip_ctx_dsm_sort_stats(amhip_ctx* ctx, int64_t* out4);
+
 /* The session's map as a grid_map_msgs/GridMap message (ROS 1 wire format): the resident layers
  * travel from the devices straight into `out`.  layer_ids[l] = the amhip layer behind message
  * layer l, or -1: host_layers[l] (rows x cols floats, column-major) is copied, NaN-filled when
