@@ -1003,6 +1003,32 @@ def main():
                     out["ortho_mismatch_cells_fast_mode"] = (
                         out["parity_sample"] if args.dsm_mode == "fast" else om.get("parity_sample", {})).get(key)
             del refs
+        # The sort's speculation (round 4, amhip_sort.hip: dsm_sort): the timed steps bring ONE cloud
+        # again and again, so every DSM call after the context's first ran on the regions its
+        # predecessor planned, without the count pass.  Said here, with the context's own counters,
+        # and with the COUNTING sort (what a context's first call, a call after a miss, or
+        # AMHIP_SORT_NO_SPECULATION=1 gets) timed beside it in the same run.
+        if not batch and not args.knn:
+            try:
+                sort_obj = {"speculation": m.dsm_sort_stats(),
+                            "note": "value / ms_per_step: every timed DSM call sized its sort regions from the "
+                                    "previous call's exact counts on the context (same cloud every step) and "
+                                    "skipped the count pass; a region that overflows sends the call through "
+                                    "the counting pipeline launched behind it -- same heights either way"}
+                if world == 1 and not args.no_second_mode:
+                    os.environ["AMHIP_SORT_NO_SPECULATION"] = "1"
+                    try:
+                        k3 = max(3, min(args.steps, 10))
+                        sec, kms = timed_loop(k3, 2)
+                    finally:
+                        os.environ.pop("AMHIP_SORT_NO_SPECULATION", None)
+                    sort_obj["counting_sort"] = {"steps": k3, "ms_per_step": round(sec * 1e3, 3),
+                                                 "Mcells_per_s": round(cells_all / sec / 1e6, 1),
+                                                 "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+                    timed_loop(1, 1)   # (leave the context as the timed steps left it: planned)
+                out["sort"] = sort_obj
+            except Exception as e:
+                out["sort"] = {"error": repr(e)}
         if world == 1 and not fixed and not args.no_rough_terrain and not args.knn and not batch:
             try:
                 out["rough_terrain"] = rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L)
