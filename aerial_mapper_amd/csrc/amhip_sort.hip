@@ -395,12 +395,16 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
               uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag) {
   __shared__ unsigned lds[1024 / 64 + 1];
-  __shared__ unsigned lds2[1024 / 64 + 1];
   if (gate && !*gate) return;
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
+  // (launched with TWO workgroups when there is a plan to write: the second one scans the regions'
+  // sizes instead of the counts -- in the same workgroup the two arrays of 32 prefixes per thread
+  // spilled and the kernel took 50 us instead of 17)
+  const bool plan_block = blockIdx.x == 1;
+  if (plan_block && !plan) return;
   unsigned carry = 0;
-  if (threadIdx.x == 0) big_list[0] = 0;
+  if (threadIdx.x == 0 && !plan_block) big_list[0] = 0;
   __syncthreads();
   // A wave owns a contiguous segment of the counters and walks it 64 at a time (coalesced; all
   // its loads in flight at once, wave scans without barriers), the workgroup scans the 16 segment
@@ -413,8 +417,8 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
     const int seg = ((nk + 16 * 64 - 1) / (16 * 64)) * 64;  // counters per wave, a multiple of 64
     const int iters = seg / 64;
     const int w0 = wid * seg;
-    unsigned v[kMaxIt];  // the counter, then its exclusive prefix inside the wave's segment
-    unsigned r[kMaxIt];  // the same for the next call's regions (plan)
+    unsigned v[kMaxIt];  // the counter (plan_block: the region's size), then its exclusive prefix
+                         // inside the wave's segment
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
       const int i = w0 + q * 64 + lane;
@@ -426,44 +430,32 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
       } else {
         v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
       }
+      if (plan_block) v[q] = (q < iters && i < nk) ? v[q] + (v[q] >> 3) + 32u : 0u;
     }
     unsigned run = 0;   // (wave-uniform)
-    unsigned run2 = 0;
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
       if (q < iters) {
-        if (plan) {
-          const int i = w0 + q * 64 + lane;
-          const unsigned room = i < nk ? v[q] + (v[q] >> 3) + 32u : 0u;
-          const unsigned incl2 = wave_incl_scan(room, lane);
-          r[q] = run2 + incl2 - room;
-          run2 += __shfl(incl2, 63, 64);
-        }
         // sub-partitions too full for k_dsm_p3_place's registers but not for a whole
         // CU's LDS (denser parts of a non-uniform cloud): k_dsm_p3_place_big's list
         // (no upper bound: beyond a CU's LDS the big kernel places in several rounds)
-        if (v[q] > cap_small)
+        if (!plan_block && v[q] > cap_small)
           big_list[1 + atomicAdd(&big_list[0], 1u)] = (uint32_t)(w0 + q * 64 + lane);
         const unsigned incl = wave_incl_scan(v[q], lane);
         v[q] = run + incl - v[q];
         run += __shfl(incl, 63, 64);
       }
     }
-    if (lane == 0) {
-      lds[wid] = run;
-      lds2[wid] = run2;
-    }
+    if (lane == 0) lds[wid] = run;
     __syncthreads();
-    unsigned base = 0, total = 0, base2 = 0, total2 = 0;
+    unsigned base = 0, total = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-      const unsigned t = lds[w], t2 = lds2[w];
+      const unsigned t = lds[w];
       if (w < wid) base += t;
       total += t;
-      if (w < wid) base2 += t2;
-      total2 += t2;
     }
-    if (plan) {
+    if (plan_block) {
       uint32_t* const pstart2 = plan;
       uint32_t* const pcur2 = plan + nk + 1;
       uint32_t* const pstart1 = pcur2 + nk;
@@ -472,7 +464,7 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
       for (int q = 0; q < kMaxIt; ++q) {
         const int i = w0 + q * 64 + lane;
         if (q < iters && i < nk) {
-          const unsigned st = base2 + r[q];
+          const unsigned st = base + v[q];
           pstart2[i] = st;
           pcur2[i] = st;
           if (i % n2 == 0) {
@@ -482,10 +474,11 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
         }
       }
       if (threadIdx.x == 0) {
-        pstart2[nk] = total2;
-        pstart1[n1] = total2;
+        pstart2[nk] = total;
+        pstart1[n1] = total;
         plan_flag[0] = 0u;
       }
+      return;  // (the whole workgroup)
     }
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
@@ -1976,7 +1969,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       {
         ScopedTimer t(c, AMHIP_K_DSM_SCAN);
         // (this call's exact counts are what pass 2 appended; the same kernel plans the next call)
-        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
+        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next);
         hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
@@ -1995,7 +1988,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                            (double*)nullptr, spec_flag);
         hipLaunchKernelGGL(k_dsm_p3_reduce_gated, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, c->stream,
                            hist_rows, (int)gcount, nk, cnt, spec_flag);
-        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
+        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                            plan_next, flag_next);
@@ -2054,7 +2047,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                            (split && !g_b ? g_a : gcount) * (size_t)(kP3CountThreads / 64), c->zref);
       hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
                          c->stream, hist_rows, (int)gcount, nk, cnt);
-      hipLaunchKernelGGL(k_dsm_p3_scan, dim3(1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
+      hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
                          big_list, (unsigned)(rec ? kRecChunk : kP3Chunk), (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next);
