@@ -1696,7 +1696,9 @@ int amhip_ctx_dsm_sort_stats(amhip_ctx* h, int64_t* out4) {
   Ctx* c = &h->impl;
   if (c->spec_flag_host && c->spec_flag_host[0]) {  // (what spec_wanted would do at the next call)
     c->spec_flag_host[0] = 0u;
-    c->spec_cooldown = 8;
+    c->spec_cooldown = c->spec_backoff;
+    c->spec_backoff = std::min(2 * c->spec_backoff, 64);
+    c->spec_last_hit = false;
     ++c->spec_misses;
   }
   out4[0] = (int64_t)c->spec_calls;

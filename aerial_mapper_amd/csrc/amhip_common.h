@@ -267,6 +267,8 @@ struct Ctx {
   unsigned long long spec_sig = 0;
   size_t spec_n = 0;
   int spec_cooldown = 0;
+  int spec_backoff = 8;            // counting calls after the next miss
+  bool spec_last_hit = false;      // the previous three-pass call started speculatively
   unsigned long long spec_calls = 0, spec_hits_started = 0, spec_misses = 0;  // (three-pass FP64 calls / speculative / overflowed)
   uint8_t* tile_occ = nullptr;         // per gather tile: any point within the last radius
   size_t tile_occ_cap = 0;

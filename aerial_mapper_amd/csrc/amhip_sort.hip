@@ -1795,15 +1795,22 @@ static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
   if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
   if (c->spec_flag_host && c->spec_flag_host[0]) {  // a speculative call overflowed
     c->spec_flag_host[0] = 0u;
-    c->spec_cooldown = 8;
+    // (8 counting calls, twice as many after every further miss in a row, at most 64: a host that
+    // alternates between two surveys on one context pays for a wasted scatter ever more rarely)
+    c->spec_cooldown = c->spec_backoff;
+    c->spec_backoff = std::min(2 * c->spec_backoff, 64);
     ++c->spec_misses;
+  } else if (c->spec_last_hit) {
+    c->spec_backoff = 8;  // (the last speculative call's word arrived clear, or has not arrived yet)
   }
+  c->spec_last_hit = false;
   if (c->spec_cooldown > 0) {
     --c->spec_cooldown;
     return false;
   }
   // (more points than the margins can take, or far fewer: count first)
-  return n <= c->spec_n + c->spec_n / 16 + 1024 && 2 * n >= c->spec_n;
+  c->spec_last_hit = n <= c->spec_n + c->spec_n / 16 + 1024 && 2 * n >= c->spec_n;
+  return c->spec_last_hit;
 }
 
 // ---------------------------------------------------------------------------

@@ -587,7 +587,7 @@ int amhip_ctx_dsm_gather_stats(amhip_ctx* ctx, int64_t* out8);
  * dsm.cc:36-52 builds a kd-tree): a call whose context saw a three-pass DSM call before sizes its
  * sort regions from THAT call's exact counts instead of counting first, with the counting
  * pipeline behind it for the case that a region overflows (same result either way; a miss is
- * followed by eight counting calls).  out4 = three-pass FP64 calls so far, how many of them
+ * followed by eight counting calls, twice as many after every further miss in a row, at most 64).  out4 = three-pass FP64 calls so far, how many of them
  * started speculatively, how many of those overflowed (as far as their overflow words have
  * arrived: synchronise first for an exact figure), counting calls left before the next attempt.
  * AMHIP_SORT_NO_SPECULATION=1: always count first. */
