@@ -378,6 +378,15 @@ k_dsm_p3_reduce(const uint32_t* __restrict__ hist_rows, int nrows, int nk,
   if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
 }
 
+// layout of a speculative sort's plan (uint32 words): [cstart2: nk + 1][cstart1: n1 + 1] ... 1 KB
+// aligned: [cursor2: nk] ... [cursor1: n1]
+__host__ __device__ inline size_t p3_plan_cursor2_at(int nk, int n1) {
+  return (((size_t)nk + 1 + (size_t)n1 + 1 + 255) & ~(size_t)255) + 256;
+}
+__host__ __device__ inline size_t p3_plan_words(int nk, int n1) {
+  return p3_plan_cursor2_at(nk, n1) + (((size_t)nk + 255) & ~(size_t)255) + (((size_t)n1 + 255) & ~(size_t)255) + 256;
+}
+
 // One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
 // copy as the pass-2 append cursors; start1 / cursor1 for pass 1; blk2 = first
 // pass-2 workgroup of every k1 partition (partitions are cut into chunks).
@@ -393,7 +402,7 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               // NEXT call's regions from this call's counts, count + count / 8 + 32 each:
               // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1], and its overflow word
               const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
-              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag) {
+              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift) {
   __shared__ unsigned lds[1024 / 64 + 1];
   if (gate && !*gate) return;
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
@@ -430,7 +439,7 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
       } else {
         v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
       }
-      if (plan_block) v[q] = (q < iters && i < nk) ? v[q] + (v[q] >> 3) + 32u : 0u;
+      if (plan_block) v[q] = (q < iters && i < nk) ? v[q] + (v[q] >> room_shift) + 32u : 0u;
     }
     unsigned run = 0;   // (wave-uniform)
 #pragma unroll
@@ -456,10 +465,12 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
       total += t;
     }
     if (plan_block) {
+      // (region starts and append cursors 1 KB apart at least: the passes' key threads LOAD the
+      // starts -- their limits -- while every workgroup's atomics hammer the cursors)
       uint32_t* const pstart2 = plan;
-      uint32_t* const pcur2 = plan + nk + 1;
-      uint32_t* const pstart1 = pcur2 + nk;
-      uint32_t* const pcur1 = pstart1 + n1 + 1;
+      uint32_t* const pstart1 = plan + nk + 1;
+      uint32_t* const pcur2 = plan + p3_plan_cursor2_at(nk, n1);
+      uint32_t* const pcur1 = pcur2 + ((nk + 255) & ~255);
 #pragma unroll
       for (int q = 0; q < kMaxIt; ++q) {
         const int i = w0 + q * 64 + lane;
@@ -1836,11 +1847,29 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   // the speculative sort (three-pass, FP64 pipeline, plain DSM call): see below
   static const bool force_one_level_ = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
-  const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split;
+  // (up to 2^27 points, the sizes it was measured at: - 0.19 ms of 5.75 at 50 M points, - 0.48 of
+  // 9.50 at 100 M.  Until the plan kept its region STARTS -- which every workgroup's key threads load
+  // as their limits -- 1 KB away from the append CURSORS -- which every workgroup's atomics hammer
+  // --, the first speculative pass ran at two thirds to half speed from 100 M points on (+ 0.8 /
+  // 1.6 / 3.3 ms at 100 / 200 / 400 M: tools/sort_scale_probe.py); larger clouds were not measured
+  // again after that and keep counting first.  AMHIP_SORT_SPEC_MAX_POINTS moves the limit.)
+  static const size_t spec_max_points = getenv("AMHIP_SORT_SPEC_MAX_POINTS")
+                                            ? (size_t)atoll(getenv("AMHIP_SORT_SPEC_MAX_POINTS")) : ((size_t)1 << 27);
+  const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split &&
+                         n <= spec_max_points;
   const unsigned long long sig = spec_mode ? spec_signature(p) : 0ull;
   const bool spec = spec_mode && spec_wanted(c, n, sig);
+  // (the regions' head room: count >> room_shift; AMHIP_SORT_SPEC_MARGIN_SHIFT, 1 .. 31, experiments)
+  static const int room_shift = getenv("AMHIP_SORT_SPEC_MARGIN_SHIFT")
+                                    ? std::min(31, std::max(1, atoi(getenv("AMHIP_SORT_SPEC_MARGIN_SHIFT")))) : 3;
   // (regions of count + count / 8 + 32 over the previous call's counts)
-  const size_t spec_points = spec ? c->spec_n + c->spec_n / 8 + 32 * (size_t)p.p3_n1 * (size_t)p.p3_n2 + 64 : 0;
+  // (reserved from the context's FIRST such call on: growing the two point buffers later means
+  // freeing 2 x 9.6 GB and allocating 2 x 10.8 GB at configs[3]'s size, and the new blocks came back
+  // in small physical fragments -- the first scatter pass, whose writes roam the whole buffer, then
+  // ran at half speed on TLB misses: 9.5 ms instead of 4.6)
+  const size_t spec_basis = std::max(n, spec ? c->spec_n : (size_t)0);
+  const size_t spec_points = spec_mode ? spec_basis + (spec_basis >> room_shift) + spec_basis / 16 +
+                                             32 * (size_t)p.p3_n1 * (size_t)p.p3_n2 + 2048 : 0;
   {
     int rc;
     if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * std::max(n, spec_points)))) return rc;
@@ -1899,7 +1928,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     // The speculative sort's plans live in a buffer of their own (two of them, used alternately:
     // a call consumes the plan its predecessor's k_dsm_p3_scan wrote and writes its successor's):
     // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1] each, then the two overflow words
-    const size_t plan_words = 2 * (size_t)nk + 2 * (size_t)n1 + 4;
+    const size_t plan_words = p3_plan_words(nk, n1);
     uint32_t *plan_use = nullptr, *plan_next = nullptr, *flag_use = nullptr, *flag_next = nullptr;
     if (spec_mode) {
       uint32_t* const before = c->spec_plan;
@@ -1916,10 +1945,10 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       flag_next = c->spec_plan + 2 * plan_words + next;
       ++c->spec_calls;
     }
-    uint32_t* const cstart2 = plan_use;                                   // nk + 1
-    uint32_t* const cursor2s = plan_use ? plan_use + nk + 1 : nullptr;    // nk
-    uint32_t* const cstart1 = plan_use ? cursor2s + nk : nullptr;         // n1 + 1
-    uint32_t* const cursor1s = plan_use ? cstart1 + n1 + 1 : nullptr;     // n1
+    uint32_t* const cstart2 = plan_use;                                                     // nk + 1
+    uint32_t* const cstart1 = plan_use ? plan_use + nk + 1 : nullptr;                       // n1 + 1
+    uint32_t* const cursor2s = plan_use ? plan_use + p3_plan_cursor2_at(nk, n1) : nullptr;  // nk
+    uint32_t* const cursor1s = plan_use ? cursor2s + ((nk + 255) & ~255) : nullptr;         // n1
     uint32_t* const spec_flag = flag_use;
     if (spec) {
       // ---- the speculative sort -----------------------------------------
@@ -1978,7 +2007,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         // (this call's exact counts are what pass 2 appended; the same kernel plans the next call)
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
-                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next);
+                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift);
         hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
                            c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
                            0xFFFFFFFFu, (uint2*)nullptr, cstart2);
@@ -1998,7 +2027,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           plan_next, flag_next);
+                           plan_next, flag_next, room_shift);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
                            n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
@@ -2057,7 +2086,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
                          big_list, (unsigned)(rec ? kRecChunk : kP3Chunk), (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next, room_shift);
       AMHIP_TRY(hipGetLastError());
       if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
         c->spec_valid = true;
