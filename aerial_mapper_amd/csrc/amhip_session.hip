@@ -137,39 +137,41 @@ k_layer_hash(const float* __restrict__ layer, float constant, int rows, int cols
 // alone (0: none).  A GPU box's pod runs under such a quota: 256 hardware threads, 16 CPUs' worth of
 // time per 100 ms (tools/ubench/host_sum_bench.cc: 128 summing threads run 12 ms at 200 GB/s,
 // then the whole process is frozen until the period ends).
-static int usable_cpus(double* quota_cpus) {
-  static int cpus = 0;
-  static double quota = 0.0;
-  if (!cpus) {
-    int n = (int)std::thread::hardware_concurrency();
-    if (n <= 0) n = 8;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
-    double q = 0.0;
-    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
-      char a[64] = {0};
-      double period = 0.0;
-      if (std::fscanf(f, "%63s %lf", a, &period) == 2 && period > 0.0 && a[0] >= '0' && a[0] <= '9')
-        q = std::atof(a) / period;
-      std::fclose(f);
-    } else {
-      double qu = -1.0, period = 0.0;
-      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-        if (std::fscanf(g, "%lf", &qu) != 1) qu = -1.0;
-        std::fclose(g);
-      }
-      if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-        if (std::fscanf(g, "%lf", &period) != 1) period = 0.0;
-        std::fclose(g);
-      }
-      if (qu > 0.0 && period > 0.0) q = qu / period;
+struct CpuBudget {
+  int cpus;
+  double quota;
+};
+static CpuBudget measure_cpu_budget() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n <= 0) n = 8;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+  double q = 0.0;
+  if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char a[64] = {0};
+    double period = 0.0;
+    if (std::fscanf(f, "%63s %lf", a, &period) == 2 && period > 0.0 && a[0] >= '0' && a[0] <= '9')
+      q = std::atof(a) / period;
+    std::fclose(f);
+  } else {
+    double qu = -1.0, period = 0.0;
+    if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (std::fscanf(g, "%lf", &qu) != 1) qu = -1.0;
+      std::fclose(g);
     }
-    quota = q;
-    if (q > 0.0) n = std::min(n, std::max(1, (int)std::ceil(q)));
-    cpus = n;
+    if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (std::fscanf(g, "%lf", &period) != 1) period = 0.0;
+      std::fclose(g);
+    }
+    if (qu > 0.0 && period > 0.0) q = qu / period;
   }
-  if (quota_cpus) *quota_cpus = quota;
-  return cpus;
+  if (q > 0.0) n = std::min(n, std::max(1, (int)std::ceil(q)));
+  return {n, q};
+}
+static int usable_cpus(double* quota_cpus) {
+  static const CpuBudget b = measure_cpu_budget();  // (once per process; thread-safe initialisation)
+  if (quota_cpus) *quota_cpus = b.quota;
+  return b.cpus;
 }
 
 // threads for a pass of host threads over `bytes` of matrices

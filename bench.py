@@ -27,6 +27,11 @@ bounded sample of the same workload on this box's host cores).
 `value` is the library's DEFAULT arithmetic: the FP64 gather (the reference's doubles,
 dsm.cc:160-172).  The opt-in single-precision mode is timed in the same run and reported as
 the extra object `fast_mode`, with its own parity sample and roofline.
+
+The timed steps repeat ONE cloud, so every DSM call after the context's first runs the
+speculative sort (amhip_sort.hip: regions planned by the previous call, no count pass).  The
+extra object `sort` says so with the context's counters and times the counting sort -- what a
+context's first call gets -- beside it in the same run (`sort.counting_sort`).
 """
 import argparse
 import json
