@@ -22,7 +22,8 @@ OBJ_DIR = os.path.join(ROOT, "build", "hip_obj")
 
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
                "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip",
-               "amhip_hostsum.cc"]   # (.cc: host-only, the AVX-512 loop of the session's content sums)
+               "amhip_hostsum.cc",   # (.cc: host-only, the AVX-512 loop of the session's content sums)
+               "amhip_build_id.cc"]  # (host-only: amhip_build_id(), recompiled whenever anything else is)
 HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", "amhip_content_sum.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box
@@ -38,6 +39,19 @@ def _hipcc():
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 for gfx950)")
+
+
+def source_build_id(extra_flags=()):
+    """First 16 hex digits of the SHA-256 over the library's sources, headers and flags."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, s) for s in HIP_SOURCES if s != "amhip_build_id.cc"] + \
+        [f if os.path.isabs(f) else os.path.join(CSRC, f) for f in HIP_HEADERS]
+    for f in sorted(files):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    h.update(" ".join(list(HIPCC_FLAGS) + list(extra_flags)).encode())
+    return h.hexdigest()[:16]
 
 
 def _stale(target, deps):
@@ -62,10 +76,14 @@ def build_hip(force=False, verbose=False):
     if not os.path.exists(stamp) or open(stamp).read() != flags_now:
         force = True
     jobs = []
+    build_id = source_build_id(extra)
+    id_stamp = os.path.join(OBJ_DIR, "build_id.txt")
+    id_changed = not os.path.exists(id_stamp) or open(id_stamp).read() != build_id
     for s in HIP_SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(OBJ_DIR, s + ".o")
-        if force or _stale(obj, [src] + hdrs) or not os.path.exists(obj + ".remarks"):
+        if force or _stale(obj, [src] + hdrs) or not os.path.exists(obj + ".remarks") or \
+                (s == "amhip_build_id.cc" and id_changed):
             jobs.append((src, obj))
     objs = [os.path.join(OBJ_DIR, s + ".o") for s in HIP_SOURCES]
     if not jobs and not _stale(LIB_PATH, objs) and os.path.exists(RESOURCES_PATH):
@@ -78,6 +96,7 @@ def build_hip(force=False, verbose=False):
                             not (host_only and f.startswith("--offload-arch"))] + extra + [
             "-c"] + ([] if host_only else ["-Rpass-analysis=kernel-resource-usage"]) + [
             "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", obj] + (
+            ['-DAMHIP_BUILD_ID="%s"' % build_id] if src.endswith("amhip_build_id.cc") else []) + (
             ["-x", "c++"] if host_only else []) + [src]   # (hipcc takes any source for HIP otherwise)
         if verbose:
             print(" ".join(cmd))
@@ -106,6 +125,7 @@ def build_hip(force=False, verbose=False):
     with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(compile_one, jobs))
     open(stamp, "w").write(flags_now)
+    open(id_stamp, "w").write(build_id)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))

@@ -950,6 +950,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   if (c->host_tile_stats) (void)hipHostFree(c->host_tile_stats);
   if (c->host_bbox) (void)hipHostFree(c->host_bbox);
   if (c->spec_flag_host) (void)hipHostFree(c->spec_flag_host);
+  if (c->order_event) (void)hipEventDestroy(c->order_event);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
 }
@@ -1027,8 +1028,20 @@ static int materialize(Ctx* c, int layer) {
   return AMHIP_OK;
 }
 
+// What the last writing call can have written: the whole window, unless the call narrows it
+// afterwards (a small cloud's sub-window, a small batch's tile list).  Every writer passes here --
+// touch() / overwrite() / the fused-fill branches -- so a rectangle never outlives its call
+// (the tiled / OrthoFromPcl / empty-cloud entry points used to leave the previous one).
+static void dirty_full(Ctx* c) {
+  c->dirty_on_device = false;
+  c->dirty[0] = c->dirty[1] = 0;
+  c->dirty[2] = c->win_rows;
+  c->dirty[3] = c->win_cols;
+}
+
 // partial writer: materialize, then dirty
 static int touch(Ctx* c, int layer) {
+  dirty_full(c);
   const int rc = materialize(c, layer);
   if (rc) return rc;
   if (c->layer_state[layer] == 0) c->layer_state[layer] = 1;
@@ -1037,6 +1050,7 @@ static int touch(Ctx* c, int layer) {
 
 // full overwrite (upload): no need to fill first
 static void overwrite(Ctx* c, int layer) {
+  dirty_full(c);
   if (c->layer_state[layer] != 2) c->layer_state[layer] = 1;
   if (layer == AMHIP_LAYER_ELEVATION) c->zrange_valid = false;  // heights from outside
 }
@@ -1131,7 +1145,11 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
                           int radius_sq, double center_easting,
                           double center_northing) {
   if (!h) return arg_fail("null context");  // CHECK(map), dsm.cc:194
-  if (n == 0) return AMHIP_OK;               // empty cloud: warning + return
+  if (n == 0) {                               // empty cloud: warning + return -- nothing written
+    h->impl.dirty_on_device = false;
+    h->impl.dirty[0] = h->impl.dirty[1] = h->impl.dirty[2] = h->impl.dirty[3] = 0;
+    return AMHIP_OK;
+  }
   if (!dev_xyz) return arg_fail("amhip_dsm_process_dev: null point pointer");
   if (radius_sq <= 0)
     return arg_fail("interpolation_radius must be >= 1 (the reference loops forever on 0)");
@@ -1150,10 +1168,7 @@ int amhip_dsm_process_dev(amhip_ctx* h, const double* dev_xyz, size_t n,
     c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
   else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
     return rc;
-  c->dirty_on_device = false;
-  c->dirty[0] = c->dirty[1] = 0;
-  c->dirty[2] = c->win_rows;
-  c->dirty[3] = c->win_cols;
+  dirty_full(c);
   if (!fused_fill) {  // a small cloud onto a large materialized map: its bounding box is the window
     DsmParams ps;
     const int sw = dsm_subwindow(c, dev_xyz, n, radius_sq, center_easting, center_northing, p, &ps);
@@ -1216,6 +1231,7 @@ int amhip_ortho_from_pcl_process_dev(amhip_ctx* h, const double* dev_xyz,
   if ((rc = make_dsm_params(*c, radius_sq, 0.0, 0.0, &p, 1, 1, n))) return rc;
   if (!adaptive) {
     const bool fused_fill = c->layer_state[AMHIP_LAYER_ORTHO] == 3;
+    dirty_full(c);
     if (fused_fill)
       c->layer_state[AMHIP_LAYER_ORTHO] = 1;
     else if ((rc = touch(c, AMHIP_LAYER_ORTHO)))
@@ -1438,6 +1454,7 @@ int amhip_dsm_tiled_finish_dev(amhip_ctx* h) {
   hipLaunchKernelGGL(k_halo_overflow_check, dim3(1), dim3(64), 0, c->stream, sp.halo_counts,
                      sp.hp.nd, sp.hp.cap, c->dev_err);
   const bool fused_fill = c->layer_state[AMHIP_LAYER_ELEVATION] == 3;
+  dirty_full(c);
   if (fused_fill)
     c->layer_state[AMHIP_LAYER_ELEVATION] = 1;
   else if ((rc = touch(c, AMHIP_LAYER_ELEVATION)))
@@ -1555,6 +1572,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   p.virt_out = 1;
   for (int k = 0; k < 3; ++k)
     if (c->layer_state[outs[k]] != 3) p.virt_out = 0;
+  dirty_full(c);  // (ortho_run narrows it to the tile list's box where one is walked)
   for (int k = 0; k < 3; ++k) {
     if (p.virt_out)
       c->layer_state[outs[k]] = 1;
@@ -1694,17 +1712,30 @@ const char* amhip_kernel_name(int kernel) {
 int amhip_ctx_dsm_sort_stats(amhip_ctx* h, int64_t* out4) {
   if (!h || !out4) return arg_fail("amhip_ctx_dsm_sort_stats: null argument");
   Ctx* c = &h->impl;
-  if (c->spec_flag_host && c->spec_flag_host[0]) {  // (what spec_wanted would do at the next call)
-    c->spec_flag_host[0] = 0u;
-    c->spec_cooldown = c->spec_backoff;
-    c->spec_backoff = std::min(2 * c->spec_backoff, 64);
-    c->spec_last_hit = false;
-    ++c->spec_misses;
-  }
+  (void)spec_poll_overflow(c);  // (the same bookkeeping the next DSM call would do: one definition)
   out4[0] = (int64_t)c->spec_calls;
   out4[1] = (int64_t)c->spec_hits_started;
   out4[2] = (int64_t)c->spec_misses;
   out4[3] = (int64_t)c->spec_cooldown;
+  return AMHIP_OK;
+}
+
+int amhip_ctx_set_dsm_sort_reuse(amhip_ctx* h, int on) {
+  if (!h) return arg_fail("null context");
+  h->impl.spec_reuse = on != 0;
+  return AMHIP_OK;
+}
+
+int amhip_ctx_order_after(amhip_ctx* h, void* other_stream) {
+  if (!h) return arg_fail("null context");
+  Ctx* c = &h->impl;
+  int rc = use_device(c);
+  if (rc) return rc;
+  hipStream_t other = static_cast<hipStream_t>(other_stream);
+  if (other == c->stream) return AMHIP_OK;  // (already ordered)
+  if (!c->order_event) AMHIP_TRY(hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
+  AMHIP_TRY(hipEventRecord(c->order_event, c->stream));
+  AMHIP_TRY(hipStreamWaitEvent(other, c->order_event, 0));
   return AMHIP_OK;
 }
 

@@ -196,6 +196,7 @@ struct Ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipEvent_t order_event = nullptr;  // amhip_ctx_order_after
   size_t cells = 0;
   int dsm_exact = 0;          // amhip_ctx_set_dsm_precision
   // single-precision mode on rough terrain (amhip_api.hip: dsm_rough_policy): when a call filed
@@ -264,6 +265,7 @@ struct Ctx {
   int spec_parity = 0;             // which of the two the next call consumes
   unsigned* spec_flag_host = nullptr;
   bool spec_valid = false;
+  bool spec_reuse = true;          // amhip_ctx_set_dsm_sort_reuse: plan a call's regions from its predecessor's counts
   unsigned long long spec_sig = 0;
   size_t spec_n = 0;
   int spec_cooldown = 0;
@@ -372,6 +374,7 @@ int make_halo_params(const Ctx& c, double center_easting, double center_northing
 // byte per cell, set where this call wrote a value; unfilled (may be null):
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
+bool spec_poll_overflow(Ctx* c);  // amhip_sort.hip: the speculative sort's miss bookkeeping
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split = nullptr);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,

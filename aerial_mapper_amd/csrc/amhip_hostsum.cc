@@ -3,7 +3,12 @@
 // chosen once at run time.  Host-only translation unit: nothing here runs on the GPU.
 // tools/ubench/host_sum_avx512.cc: 5.2 -> 33 GB/s per thread on the GPU boxes' EPYC 9575F, which
 // matters under the pod's CPU quota (16 CPUs' worth of time: amhip_session.hip, usable_cpus).
+#if defined(__x86_64__) || defined(__i386__)
+#define AMHIP_HOSTSUM_X86 1
 #include <immintrin.h>
+#else
+#define AMHIP_HOSTSUM_X86 0   // (aarch64 hosts: the portable scalar loop, host_sum_is_vectorized() == false)
+#endif
 
 #include <cstdlib>
 
@@ -19,6 +24,7 @@ static void sum_scalar(const unsigned* col, size_t n, unsigned long long g0, uns
   *b += hb;
 }
 
+#if AMHIP_HOSTSUM_X86
 __attribute__((target("avx512f,avx512dq"))) static void sum_avx512(const unsigned* col, size_t n,
                                                                    unsigned long long g0,
                                                                    unsigned long long* a,
@@ -51,14 +57,20 @@ __attribute__((target("avx512f,avx512dq"))) static void sum_avx512(const unsigne
   *b += hb;
 }
 
+#endif  // AMHIP_HOSTSUM_X86
+
 using SumFn = void (*)(const unsigned*, size_t, unsigned long long, unsigned long long*,
                        unsigned long long*);
 
 static SumFn pick() {
+#if AMHIP_HOSTSUM_X86
   if (std::getenv("AMHIP_SESSION_SCALAR_SUMS")) return sum_scalar;
   __builtin_cpu_init();
   return (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) ? sum_avx512
                                                                                     : sum_scalar;
+#else
+  return sum_scalar;
+#endif
 }
 
 static SumFn resolved() {
@@ -71,6 +83,12 @@ void host_column_sum(const unsigned* col, size_t n, unsigned long long g0, unsig
   resolved()(col, n, g0, a, b);
 }
 
-bool host_sum_is_vectorized() { return resolved() == sum_avx512; }
+bool host_sum_is_vectorized() {
+#if AMHIP_HOSTSUM_X86
+  return resolved() == sum_avx512;
+#else
+  return false;
+#endif
+}
 
 }  // namespace amhip

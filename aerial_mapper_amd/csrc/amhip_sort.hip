@@ -402,9 +402,13 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
               // NEXT call's regions from this call's counts, count + count / 8 + 32 each:
               // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1], and its overflow word
               const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
-              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift) {
+              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
+              // a speculative call's own scan: nothing to do once a region overflowed (the regions then
+              // hold gaps no run was written to; the exact pipeline behind rewrites everything, the plan too)
+              const uint32_t* __restrict__ skip_if /* may be null */) {
   __shared__ unsigned lds[1024 / 64 + 1];
   if (gate && !*gate) return;
+  if (skip_if && *skip_if) return;
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
   // (launched with TWO workgroups when there is a plan to write: the second one scans the regions'
@@ -1095,7 +1099,12 @@ __global__ void __launch_bounds__(kP3PlaceThreads)
 k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
                const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
-               uint2* __restrict__ bin_z, const uint32_t* __restrict__ src_start) {
+               uint2* __restrict__ bin_z, const uint32_t* __restrict__ src_start,
+               const uint32_t* __restrict__ skip_if /* speculative sort: its overflow word, else null */) {
+  // (an overflowed speculative sort leaves holes in its regions -- slots a dropped run reserved
+  // and never wrote: nothing there may be read as a point, ADVICE r4.  The flag is final once pass 2
+  // has run; the exact pipeline launched behind writes the whole output.)
+  if (skip_if && *skip_if) return;
   place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted,
                                                    (int)blockIdx.x, skip_lo, skip_hi, bin_z, src_start);
 }
@@ -1122,8 +1131,10 @@ k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
                    uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max,
                    const uint32_t* __restrict__ src_start /* speculative sort, else null */,
-                   const uint32_t* __restrict__ gate /* the exact pass behind one, else null */) {
+                   const uint32_t* __restrict__ gate /* the exact pass behind one, else null */,
+                   const uint32_t* __restrict__ skip_if /* a speculative sort's own pass: its overflow word */) {
   if (gate && !*gate) return;
+  if (skip_if && *skip_if) return;
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     const int sp = (int)big_list[1 + k];
@@ -1800,20 +1811,26 @@ static unsigned long long spec_signature(const DsmParams& p) {
   return h ? h : 1ull;
 }
 
-// AMHIP_SORT_NO_SPECULATION=1: always count first
+// The overflow word of the last speculative call, if it has arrived (a pinned word the host never
+// waits for): a miss starts the cooldown -- 8 counting calls, twice as many after every further
+// miss in a row, at most 64 (a host that alternates between two surveys on one context pays for a
+// wasted scatter ever more rarely).  ONE definition for dsm_sort and amhip_ctx_dsm_sort_stats.
+bool spec_poll_overflow(Ctx* c) {
+  if (!c->spec_flag_host || !c->spec_flag_host[0]) return false;
+  c->spec_flag_host[0] = 0u;
+  c->spec_cooldown = c->spec_backoff;
+  c->spec_backoff = std::min(2 * c->spec_backoff, 64);
+  c->spec_last_hit = false;
+  ++c->spec_misses;
+  return true;
+}
+
+// amhip_ctx_set_dsm_sort_reuse(ctx, 0) / AMHIP_SORT_NO_SPECULATION=1: always count first
 static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
-  const bool off = getenv("AMHIP_SORT_NO_SPECULATION") != nullptr;  // (read per call: tests flip it)
+  const bool off = !c->spec_reuse || getenv("AMHIP_SORT_NO_SPECULATION") != nullptr;  // (read per call: tests flip it)
   if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
-  if (c->spec_flag_host && c->spec_flag_host[0]) {  // a speculative call overflowed
-    c->spec_flag_host[0] = 0u;
-    // (8 counting calls, twice as many after every further miss in a row, at most 64: a host that
-    // alternates between two surveys on one context pays for a wasted scatter ever more rarely)
-    c->spec_cooldown = c->spec_backoff;
-    c->spec_backoff = std::min(2 * c->spec_backoff, 64);
-    ++c->spec_misses;
-  } else if (c->spec_last_hit) {
+  if (!spec_poll_overflow(c) && c->spec_last_hit)
     c->spec_backoff = 8;  // (the last speculative call's word arrived clear, or has not arrived yet)
-  }
   c->spec_last_hit = false;
   if (c->spec_cooldown > 0) {
     --c->spec_cooldown;
@@ -2007,13 +2024,14 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         // (this call's exact counts are what pass 2 appended; the same kernel plans the next call)
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
-                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift);
+                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift,
+                           spec_flag);
         hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
                            c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
-                           0xFFFFFFFFu, (uint2*)nullptr, cstart2);
+                           0xFFFFFFFFu, (uint2*)nullptr, cstart2, spec_flag);
         hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
                            c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, (uint2*)nullptr,
-                           cap_rounds, rounds_above, reg_max, cstart2, (const uint32_t*)nullptr);
+                           cap_rounds, rounds_above, reg_max, cstart2, (const uint32_t*)nullptr, spec_flag);
       }
       {
         // ---- the exact pipeline behind it: leaves at once unless spec_flag is up ----
@@ -2027,7 +2045,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           plan_next, flag_next, room_shift);
+                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
                            n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
@@ -2086,7 +2104,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
                          cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
                          big_list, (unsigned)(rec ? kRecChunk : kP3Chunk), (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next, room_shift);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next, room_shift,
+                         (const uint32_t*)nullptr);
       AMHIP_TRY(hipGetLastError());
       if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
         c->spec_valid = true;
@@ -2177,7 +2196,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr);
+                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
       unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
@@ -2188,7 +2207,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
                          c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }

@@ -189,8 +189,10 @@ class AerialGridMap(object):
         complete before torch work on ANOTHER stream reads it."""
         import torch
         cur = torch.cuda.current_stream(torch.device("cuda", self.device))
-        if int(cur.cuda_stream) == 0 or int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
-            self.synchronize()
+        if int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
+            # an event on the map's stream that torch's current stream waits for: the host does
+            # not wait (ADVICE r4: sync=False stays asynchronous whatever the stream arrangement)
+            L.check(self._lib.amhip_ctx_order_after(self._h, C.c_void_p(int(cur.cuda_stream))))
 
     def synchronize(self):
         """Waits for the GPU and raises if a device-side CHECK fired."""
@@ -234,6 +236,11 @@ class AerialGridMap(object):
         return {"three_pass_calls": int(out[0]), "speculative": int(out[1]), "overflowed": int(out[2]),
                 "counting_calls_left": int(out[3])}
 
+    def set_dsm_sort_reuse(self, on):
+        """amhip_ctx_set_dsm_sort_reuse: False = every DSM call counts first (what a context's first
+        call runs: the reference hosts' call pattern, one process() per process)."""
+        L.check(self._lib.amhip_ctx_set_dsm_sort_reuse(self._h, 1 if on else 0))
+
     def dsm_gather_stats(self):
         """amhip_ctx_dsm_gather_stats: where the gather tiles of the last DSM call went."""
         out = (C.c_int64 * 8)()
@@ -276,7 +283,9 @@ class Dsm(object):
         sync=False (device path): returns with the kernels enqueued on the map's stream.  The
         tensor must stay unchanged until they have run: work enqueued on the SAME stream
         afterwards is ordered automatically (map.set_stream(torch's stream)); with any other
-        stream arrangement the call waits for the device itself."""
+        stream arrangement torch's CURRENT stream is made to wait for the call on the device
+        (amhip_ctx_order_after: an event, no host wait) -- work on a third stream is the
+        caller's to order."""
         if map is None:
             raise L.AmhipError(L.ERR_ARG, "CHECK(map) (dsm.cc:194)")
         s = self.settings
@@ -298,8 +307,7 @@ class Dsm(object):
                 # doubles from the caller's cloud through the records' row indices).  The call is
                 # ordered on the context's stream; when that is torch's current stream, later
                 # torch work on the tensor is ordered behind it.  On any OTHER stream torch
-                # knows nothing of these kernels: wait here rather than let a refill of the
-                # tensor race with the gather.
+                # knows nothing of these kernels: its current stream is ordered behind them.
                 map.torch_waits()
             return
         pts = np.ascontiguousarray(point_cloud, np.float64).reshape(-1, 3)

@@ -38,6 +38,69 @@ def make_points(n, half_extent, seed, noise=0.05, center=(0.0, 0.0)):
     return pts
 
 
+class Mt19937_64(object):
+    """std::mt19937_64 (the generator SURVEY.md 8d names for the cfg inputs), vectorised over its
+    312-word state.  canonical(n) = what libstdc++'s std::generate_canonical<double, 53> makes of
+    one draw each: (double)u / 2^64, a result of 1.0 replaced by the largest double below it --
+    so uniform(a, b) reproduces std::uniform_real_distribution<double>(a, b)(engine) draw by draw."""
+    _N, _M = 312, 156
+    _A = np.uint64(0xB5026F5AA96619E9)
+    _UP, _LO = np.uint64(0xFFFFFFFF80000000), np.uint64(0x7FFFFFFF)
+
+    def __init__(self, seed):
+        mt = np.empty(self._N, np.uint64)
+        x = int(seed) & _M64
+        for i in range(self._N):
+            mt[i] = x
+            x = (6364136223846793005 * (x ^ (x >> 62)) + i + 1) & _M64
+        self._mt, self._left = mt, np.empty(0, np.uint64)
+
+    def _twist(self):
+        mt, N, M = self._mt, self._N, self._M
+        one = np.uint64(1)
+
+        def mix(cur, nxt, far):
+            y = (cur & self._UP) | (nxt & self._LO)
+            return far ^ (y >> one) ^ np.where((y & one) != 0, self._A, np.uint64(0))
+        mt[:N - M] = mix(mt[:N - M], mt[1:N - M + 1], mt[M:])          # old words only
+        mt[N - M:N - 1] = mix(mt[N - M:N - 1], mt[N - M + 1:], mt[:M - 1])  # far = words just made
+        mt[N - 1:] = mix(mt[N - 1:], mt[:1], mt[M - 1:M])
+        y = mt.copy()
+        y ^= (y >> np.uint64(29)) & np.uint64(0x5555555555555555)
+        y ^= (y << np.uint64(17)) & np.uint64(0x71D67FFFEDA60000)
+        y ^= (y << np.uint64(37)) & np.uint64(0xFFF7EEE000000000)
+        y ^= y >> np.uint64(43)
+        return y
+
+    def draws(self, n):
+        """the next n outputs of operator()"""
+        parts, have = [self._left], self._left.size
+        while have < n:
+            parts.append(self._twist())
+            have += self._N
+        allw = np.concatenate(parts)
+        self._left = allw[n:]
+        return allw[:n]
+
+    def canonical(self, n):
+        v = self.draws(n).astype(np.float64) * 2.0 ** -64    # (uint64 -> double rounds to nearest)
+        return np.minimum(v, np.nextafter(1.0, 0.0))
+
+    def uniform(self, a, b, n):
+        return self.canonical(n) * (b - a) + a
+
+
+def make_points_cfg1(n=1_000_000, half_extent=500.0, seed=42, noise=0.05):
+    """BASELINE.json configs[0] / SURVEY.md 8d cfg1: std::mt19937_64(seed); per point, in this order,
+    x, y ~ U(-half_extent, half_extent) and z = 400 + 10 sin(0.01 x) cos(0.01 y) + U(-noise, noise)."""
+    u = Mt19937_64(seed).canonical(3 * n).reshape(n, 3)
+    pts = np.empty((n, 3), np.float64)
+    pts[:, 0] = u[:, 0] * (2.0 * half_extent) + (-half_extent)
+    pts[:, 1] = u[:, 1] * (2.0 * half_extent) + (-half_extent)
+    pts[:, 2] = terrain_height(pts[:, 0], pts[:, 1]) + (u[:, 2] * (2.0 * noise) + (-noise))
+    return pts
+
+
 def splitmix64(x):
     """Vectorised splitmix64 finaliser on uint64 arrays."""
     x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(_M64)

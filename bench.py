@@ -28,10 +28,19 @@ bounded sample of the same workload on this box's host cores).
 dsm.cc:160-172).  The opt-in single-precision mode is timed in the same run and reported as
 the extra object `fast_mode`, with its own parity sample and roofline.
 
-The timed steps repeat ONE cloud, so every DSM call after the context's first runs the
-speculative sort (amhip_sort.hip: regions planned by the previous call, no count pass).  The
-extra object `sort` says so with the context's counters and times the counting sort -- what a
-context's first call gets -- beside it in the same run (`sort.counting_sort`).
+`value` is the call the reference's hosts make (main-dsm.cc:103-107, main-ortho-backward-grid.cc:
+128-141: ONE process() per process): every timed DSM call runs what a context's FIRST call runs
+-- the counting sort; the context is told not to reuse its predecessor's partition plan
+(amhip_ctx_set_dsm_sort_reuse(ctx, 0)), so repeating one cloud in the timed loop skips no work.
+The N > 1 ranks run the same pipeline (a tiled call always counts: its count pass selects the
+halo).  What a context that re-processes similar clouds gets on top (the speculative sort,
+amhip_sort.hip) is timed beside it as the extra object `sort`: the same cloud again, and three
+distinct-seed clouds in rotation (a hit there is earned: no call has seen its cloud before).
+
+The parity sample is the WHOLE map by default (--cpu-sample-side 10000: the reference's own
+Dsm::process + OrthoBackwardGrid::process on all 1e8 cells, ~1 min of host time).
+--workload cfg1 = BASELINE.json configs[0] exactly (1 M points, std::mt19937_64 seed 42,
+1000 x 1000 cells @ 1.0 m, interpolation_radius 1: 4 % of the cells take the fallback ladder).
 """
 import argparse
 import json
@@ -47,6 +56,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
     # name: (cells per side, resolution, points, frames, W, H)
+    # BASELINE.json configs[0] / SURVEY.md 8d cfg1, exactly: std::mt19937_64(42), x, y ~ U(-500, 500)
+    "cfg1": dict(side=1000, res=1.0, points=1_000_000, frames=0, W=1920, H=1080,
+                 f=1400.0, altitude=700.0, mt19937_seed=42,
+                 desc="1M pts (std::mt19937_64 seed 42, U(-500,500)^2) -> 1000x1000 @1.0m DSM "
+                      "(radius_sq=1: ~3.1 neighbours per cell, ~4 % of the cells on the fallback ladder)"),
     "cfg3": dict(side=10000, res=0.25, points=50_000_000, frames=249, W=1920, H=1080,
                  f=1400.0, altitude=700.0,
                  desc="50M pts -> 10000x10000 @0.25m DSM (radius_sq=1) + OrthoBackwardGrid, "
@@ -81,8 +95,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-side", type=int, default=4000,
-                    help="cells per side of the sub-tile the CPU oracle is timed on")
+    ap.add_argument("--cpu-sample-side", type=int, default=10000,
+                    help="cells per side of the corner sub-tile the reference's CPU path is timed on and "
+                         "the GPU layers are compared with (default: the whole 10000 x 10000 map of cfg3, "
+                         "~1 min of host time; 4000 for a quick run)")
+    ap.add_argument("--sort-reuse", action="store_true",
+                    help="let the timed steps reuse the previous call's partition plan (the speculative "
+                         "sort: repeated cloud -> no count pass).  Default off: `value` is what a "
+                         "context's first call runs; the reuse is timed beside it (`sort`)")
     ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
     ap.add_argument("--host-path", action="store_true", default=True,
                     help="(default at N = 1) also time ONE pass through the host-buffer (drop-in) "
@@ -669,6 +689,9 @@ def main():
         m.set_dsm_knn(args.knn)
     # the gather's arithmetic in the timed steps (the library's own default is EXACT since round 3)
     m.set_dsm_precision(args.dsm_mode == "exact")
+    # the sort of the timed steps: what a context's FIRST call runs (the reference hosts' call
+    # pattern: one process() per process) unless --sort-reuse
+    m.set_dsm_sort_reuse(bool(args.sort_reuse))
     # centre of this rank's window in map coordinates (x decreases with i, y with j)
     tile_center = (ox + Lx / 2.0 - (win[0] + win[2] / 2.0) * res,
                    oy + Ly / 2.0 - (win[1] + win[3] / 2.0) * res)
@@ -690,7 +713,12 @@ def main():
     # (N > 1: window edges are multiples of 64 cells, so a window is not exactly L wide;
     # its points cover exactly its own extent, no strip of the map is left without points)
     half = (win_lx / 2.0 + apron, win_ly / 2.0 + apron)
-    pts_buf[:n_pts] = synth.make_points_torch(n_pts, half, 43 + rank, dev, center=tile_center)
+    if wl.get("mt19937_seed") is not None:
+        if world != 1 or (ox, oy) != (0.0, 0.0):
+            raise SystemExit("--workload %s is a fixed single-GPU input (BASELINE.json configs[0])" % args.workload)
+        pts_buf[:n_pts] = torch.from_numpy(synth.make_points_cfg1(n_pts, L / 2.0, wl["mt19937_seed"])).to(dev)
+    else:
+        pts_buf[:n_pts] = synth.make_points_torch(n_pts, half, 43 + rank, dev, center=tile_center)
     if world > 1:
         # keep only points whose cell is inside the window (a point exactly on
         # the upper edge belongs to the neighbour)
@@ -723,11 +751,15 @@ def main():
         tiled = tiling.TiledDsm(dsm.settings, m, layout, rank, halo_cap,
                                 comm=tiling.TorchComm(via_host=True) if one_gpu else None)
 
+    ring = {"clouds": [pts], "k": 0}   # (the `sort` extra rotates distinct clouds through here)
+
     def run_dsm():
         if tiled is not None:
             tiled.process(pts_buf, n_pts, sync=False)
         else:
-            dsm.process(pts, m, sync=False)
+            cl = ring["clouds"]
+            dsm.process(cl[ring["k"] % len(cl)], m, sync=False)
+            ring["k"] += 1
 
     if batch:
         # incremental mapping: layers stay resident, every step appends the next batch
@@ -846,21 +878,33 @@ def main():
                 return int(mm.group(1)) if mm else 0
             return sorted(fs, key=key)[-1] if fs else None
 
+        from aerial_mapper_amd import hip_lib
+        lib_build = hip_lib.build_id()
+        stale = {}
+
         def evidence(mode):
-            """(traffic per slot, its file, SQ counters per kernel, their file) of `mode`"""
+            """(traffic per slot, its file, SQ counters per kernel, their file) of `mode` -- only from
+            summaries collected from THIS build of the library (amhip_build_id; VERDICT r4 weak #5: a
+            kernel change without a new tools/collect_profiles.sh run must not leave old counters in
+            the line)"""
             tr, tr_src, sq, sq_src = {}, None, None, None
             try:
                 f = newest("r*_%s_pmc_traffic.json" % mode)
                 tj = json.load(open(f))
                 if tj.get("workload") == args.workload and tj.get("dsm_mode") == mode and not args.colored:
-                    tr = {k: v["bytes"] for k, v in tj["kernels"].items()}
-                    tr_src = "profiles/" + os.path.basename(f)
+                    if tj.get("build_id") == lib_build:
+                        tr = {k: v["bytes"] for k, v in tj["kernels"].items()}
+                        tr_src = "profiles/" + os.path.basename(f)
+                    else:
+                        stale[mode] = ("profiles/%s was collected from build %s, the library is build %s: "
+                                       "not used" % (os.path.basename(f), tj.get("build_id"), lib_build))
             except Exception:
                 pass
             try:
                 f = newest("r*_%s_cfg3_pmc_sq.json" % mode)
                 sj = json.load(open(f)) if f else {}
-                if f and sj.get("dsm_mode") == mode and args.workload in ("cfg3", "cfg2") and not args.colored:
+                if f and sj.get("dsm_mode") == mode and args.workload in ("cfg3", "cfg2") and not args.colored \
+                        and sj.get("build_id") == lib_build:
                     sq, sq_src = sj["kernels"], "profiles/" + os.path.basename(f)
             except Exception:
                 pass
@@ -896,6 +940,12 @@ def main():
                                     "exact": "AMHIP_DSM_EXACT (the library's default: FP64, the "
                                              "reference's arithmetic and floats; the opt-in single-"
                                              "precision mode is timed beside it: fast_mode)"}[args.dsm_mode],
+                       "sort_pipeline": ("reuse of the previous call's partition plan allowed (--sort-reuse)"
+                                         if args.sort_reuse and tiled is None else
+                                         "counting sort on every call = what a context's FIRST call runs "
+                                         "(main-dsm.cc:103-107: one process() per process); the same "
+                                         "pipeline at every N (a tiled call always counts: its count pass "
+                                         "selects the halo)"),
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
                                "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
@@ -916,7 +966,10 @@ def main():
                                "frac": round(total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
             "kernels": kern,
             "dsm_stats": m.dsm_stats(),
+            "library_build_id": lib_build,
         }
+        if stale.get(args.dsm_mode):
+            out["roofline"]["traffic_stale"] = stale[args.dsm_mode]
         # counter traffic can only be >= what the kernel must move: a smaller figure is a broken
         # summary (round 2: every entry halved), refused rather than printed
         tr = out["roofline"]["traffic"]
@@ -1008,33 +1061,53 @@ def main():
                     out["ortho_mismatch_cells_fast_mode"] = (
                         out["parity_sample"] if args.dsm_mode == "fast" else om.get("parity_sample", {})).get(key)
             del refs
-        # The sort's speculation (round 4, amhip_sort.hip: dsm_sort): the timed steps bring ONE cloud
-        # again and again, so every DSM call after the context's first ran on the regions its
-        # predecessor planned, without the count pass.  Said here, with the context's own counters,
-        # and with the COUNTING sort (what a context's first call, a call after a miss, or
-        # AMHIP_SORT_NO_SPECULATION=1 gets) timed beside it in the same run.
+        # What a context that sees similar clouds again gets on top of `value` (the speculative sort,
+        # amhip_sort.hip: dsm_sort -- a call sizes its sort regions from its predecessor's exact counts
+        # and skips the count pass; a region that overflows sends the call through the counting
+        # pipeline launched behind it, same heights either way).  Never the headline: no reference
+        # host calls process() twice on one object's worth of state (main-dsm.cc:103-107).
         if not batch and not args.knn:
             try:
-                sort_obj = {"speculation": m.dsm_sort_stats(),
-                            "note": "value / ms_per_step: every timed DSM call sized its sort regions from the "
-                                    "previous call's exact counts on the context (same cloud every step) and "
-                                    "skipped the count pass; a region that overflows sends the call through "
-                                    "the counting pipeline launched behind it -- same heights either way"}
-                if world == 1 and not args.no_second_mode:
-                    os.environ["AMHIP_SORT_NO_SPECULATION"] = "1"
-                    try:
-                        k3 = max(3, min(args.steps, 10))
-                        sec, kms = timed_loop(k3, 2)
-                    finally:
-                        os.environ.pop("AMHIP_SORT_NO_SPECULATION", None)
-                    sort_obj["counting_sort"] = {"steps": k3, "ms_per_step": round(sec * 1e3, 3),
-                                                 "Mcells_per_s": round(cells_all / sec / 1e6, 1),
-                                                 "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
-                    timed_loop(1, 1)   # (leave the context as the timed steps left it: planned)
+                sort_obj = {"timed_steps": "reuse (speculative sort)" if args.sort_reuse else
+                            "counting sort: every call runs what a context's first call runs"}
+                if world == 1 and not args.no_second_mode and args.dsm_mode == "exact" and tiled is None:
+                    k3 = max(3, min(args.steps, 10))
+                    before = m.dsm_sort_stats()
+                    m.set_dsm_sort_reuse(True)
+                    sec, kms = timed_loop(k3, 2)
+                    m.synchronize()
+                    mid = m.dsm_sort_stats()
+                    sort_obj["reuse_same_cloud"] = {
+                        "steps": k3, "ms_per_step": round(sec * 1e3, 3),
+                        "Mcells_per_s": round(cells_all / sec / 1e6, 1),
+                        "speculative_calls": mid["speculative"] - before["speculative"],
+                        "overflowed": mid["overflowed"] - before["overflowed"],
+                        "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
+                    if not wl.get("mt19937_seed"):
+                        # three clouds of the same survey, distinct seeds: no call has seen its cloud
+                        for extra_seed in (1043, 2043):
+                            ring["clouds"].append(synth.make_points_torch(n_pts, half, extra_seed + rank, dev,
+                                                                          center=tile_center))
+                        ring["k"] = 0
+                        sec, kms = timed_loop(max(k3, 6), 3)
+                        m.synchronize()
+                        after = m.dsm_sort_stats()
+                        sort_obj["reuse_rotating_clouds"] = {
+                            "clouds": 3, "steps": max(k3, 6), "ms_per_step": round(sec * 1e3, 3),
+                            "Mcells_per_s": round(cells_all / sec / 1e6, 1),
+                            "speculative_calls": after["speculative"] - mid["speculative"],
+                            "overflowed": after["overflowed"] - mid["overflowed"],
+                            "note": "the layers after these steps are another cloud's: nothing below "
+                                    "compares them"}
+                        del ring["clouds"][1:]
+                    m.set_dsm_sort_reuse(bool(args.sort_reuse))
+                    ring["k"] = 0
+                    timed_loop(1, 0)   # (the layers hold the timed steps' cloud again)
                 out["sort"] = sort_obj
             except Exception as e:
                 out["sort"] = {"error": repr(e)}
-        if world == 1 and not fixed and not args.no_rough_terrain and not args.knn and not batch:
+        if world == 1 and not fixed and not args.no_rough_terrain and not args.knn and not batch \
+                and not wl.get("mt19937_seed"):
             try:
                 out["rough_terrain"] = rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L)
             except Exception as e:

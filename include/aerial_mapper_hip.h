@@ -590,8 +590,17 @@ int amhip_ctx_dsm_gather_stats(amhip_ctx* ctx, int64_t* out8);
  * followed by eight counting calls, twice as many after every further miss in a row, at most 64).  out4 = three-pass FP64 calls so far, how many of them
  * started speculatively, how many of those overflowed (as far as their overflow words have
  * arrived: synchronise first for an exact figure), counting calls left before the next attempt.
- * AMHIP_SORT_NO_SPECULATION=1: always count first. */
+ * Read-only apart from taking note of an overflow word that has arrived (the bookkeeping the next
+ * DSM call would do).  amhip_ctx_set_dsm_sort_reuse(ctx, 0): this context always counts first --
+ * every call then runs what a context's FIRST call runs, which is the call the reference's hosts
+ * make (main-dsm.cc:103-107: one process() per process); 1 (default): reuse as described. */
 int amhip_ctx_dsm_sort_stats(amhip_ctx* ctx, int64_t* out4);
+int amhip_ctx_set_dsm_sort_reuse(amhip_ctx* ctx, int on);
+
+/* Order `other_stream` (hipStream_t as void*) behind everything the context has enqueued so far: an
+ * event recorded on the context's stream, waited for by the other stream -- no host wait.  For
+ * callers that feed asynchronous calls (`*_dev` entry points) from buffers another stream refills. */
+int amhip_ctx_order_after(amhip_ctx* ctx, void* other_stream);
 
 /* The session's map as a grid_map_msgs/GridMap message (ROS 1 wire format): the resident layers
  * travel from the devices straight into `out`.  layer_ids[l] = the amhip layer behind message
@@ -604,6 +613,11 @@ int amhip_session_grid_map_msg(amhip_session* s, uint64_t stamp_ns, const char* 
 /* amhip_layer_to_image for the whole map of a session (every window on its own device). */
 int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float lower, float upper,
                                  uint8_t* host_image, size_t step);
+
+/* The library's build id: 16 hex digits of the SHA-256 over its sources, headers and compiler flags
+ * (aerial_mapper_amd/build.py).  Profiles collected from one build are refused as evidence for
+ * another (bench.py). */
+const char* amhip_build_id(void);
 
 #ifdef __cplusplus
 }

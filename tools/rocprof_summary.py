@@ -11,8 +11,19 @@ corrected read traffic of a wide streaming kernel is 2 x FETCH_SIZE
 (/opt/skills/guides/MI355X_MICROARCH.md, section HBM).
 """
 import argparse
+import os
 import sqlite3
 import sys
+
+
+def library_build_id():
+    """the build id of the library the profiled command loaded (the in-tree one)"""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from aerial_mapper_amd import hip_lib
+        return hip_lib.build_id()
+    except Exception:
+        return None
 
 
 def short(name):
@@ -75,7 +86,7 @@ def main():
         text = {"_comment": "rocprofv3 PMC SQ / GRBM counters, average per launch summed over XCDs / SEs, "
                             "cfg3, %s build (python bench.py --steps 5 --warmup 2 --no-cpu-baseline "
                             "--no-host-path; separate --pmc passes with --kernel-trace only). SQ_* cycle "
-                            "counters tick every 4 clocks." % a.tag, "dsm_mode": a.dsm_mode, "kernels": out}
+                            "counters tick every 4 clocks." % a.tag, "dsm_mode": a.dsm_mode, "build_id": library_build_id(), "kernels": out}
         if a.sq_json:
             json.dump(text, open(a.sq_json, "w"), indent=1)
         for k, v in out.items():
@@ -140,7 +151,8 @@ def main():
                                "written -> WRITE 400.0 MB, k_scan_partials 100.4 MB read -> FETCH 50.2 MB). bench.py "
                                "copies `bytes` of the dominant kernel into roofline.traffic when the workload matches. "
                                + a.note,
-                   "workload": a.workload, "dsm_mode": a.dsm_mode, "kernels": out}, open(a.traffic_json, "w"), indent=1)
+                   "workload": a.workload, "dsm_mode": a.dsm_mode, "build_id": library_build_id(), "kernels": out},
+                  open(a.traffic_json, "w"), indent=1)
     text = "\n".join(lines)
     if a.out:
         open(a.out, "w").write(text + "\n")
