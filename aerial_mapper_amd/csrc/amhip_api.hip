@@ -328,21 +328,22 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     B = p.w[0] / 4;
     if (B < 1) B = 1;
   }
-  // Geometry + three-pass plan for bins of bx x by cells; false: the grid has too many bins.
-  // The plan is worth it once the cloud is large enough that the sort is bandwidth bound;
-  // sub-partitions are sized for ~1.5 K points (a pass-3 workgroup sorts up to p3_cap of them in
-  // LDS, more through k_dsm_p3_place_big).
-  auto geometry = [&](int bx, int by, int M) -> bool {
-    p.Bx = bx;
-    p.By = by;
-    p.M = M;
-    const long long ex = (long long)p.rows + 2LL * p.M;
-    const long long ey = (long long)p.cols + 2LL * p.M;
-    p.nbx = static_cast<int>((ex + bx - 1) / bx);
-    p.nby = static_cast<int>((ey + by - 1) / by);
-    const unsigned long long nbins = (unsigned long long)p.nbx * (unsigned long long)p.nby;
-    if (nbins + 1 >= 0xFFFFFFFFull) return false;
-    p.p3_n1 = 0;
+  p.B = B;
+  p.M = ((wmax + B - 1) / B) * B;
+  const long long ex = (long long)p.rows + 2LL * p.M;
+  const long long ey = (long long)p.cols + 2LL * p.M;
+  p.nbx = static_cast<int>((ex + B - 1) / B);
+  p.nby = static_cast<int>((ey + B - 1) / B);
+  const unsigned long long nbins =
+      (unsigned long long)p.nbx * (unsigned long long)p.nby;
+  if (nbins + 1 >= 0xFFFFFFFFull) return arg_fail("grid too large for 32-bit bin ids");
+
+  // ---- three-pass partition sort plan (amhip_dsm.hip) ---------------------------
+  // Worth it once the cloud is large enough that the sort is bandwidth bound;
+  // sub-partitions are sized for ~1.5 K points (a pass-3 workgroup sorts up to
+  // p3_cap of them in LDS, more through a direct-placement fallback).
+  p.p3_n1 = 0;
+  {
     size_t min_pts = 1u << 20;
     if (std::getenv("AMHIP_P3_MIN_POINTS"))
       min_pts = (size_t)std::atoll(std::getenv("AMHIP_P3_MIN_POINTS"));
@@ -368,29 +369,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
         if (p.p3_cap < 64) p.p3_cap = 64;
       }
     }
-    return true;
-  };
-  // Pair bins (1 x 2 cells; DsmParams::pair_bins, amhip_dsm.hip "pair bins"): the FP64 pipeline of
-  // dsm::Dsm behind the three-pass sort.  A bin row is then one ROW PAIR of the gather's window --
-  // M has the parity of the first window so that every tile's pairs are bin rows -- and the
-  // placement pass, which is HBM bound, delivers the points in the order the FP64-issue-bound gather
-  // used to re-create per tile in LDS.  Kept to geometries whose plan holds
-  // (a 40 000-cell-wide window has too many pair bins per sub-partition: square bins as before).
-  p.pair_bins = 0;
-  {
-    const bool rec_fits_sq = (long long)p.rows + 2LL * (((wmax + B - 1) / B) * B) <= 65535 &&
-                             (long long)p.cols + 2LL * (((wmax + B - 1) / B) * B) <= 65535 &&
-                             num_points < 0xFFFFFFFFull;
-    const bool fp64_pipeline = c.dsm_exact || c.dsm_exact_now || !rec_fits_sq;
-    static const bool no_pair = std::getenv("AMHIP_DSM_NO_PAIR_BINS") != nullptr;
-    const int w0p = p.w[0];
-    if (mode == 0 && fp64_pipeline && !c.dsm_knn && !no_pair && w0p >= 1 && w0p <= kMaxW0) {
-      const int Mp = wmax + ((wmax - w0p) & 1);
-      if (geometry(1, 2, Mp) && p.p3_n1 > 0) p.pair_bins = 1;
-    }
   }
-  if (!p.pair_bins && !geometry(B, B, ((wmax + B - 1) / B) * B))
-    return arg_fail("grid too large for 32-bit bin ids");
 
   // ---- division-free keys for the sort passes (DsmParams::mul_*) --------------------------
   {
@@ -401,8 +380,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     };
     const unsigned long long cells_max =
         (unsigned long long)std::max(p.rows, p.cols) + 2ull * (unsigned long long)p.M + 1ull;
-    p.mul_Bx = magic(cells_max, p.Bx);
-    p.mul_By = magic(cells_max, p.By);
+    p.mul_B = magic(cells_max, p.B);
     p.mul_r1 = p.p3_n1 ? magic((unsigned long long)p.nby + 1ull, p.p3_r1) : 0xFFFFFFFFu;
     p.mul_w = p.p3_n1 ? magic((unsigned long long)p.nbx + 1ull, p.p3_w) : 0xFFFFFFFFu;
   }
@@ -425,14 +403,14 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     const double rho = (double)num_points / ((double)p.rows * (double)p.cols);
     auto need = [&](int tj) {
       // bins an interior tile's region spans (same integer arithmetic as the kernel)
-      const int bi = (kTileI + kTileI - 1 + w0h + p.M) / p.Bx - (kTileI - w0h + p.M) / p.Bx + 1;
-      const int bj = (tj + tj - 1 + w0h + p.M) / p.By - (tj - w0h + p.M) / p.By + 1;
-      const double e = rho * (double)(bi * p.Bx) * (double)(bj * p.By);
+      const int bi = (kTileI + kTileI - 1 + w0h + p.M) / B - (kTileI - w0h + p.M) / B + 1;
+      const int bj = (tj + tj - 1 + w0h + p.M) / B - (tj - w0h + p.M) / B + 1;
+      const double e = rho * (double)(bi * B) * (double)(bj * B);
       return e + 5.0 * std::sqrt(e);
     };
     // (single-precision mode: 16-byte records, so 4096 points still leave two workgroups per
     // CU -- clouds of ~1.2 .. 2.2 points per cell keep the one-workgroup-per-tile launch)
-    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_exact_now && !c.dsm_knn && rec_fits && !p.pair_bins;
+    const bool want_f32 = mode == 0 && !c.dsm_exact && !c.dsm_exact_now && !c.dsm_knn && rec_fits;
     if (need(16) <= 1024.0) {
       kTileJ = 16;
       cap = 1024;
@@ -475,8 +453,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       const int b = r >= 1 ? p.wr[r - 1] : 0;
       p.wr2[r] = a > b ? a : b;
     }
-    const int rw = kTileI + 2 * w0 + 2 * (p.Bx - 1);
-    const int rh = kTileJ + 2 * w0 + 2 * (p.By - 1);
+    const int rw = kTileI + 2 * w0 + 2 * (B - 1);
+    const int rh = kTileJ + 2 * w0 + 2 * (B - 1);
     for (int k = 0; k <= w0; ++k)
       p.wrp[k] = p.wr2[2 * k] > p.wr2[2 * k + 1] ? p.wr2[2 * k] : p.wr2[2 * k + 1];
     // row pairs, +1 pair for the parity shift, +1 spill; (lds_cells + 1) entries, a multiple of
@@ -496,7 +474,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.knn_k = mode == 0 ? c.dsm_knn : 0;
   if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
   p.fx_ok = 0;
-  if (p.lds_ok && mode == 0 && !c.dsm_exact && !c.dsm_exact_now && rec_fits && !p.pair_bins) {
+  if (p.lds_ok && mode == 0 && !c.dsm_exact && !c.dsm_exact_now && rec_fits) {
     int S = 28;
     while (((long long)(w0 + 2) << S) >= (1LL << 31)) --S;
     const double scale2 = std::ldexp(1.0, 2 * S);

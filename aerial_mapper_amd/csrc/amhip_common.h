@@ -46,15 +46,9 @@ struct DsmParams {
   int pcl_mode;
   // adaptive OrthoFromPcl passes: touch only cells no earlier pass has filled
   int only_unfilled;
-  // binning: bins of Bx x By cells, grid extended by M cells on every side.  Bx == By == the first
-  // search radius in cells (one ring of bins around a gather tile), or -- pair_bins, the FP64
-  // pipeline of dsm::Dsm behind the three-pass sort -- 1 x 2 cells: a bin is then a ROW PAIR of one
-  // column, exactly what a trip of the FP64 gather walks, a bin row's span of a tile's region is
-  // already in the order the gather's LDS image wants, and bin_start's row IS its cell-offset
-  // table: staging becomes a copy (amhip_dsm.hip: gather_tile, "pair bins")
+  // binning: bins of B x B cells, grid extended by M cells on every side
   double inv_res;
-  int Bx, By, M, nbx, nby;
-  int pair_bins;
+  int B, M, nbx, nby;
   // radius ladder (squared radii, exactly the doubles dsm.cc:127-144 uses)
   int nlevels;
   double T[kMaxLevels];
@@ -68,10 +62,10 @@ struct DsmParams {
   int p3_n1, p3_n2;           // partitions of pass 1; sub-partitions of each (= p3_r1 * p3_c)
   int p3_cap;                 // points a pass-3 workgroup can sort in LDS
   // Every sort pass turns every point into its keys again: four integer divisions by
-  // Bx / By / p3_r1 / p3_w per point and pass were ~half of the passes' VALU time.  Multipliers
+  // B / p3_r1 / p3_w per point and pass were ~half of the passes' VALU time.  Multipliers
   // m = floor(2^32 / d) + 1: n / d == umulhi(n, m) for n * d < 2^32 (0: d == 1; ~0: n * d may
   // reach 2^32 on this grid -> the real division); div_by() in amhip_sort.hip
-  unsigned mul_Bx, mul_By, mul_r1, mul_w;
+  unsigned mul_B, mul_r1, mul_w;
   int wr[2 * kMaxW0 + 1];
   int wr2[2 * kMaxW0 + 2];    // the same for a pair of cells (j, j+1): max of both
   int wrp[kMaxW0 + 1];        // per trip (window rows 2k, 2k+1 of the pair): max of wr2

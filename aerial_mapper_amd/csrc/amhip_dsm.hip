@@ -137,10 +137,10 @@ __device__ __forceinline__ void scan_window(const DsmParams& p,
                                             double qx, double qy, int i, int j,
                                             int w, double T, Accum* acc,
                                             double* dmin) {
-  const int bx0 = (i - w + p.M) / p.Bx;
-  const int bx1 = (i + w + p.M) / p.Bx;
-  const int by0 = (j - w + p.M) / p.By;
-  const int by1 = (j + w + p.M) / p.By;
+  const int bx0 = (i - w + p.M) / p.B;
+  const int bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B;
+  const int by1 = (j + w + p.M) / p.B;
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t s = row[bx0];
@@ -225,8 +225,8 @@ __device__ __forceinline__ void two_sum(double a, double b, double* s, double* e
 __device__ __forceinline__ void canonical_search(const DsmParams& p, const uint32_t* __restrict__ start,
                                               const Pts P, double qx, double qy, int i, int j, int w,
                                               double T, const CellOut& o) {
-  const int bx0 = (i - w + p.M) / p.Bx, bx1 = (i + w + p.M) / p.Bx;
-  const int by0 = (j - w + p.M) / p.By, by1 = (j + w + p.M) / p.By;
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
   double nh = 0.0, nl = 0.0, dh = 0.0, dl = 0.0;
   bool exact = false;
   double exact_z = 0.0;
@@ -364,8 +364,8 @@ __device__ __forceinline__ void knn_add(KnnSet* s, int k, double d2, double z) {
 __device__ __forceinline__ void knn_scan(const DsmParams& p, const uint32_t* __restrict__ start,
                                          const Pts P, double qx, double qy,
                                          int i, int j, int w, double T, KnnSet* s) {
-  const int bx0 = (i - w + p.M) / p.Bx, bx1 = (i + w + p.M) / p.Bx;
-  const int by0 = (j - w + p.M) / p.By, by1 = (j + w + p.M) / p.By;
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
   for (int by = by0; by <= by1; ++by) {
     const uint32_t* row = start + (size_t)by * p.nbx;
     const uint32_t e = row[bx1 + 1];
@@ -475,8 +475,8 @@ __device__ __forceinline__ void block_wave(const DsmParams& p, const uint32_t* _
     qx[a] = p.base_x + p.res * (-(double)(min(bi0 + a, bi1) + p.i_off));
     qy[a] = p.base_y + p.res * (-(double)(min(bj0 + a, bj1) + p.j_off));
   }
-  const int bx0 = (bi0 - w + p.M) / p.Bx, bx1 = (bi1 + w + p.M) / p.Bx;
-  const int by0 = (bj0 - w + p.M) / p.By, by1 = (bj1 + w + p.M) / p.By;
+  const int bx0 = (bi0 - w + p.M) / p.B, bx1 = (bi1 + w + p.M) / p.B;
+  const int by0 = (bj0 - w + p.M) / p.B, by1 = (bj1 + w + p.M) / p.B;
   double num[16], den[16];
 #pragma unroll
   for (int c = 0; c < 16; ++c) num[c] = den[c] = 0.0;
@@ -720,8 +720,8 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
     const int i_hi = min(i0 + kTileI, p.rows) - 1;
     const int j_hi = min(j0 + tile_j, p.cols) - 1;
     const int wl = p.w[p.nlevels - 1];
-    const int ex0 = (i0 - wl + p.M) / p.Bx, ex1 = (i_hi + wl + p.M) / p.Bx;
-    const int ey0 = (j0 - wl + p.M) / p.By, ey1 = (j_hi + wl + p.M) / p.By;
+    const int ex0 = (i0 - wl + p.M) / p.B, ex1 = (i_hi + wl + p.M) / p.B;
+    const int ey0 = (j0 - wl + p.M) / p.B, ey1 = (j_hi + wl + p.M) / p.B;
     uint32_t tot = 0;
     for (int by = ey0; by <= ey1; ++by) {
       const uint32_t* row = start + (size_t)by * p.nbx;
@@ -732,8 +732,8 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
     } else {
       // the first-level region, exactly as gather_tile() sums it
       const int w0 = p.w[0];
-      const int rbx0 = (i0 - w0 + p.M) / p.Bx, rbx1 = (i_hi + w0 + p.M) / p.Bx;
-      const int rby0 = (j0 - w0 + p.M) / p.By, rby1 = (j_hi + w0 + p.M) / p.By;
+      const int rbx0 = (i0 - w0 + p.M) / p.B, rbx1 = (i_hi + w0 + p.M) / p.B;
+      const int rby0 = (j0 - w0 + p.M) / p.B, rby1 = (j_hi + w0 + p.M) / p.B;
       uint32_t np = 0;
       for (int by = rby0; by <= rby1; ++by) {
         const uint32_t* row = start + (size_t)by * p.nbx;
@@ -850,38 +850,30 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   }
 
   // region of bins holding every first-level candidate of the tile
-  const int rbx0 = (i0 - w0 + p.M) / p.Bx;
-  const int rbx1 = (i_hi + w0 + p.M) / p.Bx;
-  const int rby0 = (j0 - w0 + p.M) / p.By;
-  const int rby1 = (j_hi + w0 + p.M) / p.By;
+  const int rbx0 = (i0 - w0 + p.M) / p.B;
+  const int rbx1 = (i_hi + w0 + p.M) / p.B;
+  const int rby0 = (j0 - w0 + p.M) / p.B;
+  const int rby1 = (j_hi + w0 + p.M) / p.B;
   const int nrb = rby1 - rby0 + 1;
-  const int RW = (rbx1 - rbx0 + 1) * p.Bx;
-  const int RH = nrb * p.By;
+  const int RW = (rbx1 - rbx0 + 1) * p.B;
+  const int RH = nrb * p.B;
   // Cell-offset table layout: window rows are walked two at a time, so the
   // cells of a ROW PAIR are interleaved (x-major, then the row of the pair):
   // the candidates of one trip -- both rows, columns ci-w .. ci+w -- are then
   // ONE contiguous span of the LDS point array.  `sh` aligns the pairs with
   // the tile's first window row (all cell pairs of a tile start on even rows).
-  const int sh = (j0 - w0 + p.M - (rby0 * p.By)) & 1;
+  const int sh = (j0 - w0 + p.M - (rby0 * p.B)) & 1;
   const int RW2 = 2 * RW;
   const int ncell = (RH / 2 + 2) * RW2;
-  const int ox = rbx0 * p.Bx;  // region origin in M-shifted cell coordinates
-  const int oy = rby0 * p.By;
+  const int ox = rbx0 * p.B;  // region origin in M-shifted cell coordinates
+  const int oy = rby0 * p.B;
 
-  // PAIR BINS (DsmParams::pair_bins: bins of 1 x 2 cells, the window's parity in M so that sh == 0):
-  // a bin row IS one row pair of this table, its span of the region already lies in the order the
-  // image wants, and bin_start's row, rebased, IS the row pair's offset table -- staging is a copy:
-  // no cell arithmetic, no LDS atomics, no scan.  The offsets then stand at [r * RW + ix] (one
-  // entry per cell pair) instead of [r * 2 RW + 2 ix + parity].
-  const bool pair = p.pair_bins != 0 && sh == 0 && P.sorted != nullptr;
-  const int xs = pair ? 1 : 2;     // table entries per region column
-  const int rs = pair ? RW : RW2;  // ... per row pair
   // (as in gather_tile_f32: the cell table is cleared / scanned / rewritten in whole quads while
   // wave 0 reads the region's bin rows and prefixes their lengths across its lanes)
   const bool geom_ok = nrb <= 64 && ncell + 3 <= p.lds_cells;
   {
     uint4* q = reinterpret_cast<uint4*>(s_off);
-    const int nq0 = geom_ok && !pair ? (ncell + 4) >> 2 : 0;
+    const int nq0 = geom_ok ? (ncell + 4) >> 2 : 0;
     for (int k = tid; k < nq0; k += NT) q[k] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (wid == 0) {
@@ -915,44 +907,6 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     return;
   }
 
-  // ---- stage the region's points in LDS -------------------------------------
-  if (pair) {
-    // offsets: row pair r of the table = bin row rby0 + r, rebased from the sorted array to the image
-    for (int r = wid; r < nrb; r += kWaves) {
-      const uint32_t* row = start + (size_t)(rby0 + r) * p.nbx + rbx0;
-      const uint32_t rebase = s_rowp[r] - s_rowg[r];
-      for (int ix = lane; ix < RW; ix += 64) s_off[r * RW + ix] = row[ix] + rebase;
-    }
-    if (tid == 0) s_off[nrb * RW] = (uint32_t)np;  // (the end of the last row pair)
-    // points: the image is the concatenation of the region's bin-row spans, in order
-    constexpr int kMaxKp = (kCap + NT - 1) / NT;
-    if (np > 0) {
-      size_t pg[kMaxKp];
-#pragma unroll
-      for (int k = 0; k < kMaxKp; ++k) {
-        const int idx = min(tid + k * NT, np - 1);
-        int r = 0;
-        while (idx >= (int)s_rowp[r + 1]) ++r;
-        pg[k] = (size_t)s_rowg[r] + (size_t)(idx - (int)s_rowp[r]);
-      }
-      double qx_[kMaxKp], qy_[kMaxKp], qz_[kMaxKp];
-#pragma unroll
-      for (int k = 0; k < kMaxKp; ++k) {   // (pair bins exist in the doubles pipeline only: P.sorted)
-        qx_[k] = P.sorted[3 * pg[k] + 0];
-        qy_[k] = P.sorted[3 * pg[k] + 1];
-        qz_[k] = P.sorted[3 * pg[k] + 2];
-      }
-#pragma unroll
-      for (int k = 0; k < kMaxKp; ++k) {
-        const int idx = tid + k * NT;
-        if (idx < np) {
-          s_xy[idx] = make_double2(qx_[k], qy_[k]);
-          s_z[idx] = qz_[k];
-        }
-      }
-    }
-    __syncthreads();
-  } else {
   // ---- stage + cell-bin the region's points in LDS --------------------------
   // pass 1: count per cell (LDS atomics), remember (cell, rank) per point
   static_assert(kCellsPerLane % 2 == 0, "cell pairs must start on even rows of the tile");
@@ -1055,7 +1009,6 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     }
   }
   __syncthreads();
-  }
   // (max |z| of the call's points: round_is_certain's bound, loaded here, used after the loop.
   // The bound's n is the lane's own candidate count: a tile-wide n -- the image's 860 points,
   // a wave-uniform bound in scalar registers -- sends 1000 cells per 1e8 to the redo instead of
@@ -1094,7 +1047,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
       // rows jA-w0 .. jA+1+w0 (the last one only matters for cell B), one row
       // pair = one contiguous span per trip (lanes wait for each other per
       // trip, and the spread of a two-row candidate count is relatively smaller).
-      const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * rs + xs * ci;
+      const uint32_t* orow = s_off + ((cj - w0 + sh) >> 1) * RW2 + 2 * ci;
       // FP64 denormals are FLUSHED while the products run (MODE.FP_DENORM[7:6] = 0):
       // a product that dips below 2^-1022 inside one trip -- hundreds of points
       // within centimetres of a centre, in a tile of a dense capacity class -- then
@@ -1123,8 +1076,8 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           // (static index: the six widths arrive with one scalar load, not one load and wait each)
           const int rr = min(r, w0);
           const int w = r <= w0 ? p.wrp[r] : 0;
-          kb_[r] = orow[rr * rs - xs * w];
-          ke_[r] = orow[rr * rs + xs * w + xs];
+          kb_[r] = orow[rr * RW2 - 2 * w];
+          ke_[r] = orow[rr * RW2 + 2 * w + 2];
         }
         auto span = [&](int r) __attribute__((always_inline)) -> uint32_t {
           const uint32_t len = r <= w0 ? ke_[r] - kb_[r] : 0u;
@@ -1152,9 +1105,9 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           key0 = key1, key1 = key2, key2 = key3, key3 = key4, key4 = key5;
         } else {
           const int w = p.wrp[r];
-          kb = orow[-xs * w];
-          ke = orow[xs * w + xs];
-          orow += rs;
+          kb = orow[-2 * w];
+          ke = orow[2 * w + 2];
+          orow += RW2;
           ncand += ke - kb;
         }
         auto candidate = [&](uint32_t k) __attribute__((always_inline)) {
@@ -1338,8 +1291,8 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
   const int w = p.w[0];
   const double T = p.T[0];
-  const int bx0 = (i - w + p.M) / p.Bx, bx1 = (i + w + p.M) / p.Bx;
-  const int by0 = (j - w + p.M) / p.By, by1 = (j + w + p.M) / p.By;
+  const int bx0 = (i - w + p.M) / p.B, bx1 = (i + w + p.M) / p.B;
+  const int by0 = (j - w + p.M) / p.B, by1 = (j + w + p.M) / p.B;
   double num = 0.0, den = 0.0;
   unsigned exact = 0;
   // The routine is a chain of dependent memory round trips, and it runs at the END of a tile
@@ -1498,18 +1451,18 @@ __device__ __forceinline__ void gather_tile_f32(const DsmParams& p, const uint32
     return;
   }
 
-  const int rbx0 = (i0 - w0 + p.M) / p.Bx;
-  const int rbx1 = (i_hi + w0 + p.M) / p.Bx;
-  const int rby0 = (j0 - w0 + p.M) / p.By;
-  const int rby1 = (j_hi + w0 + p.M) / p.By;
+  const int rbx0 = (i0 - w0 + p.M) / p.B;
+  const int rbx1 = (i_hi + w0 + p.M) / p.B;
+  const int rby0 = (j0 - w0 + p.M) / p.B;
+  const int rby1 = (j_hi + w0 + p.M) / p.B;
   const int nrb = rby1 - rby0 + 1;
-  const int RW = (rbx1 - rbx0 + 1) * p.Bx;
-  const int RH = nrb * p.By;
-  const int sh = (j0 - w0 + p.M - (rby0 * p.By)) & 1;
+  const int RW = (rbx1 - rbx0 + 1) * p.B;
+  const int RH = nrb * p.B;
+  const int sh = (j0 - w0 + p.M - (rby0 * p.B)) & 1;
   const int RW2 = 2 * RW;
   const int ncell = (RH / 2 + 2) * RW2;
-  const int ox = rbx0 * p.Bx;
-  const int oy = rby0 * p.By;
+  const int ox = rbx0 * p.B;
+  const int oy = rby0 * p.B;
 
   // (the cell table is cleared, scanned and rewritten in whole quads: entries 0 .. ncell + 3)
   const bool geom_ok = nrb <= 64 && ncell + 3 <= p.lds_cells;
@@ -1985,8 +1938,8 @@ __device__ __forceinline__ void block_wave_f32(const DsmParams& p, const uint32_
   const int S = p.fx_S - 1;
   const float thi = p.fx_thi * 0.25f, tlo = p.fx_tlo * 0.25f;  // (squared scale: one bit -> 1/4)
   const float denmax = p.fx_denmax * 4.0f;
-  const int bx0 = (bi0 - w + p.M) / p.Bx, bx1 = (bi1 + w + p.M) / p.Bx;
-  const int by0 = (bj0 - w + p.M) / p.By, by1 = (bj1 + w + p.M) / p.By;
+  const int bx0 = (bi0 - w + p.M) / p.B, bx1 = (bi1 + w + p.M) / p.B;
+  const int by0 = (bj0 - w + p.M) / p.B, by1 = (bj1 + w + p.M) / p.B;
   // reference height: the first candidate's f32 offset from zref (wave-uniform)
   float z0f = 0.0f;
   unsigned ncand = 0;
@@ -2124,20 +2077,17 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
     const int i0 = ti * kTileI, j0 = tj * tile_j;
     const int i_hi = min(i0 + kTileI, p.rows) - 1;
     const int j_hi = min(j0 + tile_j, p.cols) - 1;
-    // blocks = cells of one bin, cut into pieces of <= 4 x 4, clipped to the tile (pair bins --
-    // 1 x 2 cells, DsmParams::pair_bins --: any partition into blocks will do, block_wave() finds
-    // the bins of a block's window itself; 4 x 4 blocks then)
-    const int BB = p.Bx == p.By ? p.Bx : 4;
-    const int gb = min(BB, 4);
+    // blocks = cells of one bin, cut into pieces of <= 4 x 4, clipped to the tile
+    const int gb = min(p.B, 4);
     const int nbi = (i_hi - i0) / gb + 2, nbj = (j_hi - j0) / gb + 2;  // (upper bounds)
     int idx = 0;
-    for (int bj = ((j0 + p.M) / BB) * BB - p.M; bj <= j_hi; bj += BB)
-      for (int sj = 0; sj < BB; sj += gb)
-        for (int bi = ((i0 + p.M) / BB) * BB - p.M; bi <= i_hi; bi += BB)
-          for (int si = 0; si < BB; si += gb, ++idx) {
+    for (int bj = ((j0 + p.M) / p.B) * p.B - p.M; bj <= j_hi; bj += p.B)
+      for (int sj = 0; sj < p.B; sj += gb)
+        for (int bi = ((i0 + p.M) / p.B) * p.B - p.M; bi <= i_hi; bi += p.B)
+          for (int si = 0; si < p.B; si += gb, ++idx) {
             if ((idx & 3) != wid) continue;
-            const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + BB - 1), i_hi);
-            const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + BB - 1), j_hi);
+            const int a0 = max(bi + si, i0), a1 = min(min(bi + si + gb - 1, bi + p.B - 1), i_hi);
+            const int b0 = max(bj + sj, j0), b1 = min(min(bj + sj + gb - 1, bj + p.B - 1), j_hi);
             if (a0 > a1 || b0 > b1) continue;
             if (kF32) block_wave_f32(p, start, P, a0, a1, b0, b1, o);
             else block_wave(p, start, P, a0, a1, b0, b1, o);

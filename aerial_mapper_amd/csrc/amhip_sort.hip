@@ -48,8 +48,8 @@ __device__ __forceinline__ bool point_bin(const DsmParams& p, double px,
   int iy = (int)floor(cy + 0.5) + p.M;
   ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
   iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
-  const int bx = div_by(ix, p.Bx, p.mul_Bx);
-  const int by = div_by(iy, p.By, p.mul_By);
+  const int bx = div_by(ix, p.B, p.mul_B);
+  const int by = div_by(iy, p.B, p.mul_B);
   *bin = (uint32_t)by * (uint32_t)p.nbx + (uint32_t)bx;
   return true;
 }
@@ -134,8 +134,8 @@ __device__ __forceinline__ bool point_bin_xy(const DsmParams& p, double px, doub
   int iy = (int)floor(cy + 0.5) + p.M;
   ix = min(max(ix, 0), p.rows + 2 * p.M - 1);
   iy = min(max(iy, 0), p.cols + 2 * p.M - 1);
-  *bx = div_by(ix, p.Bx, p.mul_Bx);
-  *by = div_by(iy, p.By, p.mul_By);
+  *bx = div_by(ix, p.B, p.mul_B);
+  *by = div_by(iy, p.B, p.mul_B);
   return true;
 }
 
@@ -933,7 +933,7 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
   __syncthreads();
   // the bin of sorted point idx (PER == 0)
   auto bin_of = [&](uint32_t idx) -> int {
-    if (kRec) return div_by((int)(srcw[(size_t)kRecWords * idx] & 0xFFFFu), p.Bx, p.mul_Bx) - bx0;
+    if (kRec) return div_by((int)(srcw[(size_t)kRecWords * idx] & 0xFFFFu), p.B, p.mul_B) - bx0;
     int bx, by;
     point_bin_xy(p, srcd[3 * (size_t)idx + 0], srcd[3 * (size_t)idx + 1], &bx, &by);
     return bx - bx0;
@@ -964,7 +964,7 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
       rb[k] = -1;
       if (idx < g1) {
         if (kRec) {
-          rb[k] = div_by((int)(rw[k][0] & 0xFFFFu), p.Bx, p.mul_Bx) - bx0;
+          rb[k] = div_by((int)(rw[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
         } else {
           int bx, by;
           point_bin_xy(p, rx[k], ry[k], &bx, &by);
@@ -1232,8 +1232,8 @@ __device__ __forceinline__ bool make_record(const DsmParams& p, double px, doubl
 
 __device__ __forceinline__ void record_keys(const DsmParams& p, uint32_t w0, int* k1, int* k2,
                                             int* bx_out) {
-  const int bx = div_by((int)(w0 & 0xFFFFu), p.Bx, p.mul_Bx);
-  const int by = div_by((int)(w0 >> 16), p.By, p.mul_By);
+  const int bx = div_by((int)(w0 & 0xFFFFu), p.B, p.mul_B);
+  const int by = div_by((int)(w0 >> 16), p.B, p.mul_B);
   const int a = div_by(by, p.p3_r1, p.mul_r1);
   *k1 = a;
   *k2 = (by - a * p.p3_r1) * p.p3_c + div_by(bx, p.p3_w, p.mul_w);
@@ -1420,7 +1420,7 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
       const uint32_t idx = g0 + tid + (uint32_t)k * THREADS;
       pb[k] = -1;
       if (idx < g1) {
-        pb[k] = div_by((int)(w[k][0] & 0xFFFFu), p.Bx, p.mul_Bx) - bx0;
+        pb[k] = div_by((int)(w[k][0] & 0xFFFFu), p.B, p.mul_B) - bx0;
         atomicAdd(&s_bins[pb[k]], 1u);
         // (the bins' height ranges: read off the placed records below -- two more LDS atomics
         // per point here cost more than one pass of a thread per bin there)
@@ -1429,7 +1429,7 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
   } else {
     for (uint32_t idx = g0 + tid; idx < g1; idx += THREADS) {
       const uint32_t w0 = src[(size_t)kRecWords * idx], w3 = src[(size_t)kRecWords * idx + 3];
-      const int b = div_by((int)(w0 & 0xFFFFu), p.Bx, p.mul_Bx) - bx0;
+      const int b = div_by((int)(w0 & 0xFFFFu), p.B, p.mul_B) - bx0;
       atomicAdd(&s_bins[b], 1u);
       const uint32_t zk = zkey(w3);
       atomicMin(&s_zlo[b], zk);
@@ -1465,7 +1465,7 @@ __device__ __forceinline__ void place_records(const uint32_t* __restrict__ src, 
       uint32_t v[kRecWords];
 #pragma unroll
       for (int t = 0; t < kRecWords; ++t) v[t] = src[(size_t)kRecWords * idx + t];
-      const int b = div_by((int)(v[0] & 0xFFFFu), p.Bx, p.mul_Bx) - bx0;
+      const int b = div_by((int)(v[0] & 0xFFFFu), p.B, p.mul_B) - bx0;
       const size_t o = (size_t)g0 + atomicAdd(&s_bins[b], 1u);
       rec16[o] = make_uint4(v[0], v[1], v[2], v[3]);
       sidx[o] = v[4];
@@ -1803,7 +1803,7 @@ static unsigned long long spec_signature(const DsmParams& p) {
     const unsigned char* b = static_cast<const unsigned char*>(v);
     for (size_t k = 0; k < bytes; ++k) h = (h ^ b[k]) * 1099511628211ull;
   };
-  const int ints[] = {p.rows, p.cols, p.M, p.Bx, p.By, p.nbx, p.nby, p.i_off, p.j_off, p.p3_r1, p.p3_c,
+  const int ints[] = {p.rows, p.cols, p.M, p.B, p.nbx, p.nby, p.i_off, p.j_off, p.p3_r1, p.p3_c,
                       p.p3_w, p.p3_n1, p.p3_n2, p.p3_cap};
   const double dbls[] = {p.base_x, p.base_y, p.res, p.inv_res, p.sub_x, p.sub_y};
   mix(ints, sizeof(ints));
@@ -1893,7 +1893,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     if ((rc = ensure_capacity(&c->bin_start, &c->bin_cap, nbins + 4))) return rc;
   }
   c->last_num_bins = (int64_t)nbins;
-  c->last_bin_cells = p.Bx == p.By ? p.Bx : -(p.Bx * 16 + p.By);  // (pair bins: -(16 Bx + By))
+  c->last_bin_cells = p.B;
   c->bin_z_valid = false;
   c->pts = PtsView{c->sorted, nullptr, nullptr, dev_xyz, nullptr, p.sub_x, p.sub_y};
   // the record pipeline (the single-precision gather's mode): 16-byte records + rows + zref
