@@ -911,6 +911,12 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
       e = hipHostMalloc(reinterpret_cast<void**>(&c->host_tile_stats), 8 * sizeof(unsigned), 0);
       if (e == hipSuccess) std::memset(c->host_tile_stats, 0, 8 * sizeof(unsigned));
     }
+    if (e == hipSuccess) {
+      e = hipHostMalloc(reinterpret_cast<void**>(&c->host_sort_stats), 4 * sizeof(unsigned), 0);
+      if (e == hipSuccess) std::memset(c->host_sort_stats, 0xFF, 4 * sizeof(unsigned));  // ("unknown")
+    }
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_tickets), 16 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemsetAsync(c->dev_tickets, 0, 16 * sizeof(unsigned), c->stream);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->dev_bbox), 8 * sizeof(int));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->host_bbox), 8 * sizeof(int), 0);
     if (e == hipSuccess) e = hipMemsetAsync(c->dev_err, 0, sizeof(unsigned), c->stream);
@@ -948,6 +954,8 @@ void amhip_ctx_destroy(amhip_ctx* h) {
     if (b) (void)hipFree(b);
   if (c->host_err) (void)hipHostFree(c->host_err);
   if (c->host_tile_stats) (void)hipHostFree(c->host_tile_stats);
+  if (c->host_sort_stats) (void)hipHostFree(c->host_sort_stats);
+  if (c->dev_tickets) (void)hipFree(c->dev_tickets);
   if (c->host_bbox) (void)hipHostFree(c->host_bbox);
   if (c->spec_flag_host) (void)hipHostFree(c->spec_flag_host);
   if (c->order_event) (void)hipEventDestroy(c->order_event);

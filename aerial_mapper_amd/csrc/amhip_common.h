@@ -318,6 +318,18 @@ struct Ctx {
   int64_t last_num_bins = 0;
   int32_t last_bin_cells = 0;
   int64_t last_ntiles = 0;        // gather tiles of the last call (0: not the LDS-tiled gather)
+  // Launch bookkeeping (round 5): what the sort's single-workgroup kernel resets for the gather
+  // (SortAux), where the scatter waves' height partials end, the ticket of the count pass's
+  // reduce-then-scan kernel, and the pinned words the device leaves for the NEXT call's launch
+  // policy (never waited for): [0] sub-partitions beyond the placement workgroup's registers.
+  uint32_t* aux_zero_words = nullptr;
+  int aux_nzero = 0;
+  bool aux_done = false;
+  size_t range_parts = 0;
+  unsigned long long* range_running = nullptr;
+  unsigned* dev_tickets = nullptr;      // 16 words, zero between launches
+  unsigned* host_sort_stats = nullptr;  // pinned, 4 words
+  unsigned long long sort_stats_sig = 0, tile_stats_sig = 0;  // the geometry the pinned counters describe
   unsigned* host_tile_stats = nullptr;  // pinned mirror of the last call's tile-list counters
 
   // timing
@@ -374,7 +386,8 @@ int make_halo_params(const Ctx& c, double center_easting, double center_northing
 // byte per cell, set where this call wrote a value; unfilled (may be null):
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
-bool spec_poll_overflow(Ctx* c);  // amhip_sort.hip: the speculative sort's miss bookkeeping
+bool spec_poll_overflow(Ctx* c);
+bool no_launch_skips();            // amhip_sort.hip: AMHIP_NO_LAUNCH_SKIPS  // amhip_sort.hip: the speculative sort's miss bookkeeping
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split = nullptr);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,

@@ -114,6 +114,48 @@ __device__ __forceinline__ void range_commit_wave(double lo, double hi, double* 
   }
 }
 
+// Workgroup `block` of `nblocks` folds its share of the partial pairs into the running range
+// (may be null: the mosaic's coarse cull reads it) and the call's own range (the gather's
+// rounding guard: max |z|); one pair of atomics per workgroup.  Any block size that is a multiple
+// of 64, up to 1024; s_pair: 32 doubles of LDS.
+__device__ __forceinline__ void range_reduce_block(const double* __restrict__ part, size_t nparts,
+                                                   unsigned long long* __restrict__ range,
+                                                   unsigned long long* __restrict__ call_range,
+                                                   unsigned block, unsigned nblocks, double* s_pair) {
+  double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
+  const size_t stride = (size_t)nblocks * blockDim.x;
+  for (size_t k = (size_t)block * blockDim.x + threadIdx.x; k < nparts; k += stride) {
+    const double2 v = reinterpret_cast<const double2*>(part)[k];
+    lo = fmin(lo, v.x);
+    hi = fmax(hi, v.y);
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    lo = fmin(lo, __shfl_xor(lo, d, 64));
+    hi = fmax(hi, __shfl_xor(hi, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_pair[2 * (threadIdx.x >> 6)] = lo;
+    s_pair[2 * (threadIdx.x >> 6) + 1] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (int)(blockDim.x >> 6);
+    for (int w = 1; w < nw; ++w) {
+      lo = fmin(lo, s_pair[2 * w]);
+      hi = fmax(hi, s_pair[2 * w + 1]);
+    }
+    if (lo <= hi) {
+      if (range) {
+        atomicMin(&range[0], ordered_key(lo));
+        atomicMax(&range[1], ordered_key(hi));
+      }
+      atomicMin(&call_range[0], ordered_key(lo));
+      atomicMax(&call_range[1], ordered_key(hi));
+    }
+  }
+}
+
 }  // namespace amhip
 
 #endif  // AMHIP_DEVICE_H_

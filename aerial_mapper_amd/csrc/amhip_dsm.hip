@@ -704,8 +704,8 @@ __device__ __forceinline__ void wave_append_tile(int* __restrict__ lists, int nt
   }
 }
 
-__global__ void __launch_bounds__(256)
-k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
+__device__ __forceinline__ void
+tile_occupancy_block(const DsmParams& p, int tile_j, const uint32_t* __restrict__ start,
                      uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
                      int cap1, int cap2, const uint2* __restrict__ bin_z, int rej_own,
                      int rej_big_np, int rej_dense, const double* __restrict__ zref_dev) {
@@ -786,6 +786,51 @@ k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start
     if (m && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1)
       atomicAdd(reinterpret_cast<unsigned*>(lists) + 7, (unsigned)__popcll(m));
   }
+}
+
+// The gather's PROLOGUE (round 5: one launch for what were four).  Workgroups [0, nocc) classify the
+// tiles as described above; workgroups [nocc, nocc + nrange) fold the scatter waves' height
+// partials into the running range and the call's own (range_reduce_block: what k_range_reset +
+// k_range_reduce did); the workgroup that finishes LAST (a ticket) leaves the list counters in a
+// pinned host word array for the next call's launch policy (what a hipMemcpyAsync did).
+struct ProloguePart {
+  const double* zpart;              // the scatter waves' partial [min z, max z] pairs (may be null)
+  size_t nparts;
+  unsigned long long* range;        // running range (may be null)
+  unsigned long long* call_range;
+  unsigned nocc, nrange;
+  unsigned* ticket;                 // zero at launch, left zero
+  unsigned* host_stats;             // pinned: kListHdr words (may be null: the caller copies later)
+};
+
+__global__ void __launch_bounds__(256)
+k_dsm_tile_occupancy(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
+                     uint8_t* __restrict__ occ, int* __restrict__ lists, int list0, int cap0,
+                     int cap1, int cap2, const uint2* __restrict__ bin_z, int rej_own,
+                     int rej_big_np, int rej_dense, const double* __restrict__ zref_dev,
+                     ProloguePart pp) {
+  __shared__ double s_pair[32];
+  __shared__ unsigned s_last;
+  if (blockIdx.x >= pp.nocc) {
+    if (pp.zpart && pp.nparts)
+      range_reduce_block(pp.zpart, pp.nparts, pp.range, pp.call_range, blockIdx.x - pp.nocc, pp.nrange, s_pair);
+  } else {
+    tile_occupancy_block(p, tile_j, start, occ, lists, list0, cap0, cap1, cap2, bin_z, rej_own, rej_big_np,
+                         rej_dense, zref_dev);
+  }
+  if (!pp.host_stats || !lists) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_last = atomicAdd(pp.ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) *pp.ticket = 0u;
+  if (threadIdx.x < (unsigned)kListHdr)
+    pp.host_stats[threadIdx.x] = __hip_atomic_load(reinterpret_cast<unsigned*>(lists) + threadIdx.x,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // |v| outside [2^-960, 2^960] (within ~1e19 of the ends of the double range)
@@ -2097,6 +2142,14 @@ k_dsm_gather_dense(DsmParams p, int tile_j, const uint32_t* __restrict__ start,
   }
 }
 
+// (calls without the LDS-tiled gather: no prologue to ride on)
+__global__ void __launch_bounds__(256)
+k_range_reduce(const double* __restrict__ part, size_t nparts, unsigned long long* __restrict__ range,
+               unsigned long long* __restrict__ call_range) {
+  __shared__ double s_pair[32];
+  range_reduce_block(part, nparts, range, call_range, blockIdx.x, gridDim.x, s_pair);
+}
+
 // ---------------------------------------------------------------------------
 // host driver
 // ---------------------------------------------------------------------------
@@ -2109,6 +2162,17 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   // any other sort on this context overwrites the histogram rows a pending
   // amhip_dsm_tiled_begin_dev left behind: its finish call then fails instead of mis-binning
   if (!split) c->tiled_pending = false;
+  // (the counters of the gather's tile lists are zeroed by the sort's single-workgroup kernel on
+  // its way -- SortAux --, so the list buffer has to exist before the sort is enqueued)
+  c->aux_zero_words = nullptr;
+  c->aux_nzero = 0;
+  if (p.lds_ok) {
+    const size_t ntiles0 = (size_t)p.tiles_i * (size_t)p.tiles_j;
+    int rc;
+    if ((rc = ensure_capacity(&c->tile_list, &c->tile_list_cap, kNumLists * ntiles0 + kListHdr))) return rc;
+    c->aux_zero_words = reinterpret_cast<uint32_t*>(c->tile_list);
+    c->aux_nzero = kListHdr;
+  }
   {
     const int rc = dsm_sort(c, dev_xyz, dev_values, n, p, zrange, split);
     if (rc) return rc;
@@ -2157,7 +2221,6 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       }
       unsigned* tile_count = reinterpret_cast<unsigned*>(c->tile_list);
       int* const lists = c->tile_list;
-      AMHIP_TRY(hipMemsetAsync(tile_count, 0, kListHdr * sizeof(unsigned), c->stream));
       const bool f32 = p.fx_ok && !p.pcl_mode && !p.only_unfilled && !mask && !unfilled;
       // Single-precision mode: its records take 16 bytes against the FP64 kernel's 24, so the
       // same two LDS budgets (two workgroups per CU / one) hold more points: classes 1 and 2
@@ -2193,9 +2256,33 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         const double rejected = (double)hs[4] + (double)hs[5] + (double)hs[6] + (double)hs[7];
         rej_dense = rejected * 10.0 > (double)prev_ntiles;
       }
-      hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3((ntiles + 255) / 256), dim3(256), 0, c->stream,
+      // The capacity-class launches behind the main one (denser tiles: classes 1, 2, the wave-per-
+      // block kernel) are SKIPPED when the previous call of this kind left all three lists empty
+      // (pinned counters, never waited for): the main launch then takes every class -- a stray
+      // denser tile walks the global bins (gather_tile: use_lds false), slower, same result -- and
+      // the counters this call leaves bring the class launches back for the next one.
+      unsigned long long tsig = 1469598103934665603ull;
+      for (const int v : {p.rows, p.cols, p.i_off, p.j_off, p.tile_j, p.lds_cap, p.B, p.M, p.w[0], p.pcl_mode, cap1, cap2})
+        tsig = (tsig ^ (unsigned long long)(unsigned)v) * 1099511628211ull;
+      const volatile unsigned* hst = c->host_tile_stats;
+      const bool skip_classes = !f32 && !sparse && hst && c->tile_stats_sig == tsig && hst[1] == 0u && hst[2] == 0u &&
+                                hst[3] == 0u && !no_launch_skips();
+      c->tile_stats_sig = tsig;
+      const int main_class = skip_classes ? -1 : 0;
+      ProloguePart pp;
+      pp.zpart = c->range_parts ? c->zpart : nullptr;
+      pp.nparts = c->range_parts;
+      pp.range = c->range_running;
+      pp.call_range = c->dev_zrange + 2;
+      pp.nocc = (ntiles + 255) / 256;
+      pp.nrange = c->range_parts ? 32u : 0u;
+      pp.ticket = c->dev_tickets + 1;
+      // (single-precision mode: its gather kernels still append to lists 4 .. 6 -- copied at the end)
+      pp.host_stats = f32 ? nullptr : c->host_tile_stats;
+      c->range_parts = 0;
+      hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3(pp.nocc + pp.nrange), dim3(256), 0, c->stream,
                          p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2,
-                         bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref);
+                         bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref, pp);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
       static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
@@ -2215,7 +2302,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
     hipLaunchKernelGGL((k_dsm_gather_tiled<NT_, TJ_, CAP_>), dim3(ntiles), dim3(NT_),         \
                        p.lds_bytes, c->stream, p, c->bin_start, pts_view, c->tile_occ,       \
-                       cell_out, 0);                                                          \
+                       cell_out, main_class);                                                 \
   } while (0)
       // the FP64 kernel, one workgroup per tile, over the tiles the pre-pass classified for it
       // (occ = 1 + 4) and nothing else: hardware dispatch and the XCD-aware order instead of a
@@ -2368,7 +2455,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         else if (nt == 1024) AMHIP_LAUNCH_DENSE(1024, 32, 2048);
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
       }
-      if (p.tile_j == 16) {
+      if (skip_classes) {
+        // (nothing: the main launch took every class)
+      } else if (p.tile_j == 16) {
         if (f32) {
           AMHIP_LAUNCH_F32_CLASS(16, 4096, capf1, 1, 2048);
           AMHIP_LAUNCH_F32_CLASS(16, 7680, capf2, 2, 1024);
@@ -2400,7 +2489,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_gather_dense<true>, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
                            c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles,
                            tile_count + 3, cell_out);
-      else
+      else if (!skip_classes)
         hipLaunchKernelGGL(k_dsm_gather_dense<false>, dim3(4096), dim3(256), 0, c->stream, p, p.tile_j,
                            c->bin_start, pts_view, lists + kListHdr + (size_t)3 * ntiles,
                            tile_count + 3, cell_out);
@@ -2410,10 +2499,15 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                            c->bin_start, pts_view, lists + kListHdr + (size_t)6 * ntiles,
                            tile_count + 6, cell_out);
       // (what the next call's choice between list and dense launch reads; never waited for)
-      if (c->host_tile_stats)
+      if (c->host_tile_stats && f32)   // (FP64 pipeline: the prologue's last workgroup wrote them)
         AMHIP_TRY(hipMemcpyAsync(c->host_tile_stats, tile_count, kListHdr * sizeof(unsigned),
                                  hipMemcpyDeviceToHost, c->stream));
     } else {
+      if (c->range_parts) {
+        hipLaunchKernelGGL(k_range_reduce, dim3(32), dim3(256), 0, c->stream, (const double*)c->zpart,
+                           c->range_parts, c->range_running, c->dev_zrange + 2);
+        c->range_parts = 0;
+      }
       dim3 grid((unsigned)((p.rows + 63) / 64), (unsigned)((p.cols + 3) / 4));
       if (p.knn_k > 0)
         hipLaunchKernelGGL(k_dsm_gather_knn, grid, dim3(256), 0, c->stream, p, c->bin_start,

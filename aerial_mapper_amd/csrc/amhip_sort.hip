@@ -363,21 +363,6 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
   for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
 }
 
-__global__ void __launch_bounds__(256)
-k_dsm_p3_reduce(const uint32_t* __restrict__ hist_rows, int nrows, int nk,
-                uint32_t* __restrict__ cnt) {
-  // 64 counters per workgroup, the rows dealt to its four waves
-  __shared__ uint32_t s_part[4][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
-  uint32_t s = 0;
-  if (k < nk)
-    for (int r = wid; r < nrows; r += 4) s += hist_rows[(size_t)r * nk + k];
-  s_part[wid][lane] = s;
-  __syncthreads();
-  if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
-}
-
 // layout of a speculative sort's plan (uint32 words): [cstart2: nk + 1][cstart1: n1 + 1] ... 1 KB
 // aligned: [cursor2: nk] ... [cursor1: n1]
 __host__ __device__ inline size_t p3_plan_cursor2_at(int nk, int n1) {
@@ -387,34 +372,43 @@ __host__ __device__ inline size_t p3_plan_words(int nk, int n1) {
   return p3_plan_cursor2_at(nk, n1) + (((size_t)nk + 255) & ~(size_t)255) + (((size_t)n1 + 255) & ~(size_t)255) + 256;
 }
 
+// What the single-workgroup kernel in front of the first scatter pass (k_dsm_p3_scan /
+// k_dsm_p3_reduce_scan, k_p3_spec_mid, k_scan_top) resets on its way, so that no launch of its own
+// is spent on it: the call's own height range (k_range_reduce folds the scatter waves' partials
+// into it later) and the counters of the gather's tile lists (amhip_dsm.hip: dsm_run).
+struct SortAux {
+  unsigned long long* call_range;  // may be null
+  uint32_t* zero_words;            // may be null
+  int nzero;
+};
+__device__ __forceinline__ void aux_reset(const SortAux& a) {
+  if (threadIdx.x == 0 && a.call_range) {
+    a.call_range[0] = kOrderedPlusInf;
+    a.call_range[1] = kOrderedMinusInf;
+  }
+  if (a.zero_words && (int)threadIdx.x < a.nzero) a.zero_words[threadIdx.x] = 0u;
+}
+
 // One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
 // copy as the pass-2 append cursors; start1 / cursor1 for pass 1; blk2 = first
 // pass-2 workgroup of every k1 partition (partitions are cut into chunks).
-__global__ void __launch_bounds__(1024)
-k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
+// (the body: one workgroup of 1024 threads; plan_block: scan the NEXT call's regions instead)
+__device__ __forceinline__ void
+p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, int n2,
               uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
               uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
               uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
               uint32_t* __restrict__ big_list, unsigned chunk,
-              const uint32_t* __restrict__ gate /* may be null */,
               // the speculative sort (dsm_sort): spec_start2 / spec_cursor2 (may be null) -- the
               // counts are what pass 2 appended to its regions, not cnt[]; plan (may be null) -- the
               // NEXT call's regions from this call's counts, count + count / 8 + 32 each:
               // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1], and its overflow word
               const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
               uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
-              // a speculative call's own scan: nothing to do once a region overflowed (the regions then
-              // hold gaps no run was written to; the exact pipeline behind rewrites everything, the plan too)
-              const uint32_t* __restrict__ skip_if /* may be null */) {
+              unsigned* __restrict__ host_big /* may be null: pinned mirror of the big list's length */) {
   __shared__ unsigned lds[1024 / 64 + 1];
-  if (gate && !*gate) return;
-  if (skip_if && *skip_if) return;
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
-  // (launched with TWO workgroups when there is a plan to write: the second one scans the regions'
-  // sizes instead of the counts -- in the same workgroup the two arrays of 32 prefixes per thread
-  // spilled and the kernel took 50 us instead of 17)
-  const bool plan_block = blockIdx.x == 1;
   if (plan_block && !plan) return;
   unsigned carry = 0;
   if (threadIdx.x == 0 && !plan_block) big_list[0] = 0;
@@ -525,7 +519,82 @@ k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
   const unsigned ex = block_excl_scan<1024>(nblk, &total, lds);
   if (k < n1) blk2[k] = ex;
   if (k == 0) blk2[n1] = total;
+  // (how many sub-partitions the big placement kernel has to take: the NEXT call of this geometry
+  // launches it only if this is not zero -- a device store into pinned host memory, never waited for)
+  if (k == 0 && host_big) host_big[0] = big_list[0];
 }
+
+// One block (two when there is a plan to write: the second one scans the regions' sizes instead of
+// the counts -- in the same workgroup at the same time the two arrays of 32 prefixes per thread
+// spilled and the kernel took 50 us instead of 17).
+// gate (may be null): the exact pipeline behind a speculative sort -- leaves unless the flag is up;
+// skip_if (may be null): a speculative call's own scan -- nothing to do once a region overflowed (the
+// regions then hold gaps no run was written to; the exact pipeline behind rewrites everything).
+__global__ void __launch_bounds__(1024)
+k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
+              uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
+              uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
+              uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
+              uint32_t* __restrict__ big_list, unsigned chunk,
+              const uint32_t* __restrict__ gate,
+              const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
+              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
+              const uint32_t* __restrict__ skip_if, SortAux aux, unsigned* __restrict__ host_big) {
+  if (gate && !*gate) return;
+  if (skip_if && *skip_if) return;
+  if (blockIdx.x == 0) aux_reset(aux);
+  p3_scan_body(blockIdx.x == 1, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big,
+               big_list, chunk, spec_start2, spec_cursor2, plan, plan_flag, room_shift,
+               blockIdx.x == 0 ? host_big : nullptr);
+}
+
+// Count pass, second half: the reduction of the count workgroups' histogram rows (64 counters per
+// workgroup, the rows dealt to its 16 waves) and -- by the workgroup that finishes LAST (a ticket)
+// -- the scan above: one launch instead of two, and the scan starts the moment the last counter is
+// written.  `ticket` is zero at launch and left zero.
+__global__ void __launch_bounds__(1024)
+k_dsm_p3_reduce_scan(const uint32_t* __restrict__ hist_rows, int nrows, uint32_t* __restrict__ cnt, int n1, int n2,
+                     uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
+                     uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
+                     uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
+                     uint32_t* __restrict__ big_list, unsigned chunk,
+                     uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
+                     SortAux aux, unsigned* __restrict__ host_big, unsigned* __restrict__ ticket) {
+  __shared__ uint32_t s_part[16][64];
+  __shared__ unsigned s_last;
+  const int nk = n1 * n2;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  uint32_t sum = 0;
+  if (k < nk)
+    for (int r = wid; r < nrows; r += 16) sum += hist_rows[(size_t)r * nk + k];
+  s_part[wid][lane] = sum;
+  __syncthreads();
+  if (wid == 0 && k < nk) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += s_part[w][lane];
+    cnt[k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // (this workgroup's counters before its ticket)
+    s_last = atomicAdd(ticket, 1u) == gridDim.x - 1u ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();    // (the others' counters after the last ticket)
+  if (threadIdx.x == 0) *ticket = 0u;
+  aux_reset(aux);
+  p3_scan_body(false, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big, big_list, chunk,
+               nullptr, nullptr, nullptr, nullptr, room_shift, host_big);
+  if (plan) {
+    __syncthreads();
+    p3_scan_body(true, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big, big_list, chunk,
+                 nullptr, nullptr, plan, plan_flag, room_shift, nullptr);
+  }
+}
+
 
 // Passes 1 and 2.  kFirst: chunk of the input cloud, key k1, values/centre
 // handling of the reference; else: chunk of one k1 partition, key k2.
@@ -704,8 +773,9 @@ k_dsm_p3_scatter_pers(const double* __restrict__ src, size_t n, DsmParams p,
 // after pass 1: where every k1 partition's points end, and the chunks of pass 2
 __global__ void __launch_bounds__(1024)
 k_p3_spec_mid(const uint32_t* __restrict__ cstart1, const uint32_t* __restrict__ cursor1, int n1,
-              uint32_t* __restrict__ end1, uint32_t* __restrict__ blk2, unsigned chunk) {
+              uint32_t* __restrict__ end1, uint32_t* __restrict__ blk2, unsigned chunk, SortAux aux) {
   __shared__ unsigned lds[1024 / 64 + 1];
+  aux_reset(aux);
   const int k = threadIdx.x;
   unsigned nblk = 0;
   if (k < n1) {
@@ -1675,8 +1745,9 @@ k_scan_partials(const uint32_t* __restrict__ in, size_t n,
 // One block; exclusive scan of partials[0..nb) in place, grand total to *total.
 __global__ void __launch_bounds__(1024)
 k_scan_top(uint32_t* __restrict__ partials, size_t nb,
-           uint32_t* __restrict__ total_out) {
+           uint32_t* __restrict__ total_out, SortAux aux) {
   __shared__ unsigned lds[1024 / 64 + 1];
+  aux_reset(aux);
   unsigned carry = 0;
   for (size_t base = 0; base < nb; base += 1024) {
     const size_t i = base + threadIdx.x;
@@ -1734,52 +1805,6 @@ k_scan_final(uint32_t* __restrict__ data, size_t n,
 }
 
 
-// fold the scatter waves' [min z, max z] partials into the context's range
-// (one thread) the call's own range starts empty
-__global__ void k_range_reset(unsigned long long* __restrict__ call_range) {
-  call_range[0] = kOrderedPlusInf;
-  call_range[1] = kOrderedMinusInf;
-}
-
-// range (may be null): the context's running range since the last reset (the mosaic's coarse
-// cull); call_range: this DSM call's own (the gather's rounding guard: max |z|, amhip_dsm.hip)
-__global__ void __launch_bounds__(1024)
-k_range_reduce(const double* __restrict__ part, size_t nparts,
-               unsigned long long* __restrict__ range, unsigned long long* __restrict__ call_range) {
-  __shared__ double s_pair[2 * 16];
-  double lo = __builtin_huge_val(), hi = -__builtin_huge_val();
-  const size_t stride = (size_t)gridDim.x * 1024;  // (a handful of workgroups: few atomics)
-  for (size_t k = (size_t)blockIdx.x * 1024 + threadIdx.x; k < nparts; k += stride) {
-    const double2 v = reinterpret_cast<const double2*>(part)[k];
-    lo = fmin(lo, v.x);
-    hi = fmax(hi, v.y);
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    lo = fmin(lo, __shfl_xor(lo, d, 64));
-    hi = fmax(hi, __shfl_xor(hi, d, 64));
-  }
-  if ((threadIdx.x & 63) == 0) {
-    s_pair[2 * (threadIdx.x >> 6)] = lo;
-    s_pair[2 * (threadIdx.x >> 6) + 1] = hi;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 16; ++w) {
-      lo = fmin(lo, s_pair[2 * w]);
-      hi = fmax(hi, s_pair[2 * w + 1]);
-    }
-    if (lo <= hi) {
-      if (range) {
-        atomicMin(&range[0], ordered_key(lo));
-        atomicMax(&range[1], ordered_key(hi));
-      }
-      atomicMin(&call_range[0], ordered_key(lo));
-      atomicMax(&call_range[1], ordered_key(hi));
-    }
-  }
-}
-
 // AMHIP_P3_ROUNDS_CAP=n (tests): sub-partitions above n points are placed in rounds over an
 // image of n points -- exercises place_rounds (and its one-bin-beyond-the-image direct case)
 // on clouds of test size; normally only contexts beyond ~130 M points get there
@@ -1793,6 +1818,15 @@ static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* re
     *rounds_above = (unsigned)knob;
   }
   if (reread) *reg_max = 0u;
+}
+
+__global__ void k_aux_reset(SortAux aux) { aux_reset(aux); }
+
+// AMHIP_NO_LAUNCH_SKIPS=1 (tests, A-B): every capacity-class / big-list launch is made whatever the
+// previous call's counters say (amhip_dsm.hip: dsm_run uses the same switch)
+bool no_launch_skips() {
+  static const bool v = getenv("AMHIP_NO_LAUNCH_SKIPS") != nullptr;
+  return v;
 }
 
 // ---- the speculative sort's host side ------------------------------------------------------
@@ -1845,8 +1879,25 @@ static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
 
+static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+                         const DsmParams& p, unsigned long long* zrange, const SortSplit* split);
+
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split) {
+  const int rc = dsm_sort_impl(c, dev_xyz, dev_values, n, p, zrange, split);
+  if (rc) return rc;
+  if (!c->aux_done && !(split && split->phase == 1)) {
+    // (no path gets here: every sort hands SortAux to one of its single-workgroup kernels)
+    const SortAux aux = {c->dev_zrange + 2, c->aux_zero_words, c->aux_zero_words ? c->aux_nzero : 0};
+    hipLaunchKernelGGL(k_aux_reset, dim3(1), dim3(64), 0, c->stream, aux);
+    AMHIP_TRY(hipGetLastError());
+    c->aux_done = true;
+  }
+  return AMHIP_OK;
+}
+
+static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
+                         const DsmParams& p, unsigned long long* zrange, const SortSplit* split) {
   // [min z, max z] of the binned points (for the mosaic's coarse cull): every
   // workgroup of the first scatter pass -- it loads z anyway -- writes a
   // partial, k_range_reduce folds them into *zrange
@@ -1859,7 +1910,13 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     if (rc) return rc;
     zpart = c->zpart;
   }
-  unsigned long long* const call_range = c->dev_zrange + 2;
+  // What the single-workgroup kernel in front of the first scatter resets (SortAux): the call's own
+  // range and -- when dsm_run asked for it -- the counters of the gather's tile lists.
+  // k_range_reduce (amhip_dsm.hip: the gather's prologue) folds zpart[0 .. range_parts) afterwards.
+  const SortAux aux = {c->dev_zrange + 2, c->aux_zero_words, c->aux_zero_words ? c->aux_nzero : 0};
+  c->aux_done = false;
+  c->range_parts = 0;
+  c->range_running = zrange;
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   // the speculative sort (three-pass, FP64 pipeline, plain DSM call): see below
@@ -1872,9 +1929,11 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
   // again after that and keep counting first.  AMHIP_SORT_SPEC_MAX_POINTS moves the limit.)
   static const size_t spec_max_points = getenv("AMHIP_SORT_SPEC_MAX_POINTS")
                                             ? (size_t)atoll(getenv("AMHIP_SORT_SPEC_MAX_POINTS")) : ((size_t)1 << 27);
+  // (amhip_ctx_set_dsm_sort_reuse(ctx, 0): no plans are read OR written -- the scan's second pass goes too)
   const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split &&
-                         n <= spec_max_points;
-  const unsigned long long sig = spec_mode ? spec_signature(p) : 0ull;
+                         n <= spec_max_points && c->spec_reuse;
+  const unsigned long long geo_sig = spec_signature(p);   // (window geometry + sort plan)
+  const unsigned long long sig = spec_mode ? geo_sig : 0ull;
   const bool spec = spec_mode && spec_wanted(c, n, sig);
   // (the regions' head room: count >> room_shift; AMHIP_SORT_SPEC_MARGIN_SHIFT, 1 .. 31, experiments)
   static const int room_shift = getenv("AMHIP_SORT_SPEC_MARGIN_SHIFT")
@@ -1979,6 +2038,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       // scatters once; the context then counts first for the next eight calls.  It can only hit
       // when consecutive calls bring similarly distributed clouds.
       ++c->spec_hits_started;
+      const SortAux no_aux = {nullptr, nullptr, 0};   // (k_p3_spec_mid did it)
       const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
       const size_t lds_sc = (size_t)kP3Chunk * 28 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
       const size_t lds_cnt = (size_t)nk * sizeof(uint32_t);
@@ -2008,13 +2068,10 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scatter_spec<true>, dim3((unsigned)g1), dim3(kP3Threads), lds_sc, c->stream,
                            dev_xyz, n, p, cstart1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, cursor1s,
                            cstart1 + 1, spec_flag, c->sorted, zpart);
-        if (zpart) {
-          hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
-          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
-                             (size_t)g1 * (kP3Threads / 64), zrange, call_range);
-        }
+        c->range_parts = (size_t)g1 * (kP3Threads / 64);
         hipLaunchKernelGGL(k_p3_spec_mid, dim3(1), dim3(1024), 0, c->stream, cstart1, cursor1s, n1, end1, blk2,
-                           (unsigned)kP3Chunk);
+                           (unsigned)kP3Chunk, aux);
+        c->aux_done = true;
         hipLaunchKernelGGL(k_dsm_p3_scatter_spec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads), lds_sc,
                            c->stream, c->sorted, n, p, cstart1, end1, blk2, cursor2s, cstart2 + 1, spec_flag,
                            c->tmp_points, (double*)nullptr);
@@ -2025,7 +2082,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift,
-                           spec_flag);
+                           spec_flag, no_aux, c->host_sort_stats);
         hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
                            c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
                            0xFFFFFFFFu, (uint2*)nullptr, cstart2, spec_flag);
@@ -2045,7 +2102,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr);
+                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr, no_aux, c->host_sort_stats);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
                            n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
@@ -2099,13 +2156,12 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       if (rec)
         hipLaunchKernelGGL(k_dsm_zref, dim3(1), dim3(1024), 0, c->stream, zall,
                            (split && !g_b ? g_a : gcount) * (size_t)(kP3CountThreads / 64), c->zref);
-      hipLaunchKernelGGL(k_dsm_p3_reduce, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0,
-                         c->stream, hist_rows, (int)gcount, nk, cnt);
-      hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2,
-                         cursor2, start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap,
-                         big_list, (unsigned)(rec ? kRecChunk : kP3Chunk), (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, plan_next, flag_next, room_shift,
-                         (const uint32_t*)nullptr);
+      // (reduction of the count workgroups' rows + the scan by the workgroup that finishes last: one launch)
+      hipLaunchKernelGGL(k_dsm_p3_reduce_scan, dim3((unsigned)((nk + 63) / 64)), dim3(1024), 0, c->stream,
+                         hist_rows, (int)gcount, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2,
+                         (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list, (unsigned)(rec ? kRecChunk : kP3Chunk),
+                         plan_next, flag_next, room_shift, aux, c->host_sort_stats, c->dev_tickets);
+      c->aux_done = true;
       AMHIP_TRY(hipGetLastError());
       if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
         c->spec_valid = true;
@@ -2126,10 +2182,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
         hipLaunchKernelGGL(k_dsm_p3_scatter_rec<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
                            c->stream, dev_xyz, (const uint32_t*)nullptr, n, p, c->zref, start1, blk2,
                            cursor1, c->rec_a, zpart);
-        if (zpart)
-          { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
-          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
-                             (size_t)g1 * (kP3Threads / 64), zrange, call_range); }
+        c->range_parts = (size_t)g1 * (kP3Threads / 64);
         hipLaunchKernelGGL(k_dsm_p3_scatter_rec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
                            lds, c->stream, (const double*)nullptr, c->rec_a, n, p, c->zref, start1, blk2,
                            cursor2, c->rec_b, (double*)nullptr);
@@ -2175,10 +2228,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_p3_scatter<true>, dim3((unsigned)g1), dim3(kP3Threads), lds,
                          c->stream, dev_xyz, dev_values, n, p, start1, blk2, cursor1, c->sorted,
                          zpart);
-      if (zpart)
-        { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
-          hipLaunchKernelGGL(k_range_reduce, dim3(64), dim3(1024), 0, c->stream, zpart,
-                           (size_t)g1 * (kP3Threads / 64), zrange, call_range); }
+      c->range_parts = (size_t)g1 * (kP3Threads / 64);
       hipLaunchKernelGGL(k_dsm_p3_scatter<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads),
                          lds, c->stream, c->sorted, (const int32_t*)nullptr, n, p, start1, blk2,
                          cursor2, c->tmp_points, (double*)nullptr);
@@ -2194,9 +2244,18 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const size_t lds = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t) + zlds;
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      // Sub-partitions beyond the placement workgroup's registers (denser parts of a non-uniform
+      // cloud) are k_dsm_p3_place_big's.  Its launch is skipped when the PREVIOUS three-pass call of
+      // this geometry had none (the scan leaves their number in a pinned word, never waited for):
+      // k_dsm_p3_place then keeps nothing back and places a stray over-full sub-partition itself,
+      // directly (slower, same result) -- the word it leaves brings the big kernel back next call.
+      const bool want_big = !(c->sort_stats_sig == geo_sig && c->host_sort_stats && c->host_sort_stats[0] == 0u) ||
+                            no_launch_skips();
+      c->sort_stats_sig = geo_sig;
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         (unsigned)p.p3_cap, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                         want_big ? (unsigned)p.p3_cap : 0xFFFFFFFFu, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
       unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
@@ -2205,9 +2264,10 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                                       (size_t)cap_rounds * 24 + tables);
       AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-      hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                         c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+      if (want_big)
+        hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
+                           c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }
@@ -2244,7 +2304,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_scan_partials, dim3((unsigned)nblocks_scan), dim3(kScanT), 0,
                          c->stream, c->bin_start, nbins, c->scan_partials);
       hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, c->stream, c->scan_partials,
-                         nblocks_scan, c->bin_start + nbins);
+                         nblocks_scan, c->bin_start + nbins, aux);
+      c->aux_done = true;
       hipLaunchKernelGGL(k_scan_final, dim3((unsigned)nblocks_scan), dim3(kScanT), 0, c->stream,
                          c->bin_start, nbins, c->scan_partials);
       AMHIP_TRY(hipGetLastError());
@@ -2258,10 +2319,7 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       if (rec)
         c->pts = PtsView{c->sorted, reinterpret_cast<const uint4*>(c->rec16), c->sidx, dev_xyz, c->zref,
                          p.sub_x, p.sub_y};
-      if (zpart)
-        { hipLaunchKernelGGL(k_range_reset, dim3(1), dim3(1), 0, c->stream, call_range);
-          hipLaunchKernelGGL(k_range_reduce, dim3(16), dim3(1024), 0, c->stream, zpart,
-                           (size_t)grid_pts * 4, zrange, call_range); }
+      c->range_parts = (size_t)grid_pts * 4;
       AMHIP_TRY(hipGetLastError());
     }
   }
