@@ -23,8 +23,9 @@ OBJ_DIR = os.path.join(ROOT, "build", "hip_obj")
 HIP_SOURCES = ["amhip_api.hip", "amhip_sort.hip", "amhip_dsm.hip", "amhip_ortho.hip", "amhip_densify.hip",
                "amhip_forward.hip", "amhip_io.hip", "amhip_session.hip", "amhip_rectify.hip", "amhip_export.hip",
                "amhip_hostsum.cc",   # (.cc: host-only, the AVX-512 loop of the session's content sums)
+               "amhip_tuning.cc",    # (host-only: the tuning knobs' store, amhip_set_tuning / AMHIP_TUNING)
                "amhip_build_id.cc"]  # (host-only: amhip_build_id(), recompiled whenever anything else is)
-HIP_HEADERS = ["amhip_common.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", "amhip_content_sum.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
+HIP_HEADERS = ["amhip_common.h", "amhip_tuning.h", "amhip_device.h", "amhip_ortho_fold.h", "amhip_pow5_table.h", "amhip_atan_cr.h", "amhip_atan_table.h", "amhip_content_sum.h", os.path.join(ROOT, "include", "aerial_mapper_hip.h")]
 
 # -ffp-contract=off: every decision of the path (inside-radius test, image-box
 # test, pixel rounding, best-view comparison) must see the same doubles as the

@@ -41,8 +41,7 @@ struct MappedFile {
 };
 
 int device_index() {
-  if (const char* env = std::getenv("AERIAL_MAPPER_HIP_DEVICE")) return std::atoi(env);
-  return 0;
+  return amhip_shim::default_device();
 }
 
 }  // namespace

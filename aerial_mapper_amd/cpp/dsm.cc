@@ -9,9 +9,7 @@
 namespace dsm {
 
 static Precision default_precision() {
-  const char* fast = std::getenv("AMHIP_DSM_FAST");
-  return (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT"))
-             ? Precision::kFast : Precision::kReferenceIdentical;
+  return amhip_default_dsm_precision() == AMHIP_DSM_FAST ? Precision::kFast : Precision::kReferenceIdentical;
 }
 
 Dsm::Dsm(const Settings& settings, grid_map::GridMap* map)

@@ -23,8 +23,7 @@ OrthoForwardHomography::OrthoForwardHomography(const std::shared_ptr<aslam::NCam
   desc.ground_plane_elevation_m = settings_.ground_plane_elevation_m;
   for (int k = 0; k < 3; ++k) desc.origin[k] = settings_.origin(k);
   const amhip_camera cam = describe_camera(ncameras_->getCamera(kFrameIdx));
-  int device = 0;
-  if (const char* env = std::getenv("AERIAL_MAPPER_HIP_DEVICE")) device = std::atoi(env);
+  const int device = amhip_shim::default_device();
   amhip_shim::check_status(amhip_mosaic_create(&desc, &cam, device, &mosaic_),
                            "OrthoForwardHomography");
   const size_t n = settings_.width_mosaic_pixels * settings_.height_mosaic_pixels;

@@ -6,6 +6,13 @@
 #include <vector>
 
 namespace amhip_shim {
+
+// AERIAL_MAPPER_HIP_DEVICE: the device the drop-in classes create their contexts on (default 0)
+int default_device() {
+  const char* env = std::getenv("AERIAL_MAPPER_HIP_DEVICE");
+  return env ? std::atoi(env) : 0;
+}
+
 namespace {
 
 struct Entry {
@@ -40,9 +47,7 @@ std::vector<int32_t> device_list() {
     }
   }
   if (d.empty()) {
-    int device = 0;
-    if (const char* env = std::getenv("AERIAL_MAPPER_HIP_DEVICE")) device = std::atoi(env);
-    d.push_back(device);
+    d.push_back(default_device());
   }
   return d;
 }

@@ -21,6 +21,9 @@ inline void check_status(int status, const char* where) {
   if (status != AMHIP_OK) fatal(where, amhip_last_error());
 }
 
+// AERIAL_MAPPER_HIP_DEVICE: the device the drop-in classes create their contexts on (default 0)
+int default_device();
+
 inline amhip_grid_desc describe(const grid_map::GridMap& map) {
   // the raw matrices are addressed from (0, 0): a map that was move()d (circular buffer start
   // index != 0) would be mis-addressed -- the hot path never moves the map, refuse if it was
@@ -47,9 +50,7 @@ inline void ensure_context(amhip_ctx** ctx, int* rows, int* cols, double* geom,
     return;
   if (*ctx) amhip_ctx_destroy(*ctx);
   *ctx = nullptr;
-  int device = 0;
-  if (const char* env = std::getenv("AERIAL_MAPPER_HIP_DEVICE")) device = std::atoi(env);
-  check_status(amhip_ctx_create(&g, device, ctx), where);
+  check_status(amhip_ctx_create(&g, default_device(), ctx), where);
   *rows = g.rows;
   *cols = g.cols;
   geom[0] = g.resolution;

@@ -196,7 +196,7 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
 // single-precision pipeline is tried once more.  Results: FP64 is the stricter arithmetic, every
 // bar of the single-precision mode holds.  AMHIP_DSM_NO_ROUGH_SWITCH=1 disables the switch.
 static void dsm_rough_policy(Ctx* c) {
-  const bool off = std::getenv("AMHIP_DSM_NO_ROUGH_SWITCH") != nullptr;  // (read per call: tests toggle it)
+  const bool off = tuning_on("dsm_no_rough_switch");  // (looked up per call: tests toggle it)
   c->dsm_exact_now = 0;
   if (c->dsm_exact || c->dsm_knn || off) return;
   if (c->rough_hold > 0) {
@@ -231,7 +231,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq, double center_easting, d
 static int dsm_subwindow(Ctx* c, const double* dev_xyz, size_t n, int radius_sq, double center_easting,
                          double center_northing, const DsmParams& p_full, DsmParams* p_sub) {
   if (n > (1u << 20) || c->cells < (size_t)(4u << 20) || !c->dev_bbox || !c->host_bbox ||
-      std::getenv("AMHIP_DSM_NO_SUBWINDOW"))
+      tuning_on("dsm_no_subwindow"))
     return 0;
   int rc;
   if ((rc = dsm_bbox_run(c, dev_xyz, n, p_full, c->dev_bbox))) return -rc;
@@ -284,8 +284,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   p.sub_x = center_northing;  // dsm.cc:42
   p.sub_y = center_easting;   // dsm.cc:43
   {
-    static const bool canon_all = std::getenv("AMHIP_DSM_CANON_ALL") != nullptr;
-    p.canon_all = canon_all ? 1 : 0;
+    p.canon_all = tuning_on("dsm_canon_all") ? 1 : 0;
   }
 
   // Squared search radii in the order dsm.cc:127-144 tries them: the initial
@@ -344,15 +343,12 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   // p3_cap of them in LDS, more through a direct-placement fallback).
   p.p3_n1 = 0;
   {
-    size_t min_pts = 1u << 20;
-    if (std::getenv("AMHIP_P3_MIN_POINTS"))
-      min_pts = (size_t)std::atoll(std::getenv("AMHIP_P3_MIN_POINTS"));
+    const size_t min_pts = (size_t)tuning("p3_min_points", (double)(1u << 20));
     const int r1 = (p.nby + 127) / 128;
     const int n1 = (p.nby + r1 - 1) / r1;
     int cmax = 256 / r1;
     if (r1 <= 256 && cmax >= 1 && num_points >= min_pts) {
-      double target = 1536.0;
-      if (std::getenv("AMHIP_P3_TARGET")) target = std::atof(std::getenv("AMHIP_P3_TARGET"));
+      const double target = tuning("p3_target", 1536.0);
       int cc = static_cast<int>((double)num_points / ((double)p.nby * target) + 0.5);
       if (cc < 1) cc = 1;
       if (cc > cmax) cc = cmax;
@@ -364,7 +360,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
         p.p3_w = w;
         p.p3_n1 = n1;
         p.p3_n2 = r1 * cc;
-        p.p3_cap = std::getenv("AMHIP_P3_CAP") ? std::atoi(std::getenv("AMHIP_P3_CAP")) : 2048;
+        p.p3_cap = (int)tuning("p3_cap", 2048.0);
         if (p.p3_cap > 2048) p.p3_cap = 2048;  // kP3PlaceMaxCap
         if (p.p3_cap < 64) p.p3_cap = 64;
       }
@@ -425,8 +421,8 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
       cap = need(16) <= 4096.0 ? 4096 : 7680;  // (7680: one workgroup per CU)
     }
 #ifdef AMHIP_TIMING_PROBES
-    if (std::getenv("AMHIP_GATHER_TJ")) {  // tuning knob
-      kTileJ = std::atoi(std::getenv("AMHIP_GATHER_TJ")) == 16 ? 16 : 32;
+    if (tuning("gather_tj", 0.0) != 0.0) {  // tuning knob
+      kTileJ = (int)tuning("gather_tj", 0.0) == 16 ? 16 : 32;
       cap = (kTileJ == 16 && need(16) <= 1024.0) ? 1024 : 2048;  // (the density still picks the capacity)
     }
 #endif
@@ -487,7 +483,7 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
     // a tile's height half-range limit goes from 7.6 to 6.2 m; measured)
     double theta = 0.005;  // cells
 #ifdef AMHIP_TIMING_PROBES
-    if (std::getenv("AMHIP_FX_THETA")) theta = std::atof(std::getenv("AMHIP_FX_THETA"));
+    theta = tuning("fx_theta", theta);
 #endif
     const double q = std::ldexp(1.0, -(S + 1));
     p.fx_S = S;
@@ -704,7 +700,7 @@ static void make_ortho_params(Ctx& c, const amhip_camera& cam,
   double cone = 0.0;
   bool have_cone = false;
   if (cam.distortion != AMHIP_DIST_NONE && cam.fu > 0.0 && cam.fv > 0.0 &&
-      !std::getenv("AMHIP_NO_DISTORTED_CULL")) {
+      !tuning_on("no_distorted_cull")) {
     // (a few hundred thousand evaluations: cached per camera)
     if (c.cone_state == 0 || std::memcmp(&c.cone_cam, &cam, sizeof(cam)) != 0) {
       c.cone_cam = cam;
@@ -724,8 +720,8 @@ static void make_ortho_params(Ctx& c, const amhip_camera& cam,
     }
     ax = c.cone_ax;
     ay = c.cone_ay;
-    if (!std::getenv("AMHIP_NO_DISTORTED_PRUNE")) p.r_in = c.cone_rin;
-    if (std::getenv("AMHIP_DISTORTED_SQUARE_CULL")) ax = ay = cone;  // (A/B: the circumscribed square)
+    if (!tuning_on("no_distorted_prune")) p.r_in = c.cone_rin;
+    if (tuning_on("distorted_square_cull")) ax = ay = cone;  // (A/B: the circumscribed square)
   }
   if (have_cone) {
     // every visible landmark has |x| <= ax * z and |y| <= ay * z
@@ -888,8 +884,7 @@ int amhip_ctx_create_window(const amhip_grid_desc* grid, int i0, int j0, int row
   // reference-identical by default; FAST is opt-in (setter, or AMHIP_DSM_FAST=1 for hosts that
   // cannot be recompiled; AMHIP_DSM_EXACT=1 wins over it)
   {
-    const char* fast = std::getenv("AMHIP_DSM_FAST");
-    c->dsm_exact = (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT")) ? 0 : 1;
+    c->dsm_exact = amhip_default_dsm_precision() == AMHIP_DSM_EXACT ? 1 : 0;
   }
   int rc = AMHIP_OK;
   do {
@@ -1007,7 +1002,7 @@ int amhip_layers_reset(amhip_ctx* h) {
   // needs the memory (download, device pointer, a partial writer) fills it
   // first (materialize()).  Layers whose device pointer was handed out are
   // refilled eagerly.  AMHIP_EAGER_RESET=1 restores the plain fills.
-  static const bool eager = std::getenv("AMHIP_EAGER_RESET") != nullptr;
+  const bool eager = tuning_on("eager_reset");
   {  // every elevation is NaN again: empty height range
     static const unsigned long long empty[2] = {0xFFF0000000000000ull, 0x000FFFFFFFFFFFFFull};
     AMHIP_TRY(hipMemcpyAsync(c->dev_zrange, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
@@ -1538,7 +1533,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   FrameFast* fast = reinterpret_cast<FrameFast*>(inv.data() + F);
   double qdev = 0.0;  // max | |q|^2 - 1 |
   bool fast_ok = cam->distortion == AMHIP_DIST_NONE && cam->fu > 0.0 && cam->fv > 0.0 &&
-                 !std::getenv("AMHIP_ORTHO_EXACT_FOLD");
+                 !tuning_on("ortho_exact_fold");
   for (size_t f = 0; f < F; ++f) {
     const HPose T = hpose_inverse(hpose_from7(host_T_G_C + 7 * f));
     inv[f].qw = T.qw;
@@ -1590,7 +1585,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   p.radius_scale = 1.0 + 2.0 * qdev;
   if (!(qdev < 0.25)) p.cull = 0;  // not a rotation at all (or NaN): every frame is tested
   // small batches on a big map: most tiles are out of every frame's sight
-  p.coarse = (p.cull && c->zrange_valid && F <= 64 && !std::getenv("AMHIP_NO_COARSE_CULL")) ? 1 : 0;
+  p.coarse = (p.cull && c->zrange_valid && F <= 64 && !tuning_on("no_coarse_cull")) ? 1 : 0;
   // num_observations is zero everywhere while it holds its initial value,
   // filled (0) or not (3): `+= itself` keeps it zero, the kernel neither reads
   // nor writes it and the layer stays in that state
@@ -1600,7 +1595,7 @@ int amhip_ortho_backward_process_dev(amhip_ctx* h, const amhip_camera* cam,
   }
   if (!p.virt_nobs && (rc = touch(c, AMHIP_LAYER_NUM_OBSERVATIONS))) return rc;
   p.prune = (p.cull && (cam->distortion == AMHIP_DIST_NONE || p.r_in > 0.0) && p.virt_nobs &&
-             !std::getenv("AMHIP_ORTHO_NO_PRUNE")) ? 1 : 0;
+             !tuning_on("ortho_no_prune")) ? 1 : 0;
   p.fast = fast_ok ? 1 : 0;
   p.fold = make_fold_cam(cam->fu, cam->fv, cam->cu, cam->cv, cam->width, cam->height);
   return ortho_run(c, p, c->frame_poses, reinterpret_cast<const FrameFast*>(c->frame_poses + F),
@@ -1726,6 +1721,20 @@ int amhip_ctx_dsm_sort_stats(amhip_ctx* h, int64_t* out4) {
   out4[2] = (int64_t)c->spec_misses;
   out4[3] = (int64_t)c->spec_cooldown;
   return AMHIP_OK;
+}
+
+int amhip_set_tuning(const char* key, double value) {
+  if (!tuning_set(key, value)) return arg_fail("amhip_set_tuning: unknown key (include/aerial_mapper_hip.h lists them)");
+  return AMHIP_OK;
+}
+
+double amhip_get_tuning(const char* key, double dflt) { return key ? tuning(key, dflt) : dflt; }
+
+int amhip_default_dsm_precision(void) {
+  // AMHIP_DSM_FAST=1 (and not AMHIP_DSM_EXACT): hosts that cannot be recompiled opt in to the
+  // single-precision gather; everything else starts in the reference's arithmetic
+  const char* fast = std::getenv("AMHIP_DSM_FAST");
+  return (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT")) ? AMHIP_DSM_FAST : AMHIP_DSM_EXACT;
 }
 
 int amhip_ctx_set_dsm_sort_reuse(amhip_ctx* h, int on) {

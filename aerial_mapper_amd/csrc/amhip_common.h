@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "aerial_mapper_hip.h"
+#include "amhip_tuning.h"
 #include "amhip_ortho_fold.h"
 
 namespace amhip {

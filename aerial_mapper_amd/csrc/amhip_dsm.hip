@@ -2233,8 +2233,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const int capf2 = std::max(capf1, std::min(7680, cap_fit32(150 * 1024)));
       int ccap0 = cap0, ccap1 = f32 ? capf1 : cap1, ccap2 = f32 ? capf2 : cap2;  // classification
 #ifdef AMHIP_TIMING_PROBES
-      if (const char* e = getenv("AMHIP_GATHER_CLASS_CAPS"))  // debugging: "c0,c1,c2"
-        sscanf(e, "%d,%d,%d", &ccap0, &ccap1, &ccap2);
+      ccap0 = (int)tuning("gather_class_cap0", ccap0);   // (debugging)
+      ccap1 = (int)tuning("gather_class_cap1", ccap1);
+      ccap2 = (int)tuning("gather_class_cap2", ccap2);
 #endif
       // single-precision mode after the three-pass sort: tiles whose height range leaves no room
       // under the error bound go straight onto the FP64 list the kernel would hand them to --
@@ -2285,7 +2286,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
                          bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref, pp);
       // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
-      static const int nt = getenv("AMHIP_GATHER_NT") ? atoi(getenv("AMHIP_GATHER_NT")) : 512;
+      const int nt = (int)tuning("gather_nt", 512.0);
 #else
       constexpr int nt = 512;
 #endif
@@ -2388,7 +2389,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
     if (own) AMHIP_LAUNCH_LIST_EX(512, TJ_, 4096, cap0, 4, 4096);                             \
   } while (0)
 #ifdef AMHIP_TIMING_PROBES
-      static const int f32_variant = getenv("AMHIP_F32_VARIANT") ? atoi(getenv("AMHIP_F32_VARIANT")) : 0;
+      const int f32_variant = (int)tuning("f32_variant", 0.0);
 #define AMHIP_PROBE_SELECTED(TJ_, CAP_) (f32_variant && (TJ_) == 16 && (CAP_) == 1024)
 #else
       constexpr int f32_variant = 0;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "amhip_content_sum.h"
+#include "amhip_tuning.h"
 
 namespace amhip {
 
@@ -64,7 +65,7 @@ using SumFn = void (*)(const unsigned*, size_t, unsigned long long, unsigned lon
 
 static SumFn pick() {
 #if AMHIP_HOSTSUM_X86
-  if (std::getenv("AMHIP_SESSION_SCALAR_SUMS")) return sum_scalar;
+  if (tuning_on("session_scalar_sums")) return sum_scalar;
   __builtin_cpu_init();
   return (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq")) ? sum_avx512
                                                                                     : sum_scalar;

@@ -975,8 +975,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
             (unsigned)((p.cols + kTileJ - 1) / kTileJ));
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
-  const char* fw = std::getenv("AMHIP_ORTHO_FAST_WAVES");  // A/B knob, DESIGN.md section 8
-  const int fast_waves = fw ? std::atoi(fw) : 4;
+  const int fast_waves = (int)tuning("ortho_fast_waves", 4.0);  // (A-B knob)
   auto kernel = !p.fast ? k_ortho_backward
                         : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
   c->dirty_on_device = false;  // (a dense launch can write anywhere in the window)
@@ -988,7 +987,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   // lazily initial: the kernels neither read nor write it then.
   const size_t ntiles = (size_t)grid.x * (size_t)grid.y;
   // (from 16 K tiles: below, dispatching every tile costs less than the list's extra launch)
-  if (p.coarse && !p.virt_out && ntiles >= 16384 && !std::getenv("AMHIP_ORTHO_NO_TILE_LIST")) {
+  if (p.coarse && !p.virt_out && ntiles >= 16384 && !tuning_on("ortho_no_tile_list")) {
     int rc;
     if ((rc = ensure_capacity(&c->ortho_list, &c->ortho_list_cap, ntiles + 16))) return rc;
     unsigned* cnt = reinterpret_cast<unsigned*>(c->ortho_list);

@@ -95,7 +95,7 @@ struct PhaseClock {
   const char* call;
   std::chrono::steady_clock::time_point t0;
   explicit PhaseClock(const char* name)
-      : on(std::getenv("AMHIP_SESSION_TRACE") != nullptr), call(name), t0(std::chrono::steady_clock::now()) {}
+      : on(tuning_on("session_trace")), call(name), t0(std::chrono::steady_clock::now()) {}
   void mark(const char* phase, hipStream_t wait_for = nullptr, bool wait = false) {
     if (!on) return;
     if (wait) (void)hipStreamSynchronize(wait_for);
@@ -176,7 +176,7 @@ static int usable_cpus(double* quota_cpus) {
 
 // threads for a pass of host threads over `bytes` of matrices
 static int host_threads(size_t bytes) {
-  if (const char* e = std::getenv("AMHIP_SESSION_THREADS")) return std::max(1, std::atoi(e));
+  if (tuning("session_threads", 0.0) > 0.0) return std::max(1, (int)tuning("session_threads", 0.0));
   unsigned hw = std::thread::hardware_concurrency();
   double quota = 0.0;
   const int cpus = usable_cpus(&quota);
@@ -333,7 +333,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
   bool run[AMHIP_NUM_LAYERS] = {};
   int rect[4] = {0, 0, w.rows, w.cols};
   bool partial = false;
-  if (dirty_ok && !s.always_copy && !std::getenv("AMHIP_SESSION_NO_PARTIAL")) {
+  if (dirty_ok && !s.always_copy && !tuning_on("session_no_partial")) {
     if ((rc = ctx_last_dirty(c, rect))) return rc;
     partial = rect[2] > 0 && rect[3] > 0 && rect[0] >= 0 && rect[1] >= 0 &&
               rect[0] + rect[2] <= w.rows && rect[1] + rect[3] <= w.cols &&
@@ -496,8 +496,8 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
   s.grid = *grid;
   s.ti = tiles_i;
   s.tj = tiles_j;
-  s.always_copy = std::getenv("AMHIP_SESSION_ALWAYS_COPY") != nullptr;
-  s.verify_partial = std::getenv("AMHIP_SESSION_VERIFY_PARTIAL") != nullptr;
+  s.always_copy = tuning_on("session_always_copy");
+  s.verify_partial = tuning_on("session_verify_partial");
   // window edges on multiples of the gather tile (64 x 32 cells) except at the map border
   auto edges = [](int n, int parts, int align, std::vector<int>* e) {
     e->assign(1, 0);

@@ -1811,8 +1811,8 @@ k_scan_final(uint32_t* __restrict__ data, size_t n,
 // AMHIP_P3_ROUNDS_REREAD=1: the rounds re-read the sub-partition instead of keeping it in registers
 // (the path of sub-partitions beyond 14 K points)
 static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* reg_max) {
-  static const int knob = getenv("AMHIP_P3_ROUNDS_CAP") ? atoi(getenv("AMHIP_P3_ROUNDS_CAP")) : 0;
-  static const bool reread = getenv("AMHIP_P3_ROUNDS_REREAD") != nullptr;
+  const int knob = (int)tuning("p3_rounds_cap", 0.0);
+  const bool reread = tuning_on("p3_rounds_reread");
   if (knob >= 16 && knob < *cap_rounds) {
     *cap_rounds = knob;
     *rounds_above = (unsigned)knob;
@@ -1825,8 +1825,7 @@ __global__ void k_aux_reset(SortAux aux) { aux_reset(aux); }
 // AMHIP_NO_LAUNCH_SKIPS=1 (tests, A-B): every capacity-class / big-list launch is made whatever the
 // previous call's counters say (amhip_dsm.hip: dsm_run uses the same switch)
 bool no_launch_skips() {
-  static const bool v = getenv("AMHIP_NO_LAUNCH_SKIPS") != nullptr;
-  return v;
+  return tuning_on("no_launch_skips");
 }
 
 // ---- the speculative sort's host side ------------------------------------------------------
@@ -1861,7 +1860,7 @@ bool spec_poll_overflow(Ctx* c) {
 
 // amhip_ctx_set_dsm_sort_reuse(ctx, 0) / AMHIP_SORT_NO_SPECULATION=1: always count first
 static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
-  const bool off = !c->spec_reuse || getenv("AMHIP_SORT_NO_SPECULATION") != nullptr;  // (read per call: tests flip it)
+  const bool off = !c->spec_reuse || tuning_on("sort_no_speculation");  // (looked up per call: tests flip it)
   if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
   if (!spec_poll_overflow(c) && c->spec_last_hit)
     c->spec_backoff = 8;  // (the last speculative call's word arrived clear, or has not arrived yet)
@@ -1920,15 +1919,14 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
   // the speculative sort (three-pass, FP64 pipeline, plain DSM call): see below
-  static const bool force_one_level_ = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
+  const bool force_one_level_ = tuning_on("sort_one_level");
   // (up to 2^27 points, the sizes it was measured at: - 0.19 ms of 5.75 at 50 M points, - 0.48 of
   // 9.50 at 100 M.  Until the plan kept its region STARTS -- which every workgroup's key threads load
   // as their limits -- 1 KB away from the append CURSORS -- which every workgroup's atomics hammer
   // --, the first speculative pass ran at two thirds to half speed from 100 M points on (+ 0.8 /
   // 1.6 / 3.3 ms at 100 / 200 / 400 M: tools/sort_scale_probe.py); larger clouds were not measured
   // again after that and keep counting first.  AMHIP_SORT_SPEC_MAX_POINTS moves the limit.)
-  static const size_t spec_max_points = getenv("AMHIP_SORT_SPEC_MAX_POINTS")
-                                            ? (size_t)atoll(getenv("AMHIP_SORT_SPEC_MAX_POINTS")) : ((size_t)1 << 27);
+  const size_t spec_max_points = (size_t)tuning("sort_spec_max_points", (double)((size_t)1 << 27));
   // (amhip_ctx_set_dsm_sort_reuse(ctx, 0): no plans are read OR written -- the scan's second pass goes too)
   const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split &&
                          n <= spec_max_points && c->spec_reuse;
@@ -1936,8 +1934,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
   const unsigned long long sig = spec_mode ? geo_sig : 0ull;
   const bool spec = spec_mode && spec_wanted(c, n, sig);
   // (the regions' head room: count >> room_shift; AMHIP_SORT_SPEC_MARGIN_SHIFT, 1 .. 31, experiments)
-  static const int room_shift = getenv("AMHIP_SORT_SPEC_MARGIN_SHIFT")
-                                    ? std::min(31, std::max(1, atoi(getenv("AMHIP_SORT_SPEC_MARGIN_SHIFT")))) : 3;
+  const int room_shift = std::min(31, std::max(1, (int)tuning("sort_spec_margin_shift", 3.0)));
   // (regions of count + count / 8 + 32 over the previous call's counts)
   // (reserved from the context's FIRST such call on: growing the two point buffers later means
   // freeing 2 x 9.6 GB and allocating 2 x 10.8 GB at configs[3]'s size, and the new blocks came back
@@ -1964,7 +1961,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
     if ((rc = ensure_capacity(&c->zref, &c->zref_cap, (size_t)8))) return rc;
   }
 
-  static const bool force_one_level = getenv("AMHIP_SORT_ONE_LEVEL") != nullptr;
+  const bool force_one_level = force_one_level_;
   const bool three_pass = p.p3_n1 > 0 && !force_one_level;
   if (split && split->phase == 1 && !three_pass)  // small clouds: selection in a pass of its own
     return halo_select_run(c, dev_xyz, split->n_prefix, split->hp, split->halo_out,

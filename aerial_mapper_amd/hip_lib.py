@@ -45,7 +45,7 @@ EXPORTS = [
     "amhip_densify_dev", "amhip_rectify_stereo_pair_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
     "amhip_dsm_tiled_finish_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
-    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats", "amhip_ctx_dsm_gather_stats", "amhip_ctx_dsm_sort_stats", "amhip_ctx_set_dsm_sort_reuse", "amhip_ctx_order_after", "amhip_build_id",
+    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats", "amhip_ctx_dsm_gather_stats", "amhip_ctx_dsm_sort_stats", "amhip_ctx_set_dsm_sort_reuse", "amhip_ctx_order_after", "amhip_build_id", "amhip_set_tuning", "amhip_get_tuning", "amhip_default_dsm_precision",
     "amhip_mosaic_create", "amhip_mosaic_destroy", "amhip_mosaic_set_stream",
     "amhip_mosaic_synchronize", "amhip_mosaic_reset", "amhip_mosaic_batch",
     "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
@@ -180,6 +180,10 @@ def load():
     lib.amhip_ctx_timing_reset.argtypes = [vp]
     lib.amhip_ctx_kernel_time.argtypes = [vp, C.c_int, f64p, C.POINTER(C.c_int64)]
     lib.amhip_kernel_name.restype = C.c_char_p
+    lib.amhip_set_tuning.argtypes = [C.c_char_p, C.c_double]
+    lib.amhip_get_tuning.restype = C.c_double
+    lib.amhip_get_tuning.argtypes = [C.c_char_p, C.c_double]
+    lib.amhip_default_dsm_precision.argtypes = []
     lib.amhip_build_id.restype = C.c_char_p
     lib.amhip_build_id.argtypes = []
     lib.amhip_kernel_name.argtypes = [C.c_int]
@@ -235,6 +239,16 @@ def load():
                           % (lib.amhip_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+def set_tuning(key, value=1.0):
+    """amhip_set_tuning: a process-wide knob that selects among correct implementations (None clears)."""
+    check(load().amhip_set_tuning(key.encode(), float("nan") if value is None else float(value)))
+
+
+def tuning_env(**knobs):
+    """{"AMHIP_TUNING": "key=value,..."} for a child process's environment"""
+    return {"AMHIP_TUNING": ",".join("%s=%s" % (k, v) for k, v in knobs.items())}
 
 
 def build_id():

@@ -948,7 +948,7 @@ def main():
                                          "selects the halo)"),
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
-                               "produce the layers; AMHIP_EAGER_RESET=1 for plain fills) + "
+                               "produce the layers; AMHIP_TUNING=eager_reset for plain fills) + "
                                "%sDsm::process + OrthoBackwardGrid::process, inputs resident in HBM" %
                                ("halo exchange (RCCL all_to_all) + " if world > 1 else ""),
                        "parallelism": "one map, %d x %d windows, one per GPU" % (layout.tiles_i, layout.tiles_j)},

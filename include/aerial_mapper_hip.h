@@ -614,6 +614,47 @@ int amhip_session_grid_map_msg(amhip_session* s, uint64_t stamp_ns, const char* 
 int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float lower, float upper,
                                  uint8_t* host_image, size_t step);
 
+/* ---- tuning knobs: the ONE door for switches that select among correct implementations ----------
+ * (tests force every path through them, A-B timing flips them; none is needed in normal use).
+ * amhip_set_tuning(key, value) -- value NaN clears the key -- or, for hosts that cannot be
+ * recompiled, AMHIP_TUNING="key=value,key,..." in the environment (read once; a bare key = 1).
+ * Unknown keys are an error (AMHIP_ERR_ARG) / a warning on stderr.  Process-wide; looked up when a
+ * call is made.  Keys:
+ *   sort_one_level            clouds of any size take the one-level counting sort
+ *   p3_min_points (2^20)      cloud size from which the three-pass partition sort is used
+ *   p3_target (1536)          points per sub-partition the sort's plan aims for
+ *   p3_cap (2048)             points a placement workgroup sorts in its registers / LDS
+ *   p3_rounds_cap, p3_rounds_reread   placement in rounds (sub-partitions beyond one LDS image)
+ *                             forced at test size: image of n points / re-reading instead of registers
+ *   sort_no_speculation       the FP64 pipeline's sort always counts first (see
+ *                             amhip_ctx_set_dsm_sort_reuse for the per-context switch)
+ *   sort_spec_max_points (2^27), sort_spec_margin_shift (3)   largest cloud the sort reuses a plan
+ *                             on / head room of a planned region: count >> shift
+ *   no_launch_skips           launch every capacity-class / big-list kernel whatever the previous
+ *                             call's counters say
+ *   dsm_canon_all             every FP64 quotient goes through the order-independent double-double sums
+ *   dsm_no_rough_switch       the single-precision mode stays in its own pipeline on rough scenes
+ *   dsm_no_subwindow          small clouds onto large maps are binned over the whole window
+ *   eager_reset               amhip_layers_reset fills the layers at once (default: fused into producers)
+ *   ortho_exact_fold, ortho_no_prune, ortho_fast_waves (4), no_coarse_cull, ortho_no_tile_list
+ *                             mosaic: every pair in the reference's arithmetic / keep dominated frames /
+ *                             3- or 4-waves build of the guarded kernel / no small-batch pre-cull /
+ *                             dispatch every tile of a large map instead of a list of visible ones
+ *   no_distorted_cull, no_distorted_prune, distorted_square_cull   cameras with a distortion model
+ *   session_always_copy, session_threads, session_scalar_sums, session_no_partial,
+ *   session_verify_partial, session_trace          amhip_session: every matrix both ways on every
+ *                             call / host threads of the content sums / scalar sums / whole-window
+ *                             downloads / re-sum partial downloads / phase timings on stderr
+ *   (lab builds, -DAMHIP_TIMING_PROBES: gather_tj, gather_nt, gather_class_cap0..2, f32_variant, fx_theta)
+ * Environment variables the library itself reads, all of them: AMHIP_TUNING (above), AMHIP_DSM_FAST /
+ * AMHIP_DSM_EXACT (amhip_default_dsm_precision); the C++ drop-in classes add AERIAL_MAPPER_HIP_DEVICE
+ * and AERIAL_MAPPER_HIP_DEVICES (aerial_mapper_amd/cpp/shim_common.*). */
+int amhip_set_tuning(const char* key, double value);
+double amhip_get_tuning(const char* key, double dflt);
+/* AMHIP_DSM_EXACT unless the environment says AMHIP_DSM_FAST=1 (and not AMHIP_DSM_EXACT): what new
+ * contexts, sessions and dsm::Dsm objects start with. */
+int amhip_default_dsm_precision(void);
+
 /* The library's build id: 16 hex digits of the SHA-256 over its sources, headers and compiler flags
  * (aerial_mapper_amd/build.py).  Profiles collected from one build are refused as evidence for
  * another (bench.py). */

@@ -161,3 +161,40 @@ def test_catkin_package_builds_the_same_sources():
     for f in sorted(os.listdir(cpp)):
         if f.endswith(".cc"):
             assert f in cm or "*.cc" in cm or "GLOB" in cm, f
+
+
+def test_tuning_knobs_go_through_one_door():
+    """amhip_set_tuning / AMHIP_TUNING (include/aerial_mapper_hip.h): known keys only, process-wide,
+    and the library's own getenv sites stay the documented handful (VERDICT r4 next #9)."""
+    import re
+    import subprocess
+    import sys
+    from aerial_mapper_amd import hip_lib
+    lib = hip_lib.load()
+    assert lib.amhip_get_tuning(b"p3_target", 1536.0) == 1536.0
+    hip_lib.set_tuning("p3_target", 48)
+    assert lib.amhip_get_tuning(b"p3_target", 1536.0) == 48.0
+    hip_lib.set_tuning("p3_target", None)
+    assert lib.amhip_get_tuning(b"p3_target", 1536.0) == 1536.0
+    assert lib.amhip_set_tuning(b"no_such_knob", 1.0) == hip_lib.ERR_ARG
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from aerial_mapper_amd import hip_lib\n"
+            "l = hip_lib.load()\n"
+            "print(l.amhip_get_tuning(b'p3_cap', 2048.0), l.amhip_get_tuning(b'sort_one_level', 0.0), "
+            "l.amhip_get_tuning(b'p3_target', 7.0), l.amhip_default_dsm_precision())\n" % ROOT)
+    env = dict(os.environ, AMHIP_TUNING="p3_cap=64, sort_one_level", AMHIP_DSM_FAST="1")
+    env.pop("AMHIP_DSM_EXACT", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                         universal_newlines=True, check=True).stdout.split()
+    assert out == ["64.0", "1.0", "7.0", "0"], out
+    # every environment variable the shipped sources read
+    seen = set()
+    for base in ("csrc", "cpp"):
+        d = os.path.join(ROOT, "aerial_mapper_amd", base)
+        for f in sorted(os.listdir(d)):
+            seen |= set(re.findall(r'getenv\("([A-Z_0-9a-z]+)"\)', open(os.path.join(d, f)).read()))
+    assert seen == {"AMHIP_TUNING", "AMHIP_DSM_FAST", "AMHIP_DSM_EXACT", "AERIAL_MAPPER_HIP_DEVICE",
+                    "AERIAL_MAPPER_HIP_DEVICES"}, seen
+    hdr = open(os.path.join(ROOT, "include", "aerial_mapper_hip.h")).read()
+    for name in seen:
+        assert name in hdr, name

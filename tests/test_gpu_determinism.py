@@ -7,7 +7,7 @@ every value within its own error bound of h rounds to that float; the few cells 
 sit on a float rounding boundary are redone in double-double sums of the reference's terms,
 where the order of the additions cannot reach the 24th bit.  Two consequences are tested:
   * N runs on one cloud -- and a run on a PERMUTED cloud -- give equal bits in all 1e8 cells;
-  * forcing EVERY cell through canonical_search (AMHIP_DSM_CANON_ALL=1) gives the same bits as
+  * forcing EVERY cell through canonical_search (tuning knob dsm_canon_all) gives the same bits as
     the normal run: the error bound really covers the distance between the two arithmetics."""
 import os
 import subprocess
@@ -97,8 +97,8 @@ with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y,
 def _child(env_extra, tmp_path, tag):
     path = str(tmp_path / ("elev_%s.npz" % tag))
     code = _CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "scenes": _SCENES}
-    env = dict(os.environ, **env_extra)
-    env.pop("AMHIP_DSM_CANON_ALL", None) if not env_extra else None
+    from conftest import tuning_env
+    env = tuning_env(**env_extra)
     r = subprocess.run([sys.executable, "-c", code, path], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-3000:]
@@ -107,7 +107,7 @@ def _child(env_extra, tmp_path, tag):
 
 def test_canonical_arithmetic_in_every_cell_gives_the_same_floats(tmp_path):
     normal = _child({}, tmp_path, "normal")
-    canon = _child({"AMHIP_DSM_CANON_ALL": "1"}, tmp_path, "canon")
+    canon = _child({"dsm_canon_all": 1}, tmp_path, "canon")
     assert sorted(normal) == sorted(canon) and len(normal) == 6
     for name in normal:
         a, b = normal[name], canon[name]
@@ -130,7 +130,7 @@ def test_canonical_arithmetic_matches_the_oracle():
     import tempfile
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "e.npz")
-        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, AMHIP_DSM_CANON_ALL="1"),
+        r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, AMHIP_TUNING="dsm_canon_all"),
                            stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
         assert r.returncode == 0, r.stdout.decode()[-3000:]
         got = dict(np.load(path))

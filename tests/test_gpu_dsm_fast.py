@@ -209,7 +209,7 @@ def _run_stats(scene, exact, radius=1):
         return m.get("elevation"), m.dsm_gather_stats()
 
 
-def test_rough_tiles_are_sorted_onto_the_fp64_lists_before_they_are_staged(monkeypatch):
+def test_rough_tiles_are_sorted_onto_the_fp64_lists_before_they_are_staged(tuning):
     """Round 3: after the three-pass sort the placement pass leaves every bin's height range, and
     the occupancy pre-pass applies the gather's own error bound to a tile's region BEFORE anything
     is staged -- tiles without room go straight to the FP64 lists (amhip_ctx_dsm_gather_stats
@@ -219,9 +219,9 @@ def test_rough_tiles_are_sorted_onto_the_fp64_lists_before_they_are_staged(monke
     x, y = sc.points[:, 0], sc.points[:, 1]
     sc.points[:, 2] += np.where((np.abs(x) < 30.0) & (np.abs(y) < 20.0), 25.0, 0.0)   # a "building"
     want = _oracle(sc)
-    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")       # three-pass sort for this small cloud
+    tuning(p3_min_points=1000)       # three-pass sort for this small cloud
     got3, st3 = _run_stats(sc, False)
-    monkeypatch.delenv("AMHIP_P3_MIN_POINTS")               # (< 2^20 points: the one-level sort)
+    tuning(p3_min_points=None)               # (< 2^20 points: the one-level sort)
     got1, st1 = _run_stats(sc, False)
     for got in (got3, got1):
         frac, _ = _check(got, want)
@@ -232,14 +232,14 @@ def test_rough_tiles_are_sorted_onto_the_fp64_lists_before_they_are_staged(monke
     assert 0 < st3["f32_to_fp64"] < 0.5 * st3["tiles"]
     # smooth terrain: nothing is rejected, by either route
     sm = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=312)
-    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    tuning(p3_min_points=1000)
     got, st = _run_stats(sm, False)
     _check(got, _oracle(sm))
     assert st["f32_to_fp64"] == 0 and st["f32_to_fp64_beyond"] == 0
 
 
 @pytest.mark.parametrize("density", [2.5, 6.0])
-def test_rough_dense_tiles_of_the_capacity_classes_are_pre_classified_too(monkeypatch, density):
+def test_rough_dense_tiles_of_the_capacity_classes_are_pre_classified_too(tuning, density):
     """Denser clouds (capacity classes 1 / 2 and the wide main launch) with +-30 m of noise: every
     occupied tile is rejected up front, onto list 5 / 6 where the FP64 image of the main launch
     does not fit a CU."""
@@ -248,14 +248,14 @@ def test_rough_dense_tiles_of_the_capacity_classes_are_pre_classified_too(monkey
     rng = np.random.default_rng(9)
     sc.points[:, 2] += rng.uniform(-30.0, 30.0, sc.points.shape[0])
     want = _oracle(sc)
-    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    tuning(p3_min_points=1000)
     got, st = _run_stats(sc, False)
     frac, _ = _check(got, want)
     assert frac > 0.999                                   # all of it is the FP64 arithmetic
     assert st["f32_to_fp64"] + st["f32_to_fp64_beyond"] + st["beyond_lds"] > 0.8 * st["tiles"]
 
 
-def test_rough_scene_second_call_takes_the_dense_fp64_launch(monkeypatch):
+def test_rough_scene_second_call_takes_the_dense_fp64_launch(tuning):
     """When the previous call pre-classified more than a tenth of its tiles, the FP64 kernel is
     launched densely over them (filtering on the occupancy byte) instead of walking list 4: same
     heights, same counts."""
@@ -265,10 +265,10 @@ def test_rough_scene_second_call_takes_the_dense_fp64_launch(monkeypatch):
     rough = sc.points[:, 0] < 10.0                                   # two thirds of the map
     sc.points[rough, 2] += rng.uniform(-30.0, 30.0, int(rough.sum()))
     want = _oracle(sc)
-    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
+    tuning(p3_min_points=1000)
     # (this test is about the two launch forms of the single-precision pipeline: keep the context
     # from leaving that pipeline altogether, test_rough_scene_switches_to_the_fp64_pipeline)
-    monkeypatch.setenv("AMHIP_DSM_NO_ROUGH_SWITCH", "1")
+    tuning(dsm_no_rough_switch=1)
     g = sc.grid
     with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
         m.set_dsm_precision(False)
@@ -337,14 +337,14 @@ def test_maps_longer_than_the_records_cell_field_fall_back_to_fp64():
     _check(fast, _oracle(sc))
 
 
-def test_rough_scene_switches_to_the_fp64_pipeline(monkeypatch):
+def test_rough_scene_switches_to_the_fp64_pipeline(tuning):
     """ the opt-in mode protects itself: when a call filed more than half of
     its tiles for the FP64 kernel, the following calls on the context run the FP64 pipeline
     outright (sorted doubles; the records' FP64 redo would stage from the unsorted cloud), and the
     single-precision pipeline is tried again after 15 calls.  A smooth scene never switches."""
     import aerial_mapper_amd as A
-    monkeypatch.setenv("AMHIP_P3_MIN_POINTS", "1000")
-    monkeypatch.delenv("AMHIP_DSM_NO_ROUGH_SWITCH", raising=False)
+    tuning(p3_min_points=1000)
+    tuning(dsm_no_rough_switch=None)
     sc = S.Scene(160.0, 120.0, 0.25, int(8 * 168 * 128), seed=315)
     rng = np.random.default_rng(12)
     rough_pts = sc.points.copy()

@@ -17,8 +17,8 @@ from aerial_mapper_amd import synth
 pytestmark = pytest.mark.gpu
 
 LAYERS = ["elevation_angle", "observation_index", "num_observations", "ortho", "colored_ortho"]
-VARIANTS = [{"AMHIP_ORTHO_EXACT_FOLD": "1"}, {"AMHIP_ORTHO_FAST_WAVES": "3"},
-            {"AMHIP_ORTHO_FAST_WAVES": "4"}]
+VARIANTS = [{"ortho_exact_fold": "1"}, {"ortho_fast_waves": "3"},
+            {"ortho_fast_waves": "4"}]
 IDS = ["exact", "fast3", "fast4"]
 
 
@@ -64,9 +64,9 @@ def frames_for(F, cam, salt):
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=IDS)
-def test_ties_borders_and_odd_elevations(monkeypatch, env):
+def test_ties_borders_and_odd_elevations(tuning, env):
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tuning(**{k: v})
 
     # (1) duplicate and minutely perturbed poses: exact and near ties
     g = O.make_grid(100.0, 70.0, 0.5)
@@ -110,9 +110,9 @@ def test_ties_borders_and_odd_elevations(monkeypatch, env):
 
 
 @pytest.mark.parametrize("env", VARIANTS, ids=IDS)
-def test_utm_flight_in_batches_and_replay(monkeypatch, env):
+def test_utm_flight_in_batches_and_replay(tuning, env):
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tuning(**{k: v})
     c = (464980.25, 5272690.5)
     g = O.make_grid(150.0, 110.0, 0.5, c[0], c[1])
     cam = S.camera()
@@ -135,7 +135,7 @@ def test_utm_flight_in_batches_and_replay(monkeypatch, env):
 
 @pytest.mark.parametrize("origin", [(0.0, 0.0), (464980.25, 5272690.5), (-2.1e7, 3.3e7)],
                          ids=["local", "utm", "3e7"])
-def test_fast_and_exact_kernels_agree_on_a_large_map(monkeypatch, origin):
+def test_fast_and_exact_kernels_agree_on_a_large_map(tuning, origin):
     """Differential test at a scale the CPU oracle cannot reach in a unit test: 16 M cells x
     249 frames (the bench geometry), random terrain with holes, three coordinate magnitudes;
     the margin-guarded kernel (with and without frame-list pruning) against the kernel that
@@ -156,12 +156,12 @@ def test_fast_and_exact_kernels_agree_on_a_large_map(monkeypatch, origin):
     poses = synth.make_lawnmower_poses(F, L / 2.0 * 1.3, 700.0, 79, tilt_deg=7.0, center=origin)
     ncam = A.NCamera(1400.0, 1400.0, (W - 1) / 2.0, (H - 1) / 2.0, W, H)
     results = {}
-    for name, env in (("exact", {"AMHIP_ORTHO_EXACT_FOLD": "1", "AMHIP_ORTHO_NO_PRUNE": "1"}),
-                      ("fast", {}), ("fast_noprune", {"AMHIP_ORTHO_NO_PRUNE": "1"})):
-        for k in ("AMHIP_ORTHO_EXACT_FOLD", "AMHIP_ORTHO_NO_PRUNE"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("exact", {"ortho_exact_fold": "1", "ortho_no_prune": "1"}),
+                      ("fast", {}), ("fast_noprune", {"ortho_no_prune": "1"})):
+        for k in ("ortho_exact_fold", "ortho_no_prune"):
+            tuning(**{k: None})
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tuning(**{k: v})
         with A.AerialGridMap(A.GridMapSettings(origin[0], origin[1], L, L, res)) as m:
             m.set("elevation", elev)
             mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
@@ -181,7 +181,7 @@ def test_fast_and_exact_kernels_agree_on_a_large_map(monkeypatch, origin):
     ("equidistant", (-0.01, 0.02, -0.005, 0.001)),
     ("equidistant", (0.08, -0.03, 0.0, 0.0)),
 ])
-def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(monkeypatch, kind, dist):
+def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(tuning, kind, dist):
     """Cameras with a distortion model on a 9 M-cell rough map, 120 frames: the frame-list
     pruning (inner cone = 'fully visible') and the rectangular outer cull against the plain
     circumscribed-square cull without pruning -- which tests/test_gpu_parity.py checks
@@ -203,12 +203,12 @@ def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(monkeypatch, 
     model = L.DIST_RADTAN if kind == "radtan" else L.DIST_EQUIDISTANT
     ncam = A.NCamera(700.0, 690.0, 470.0, 280.0, W, H, model, dist)
     results = {}
-    for name, env in (("plain", {"AMHIP_NO_DISTORTED_PRUNE": "1", "AMHIP_DISTORTED_SQUARE_CULL": "1"}),
-                      ("rect", {"AMHIP_NO_DISTORTED_PRUNE": "1"}), ("pruned", {})):
-        for k in ("AMHIP_NO_DISTORTED_PRUNE", "AMHIP_DISTORTED_SQUARE_CULL"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("plain", {"no_distorted_prune": "1", "distorted_square_cull": "1"}),
+                      ("rect", {"no_distorted_prune": "1"}), ("pruned", {})):
+        for k in ("no_distorted_prune", "distorted_square_cull"):
+            tuning(**{k: None})
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tuning(**{k: v})
         with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, Lm, Lm, res)) as m:
             m.set("elevation", elev)
             mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)
@@ -221,12 +221,12 @@ def test_distorted_cameras_prune_and_rectangle_cull_change_nothing(monkeypatch, 
         S.assert_layers_equal(results[name], want, LAYERS)
 
 
-def test_small_batches_onto_a_large_map_walk_a_tile_list(monkeypatch):
+def test_small_batches_onto_a_large_map_walk_a_tile_list(tuning):
     """Round 4: a small batch (<= 64 frames) onto a map of >= 16 384 mosaic tiles with materialized
     layers does not dispatch a workgroup per tile: one lane per tile asks the dense launch's own first
     question (can any frame see the tile's bounding sphere?) and a fixed grid walks the list
     (k_ortho_tile_list / k_ortho_backward_fast4_list).  Same layers, bit for bit, as the dense launch
-    (AMHIP_ORTHO_NO_TILE_LIST=1), which the oracle tests hold to the reference."""
+    (tuning knob ortho_no_tile_list), which the oracle tests hold to the reference."""
     import torch
     import aerial_mapper_amd as A
     from aerial_mapper_amd import synth
@@ -242,9 +242,9 @@ def test_small_batches_onto_a_large_map_walk_a_tile_list(monkeypatch):
 
     def run(dense):
         if dense:
-            monkeypatch.setenv("AMHIP_ORTHO_NO_TILE_LIST", "1")
+            tuning(ortho_no_tile_list=1)
         else:
-            monkeypatch.delenv("AMHIP_ORTHO_NO_TILE_LIST", raising=False)
+            tuning(ortho_no_tile_list=None)
         with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, res)) as m:
             A.Dsm(A.DsmSettings(), m).process(pts, m)
             mosaic = A.OrthoBackwardGrid(ncam, A.OrthoSettings(), m)

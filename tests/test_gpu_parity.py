@@ -412,14 +412,14 @@ def test_dsm_dense_clouds_take_the_wave_per_cell_path(dens):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"AMHIP_SORT_ONE_LEVEL": "1"},
-    {"AMHIP_P3_MIN_POINTS": "0"},
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "48"},
+    {"sort_one_level": "1"},
+    {"p3_min_points": "0"},
+    {"p3_min_points": "0", "p3_target": "48"},
     # sub-partitions beyond one LDS image (contexts of > 130 M points; here forced at test size):
     # placed in rounds, a single over-full bin directly -- k_dsm_p3_place(_rec)_big / place_rounds
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96"},
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96",
-     "AMHIP_P3_ROUNDS_REREAD": "1"},
+    {"p3_min_points": "0", "p3_target": "4000", "p3_cap": "64", "p3_rounds_cap": "96"},
+    {"p3_min_points": "0", "p3_target": "4000", "p3_cap": "64", "p3_rounds_cap": "96",
+     "p3_rounds_reread": "1"},
 ], ids=["one-level", "three-pass", "three-pass-many-blocks", "three-pass-rounds", "three-pass-rounds-reread"])
 def test_dsm_every_sort_path_matches(knobs):
     # The binning sort has two implementations (one-level counting sort for
@@ -455,7 +455,8 @@ def test_dsm_every_sort_path_matches(knobs):
         "sc.points = np.ascontiguousarray(np.concatenate([sc.points, dense]))\n"
         "run(sc)\n"
         "print('SORT_PATH_OK')\n" % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
-    env = dict(os.environ, **knobs)
+    from conftest import tuning_env
+    env = tuning_env(**knobs)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b"SORT_PATH_OK" in r.stdout, r.stdout.decode()[-2000:]
@@ -610,7 +611,7 @@ def _lazy_reset_scenario():
 
 def test_lazy_reset_is_indistinguishable_from_eager_fills():
     # amhip_layers_reset writes nothing; the producers fuse the fill.  Every layer
-    # must hold exactly what plain fills would have left (AMHIP_EAGER_RESET=1).
+    # must hold exactly what plain fills would have left (AMHIP_TUNING=eager_reset).
     import os
     import pickle
     import subprocess
@@ -620,7 +621,7 @@ def test_lazy_reset_is_indistinguishable_from_eager_fills():
             "import test_gpu_parity as T\n"
             "sys.stdout.buffer.write(pickle.dumps(T._lazy_reset_scenario()))\n"
             % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMHIP_EAGER_RESET="1"),
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AMHIP_TUNING="eager_reset"),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     eager = pickle.loads(r.stdout)
@@ -819,11 +820,11 @@ def test_ortho_coarse_cull_with_the_tracked_height_range():
             m.reset()
 
 
-def test_dsm_small_cloud_on_a_large_map_runs_on_its_bounding_box(monkeypatch):
+def test_dsm_small_cloud_on_a_large_map_runs_on_its_bounding_box(tuning):
     """Round 4: a cloud of < 2^20 points onto a materialized map of >= 4 M cells is binned and
     gathered on a SUB-window around its bounding box (amhip_api.hip: dsm_subwindow), writing into
     the full layer -- the incremental demo's call per stereo pair.  Same heights as the whole-window
-    call (AMHIP_DSM_NO_SUBWINDOW=1) in both modes, cells outside the box untouched, clouds across
+    call (tuning knob dsm_no_subwindow) in both modes, cells outside the box untouched, clouds across
     the map's corner and wholly beyond its border included; against the oracle on the whole map."""
     A = _A()
     rows, cols, res = 2304, 2048, 0.5                      # 4.7 M cells
@@ -846,9 +847,9 @@ def test_dsm_small_cloud_on_a_large_map_runs_on_its_bounding_box(monkeypatch):
         outs = {}
         for sub in (True, False):
             if sub:
-                monkeypatch.delenv("AMHIP_DSM_NO_SUBWINDOW", raising=False)
+                tuning(dsm_no_subwindow=None)
             else:
-                monkeypatch.setenv("AMHIP_DSM_NO_SUBWINDOW", "1")
+                tuning(dsm_no_subwindow=1)
             with A.AerialGridMap(st) as m:
                 m.set_dsm_precision(exact)
                 m.set("elevation", base)                   # a materialized layer with earlier content

@@ -217,13 +217,13 @@ def test_session_on_distinct_devices_when_the_node_has_them():
 
 
 @pytest.mark.parametrize("tiles", [(1, 1), (2, 1)])
-def test_session_downloads_only_the_rectangle_a_small_call_wrote(monkeypatch, tiles):
+def test_session_downloads_only_the_rectangle_a_small_call_wrote(tuning, tiles):
     """Round 4: on a large map the incremental calls -- one stereo pair's cloud (the DSM's
     sub-window), a few frames (the mosaic's tile list) -- know which rectangle of the window they can
     have written; a host matrix that equalled the device layer before the call gets that rectangle
     only (amhip_session.hip: sync_out).  Same matrices, bit for bit, as with whole-window downloads
-    (AMHIP_SESSION_NO_PARTIAL=1); host edits far from the rectangle survive; the traffic counters
-    show the difference.  AMHIP_SESSION_VERIFY_PARTIAL=1: the session re-sums every partially
+    (tuning knob session_no_partial); host edits far from the rectangle survive; the traffic counters
+    show the difference.  session_verify_partial: the session re-sums every partially
     downloaded matrix against the device's content sum."""
     import torch
     import aerial_mapper_amd as A
@@ -242,13 +242,13 @@ def test_session_downloads_only_the_rectangle_a_small_call_wrote(monkeypatch, ti
     pair = np.c_[rng.uniform(-40.0, 40.0, 60000), rng.uniform(400.0, 450.0, 60000),
                  float(np.median(pts[:, 2])) + 5.0 + rng.uniform(-1.0, 1.0, 60000)]
     st = A.GridMapSettings(0.0, 0.0, L, L, res)
-    monkeypatch.setenv("AMHIP_SESSION_VERIFY_PARTIAL", "1")
+    tuning(session_verify_partial=1)
 
     def run(partial):
         if partial:
-            monkeypatch.delenv("AMHIP_SESSION_NO_PARTIAL", raising=False)
+            tuning(session_no_partial=None)
         else:
-            monkeypatch.setenv("AMHIP_SESSION_NO_PARTIAL", "1")
+            tuning(session_no_partial=1)
         down = {}
         with A.HostSession(st, tiles=tiles) as hs:
             hs.set_dsm_precision(True)

@@ -3,7 +3,7 @@ call of >= 2^20 points whose context saw such a call before sizes the regions of
 passes from THAT call's exact (k1, k2) counts instead of counting first; the counting pipeline is
 launched behind it as fixed grids that leave at once unless a region overflowed.  Whatever
 happens -- a hit, a miss with the exact passes running behind it, the counting calls after a
-miss -- the heights are those of a context that always counts first (AMHIP_SORT_NO_SPECULATION=1),
+miss -- the heights are those of a context that always counts first (tuning knob sort_no_speculation),
 bit for bit: the default mode's floats do not depend on the order of the points."""
 import numpy as np
 import pytest
@@ -41,16 +41,16 @@ def _run(A, st, clouds, radius=1):
     return out, stats
 
 
-def test_speculative_sort_gives_the_counting_sorts_heights(monkeypatch):
+def test_speculative_sort_gives_the_counting_sorts_heights(tuning):
     import aerial_mapper_amd as A
     res, rows, cols = 0.5, 1536, 1280
     lx, ly = rows * res, cols * res
     g = O.make_grid(lx, ly, res, 50.0, -20.0)
     st = A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)
     clouds = _clouds(g, lx, ly)
-    monkeypatch.delenv("AMHIP_SORT_NO_SPECULATION", raising=False)
+    tuning(sort_no_speculation=None)
     got, stats = _run(A, st, clouds)
-    monkeypatch.setenv("AMHIP_SORT_NO_SPECULATION", "1")
+    tuning(sort_no_speculation=1)
     want, stats_off = _run(A, st, clouds)
     for k, (name, _) in enumerate(clouds):
         a, b = got[k], want[k]
@@ -75,11 +75,11 @@ def test_speculative_sort_gives_the_counting_sorts_heights(monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"AMHIP_P3_MIN_POINTS": "0"},
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "48"},
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96"},
-    {"AMHIP_P3_MIN_POINTS": "0", "AMHIP_P3_TARGET": "4000", "AMHIP_P3_CAP": "64", "AMHIP_P3_ROUNDS_CAP": "96",
-     "AMHIP_P3_ROUNDS_REREAD": "1"},
+    {"p3_min_points": "0"},
+    {"p3_min_points": "0", "p3_target": "48"},
+    {"p3_min_points": "0", "p3_target": "4000", "p3_cap": "64", "p3_rounds_cap": "96"},
+    {"p3_min_points": "0", "p3_target": "4000", "p3_cap": "64", "p3_rounds_cap": "96",
+     "p3_rounds_reread": "1"},
 ], ids=["three-pass", "three-pass-many-blocks", "three-pass-rounds", "three-pass-rounds-reread"])
 def test_speculative_sort_on_every_placement_path(knobs):
     """The speculative passes feed every form of the placement pass (one LDS image, the big image,
@@ -109,8 +109,8 @@ def test_speculative_sort_on_every_placement_path(knobs):
         "want = {'U': oracle(U), 'U2': oracle(U2), 'C': oracle(C)}\n"
         "clouds = {'U': U, 'U2': U2, 'C': C}\n"
         "def run(seq, spec):\n"
-        "    if spec: os.environ.pop('AMHIP_SORT_NO_SPECULATION', None)\n"
-        "    else: os.environ['AMHIP_SORT_NO_SPECULATION'] = '1'\n"
+        "    from aerial_mapper_amd import hip_lib\n"
+        "    hip_lib.set_tuning('sort_no_speculation', None if spec else 1)\n"
         "    out = []\n"
         "    with A.AerialGridMap(st) as m:\n"
         "        m.set_dsm_precision(True)\n"
@@ -124,8 +124,8 @@ def test_speculative_sort_on_every_placement_path(knobs):
         "    for x, y in zip(a, b):\n"
         "        assert ((x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))).all(), seq\n"
         "print('SPEC_PATH_OK')\n" % (S.__file__.rsplit('/tests/', 1)[0], S.__file__.rsplit('/', 1)[0]))
-    env = dict(os.environ, **knobs)
-    env.pop("AMHIP_SORT_NO_SPECULATION", None)
+    from conftest import tuning_env
+    env = tuning_env(**knobs)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0 and b"SPEC_PATH_OK" in r.stdout, r.stdout.decode()[-2000:]

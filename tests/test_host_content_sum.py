@@ -18,7 +18,7 @@ def _build(tmp, env=None):
     csrc = os.path.join(ROOT, "aerial_mapper_amd", "csrc")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + csrc,
                            os.path.join(ROOT, "tests", "cpp", "hostsum_host.cc"),
-                           os.path.join(csrc, "amhip_hostsum.cc"), "-o", out])
+                           os.path.join(csrc, "amhip_hostsum.cc"), os.path.join(csrc, "amhip_tuning.cc"), "-o", out])
     h = C.CDLL(out)
     for f in (h.amt_sum_dispatch, h.amt_sum_plain):
         f.argtypes = [C.c_void_p, C.c_long, C.c_ulonglong, C.c_void_p]

@@ -1,6 +1,6 @@
 """What the incremental demo's calls cost through the HOST-matrix route on a large map: one stereo
 pair's cloud and one frame per call onto a `side`^2 map (default 20 000^2 cells: 1.6 GB per layer),
-with whole-window downloads (AMHIP_SESSION_NO_PARTIAL=1) and with the dirty rectangle only.  The
+with whole-window downloads (tuning knob session_no_partial) and with the dirty rectangle only.  The
 host-side content sums (O(map) per call) stay in both.  Prints one JSON line."""
 import argparse
 import json
@@ -20,6 +20,7 @@ def main():
     args = ap.parse_args()
     import torch
     import aerial_mapper_amd as A
+    from aerial_mapper_amd import hip_lib
     from aerial_mapper_amd import synth
     side, res = args.side, 0.25
     L = side * res
@@ -35,9 +36,9 @@ def main():
     out = {"side": side, "layer_MB": side * side * 4 / 1e6}
     for mode in ("window", "rectangle"):
         if mode == "window":
-            os.environ["AMHIP_SESSION_NO_PARTIAL"] = "1"
+            hip_lib.set_tuning("session_no_partial", 1)
         else:
-            os.environ.pop("AMHIP_SESSION_NO_PARTIAL", None)
+            hip_lib.set_tuning("session_no_partial", None)
         with A.HostSession(A.GridMapSettings(0.0, 0.0, L, L, res)) as hs:
             hs.dsm_process(A.DsmSettings(1), pts)
             hs.ortho_process(ncam, A.OrthoSettings(), poses[:2], frames[:2])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Probe: the sort's passes with and without the speculative regions (AMHIP_SORT_NO_SPECULATION)
+"""Probe: the sort's passes with and without the speculative regions (tuning knob sort_no_speculation)
 as the cloud grows from cfg3's 50 M points towards configs[3]'s 400 M on one GPU (0.5 points per
 0.25 m cell throughout).  Prints the scatter / count / place slots per DSM call."""
 import os, sys, time
@@ -7,6 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import aerial_mapper_amd as A
+from aerial_mapper_amd import hip_lib
 from aerial_mapper_amd import synth
 
 dev = torch.device("cuda", 0)
@@ -17,9 +18,9 @@ for npts in [int(v) for v in os.environ.get("AMHIP_PROBE_POINTS", "100000000,200
     pts = synth.make_points_torch(npts, L / 2 + 4, 43, dev)
     for spec in (True, False):
         if spec:
-            os.environ.pop("AMHIP_SORT_NO_SPECULATION", None)
+            hip_lib.set_tuning("sort_no_speculation", None)
         else:
-            os.environ["AMHIP_SORT_NO_SPECULATION"] = "1"
+            hip_lib.set_tuning("sort_no_speculation", 1)
         with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, res)) as m:
             dsm = A.Dsm(A.DsmSettings(), m)
             for _ in range(2):
