@@ -1935,8 +1935,12 @@ k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
 // (which share halo points) go to the same XCD's L2.  Blocks are dealt
 // round-robin to the 8 XCDs, so XCD x gets the x-th contiguous chunk of the tile
 // list (bijective for any count).
+// 8 waves per SIMD (64 VGPRs; left to itself the compiler takes 65 = 7 waves, i.e. THREE 512-thread
+// workgroups per CU): the 64 x 16 / 1024-point image is sized so that FOUR fit a CU's LDS, and the
+// fourth hides the other three's staging and epilogue phases -- same box 2.67 -> 2.54 ms per 1e8
+// cells (round 5; the loop itself is FP64-issue bound either way).
 template <int NT, int kTileJ, int kCap>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
                    const Pts P, const uint8_t* __restrict__ tile_occ,
                    CellOut o, int my_class) {

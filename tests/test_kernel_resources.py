@@ -36,7 +36,7 @@ BUDGETS = [
     # (mangled-name fragment, min waves/SIMD, max spilled VGPRs)
     ("k_dsm_gather_f32ILi512ELi16ELi1024ELi0E", 8, 0),   # the default DSM gather
     ("k_dsm_gather_f32ILi512ELi16ELi2048ELi0E", 8, 0),
-    ("k_dsm_gather_tiledILi512ELi16ELi1024E", 7, 0),      # FP64 mode
+    ("k_dsm_gather_tiledILi512ELi16ELi1024E", 8, 0),      # FP64 mode: the default DSM gather (four workgroups per CU)
     ("k_dsm_p3_countILb0E", 8, 0),
     # (the scatter passes: 70+ KB of LDS per workgroup allow two of them = 4 waves per SIMD; all of a
     # thread's loads are in flight at once, which takes more than 64 registers in the first pass)
