@@ -387,6 +387,63 @@ def test_dsm_uneven_density_takes_every_capacity_class():
     S.assert_dsm_close(got2, want2)
 
 
+def test_dsm_class_launches_skipped_after_a_uniform_call_still_serve_an_uneven_cloud():
+    """Round 5's launch policy: after a call whose capacity-class lists and big-sub-partition list
+    were all empty, the next call of the same geometry does not launch those kernels -- the main
+    gather launch then takes every class (denser tiles walk the global bins) and the placement
+    kernel places over-full sub-partitions itself.  The pinned counters that call leaves bring the
+    class launches back for the one after.  All three calls against the oracle, and the skipped
+    form bit for bit against the full one (FP64 mode)."""
+    rng = np.random.default_rng(23)
+    lx, ly, res = 520.0, 380.0, 0.25
+    g = O.make_grid(lx, ly, res)
+    n0 = int(0.5 * g.rows * g.cols)
+    uni = np.empty((n0, 3))
+    uni[:, 0] = rng.uniform(-lx / 2 - 2, lx / 2 + 2, n0)
+    uni[:, 1] = rng.uniform(-ly / 2 - 2, ly / 2 + 2, n0)
+    uni[:, 2] = synth.terrain_height(uni[:, 0], uni[:, 1]) + rng.uniform(-0.3, 0.3, n0)
+    parts = [uni[:int(0.8 * n0), :2]]
+    for k, dens in enumerate([1.5, 3.0, 6.0, 14.0]):
+        side = 60.0 if dens < 6 else 30.0
+        cx0, cy0 = -200.0 + 110.0 * k, -100.0 + 50.0 * k
+        nk = int(dens * (side / res) ** 2)
+        parts.append(np.c_[rng.uniform(cx0, cx0 + side, nk), rng.uniform(cy0, cy0 + side, nk)])
+    xy = np.concatenate(parts)
+    # (about as many points as the uniform cloud: the sort reuses its plan's geometry)
+    uneven = np.empty((xy.shape[0], 3))
+    uneven[:, :2] = xy
+    uneven[:, 2] = synth.terrain_height(xy[:, 0], xy[:, 1]) + rng.uniform(-0.3, 0.3, xy.shape[0])
+    assert uni.shape[0] > (1 << 20) and uneven.shape[0] > (1 << 20)
+    A = _A()
+    rc, want_u, _ = O.dsm_process(uni, g)
+    assert rc == O.OK
+    rc, want_e, _ = O.dsm_process(uneven, g)
+    assert rc == O.OK
+    tol = 1e-6 if _EXACT else 1e-4
+    with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, lx, ly, res)) as m:
+        m.set_dsm_precision(_EXACT)
+        m.set_dsm_sort_reuse(False)
+        dsm = A.Dsm(A.DsmSettings(), m)
+        for _ in range(2):                   # (the second call reads the first one's counters: all zero)
+            m.reset()
+            dsm.process(uni, m)
+            S.assert_dsm_close(m.get("elevation"), want_u, tol=tol)
+        st = m.dsm_gather_stats()
+        assert st["class1"] == 0 and st["class2"] == 0 and st["beyond_lds"] == 0
+        m.reset()
+        dsm.process(uneven, m)               # class launches skipped: the main launch serves every tile
+        skipped = m.get("elevation")
+        S.assert_dsm_close(skipped, want_e, tol=tol)
+        st = m.dsm_gather_stats()
+        assert st["class1"] > 0 and st["class2"] > 0   # (classified all the same: the next call's policy)
+        m.reset()
+        dsm.process(uneven, m)               # ... and launched again
+        full = m.get("elevation")
+        S.assert_dsm_close(full, want_e, tol=tol)
+        if _EXACT:
+            assert ((skipped.view(np.uint32) == full.view(np.uint32)) | (np.isnan(skipped) & np.isnan(full))).all()
+
+
 @pytest.mark.parametrize("dens", [4.0, 9.0, 30.0])
 def test_dsm_dense_clouds_take_the_wave_per_cell_path(dens):
     # Dense stereo clouds put tens of points into a 0.25 m cell and hundreds of neighbours
