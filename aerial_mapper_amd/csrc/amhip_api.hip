@@ -194,7 +194,7 @@ static void grid_bases(const amhip_grid_desc& g, double* bx, double* by) {
 // its tile counters, never waited for -- a value one or two calls late is as good): above one
 // half, this call and the next 15 run the FP64 pipeline outright (sorted doubles), then the
 // single-precision pipeline is tried once more.  Results: FP64 is the stricter arithmetic, every
-// bar of the single-precision mode holds.  AMHIP_DSM_NO_ROUGH_SWITCH=1 disables the switch.
+// bar of the single-precision mode holds.  tuning knob dsm_no_rough_switch disables the switch.
 static void dsm_rough_policy(Ctx* c) {
   const bool off = tuning_on("dsm_no_rough_switch");  // (looked up per call: tests toggle it)
   c->dsm_exact_now = 0;
@@ -223,7 +223,7 @@ static void dsm_rough_policy(Ctx* c) {
 // grown by the last fallback radius -- no cell outside it can receive a value -- becomes the
 // window of THIS call; the kernels run unchanged on it and write into the full layer
 // (DsmParams::out_*).  Only while the layer is materialized (a lazily reset layer has to be
-// written everywhere).  AMHIP_DSM_NO_SUBWINDOW=1: never.
+// written everywhere).  tuning knob dsm_no_subwindow: never.
 // Returns 1: *p_sub is the call's parameter set; 0: run on the whole window; 2: no point near the
 // window, nothing to do; < 0: error.
 static int make_dsm_params(const Ctx& c, int radius_sq, double center_easting, double center_northing,
@@ -1001,7 +1001,7 @@ int amhip_layers_reset(amhip_ctx* h) {
   // value into the cells it leaves alone (fused fill), anything else that
   // needs the memory (download, device pointer, a partial writer) fills it
   // first (materialize()).  Layers whose device pointer was handed out are
-  // refilled eagerly.  AMHIP_EAGER_RESET=1 restores the plain fills.
+  // refilled eagerly.  tuning knob eager_reset restores the plain fills.
   const bool eager = tuning_on("eager_reset");
   {  // every elevation is NaN again: empty height range
     static const unsigned long long empty[2] = {0xFFF0000000000000ull, 0x000FFFFFFFFFFFFFull};

@@ -388,7 +388,7 @@ int make_halo_params(const Ctx& c, double center_easting, double center_northing
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
 bool spec_poll_overflow(Ctx* c);
-bool no_launch_skips();            // amhip_sort.hip: AMHIP_NO_LAUNCH_SKIPS  // amhip_sort.hip: the speculative sort's miss bookkeeping
+bool no_launch_skips();            // amhip_sort.hip: tuning knob no_launch_skips  // amhip_sort.hip: the speculative sort's miss bookkeeping
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split = nullptr);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,

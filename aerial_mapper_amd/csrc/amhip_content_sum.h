@@ -36,7 +36,7 @@ AMHIP_SUM_HD void cell_mix(unsigned bits, unsigned long long g, unsigned long lo
 
 // *a, *b += the sums of cells col[0 .. n) at positions g0 .. g0 + n - 1 (host; picks the AVX-512
 // loop where the CPU has avx512dq -- 6 x the scalar loop per thread on Zen 5 -- unless
-// AMHIP_SESSION_SCALAR_SUMS is set).  host_sum_is_vectorized(): which one.
+// tuning knob session_scalar_sums is set).  host_sum_is_vectorized(): which one.
 void host_column_sum(const unsigned* col, size_t n, unsigned long long g0, unsigned long long* a,
                      unsigned long long* b);
 bool host_sum_is_vectorized();

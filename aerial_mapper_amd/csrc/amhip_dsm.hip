@@ -107,7 +107,7 @@ struct Accum {
 __device__ __forceinline__ bool round_is_certain(double h, double err) {
   return (float)(h - err) == (float)(h + err);
 }
-// (p.canon_all -- AMHIP_DSM_CANON_ALL=1, tests: every quotient counts as uncertain, so every cell
+// (p.canon_all -- tuning knob dsm_canon_all, tests: every quotient counts as uncertain, so every cell
 // with a hit is stored by canonical_search())
 __device__ __forceinline__ double idw_err_bound(const DsmParams& p, unsigned n, double zmax) {
   return p.canon_all ? __builtin_huge_val() : ((double)(4u * n + 8u) * 0x1p-53) * zmax;
@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
   // a wave-uniform bound in scalar registers -- sends 1000 cells per 1e8 to the redo instead of
   // 60, and a redo is a serial walk of global memory as long as a whole tile: measured slower.)
   // err = (4 n + 8) 2^-53 max|z| as ONE fma per cell pair: c1 n + c0 (wave-uniform constants;
-  // AMHIP_DSM_CANON_ALL makes them infinite)
+  // tuning knob dsm_canon_all makes them infinite)
   const double zmax_tile = p.canon_all ? __builtin_huge_val() : call_zmax(o);
   const double err_c1 = 0x1p-51 * zmax_tile, err_c0 = 0x1p-50 * zmax_tile;
 
@@ -1440,7 +1440,7 @@ __device__ __forceinline__ void cell_wave_exact(const DsmParams& p, const uint32
 
 // kVar: 0 = the product kernel.  1, 2, 5, 6 = TIMING PROBES (1: candidate loop without the
 // hit updates, 2: no candidate loop -- both give wrong heights; 5 / 6: leave after the staging /
-// after the loads): instantiated and selectable (AMHIP_F32_VARIANT) ONLY in a build with
+// after the loads): instantiated and selectable (tuning knob f32_variant) ONLY in a build with
 // -DAMHIP_TIMING_PROBES (AMHIP_BUILD_DEFINES=-DAMHIP_TIMING_PROBES python -m
 // aerial_mapper_amd.build --force); the shipped library holds kVar = 0 alone.
 template <int NT, int kTileJ, int kCap, int kVar = 0>
@@ -2288,7 +2288,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3(pp.nocc + pp.nrange), dim3(256), 0, c->stream,
                          p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2,
                          bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref, pp);
-      // AMHIP_GATHER_NT: threads per gather workgroup (tuning knob; 512 measured best)
+      // tuning knob gather_nt: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
       const int nt = (int)tuning("gather_nt", 512.0);
 #else

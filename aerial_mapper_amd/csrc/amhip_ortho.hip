@@ -877,7 +877,7 @@ k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(false, 16)
 }
 // margin-guarded fold, four cells per lane, registers as they come (3 waves per SIMD):
-// AMHIP_ORTHO_FAST_WAVES=3 (A-B knob)
+// tuning knob ortho_fast_waves=3 (A-B knob)
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
 k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(true, 16)
@@ -983,7 +983,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
   c->dirty[2] = c->win_rows;
   c->dirty[3] = c->win_cols;
   // small batch, big map, the output layers materialized: only the tiles some frame can see
-  // (AMHIP_ORTHO_NO_TILE_LIST=1: the dense launch -- A-B and tests).  num_observations may stay
+  // (tuning knob ortho_no_tile_list: the dense launch -- A-B and tests).  num_observations may stay
   // lazily initial: the kernels neither read nor write it then.
   const size_t ntiles = (size_t)grid.x * (size_t)grid.y;
   // (from 16 K tiles: below, dispatching every tile costs less than the list's extra launch)

@@ -21,7 +21,7 @@
 //                a matrix that holds its initial constant -> a lazy device-side reset instead
 //                of an upload; anything else is uploaded.  Outputs the kernels did not change
 //                (num_observations: `+= itself`, ortho-backward-grid.cc:183) are not downloaded.
-//                AMHIP_SESSION_ALWAYS_COPY=1: every matrix up and down, like round 1.
+//                tuning knob session_always_copy: every matrix up and down, like round 1.
 #include <sched.h>
 
 #include <algorithm>
@@ -83,12 +83,12 @@ struct Session {
   std::vector<unsigned long long*> dev_hash;   // device scratch: two u64 per layer
   std::vector<float*> pin;                     // pinned host staging of partial downloads
   std::vector<size_t> pin_cap;                 // floats
-  bool verify_partial = false;                 // AMHIP_SESSION_VERIFY_PARTIAL: re-sum the host matrix
+  bool verify_partial = false;                 // tuning knob session_verify_partial: re-sum the host matrix
   std::atomic<unsigned long long> up_bytes{0}, down_bytes{0};  // layer traffic (amhip_session_transfer_stats)
   int W() const { return (int)ctx.size(); }
 };
 
-// AMHIP_SESSION_TRACE=1: wall time of every phase of a call on stderr (where does a host-matrix
+// tuning knob session_trace: wall time of every phase of a call on stderr (where does a host-matrix
 // call spend its time: content sums, uploads, kernels, downloads?)
 struct PhaseClock {
   bool on;
@@ -320,7 +320,7 @@ static void unpack_block(const float* packed, float* host, const Session& s, int
 // a small batch's tile list.  A host matrix that equalled the device layer BEFORE the call (what
 // sync_in establishes) differs from it only there: that rectangle is downloaded (device -> pinned
 // staging -> the matrix's columns) instead of the window -- the incremental use case on a large
-// map downloads megabytes instead of gigabytes per call.  AMHIP_SESSION_NO_PARTIAL=1: always the
+// map downloads megabytes instead of gigabytes per call.  tuning knob session_no_partial: always the
 // whole window (A-B, tests).
 static int sync_out(Session& s, int k, const int* layers, float* const* hosts, int nl,
                     bool dirty_ok = false) {

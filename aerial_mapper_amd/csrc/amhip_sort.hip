@@ -1805,10 +1805,10 @@ k_scan_final(uint32_t* __restrict__ data, size_t n,
 }
 
 
-// AMHIP_P3_ROUNDS_CAP=n (tests): sub-partitions above n points are placed in rounds over an
+// tuning knob p3_rounds_cap=n (tests): sub-partitions above n points are placed in rounds over an
 // image of n points -- exercises place_rounds (and its one-bin-beyond-the-image direct case)
 // on clouds of test size; normally only contexts beyond ~130 M points get there
-// AMHIP_P3_ROUNDS_REREAD=1: the rounds re-read the sub-partition instead of keeping it in registers
+// tuning knob p3_rounds_reread: the rounds re-read the sub-partition instead of keeping it in registers
 // (the path of sub-partitions beyond 14 K points)
 static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* reg_max) {
   const int knob = (int)tuning("p3_rounds_cap", 0.0);
@@ -1822,7 +1822,7 @@ static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* re
 
 __global__ void k_aux_reset(SortAux aux) { aux_reset(aux); }
 
-// AMHIP_NO_LAUNCH_SKIPS=1 (tests, A-B): every capacity-class / big-list launch is made whatever the
+// tuning knob no_launch_skips (tests, A-B): every capacity-class / big-list launch is made whatever the
 // previous call's counters say (amhip_dsm.hip: dsm_run uses the same switch)
 bool no_launch_skips() {
   return tuning_on("no_launch_skips");
@@ -1858,7 +1858,7 @@ bool spec_poll_overflow(Ctx* c) {
   return true;
 }
 
-// amhip_ctx_set_dsm_sort_reuse(ctx, 0) / AMHIP_SORT_NO_SPECULATION=1: always count first
+// amhip_ctx_set_dsm_sort_reuse(ctx, 0) / tuning knob sort_no_speculation: always count first
 static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
   const bool off = !c->spec_reuse || tuning_on("sort_no_speculation");  // (looked up per call: tests flip it)
   if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
@@ -1925,7 +1925,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
   // as their limits -- 1 KB away from the append CURSORS -- which every workgroup's atomics hammer
   // --, the first speculative pass ran at two thirds to half speed from 100 M points on (+ 0.8 /
   // 1.6 / 3.3 ms at 100 / 200 / 400 M: tools/sort_scale_probe.py); larger clouds were not measured
-  // again after that and keep counting first.  AMHIP_SORT_SPEC_MAX_POINTS moves the limit.)
+  // again after that and keep counting first.  tuning knob sort_spec_max_points moves the limit.)
   const size_t spec_max_points = (size_t)tuning("sort_spec_max_points", (double)((size_t)1 << 27));
   // (amhip_ctx_set_dsm_sort_reuse(ctx, 0): no plans are read OR written -- the scan's second pass goes too)
   const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split &&
@@ -1933,7 +1933,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
   const unsigned long long geo_sig = spec_signature(p);   // (window geometry + sort plan)
   const unsigned long long sig = spec_mode ? geo_sig : 0ull;
   const bool spec = spec_mode && spec_wanted(c, n, sig);
-  // (the regions' head room: count >> room_shift; AMHIP_SORT_SPEC_MARGIN_SHIFT, 1 .. 31, experiments)
+  // (the regions' head room: count >> room_shift; tuning knob sort_spec_margin_shift, 1 .. 31, experiments)
   const int room_shift = std::min(31, std::max(1, (int)tuning("sort_spec_margin_shift", 3.0)));
   // (regions of count + count / 8 + 32 over the previous call's counts)
   // (reserved from the context's FIRST such call on: growing the two point buffers later means

@@ -198,7 +198,7 @@ int amhip_ctx_synchronize(amhip_ctx* ctx);
  * initial value into the cells it leaves alone, and anything else that needs
  * the memory (download, device pointer, a batch on top of uploaded layers)
  * fills the layer first.  Observable contents are always those of an eager
- * fill; AMHIP_EAGER_RESET=1 in the environment restores the plain fills. */
+ * fill; the tuning knob eager_reset (amhip_set_tuning) restores the plain fills. */
 int amhip_layers_reset(amhip_ctx* ctx);
 int amhip_layer_upload(amhip_ctx* ctx, int layer, const float* host);
 int amhip_layer_download(amhip_ctx* ctx, int layer, float* host);
@@ -527,9 +527,9 @@ int amhip_rectify_stereo_pair_dev(amhip_ctx* ctx, const double* K, const double*
  * else: uploaded.  Outputs the kernels left unchanged are not downloaded; of a layer that a call
  * changed only inside a rectangle it knows (a small cloud's bounding box on a large map, the
  * tiles a small batch of frames can see: the incremental use case) only that rectangle is
- * (AMHIP_SESSION_NO_PARTIAL=1: whole windows).  Results are those of the single-context calls
+ * (tuning knob session_no_partial: whole windows).  Results are those of the single-context calls
  * (same kernels; windows reproduce the full map).
- * AMHIP_SESSION_ALWAYS_COPY=1 / amhip_session_set_always_copy: every matrix up and down.
+ * tuning knob session_always_copy / amhip_session_set_always_copy: every matrix up and down.
  * amhip_session_transfer_stats: bytes of layer data uploaded / downloaded since the session was
  * created (clouds and frames not counted). */
 typedef struct amhip_session amhip_session;

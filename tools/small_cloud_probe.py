@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DSM calls with clouds below the three-pass sort's threshold (incremental mapping: one stereo
 pair's cloud onto a large resident map; small surveys): ms per Dsm::process under the sort
-implementations (AMHIP_SORT_ONE_LEVEL=1, AMHIP_P3_MIN_POINTS=50000, default select).  Round 2, with the
+implementations (tuning knob sort_one_level, tuning knob p3_min_points=50000, default select).  Round 2, with the
 two-level stripe sort still in: one-level 0.269 / 0.141 / 0.174 / 0.107 ms, two-level 0.255 / 0.169 / 0.263 /
 0.118 ms, three-pass 0.245 / 0.158 / 0.172 / 0.120 ms on the four cases below -> the stripe sort was retired.
     python tools/small_cloud_probe.py"""
