@@ -1155,9 +1155,9 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
           orow += RW2;
           ncand += ke - kb;
         }
-        auto candidate = [&](uint32_t k) __attribute__((always_inline)) {
-          const double2 xy = s_xy[k];
-          const double z = s_z[k];
+        auto candidate = [&](const double2* __restrict__ cxy, const double* __restrict__ cz) __attribute__((always_inline)) {
+          const double2 xy = *cxy;
+          const double z = *cz;
           // L2_Adaptor, size == 2 (nanoflann.hpp:319-322): 0 + dx*dx, + dy*dy
           const double dx = qx - xy.x;
           const double dx2 = dx * dx;
@@ -1193,14 +1193,23 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
 #if AMHIP_GATHER_UNROLL > 1
         // (unrolled by hand: the loop bookkeeping is a quarter of the loop's
         // instructions otherwise)
-        uint32_t k = kb;
-        for (; k + (AMHIP_GATHER_UNROLL - 1) < ke; k += AMHIP_GATHER_UNROLL) {
-#pragma unroll
-          for (uint32_t q = 0; q < AMHIP_GATHER_UNROLL; ++q) candidate(k + q);
+        // (pointers, not indices: the latch is then two adds and a compare instead of six VALU
+        // instructions per pair of candidates)
+        const double2* pxy = s_xy + kb;
+        const double* pz = s_z + kb;
+        const double2* const pend = s_xy + ke;
+        const double2* const plim = pend - 1;   // (a pair starts below it)
+        if (pxy < plim) {
+          do {
+            candidate(pxy, pz);
+            candidate(pxy + 1, pz + 1);
+            pxy += 2;
+            pz += 2;
+          } while (pxy < plim);
         }
-        for (; k < ke; ++k) candidate(k);
+        if (pxy < pend) candidate(pxy, pz);
 #else
-        for (uint32_t k = kb; k < ke; ++k) candidate(k);
+        for (uint32_t k = kb; k < ke; ++k) candidate(s_xy + k, s_z + k);
 #endif
         // keep the running products inside the double range (exact scaling by
         // powers of two; N, D, P share the factor so N/D is unaffected).  The
