@@ -1198,8 +1198,8 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
         const double2* pxy = s_xy + kb;
         const double* pz = s_z + kb;
         const double2* const pend = s_xy + ke;
-        const double2* const plim = pend - 1;   // (a pair starts below it)
-        if (pxy < plim) {
+        if (kb + 1u < ke) {                     // (at least one pair: ke >= 2, so pend - 1 is inside the image)
+          const double2* const plim = pend - 1;  // (a pair starts below it)
           do {
             candidate(pxy, pz);
             candidate(pxy + 1, pz + 1);
