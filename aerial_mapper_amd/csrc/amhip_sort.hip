@@ -1170,7 +1170,12 @@ k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
                const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
                uint2* __restrict__ bin_z, const uint32_t* __restrict__ src_start,
-               const uint32_t* __restrict__ skip_if /* speculative sort: its overflow word, else null */) {
+               const uint32_t* __restrict__ skip_if /* speculative sort: its overflow word, else null */,
+               // (how many sub-partitions the big placement kernel has to take, left in a pinned host
+               // word for the NEXT call's launch policy by one thread of this large kernel -- not by
+               // the single-workgroup scan every pass waits for; may be null)
+               const uint32_t* __restrict__ big_list, unsigned* __restrict__ host_big) {
+  if (host_big && blockIdx.x == 0 && threadIdx.x == 0) host_big[0] = big_list[0];
   // (an overflowed speculative sort leaves holes in its regions -- slots a dropped run reserved
   // and never wrote: nothing there may be read as a point, ADVICE r4.  The flag is final once pass 2
   // has run; the exact pipeline launched behind writes the whole output.)
@@ -2079,10 +2084,10 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift,
-                           spec_flag, no_aux, c->host_sort_stats);
+                           spec_flag, no_aux, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
                            c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
-                           0xFFFFFFFFu, (uint2*)nullptr, cstart2, spec_flag);
+                           0xFFFFFFFFu, (uint2*)nullptr, cstart2, spec_flag, (const uint32_t*)nullptr, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
                            c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, (uint2*)nullptr,
                            cap_rounds, rounds_above, reg_max, cstart2, (const uint32_t*)nullptr, spec_flag);
@@ -2099,7 +2104,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
         hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
                            start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
                            (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr, no_aux, c->host_sort_stats);
+                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr, no_aux, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
                            n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
         hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
@@ -2157,7 +2162,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
       hipLaunchKernelGGL(k_dsm_p3_reduce_scan, dim3((unsigned)((nk + 63) / 64)), dim3(1024), 0, c->stream,
                          hist_rows, (int)gcount, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2,
                          (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list, (unsigned)(rec ? kRecChunk : kP3Chunk),
-                         plan_next, flag_next, room_shift, aux, c->host_sort_stats, c->dev_tickets);
+                         plan_next, flag_next, room_shift, aux, (unsigned*)nullptr, c->dev_tickets);
       c->aux_done = true;
       AMHIP_TRY(hipGetLastError());
       if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
@@ -2252,7 +2257,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
                          want_big ? (unsigned)p.p3_cap : 0xFFFFFFFFu, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr);
+                         (const uint32_t*)nullptr, (const uint32_t*)big_list, c->host_sort_stats);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
       unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
