@@ -198,3 +198,25 @@ def test_tuning_knobs_go_through_one_door():
     hdr = open(os.path.join(ROOT, "include", "aerial_mapper_hip.h")).read()
     for name in seen:
         assert name in hdr, name
+
+
+def test_committed_pmc_evidence_is_of_this_build():
+    """The newest rocprofv3 counter summaries under profiles/ (what bench.py copies `roofline.traffic`
+    and the VALU figures from) were collected from THIS source tree: their build id is the SHA-256
+    prefix aerial_mapper_amd/build.py computes over the library's sources, headers and flags -- the
+    same string amhip_build_id() returns.  A kernel change without a new tools/collect_profiles.sh run
+    fails here (and bench.py then prints `traffic: null` with the reason instead of a stale figure)."""
+    import glob
+    import json
+    import re
+    from aerial_mapper_amd import build, hip_lib
+    want = build.source_build_id()
+    assert hip_lib.build_id() == want, "the built library is not of these sources: rebuild"
+
+    def newest(pattern):
+        fs = glob.glob(os.path.join(ROOT, "profiles", pattern))
+        return sorted(fs, key=lambda f: int(re.search(r"r(\d+)_", os.path.basename(f)).group(1)))[-1]
+    for mode in ("exact", "fast"):
+        for pattern in ("r*_%s_pmc_traffic.json" % mode, "r*_%s_cfg3_pmc_sq.json" % mode):
+            f = newest(pattern)
+            assert json.load(open(f)).get("build_id") == want, os.path.basename(f)
