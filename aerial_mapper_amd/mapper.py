@@ -189,7 +189,8 @@ class AerialGridMap(object):
         complete before torch work on ANOTHER stream reads it."""
         import torch
         cur = torch.cuda.current_stream(torch.device("cuda", self.device))
-        if int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
+        # (handle 0 = the map runs on its OWN stream, which is never torch's: always order)
+        if int(cur.cuda_stream) == 0 or int(cur.cuda_stream) != getattr(self, "_stream_handle", 0):
             # an event on the map's stream that torch's current stream waits for: the host does
             # not wait (ADVICE r4: sync=False stays asynchronous whatever the stream arrangement)
             L.check(self._lib.amhip_ctx_order_after(self._h, C.c_void_p(int(cur.cuda_stream))))
