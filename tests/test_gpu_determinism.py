@@ -178,3 +178,28 @@ def test_two_runs_and_a_permuted_cloud_give_the_same_bits(seed):
     assert (~np.isnan(maps[0].view(np.float32))).any()
     assert np.array_equal(maps[0], maps[1]), int((maps[0] != maps[1]).sum())
     assert np.array_equal(maps[0], maps[2]), int((maps[0] != maps[2]).sum())
+
+
+def test_async_call_orders_torchs_stream_behind_the_maps_own():
+    """Dsm.process(sync=False) on a map that runs on its OWN stream: torch's current stream is made to
+    wait for the call on the device (amhip_ctx_order_after: an event, no host wait), so a torch read
+    of the layer enqueued right behind the call sees the finished DSM -- and refilling the cloud
+    tensor there cannot race with the gather."""
+    import torch
+    import aerial_mapper_amd as A
+    sc = S.Scene(400.0, 300.0, 0.25, int(1.3e6), seed=77)
+    rc, want, _ = O.dsm_process(sc.points, sc.grid)
+    assert rc == O.OK
+    g = sc.grid
+    with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
+        m.set_dsm_precision(True)
+        pts = torch.from_numpy(sc.points).to("cuda:0")
+        layer = m.as_torch("elevation")          # (a view of the device layer; torch reads it on ITS stream)
+        torch.cuda.synchronize()
+        A.Dsm(A.DsmSettings(), m).process(pts, m, sync=False)
+        got = layer.clone()                      # torch's stream: ordered behind the call by the event
+        pts.fill_(float("nan"))                  # ... and so is this overwrite of the input
+        torch.cuda.synchronize()
+        m.synchronize()
+        S.assert_dsm_close(got.cpu().numpy(), want, tol=1e-6)
+        S.assert_dsm_close(m.get("elevation"), want, tol=1e-6)
