@@ -266,7 +266,7 @@ struct Ctx {
   int spec_parity = 0;             // which of the two the next call consumes
   unsigned* spec_flag_host = nullptr;
   bool spec_valid = false;
-  bool spec_reuse = true;          // amhip_ctx_set_dsm_sort_reuse: plan a call's regions from its predecessor's counts
+  bool spec_reuse = false;         // amhip_ctx_set_dsm_sort_reuse (opt-in): plan a call's regions from its predecessor's counts
   unsigned long long spec_sig = 0;
   size_t spec_n = 0;
   int spec_cooldown = 0;

@@ -238,8 +238,9 @@ class AerialGridMap(object):
                 "counting_calls_left": int(out[3])}
 
     def set_dsm_sort_reuse(self, on):
-        """amhip_ctx_set_dsm_sort_reuse: False = every DSM call counts first (what a context's first
-        call runs: the reference hosts' call pattern, one process() per process)."""
+        """amhip_ctx_set_dsm_sort_reuse: False (the default) = every DSM call counts first (what a
+        context's first call runs: the reference hosts' call pattern, one process() per process);
+        True = a call may size its sort regions from its predecessor's counts (opt-in)."""
         L.check(self._lib.amhip_ctx_set_dsm_sort_reuse(self._h, 1 if on else 0))
 
     def dsm_gather_stats(self):

@@ -30,8 +30,8 @@ the extra object `fast_mode`, with its own parity sample and roofline.
 
 `value` is the call the reference's hosts make (main-dsm.cc:103-107, main-ortho-backward-grid.cc:
 128-141: ONE process() per process): every timed DSM call runs what a context's FIRST call runs
--- the counting sort; the context is told not to reuse its predecessor's partition plan
-(amhip_ctx_set_dsm_sort_reuse(ctx, 0)), so repeating one cloud in the timed loop skips no work.
+-- the counting sort: the library's default since round 5 (reusing a predecessor's partition plan is
+opt-in, amhip_ctx_set_dsm_sort_reuse(ctx, 1)), so repeating one cloud in the timed loop skips no work.
 The N > 1 ranks run the same pipeline (a tiled call always counts: its count pass selects the
 halo).  What a context that re-processes similar clouds gets on top (the speculative sort,
 amhip_sort.hip) is timed beside it as the extra object `sort`: the same cloud again, and three
@@ -690,7 +690,7 @@ def main():
     # the gather's arithmetic in the timed steps (the library's own default is EXACT since round 3)
     m.set_dsm_precision(args.dsm_mode == "exact")
     # the sort of the timed steps: what a context's FIRST call runs (the reference hosts' call
-    # pattern: one process() per process) unless --sort-reuse
+    # pattern: one process() per process; the library's default) unless --sort-reuse
     m.set_dsm_sort_reuse(bool(args.sort_reuse))
     # centre of this rank's window in map coordinates (x decreases with i, y with j)
     tile_center = (ox + Lx / 2.0 - (win[0] + win[2] / 2.0) * res,

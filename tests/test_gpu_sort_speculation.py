@@ -32,6 +32,7 @@ def _clouds(g, lx, ly):
 def _run(A, st, clouds, radius=1):
     out, stats = [], []
     with A.AerialGridMap(st) as m:
+        m.set_dsm_sort_reuse(True)          # (opt-in since round 5)
         dsm = A.Dsm(A.DsmSettings(radius), m)
         for _, pts in clouds:
             m.reset()
@@ -113,7 +114,7 @@ def test_speculative_sort_on_every_placement_path(knobs):
         "    hip_lib.set_tuning('sort_no_speculation', None if spec else 1)\n"
         "    out = []\n"
         "    with A.AerialGridMap(st) as m:\n"
-        "        m.set_dsm_precision(True)\n"
+        "        m.set_dsm_precision(True); m.set_dsm_sort_reuse(True)\n"
         "        for name in seq:\n"
         "            m.reset(); A.Dsm(A.DsmSettings(), m).process(clouds[name], m)\n"
         "            e = m.get('elevation'); S.assert_dsm_close(e, want[name], tol=1e-6); out.append(e)\n"

@@ -22,6 +22,7 @@ for npts in [int(v) for v in os.environ.get("AMHIP_PROBE_POINTS", "100000000,200
         else:
             hip_lib.set_tuning("sort_no_speculation", 1)
         with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, res)) as m:
+            m.set_dsm_sort_reuse(True)      # (opt-in since round 5; the knob above switches it off)
             dsm = A.Dsm(A.DsmSettings(), m)
             for _ in range(2):
                 m.reset(); dsm.process(pts, m)
