@@ -2,7 +2,7 @@
 # Collect the round's rocprofv3 evidence ON the GPU box, for BOTH arithmetic modes of the DSM
 # gather, and leave only the small summaries in gpurun_out/profiles_out/ (the rocpd databases
 # exceed what gpurun copies back).  Usage (from the repo root, through gpurun):
-#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r04 [modes]'
+#   gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r05 [modes]'
 # modes: "exact fast" (default; exact = the library's default = bench.py's headline) or one of them.
 # Per mode M:  <round>_M_cfg3_rocprofv3.md          kernel trace + FETCH_SIZE / WRITE_SIZE passes
 #              <round>_M_pmc_traffic.json           HBM bytes per bench step and kernel slot
@@ -12,7 +12,7 @@
 # Counter passes run on their own, with --kernel-trace only (gpurun refuses --pmc next to
 # --sys-trace / hip / hsa traces).
 set -u
-RND=${1:-r04}
+RND=${1:-r05}
 MODES=${2:-"exact fast"}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=/tmp/amhip_prof_$$
