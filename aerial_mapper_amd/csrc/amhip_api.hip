@@ -238,8 +238,10 @@ static int dsm_subwindow(Ctx* c, const double* dev_xyz, size_t n, int radius_sq,
   if (hipMemcpyAsync(c->host_bbox, c->dev_bbox, 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
       hipStreamSynchronize(c->stream) != hipSuccess)
     return -hip_fail(hipGetLastError(), "bounding box of the cloud", __FILE__, __LINE__);
-  const int* b = c->host_bbox;
-  if (b[4] == 0) return 2;
+  if (c->host_bbox[4] == 0) return 2;
+  // (k_dsm_bbox's biased words: an all-zero buffer is the empty box)
+  const int b[4] = {kBboxBias - c->host_bbox[0], c->host_bbox[1] - kBboxBias,
+                    kBboxBias - c->host_bbox[2], c->host_bbox[3] - kBboxBias};
   const int grow = p_full.w[p_full.nlevels - 1] + 2;   // last radius of the ladder, in cells (+ slack)
   const int i_lo = std::max(0, b[0] - grow), i_hi = std::min(p_full.rows - 1, b[1] + grow);
   const int j_lo = std::max(0, b[2] - grow), j_hi = std::min(p_full.cols - 1, b[3] + grow);
@@ -943,7 +945,7 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   }
   for (int l = 0; l < AMHIP_NUM_LAYERS; ++l)
     if (c->layers[l]) (void)hipFree(c->layers[l]);
-  void* bufs[] = {c->spec_plan, c->dev_bbox, c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
+  void* bufs[] = {c->dev_bbox, c->ortho_list, c->zpart, c->dev_zrange, c->tile_list, c->tile_occ, c->fill_mask, c->stage_values, c->dev_err, c->sorted,       c->rank,        c->bin_start, c->bin_z, c->rec_a, c->rec_b, c->rec16, c->sidx, c->zref, c->zall, c->tmp_points, c->stripe_ws,
                   c->scan_partials, c->stage_points, c->frame_poses, c->stage_frames};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -952,7 +954,6 @@ void amhip_ctx_destroy(amhip_ctx* h) {
   if (c->host_sort_stats) (void)hipHostFree(c->host_sort_stats);
   if (c->dev_tickets) (void)hipFree(c->dev_tickets);
   if (c->host_bbox) (void)hipHostFree(c->host_bbox);
-  if (c->spec_flag_host) (void)hipHostFree(c->spec_flag_host);
   if (c->order_event) (void)hipEventDestroy(c->order_event);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete h;
@@ -1712,17 +1713,6 @@ const char* amhip_kernel_name(int kernel) {
   }
 }
 
-int amhip_ctx_dsm_sort_stats(amhip_ctx* h, int64_t* out4) {
-  if (!h || !out4) return arg_fail("amhip_ctx_dsm_sort_stats: null argument");
-  Ctx* c = &h->impl;
-  (void)spec_poll_overflow(c);  // (the same bookkeeping the next DSM call would do: one definition)
-  out4[0] = (int64_t)c->spec_calls;
-  out4[1] = (int64_t)c->spec_hits_started;
-  out4[2] = (int64_t)c->spec_misses;
-  out4[3] = (int64_t)c->spec_cooldown;
-  return AMHIP_OK;
-}
-
 int amhip_set_tuning(const char* key, double value) {
   if (!tuning_set(key, value)) return arg_fail("amhip_set_tuning: unknown key (include/aerial_mapper_hip.h lists them)");
   return AMHIP_OK;
@@ -1735,12 +1725,6 @@ int amhip_default_dsm_precision(void) {
   // single-precision gather; everything else starts in the reference's arithmetic
   const char* fast = std::getenv("AMHIP_DSM_FAST");
   return (fast && fast[0] && fast[0] != '0' && !std::getenv("AMHIP_DSM_EXACT")) ? AMHIP_DSM_FAST : AMHIP_DSM_EXACT;
-}
-
-int amhip_ctx_set_dsm_sort_reuse(amhip_ctx* h, int on) {
-  if (!h) return arg_fail("null context");
-  h->impl.spec_reuse = on != 0;
-  return AMHIP_OK;
 }
 
 int amhip_ctx_order_after(amhip_ctx* h, void* other_stream) {

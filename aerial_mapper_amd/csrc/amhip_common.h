@@ -257,22 +257,6 @@ struct Ctx {
   size_t tmp_points_cap = 0;
   uint32_t* stripe_ws = nullptr;   // stripe counts / starts / cursors
   size_t stripe_ws_cap = 0;
-  // The speculative sort (amhip_sort.hip, dsm_sort): the regions the previous three-pass call in the
-  // FP64 pipeline on this context planned for its successor from its own exact (k1, k2) counts --
-  // the next call appends into them instead of counting first --, what that call looked like, and
-  // the overflow word of the last speculative call (pinned mirror, never waited for).
-  uint32_t* spec_plan = nullptr;   // two plans (regions + cursors of both passes) + two overflow words
-  size_t spec_plan_cap = 0;
-  int spec_parity = 0;             // which of the two the next call consumes
-  unsigned* spec_flag_host = nullptr;
-  bool spec_valid = false;
-  bool spec_reuse = false;         // amhip_ctx_set_dsm_sort_reuse (opt-in): plan a call's regions from its predecessor's counts
-  unsigned long long spec_sig = 0;
-  size_t spec_n = 0;
-  int spec_cooldown = 0;
-  int spec_backoff = 8;            // counting calls after the next miss
-  bool spec_last_hit = false;      // the previous three-pass call started speculatively
-  unsigned long long spec_calls = 0, spec_hits_started = 0, spec_misses = 0;  // (three-pass FP64 calls / speculative / overflowed)
   uint8_t* tile_occ = nullptr;         // per gather tile: any point within the last radius
   size_t tile_occ_cap = 0;
   int* tile_list = nullptr;            // sparse gather: [count (4 ints)] [occupied tile ids]
@@ -375,7 +359,9 @@ int densify_run(Ctx* c, const DensifyParams& p, const float* dev_disparity,
 int halo_select_run(Ctx* c, const double* dev_xyz, size_t n, const HaloParams& hp,
                     double* dev_out, unsigned long long* dev_counts);
 // cells (of p's window, point_bin's arithmetic) the points of a cloud fall into: dev_bbox5 =
-// [min i, max i, min j, max j, points inside the binned area] (amhip_sort.hip)
+// [kBboxBias - min i, max i + kBboxBias, kBboxBias - min j, max j + kBboxBias, points inside the
+// binned area] (amhip_sort.hip; all zero = the empty box)
+constexpr int kBboxBias = 1 << 30;
 int dsm_bbox_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p, int* dev_bbox5);
 // geometry of a selection for `nd` destination windows (amhip_api.hip); off / cap_d are set to
 // the equal-split layout (d * cap_per_dest, cap_per_dest)
@@ -387,8 +373,7 @@ int make_halo_params(const Ctx& c, double center_easting, double center_northing
 // byte per cell, set where this call wrote a value; unfilled (may be null):
 // device counter of cells left without a value.
 // amhip_sort.hip: bin-sort the cloud into c->sorted / c->bin_start
-bool spec_poll_overflow(Ctx* c);
-bool no_launch_skips();            // amhip_sort.hip: tuning knob no_launch_skips  // amhip_sort.hip: the speculative sort's miss bookkeeping
+bool no_launch_skips();            // amhip_sort.hip: tuning knob no_launch_skips
 int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split = nullptr);
 int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,

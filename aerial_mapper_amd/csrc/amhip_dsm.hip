@@ -1948,8 +1948,12 @@ k_dsm_gather_f32_list(DsmParams p, const uint32_t* __restrict__ start,
 // workgroups per CU): the 64 x 16 / 1024-point image is sized so that FOUR fit a CU's LDS, and the
 // fourth hides the other three's staging and epilogue phases -- same box 2.67 -> 2.54 ms per 1e8
 // cells (round 5; the loop itself is FP64-issue bound either way).
+// (Only that instantiation: the larger images' occupancy is limited by their LDS anyway, and the
+// 64-register cap cost them spills -- ADVICE r5.)
 template <int NT, int kTileJ, int kCap>
-__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(NT)
+    __attribute__((amdgpu_waves_per_eu((NT == 512 && kTileJ == 16 && kCap == 1024) ? 8 : 1,
+                                       (NT == 512 && kTileJ == 16 && kCap == 1024) ? 8 : 10)))
 k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
                    const Pts P, const uint8_t* __restrict__ tile_occ,
                    CellOut o, int my_class) {

@@ -296,10 +296,8 @@ template <bool kHalo>
 __global__ void __launch_bounds__(kP3CountThreads)
 k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
                uint32_t* __restrict__ hist_rows, HaloParams hp, double* __restrict__ halo_out,
-               unsigned long long* __restrict__ halo_counts, double* __restrict__ zall,
-               const uint32_t* __restrict__ gate /* may be null: dsm_sort's speculation */) {
+               unsigned long long* __restrict__ halo_counts, double* __restrict__ zall) {
   extern __shared__ uint32_t s_hist[];
-  if (gate && !*gate) return;
   const int nk = p.p3_n1 * p.p3_n2;
   // (kHalo: the staging area follows the histogram, 8-byte aligned)
   HaloStage* const stage = reinterpret_cast<HaloStage*>(s_hist + ((nk + 1) & ~1));
@@ -363,17 +361,8 @@ k_dsm_p3_count(const double* __restrict__ xyz, size_t n, DsmParams p,
   for (int k = threadIdx.x; k < nk; k += kP3CountThreads) row[k] = s_hist[k];
 }
 
-// layout of a speculative sort's plan (uint32 words): [cstart2: nk + 1][cstart1: n1 + 1] ... 1 KB
-// aligned: [cursor2: nk] ... [cursor1: n1]
-__host__ __device__ inline size_t p3_plan_cursor2_at(int nk, int n1) {
-  return (((size_t)nk + 1 + (size_t)n1 + 1 + 255) & ~(size_t)255) + 256;
-}
-__host__ __device__ inline size_t p3_plan_words(int nk, int n1) {
-  return p3_plan_cursor2_at(nk, n1) + (((size_t)nk + 255) & ~(size_t)255) + (((size_t)n1 + 255) & ~(size_t)255) + 256;
-}
-
-// What the single-workgroup kernel in front of the first scatter pass (k_dsm_p3_scan /
-// k_dsm_p3_reduce_scan, k_p3_spec_mid, k_scan_top) resets on its way, so that no launch of its own
+// What the single-workgroup kernel in front of the first scatter pass (k_dsm_p3_reduce_scan,
+// k_scan_top) resets on its way, so that no launch of its own
 // is spent on it: the call's own height range (k_range_reduce folds the scatter waves' partials
 // into it later) and the counters of the gather's tile lists (amhip_dsm.hip: dsm_run).
 struct SortAux {
@@ -392,26 +381,19 @@ __device__ __forceinline__ void aux_reset(const SortAux& a) {
 // One block.  start2 = exclusive scan of the (k1, k2) counts (+ total) and a
 // copy as the pass-2 append cursors; start1 / cursor1 for pass 1; blk2 = first
 // pass-2 workgroup of every k1 partition (partitions are cut into chunks).
-// (the body: one workgroup of 1024 threads; plan_block: scan the NEXT call's regions instead)
+// (the body: one workgroup of 1024 threads)
 __device__ __forceinline__ void
-p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, int n2,
+p3_scan_body(const uint32_t* __restrict__ cnt, int n1, int n2,
               uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
               uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
               uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
               uint32_t* __restrict__ big_list, unsigned chunk,
-              // the speculative sort (dsm_sort): spec_start2 / spec_cursor2 (may be null) -- the
-              // counts are what pass 2 appended to its regions, not cnt[]; plan (may be null) -- the
-              // NEXT call's regions from this call's counts, count + count / 8 + 32 each:
-              // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1], and its overflow word
-              const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
-              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
               unsigned* __restrict__ host_big /* may be null: pinned mirror of the big list's length */) {
   __shared__ unsigned lds[1024 / 64 + 1];
   __shared__ unsigned s_start1[kP3MaxKeys + 1];
   const int nk = n1 * n2;
-  if (plan_block && !plan) return;
   unsigned carry = 0;
-  if (threadIdx.x == 0 && !plan_block) big_list[0] = 0;
+  if (threadIdx.x == 0) big_list[0] = 0;
   __syncthreads();
   // A wave owns a contiguous segment of the counters and walks it 64 at a time (coalesced; all
   // its loads in flight at once, wave scans without barriers), the workgroup scans the 16 segment
@@ -424,20 +406,11 @@ p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, in
     const int seg = ((nk + 16 * 64 - 1) / (16 * 64)) * 64;  // counters per wave, a multiple of 64
     const int iters = seg / 64;
     const int w0 = wid * seg;
-    unsigned v[kMaxIt];  // the counter (plan_block: the region's size), then its exclusive prefix
-                         // inside the wave's segment
+    unsigned v[kMaxIt];  // the counter, then its exclusive prefix inside the wave's segment
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
       const int i = w0 + q * 64 + lane;
-      if (spec_start2) {
-        const unsigned a = (q < iters && i < nk) ? spec_start2[i] : 0u;
-        const unsigned e = (q < iters && i < nk) ? spec_start2[i + 1] : 0u;
-        const unsigned cu = (q < iters && i < nk) ? spec_cursor2[i] : 0u;
-        v[q] = min(cu, e) - a;
-      } else {
-        v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
-      }
-      if (plan_block) v[q] = (q < iters && i < nk) ? v[q] + (v[q] >> room_shift) + 32u : 0u;
+      v[q] = (q < iters && i < nk) ? cnt[i] : 0u;
     }
     unsigned run = 0;   // (wave-uniform)
 #pragma unroll
@@ -446,7 +419,7 @@ p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, in
         // sub-partitions too full for k_dsm_p3_place's registers but not for a whole
         // CU's LDS (denser parts of a non-uniform cloud): k_dsm_p3_place_big's list
         // (no upper bound: beyond a CU's LDS the big kernel places in several rounds)
-        if (!plan_block && v[q] > cap_small)
+        if (v[q] > cap_small)
           big_list[1 + atomicAdd(&big_list[0], 1u)] = (uint32_t)(w0 + q * 64 + lane);
         const unsigned incl = wave_incl_scan(v[q], lane);
         v[q] = run + incl - v[q];
@@ -461,33 +434,6 @@ p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, in
       const unsigned t = lds[w];
       if (w < wid) base += t;
       total += t;
-    }
-    if (plan_block) {
-      // (region starts and append cursors 1 KB apart at least: the passes' key threads LOAD the
-      // starts -- their limits -- while every workgroup's atomics hammer the cursors)
-      uint32_t* const pstart2 = plan;
-      uint32_t* const pstart1 = plan + nk + 1;
-      uint32_t* const pcur2 = plan + p3_plan_cursor2_at(nk, n1);
-      uint32_t* const pcur1 = pcur2 + ((nk + 255) & ~255);
-#pragma unroll
-      for (int q = 0; q < kMaxIt; ++q) {
-        const int i = w0 + q * 64 + lane;
-        if (q < iters && i < nk) {
-          const unsigned st = base + v[q];
-          pstart2[i] = st;
-          pcur2[i] = st;
-          if (i % n2 == 0) {
-            pstart1[i / n2] = st;
-            pcur1[i / n2] = st;
-          }
-        }
-      }
-      if (threadIdx.x == 0) {
-        pstart2[nk] = total;
-        pstart1[n1] = total;
-        plan_flag[0] = 0u;
-      }
-      return;  // (the whole workgroup)
     }
 #pragma unroll
     for (int q = 0; q < kMaxIt; ++q) {
@@ -524,30 +470,6 @@ p3_scan_body(const bool plan_block, const uint32_t* __restrict__ cnt, int n1, in
   if (k == 0 && host_big) host_big[0] = big_list[0];
 }
 
-// One block (two when there is a plan to write: the second one scans the regions' sizes instead of
-// the counts -- in the same workgroup at the same time the two arrays of 32 prefixes per thread
-// spilled and the kernel took 50 us instead of 17).
-// gate (may be null): the exact pipeline behind a speculative sort -- leaves unless the flag is up;
-// skip_if (may be null): a speculative call's own scan -- nothing to do once a region overflowed (the
-// regions then hold gaps no run was written to; the exact pipeline behind rewrites everything).
-__global__ void __launch_bounds__(1024)
-k_dsm_p3_scan(const uint32_t* __restrict__ cnt, int n1, int n2,
-              uint32_t* __restrict__ start2, uint32_t* __restrict__ cursor2,
-              uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
-              uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
-              uint32_t* __restrict__ big_list, unsigned chunk,
-              const uint32_t* __restrict__ gate,
-              const uint32_t* __restrict__ spec_start2, const uint32_t* __restrict__ spec_cursor2,
-              uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
-              const uint32_t* __restrict__ skip_if, SortAux aux, unsigned* __restrict__ host_big) {
-  if (gate && !*gate) return;
-  if (skip_if && *skip_if) return;
-  if (blockIdx.x == 0) aux_reset(aux);
-  p3_scan_body(blockIdx.x == 1, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big,
-               big_list, chunk, spec_start2, spec_cursor2, plan, plan_flag, room_shift,
-               blockIdx.x == 0 ? host_big : nullptr);
-}
-
 // Count pass, second half: the reduction of the count workgroups' histogram rows (64 counters per
 // workgroup, the rows dealt to its 16 waves) and -- by the workgroup that finishes LAST (a ticket)
 // -- the scan above: one launch instead of two, and the scan starts the moment the last counter is
@@ -558,7 +480,6 @@ k_dsm_p3_reduce_scan(const uint32_t* __restrict__ hist_rows, int nrows, uint32_t
                      uint32_t* __restrict__ start1, uint32_t* __restrict__ cursor1,
                      uint32_t* __restrict__ blk2, unsigned cap_small, unsigned cap_big,
                      uint32_t* __restrict__ big_list, unsigned chunk,
-                     uint32_t* __restrict__ plan, uint32_t* __restrict__ plan_flag, int room_shift,
                      SortAux aux, unsigned* __restrict__ host_big, unsigned* __restrict__ ticket) {
   __shared__ uint32_t s_part[16][64];
   __shared__ unsigned s_last;
@@ -586,31 +507,19 @@ k_dsm_p3_reduce_scan(const uint32_t* __restrict__ hist_rows, int nrows, uint32_t
   __threadfence();    // (the others' counters after the last ticket)
   if (threadIdx.x == 0) *ticket = 0u;
   aux_reset(aux);
-  p3_scan_body(false, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big, big_list, chunk,
-               nullptr, nullptr, nullptr, nullptr, room_shift, host_big);
-  if (plan) {
-    __syncthreads();
-    p3_scan_body(true, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big, big_list, chunk,
-                 nullptr, nullptr, plan, plan_flag, room_shift, nullptr);
-  }
+  p3_scan_body(cnt, n1, n2, start2, cursor2, start1, cursor1, blk2, cap_small, cap_big, big_list, chunk, host_big);
 }
 
 
 // Passes 1 and 2.  kFirst: chunk of the input cloud, key k1, values/centre
 // handling of the reference; else: chunk of one k1 partition, key k2.
-// kSpec (the speculative sort, dsm_sort): the regions come from the previous call's counts plus
-// a margin, `limit[key]` is the end of key's region; a run that does not fit is NOT written and
-// raises *flag -- the exact pipeline then runs behind (k_dsm_p3_scatter_pers).  `end1`: the end of
-// every k1 partition's points in `src` (pass 2; exact pipeline: start1 + 1).  vb: the chunk.
-template <bool kFirst, bool kSpec>
+// vb: the chunk.
+template <bool kFirst>
 __device__ __forceinline__ void p3_scatter_body(const unsigned vb, const double* __restrict__ src,
                                                 const int32_t* __restrict__ values, size_t n,
                                                 const DsmParams& p, const uint32_t* __restrict__ start1,
-                                                const uint32_t* __restrict__ end1,
                                                 const uint32_t* __restrict__ blk2,
-                                                uint32_t* __restrict__ cursor,
-                                                const uint32_t* __restrict__ limit,
-                                                uint32_t* __restrict__ flag, double* __restrict__ dst,
+                                                uint32_t* __restrict__ cursor, double* __restrict__ dst,
                                                 double* __restrict__ zpart) {
   extern __shared__ double s_pts[];                                       // 3 * kP3Chunk
   uint32_t* s_dest = reinterpret_cast<uint32_t*>(s_pts + 3 * kP3Chunk);   // kP3Chunk
@@ -635,10 +544,9 @@ __device__ __forceinline__ void p3_scatter_body(const unsigned vb, const double*
       if (blk2[mid] <= b) lo = mid; else hi = mid;
     }
     c0 = (size_t)start1[lo] + (size_t)(b - blk2[lo]) * kP3Chunk;
-    c1 = min(c0 + (size_t)kP3Chunk, (size_t)end1[lo]);
+    c1 = min(c0 + (size_t)kP3Chunk, (size_t)start1[lo + 1]);
     nkeys = p.p3_n2;
     cursor += (size_t)lo * p.p3_n2;
-    if (kSpec) limit += (size_t)lo * p.p3_n2;
   }
   if (tid < kP3MaxKeys) s_cnt[tid] = 0;
   __syncthreads();
@@ -687,10 +595,8 @@ __device__ __forceinline__ void p3_scatter_body(const unsigned vb, const double*
     range_commit_wave(zlo, zhi, zpart, (size_t)vb * (kP3Threads / 64) + (tid >> 6));
   __syncthreads();
   unsigned my_base = 0;  // first slot of key `tid`'s run in the destination
-  unsigned my_count = 0;
   {
     const unsigned c = (tid < nkeys) ? s_cnt[tid] : 0u;
-    my_count = c;
     unsigned total;
     const unsigned ex = block_excl_scan<kP3Threads>(c, &total, s_scan);
     if (tid < nkeys) {
@@ -713,20 +619,14 @@ __device__ __forceinline__ void p3_scatter_body(const unsigned vb, const double*
       s_dest[q] = slot[k];
     }
   }
-  if (tid < nkeys) {
-    if (kSpec && my_count && (unsigned long long)my_base + my_count > (unsigned long long)limit[tid]) {
-      my_base = 0xFFFFFFFFu;  // (the run does not fit its region: dropped, the exact pipeline follows)
-      *flag = 1u;
-    }
-    s_base[tid] = my_base;
-  }
+  if (tid < nkeys) s_base[tid] = my_base;
   __syncthreads();
   const uint32_t ne = 3u * s_scan[23];
   for (uint32_t e = tid; e < ne; e += kP3Threads) {
     const uint32_t q = e / 3u;
     const uint32_t d = s_dest[q];
     const uint32_t b = s_base[d >> 13];
-    if (!kSpec || b != 0xFFFFFFFFu) dst[3 * (size_t)(b + (d & 0x1FFFu)) + (e - 3u * q)] = s_pts[e];
+    dst[3 * (size_t)(b + (d & 0x1FFFu)) + (e - 3u * q)] = s_pts[e];
   }
 }
 
@@ -736,73 +636,7 @@ k_dsm_p3_scatter(const double* __restrict__ src, const int32_t* __restrict__ val
                  DsmParams p, const uint32_t* __restrict__ start1,
                  const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
                  double* __restrict__ dst, double* __restrict__ zpart) {
-  p3_scatter_body<kFirst, false>(blockIdx.x, src, values, n, p, start1, start1 + 1, blk2, cursor, nullptr,
-                                 nullptr, dst, zpart);
-}
-
-// the speculative sort's passes (regions from the previous call's counts: dsm_sort)
-template <bool kFirst>
-__global__ void __launch_bounds__(kP3Threads)
-k_dsm_p3_scatter_spec(const double* __restrict__ src, size_t n, DsmParams p,
-                      const uint32_t* __restrict__ start1, const uint32_t* __restrict__ end1,
-                      const uint32_t* __restrict__ blk2, uint32_t* __restrict__ cursor,
-                      const uint32_t* __restrict__ limit, uint32_t* __restrict__ flag,
-                      double* __restrict__ dst, double* __restrict__ zpart) {
-  p3_scatter_body<kFirst, true>(blockIdx.x, src, nullptr, n, p, start1, end1, blk2, cursor, limit, flag, dst,
-                                zpart);
-}
-
-// the exact passes BEHIND a speculative sort: a fixed grid that leaves at once unless the
-// speculation overflowed (*gate != 0), and walks the chunks itself if it did (a dense launch of
-// 20 K workgroups that all return costs 0.5 ms; 256 cost 7 us)
-template <bool kFirst>
-__global__ void __launch_bounds__(kP3Threads)
-k_dsm_p3_scatter_pers(const double* __restrict__ src, size_t n, DsmParams p,
-                      const uint32_t* __restrict__ start1, const uint32_t* __restrict__ blk2,
-                      uint32_t* __restrict__ cursor, double* __restrict__ dst,
-                      const uint32_t* __restrict__ gate, unsigned nvb) {
-  if (!*gate) return;
-  for (unsigned vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-    p3_scatter_body<kFirst, false>(vb, src, nullptr, n, p, start1, start1 + 1, blk2, cursor, nullptr, nullptr,
-                                   dst, nullptr);
-    __syncthreads();
-  }
-}
-
-// ---- the speculative sort's small kernel between its passes --------------------------------
-// after pass 1: where every k1 partition's points end, and the chunks of pass 2
-__global__ void __launch_bounds__(1024)
-k_p3_spec_mid(const uint32_t* __restrict__ cstart1, const uint32_t* __restrict__ cursor1, int n1,
-              uint32_t* __restrict__ end1, uint32_t* __restrict__ blk2, unsigned chunk, SortAux aux) {
-  __shared__ unsigned lds[1024 / 64 + 1];
-  aux_reset(aux);
-  const int k = threadIdx.x;
-  unsigned nblk = 0;
-  if (k < n1) {
-    const unsigned e = min(cursor1[k], cstart1[k + 1]);
-    end1[k] = e;
-    nblk = (e - cstart1[k] + chunk - 1) / chunk;
-  }
-  unsigned total;
-  const unsigned ex = block_excl_scan<1024>(nblk, &total, lds);
-  if (k < n1) blk2[k] = ex;
-  if (k == 0) blk2[n1] = total;
-}
-
-// (the exact pipeline's small kernels behind a speculative sort: only if it overflowed)
-__global__ void __launch_bounds__(256)
-k_dsm_p3_reduce_gated(const uint32_t* __restrict__ hist_rows, int nrows, int nk, uint32_t* __restrict__ cnt,
-                      const uint32_t* __restrict__ gate) {
-  if (!*gate) return;
-  __shared__ uint32_t s_part[4][64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
-  uint32_t sum = 0;
-  if (k < nk)
-    for (int r = wid; r < nrows; r += 4) sum += hist_rows[(size_t)r * nk + k];
-  s_part[wid][lane] = sum;
-  __syncthreads();
-  if (wid == 0 && k < nk) cnt[k] = s_part[0][lane] + s_part[1][lane] + s_part[2][lane] + s_part[3][lane];
+  p3_scatter_body<kFirst>(blockIdx.x, src, values, n, p, start1, blk2, cursor, dst, zpart);
 }
 
 // Pass 3: one workgroup per (k1, k2) sub-partition.
@@ -818,8 +652,7 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
                                                    uint32_t* __restrict__ bin_start,
                                                    double* __restrict__ sorted, int sp,
                                                    unsigned skip_lo, unsigned skip_hi,
-                                                   uint2* __restrict__ bin_z,
-                                                   const uint32_t* __restrict__ src_start = nullptr) {
+                                                   uint2* __restrict__ bin_z) {
   extern __shared__ double s_pts[];                                  // 3 * cap
   uint32_t* s_bins = reinterpret_cast<uint32_t*>(s_pts + 3 * cap);   // p3_w
   uint32_t* s_scan = s_bins + p.p3_w;                                // 24
@@ -835,9 +668,6 @@ __device__ __forceinline__ void place_subpartition(const double* __restrict__ sr
     bin_start[(size_t)p.nbx * p.nby] = start2[p.p3_n1 * p.p3_n2];
   if (row >= p.nby || nbw <= 0) return;  // no bins (and therefore no points)
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
-  // (speculative sort: the sub-partition's points lie at src_start[sp] of `src`, their final
-  // place is g0 -- every read below indexes src with FINAL positions)
-  if (src_start) src += 3 * ((long long)src_start[sp] - (long long)g0);
   for (int k = tid; k < nbw; k += THREADS) {
     s_bins[k] = 0;
     if (bin_z) {
@@ -968,8 +798,7 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
                                              const uint32_t* __restrict__ start2,
                                              uint32_t* __restrict__ bin_start, double* __restrict__ sorted,
                                              uint4* __restrict__ rec16, uint32_t* __restrict__ sidx,
-                                             uint2* __restrict__ bin_z, int sp,
-                                             const uint32_t* __restrict__ src_start = nullptr) {
+                                             uint2* __restrict__ bin_z, int sp) {
   // PER > 0: the sub-partition holds at most THREADS * PER points and a thread keeps its PER of
   // them in REGISTERS from the one read to the last round (configs[3] on one GPU: 13.3 K points
   // per sub-partition, 14 per thread); PER == 0: any size, every round re-reads it (from the L2).
@@ -992,7 +821,6 @@ __device__ __forceinline__ void place_rounds(const void* __restrict__ src_v, con
   const int nbw = min(p.p3_w, p.nbx - bx0);
   if (row >= p.nby || nbw <= 0) return;
   const uint32_t g0 = start2[sp], g1 = start2[sp + 1];
-  if (!kRec && src_start) srcd += 3 * ((long long)src_start[sp] - (long long)g0);  // (see place_subpartition)
   auto zkey = [](uint32_t fbits) { return (fbits >> 31) ? ~fbits : (fbits | 0x80000000u); };
   for (int k = tid; k <= nbw; k += THREADS) s_bins[k] = 0;
   if (bin_z)
@@ -1169,60 +997,36 @@ __global__ void __launch_bounds__(kP3PlaceThreads)
 k_dsm_p3_place(const double* __restrict__ src, DsmParams p, int cap,
                const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
-               uint2* __restrict__ bin_z, const uint32_t* __restrict__ src_start,
-               const uint32_t* __restrict__ skip_if /* speculative sort: its overflow word, else null */,
+               uint2* __restrict__ bin_z,
                // (how many sub-partitions the big placement kernel has to take, left in a pinned host
                // word for the NEXT call's launch policy by one thread of this large kernel -- not by
                // the single-workgroup scan every pass waits for; may be null)
                const uint32_t* __restrict__ big_list, unsigned* __restrict__ host_big) {
   if (host_big && blockIdx.x == 0 && threadIdx.x == 0) host_big[0] = big_list[0];
-  // (an overflowed speculative sort leaves holes in its regions -- slots a dropped run reserved
-  // and never wrote: nothing there may be read as a point, ADVICE r4.  The flag is final once pass 2
-  // has run; the exact pipeline launched behind writes the whole output.)
-  if (skip_if && *skip_if) return;
   place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted,
-                                                   (int)blockIdx.x, skip_lo, skip_hi, bin_z, src_start);
-}
-
-// (behind a speculative sort: see k_dsm_p3_scatter_pers)
-__global__ void __launch_bounds__(kP3PlaceThreads)
-k_dsm_p3_place_pers(const double* __restrict__ src, DsmParams p, int cap,
-                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
-                    double* __restrict__ sorted, unsigned skip_lo, unsigned skip_hi,
-                    const uint32_t* __restrict__ gate, int nsp) {
-  if (!*gate) return;
-  for (int sp = (int)blockIdx.x; sp < nsp; sp += (int)gridDim.x) {
-    place_subpartition<kP3PlaceThreads, kP3PlacePer>(src, p, cap, start2, bin_start, sorted, sp, skip_lo,
-                                                     skip_hi, nullptr);
-    __syncthreads();
-  }
+                                                   (int)blockIdx.x, skip_lo, skip_hi, bin_z);
 }
 
 // The same with 1024 threads and a whole CU's LDS (kP3BigCap points), walking
-// the list k_dsm_p3_scan made of the sub-partitions in (skip_lo, skip_hi].
+// the list the scan made of the sub-partitions in (skip_lo, skip_hi].
 __global__ void __launch_bounds__(kP3BigThreads)
 k_dsm_p3_place_big(const double* __restrict__ src, DsmParams p,
                    const uint32_t* __restrict__ start2, uint32_t* __restrict__ bin_start,
                    double* __restrict__ sorted, const uint32_t* __restrict__ big_list,
-                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max,
-                   const uint32_t* __restrict__ src_start /* speculative sort, else null */,
-                   const uint32_t* __restrict__ gate /* the exact pass behind one, else null */,
-                   const uint32_t* __restrict__ skip_if /* a speculative sort's own pass: its overflow word */) {
-  if (gate && !*gate) return;
-  if (skip_if && *skip_if) return;
+                   uint2* __restrict__ bin_z, int cap_rounds, unsigned rounds_above, unsigned reg_max) {
   const unsigned count = big_list[0];
   for (unsigned k = blockIdx.x; k < count; k += gridDim.x) {
     const int sp = (int)big_list[1 + k];
     const uint32_t cnt = start2[sp + 1] - start2[sp];
     if (cnt > rounds_above && cnt <= min(reg_max, (unsigned)(kP3BigThreads * kP3RoundsPer)))
       place_rounds<kP3BigThreads, false, kP3RoundsPer>(src, p, cap_rounds, start2, bin_start, sorted, nullptr,
-                                                       nullptr, bin_z, sp, src_start);
+                                                       nullptr, bin_z, sp);
     else if (cnt > rounds_above)
       place_rounds<kP3BigThreads, false, 0>(src, p, cap_rounds, start2, bin_start, sorted, nullptr, nullptr,
-                                            bin_z, sp, src_start);
+                                            bin_z, sp);
     else
       place_subpartition<kP3BigThreads, kP3BigPer>(src, p, kP3BigCap, start2, bin_start, sorted, sp, 0u,
-                                                   0u, bin_z, src_start);
+                                                   0u, bin_z);
     __syncthreads();
   }
 }
@@ -1693,25 +1497,19 @@ k_dsm_bbox(const double* __restrict__ xyz, size_t n, DsmParams p, int* __restric
       total += (unsigned)s_box[k][4];
     }
     if (total) {
-      atomicMin(&out5[0], lo_i);
-      atomicMax(&out5[1], hi_i);
-      atomicMin(&out5[2], lo_j);
-      atomicMax(&out5[3], hi_j);
+      // (biased so that an all-zero buffer is the empty box: the reset is a memset, not a launch)
+      atomicMax(&out5[0], kBboxBias - lo_i);
+      atomicMax(&out5[1], hi_i + kBboxBias);
+      atomicMax(&out5[2], kBboxBias - lo_j);
+      atomicMax(&out5[3], hi_j + kBboxBias);
       atomicAdd(reinterpret_cast<unsigned*>(&out5[4]), total);
     }
   }
 }
-__global__ void k_dsm_bbox_reset(int* __restrict__ out5) {
-  out5[0] = 0x7FFFFFFF;
-  out5[1] = -0x7FFFFFFF;
-  out5[2] = 0x7FFFFFFF;
-  out5[3] = -0x7FFFFFFF;
-  out5[4] = 0;
-}
 
 int dsm_bbox_run(Ctx* c, const double* dev_xyz, size_t n, const DsmParams& p, int* dev_bbox5) {
   ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
-  hipLaunchKernelGGL(k_dsm_bbox_reset, dim3(1), dim3(1), 0, c->stream, dev_bbox5);
+  AMHIP_TRY(hipMemsetAsync(dev_bbox5, 0, 5 * sizeof(int), c->stream));
   size_t grid = std::min<size_t>((n + 2047) / 2048, 128);
   hipLaunchKernelGGL(k_dsm_bbox, dim3((unsigned)grid), dim3(256), 0, c->stream, dev_xyz, n, p, dev_bbox5);
   AMHIP_TRY(hipGetLastError());
@@ -1825,17 +1623,14 @@ static void p3_rounds_knob(int* cap_rounds, unsigned* rounds_above, unsigned* re
   if (reread) *reg_max = 0u;
 }
 
-__global__ void k_aux_reset(SortAux aux) { aux_reset(aux); }
-
 // tuning knob no_launch_skips (tests, A-B): every capacity-class / big-list launch is made whatever the
 // previous call's counters say (amhip_dsm.hip: dsm_run uses the same switch)
 bool no_launch_skips() {
   return tuning_on("no_launch_skips");
 }
 
-// ---- the speculative sort's host side ------------------------------------------------------
-// what the previous call's counts are counts OF: the window's geometry and the sort's plan
-static unsigned long long spec_signature(const DsmParams& p) {
+// what a call's pinned launch-policy counters are counters OF: the window's geometry and the sort's plan
+static unsigned long long sort_geometry_signature(const DsmParams& p) {
   unsigned long long h = 1469598103934665603ull;
   auto mix = [&](const void* v, size_t bytes) {
     const unsigned char* b = static_cast<const unsigned char*>(v);
@@ -1849,36 +1644,6 @@ static unsigned long long spec_signature(const DsmParams& p) {
   return h ? h : 1ull;
 }
 
-// The overflow word of the last speculative call, if it has arrived (a pinned word the host never
-// waits for): a miss starts the cooldown -- 8 counting calls, twice as many after every further
-// miss in a row, at most 64 (a host that alternates between two surveys on one context pays for a
-// wasted scatter ever more rarely).  ONE definition for dsm_sort and amhip_ctx_dsm_sort_stats.
-bool spec_poll_overflow(Ctx* c) {
-  if (!c->spec_flag_host || !c->spec_flag_host[0]) return false;
-  c->spec_flag_host[0] = 0u;
-  c->spec_cooldown = c->spec_backoff;
-  c->spec_backoff = std::min(2 * c->spec_backoff, 64);
-  c->spec_last_hit = false;
-  ++c->spec_misses;
-  return true;
-}
-
-// amhip_ctx_set_dsm_sort_reuse(ctx, 0) / tuning knob sort_no_speculation: always count first
-static bool spec_wanted(Ctx* c, size_t n, unsigned long long sig) {
-  const bool off = !c->spec_reuse || tuning_on("sort_no_speculation");  // (looked up per call: tests flip it)
-  if (off || !c->spec_valid || c->spec_sig != sig || !c->spec_plan) return false;
-  if (!spec_poll_overflow(c) && c->spec_last_hit)
-    c->spec_backoff = 8;  // (the last speculative call's word arrived clear, or has not arrived yet)
-  c->spec_last_hit = false;
-  if (c->spec_cooldown > 0) {
-    --c->spec_cooldown;
-    return false;
-  }
-  // (more points than the margins can take, or far fewer: count first)
-  c->spec_last_hit = n <= c->spec_n + c->spec_n / 16 + 1024 && 2 * n >= c->spec_n;
-  return c->spec_last_hit;
-}
-
 // ---------------------------------------------------------------------------
 // host driver: sort `n` points into c->sorted / c->bin_start
 // ---------------------------------------------------------------------------
@@ -1890,13 +1655,8 @@ int dsm_sort(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
              const DsmParams& p, unsigned long long* zrange, const SortSplit* split) {
   const int rc = dsm_sort_impl(c, dev_xyz, dev_values, n, p, zrange, split);
   if (rc) return rc;
-  if (!c->aux_done && !(split && split->phase == 1)) {
-    // (no path gets here: every sort hands SortAux to one of its single-workgroup kernels)
-    const SortAux aux = {c->dev_zrange + 2, c->aux_zero_words, c->aux_zero_words ? c->aux_nzero : 0};
-    hipLaunchKernelGGL(k_aux_reset, dim3(1), dim3(64), 0, c->stream, aux);
-    AMHIP_TRY(hipGetLastError());
-    c->aux_done = true;
-  }
+  // (every sort hands SortAux to one of its single-workgroup kernels)
+  if (!c->aux_done && !(split && split->phase == 1)) return arg_failure("dsm_sort: the call's range was not reset");
   return AMHIP_OK;
 }
 
@@ -1923,34 +1683,11 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
   c->range_running = zrange;
   const size_t nbins = (size_t)p.nbx * (size_t)p.nby;
   const size_t nblocks_scan = (nbins + kScanE - 1) / kScanE;
-  // the speculative sort (three-pass, FP64 pipeline, plain DSM call): see below
   const bool force_one_level_ = tuning_on("sort_one_level");
-  // (up to 2^27 points, the sizes it was measured at: - 0.19 ms of 5.75 at 50 M points, - 0.48 of
-  // 9.50 at 100 M.  Until the plan kept its region STARTS -- which every workgroup's key threads load
-  // as their limits -- 1 KB away from the append CURSORS -- which every workgroup's atomics hammer
-  // --, the first speculative pass ran at two thirds to half speed from 100 M points on (+ 0.8 /
-  // 1.6 / 3.3 ms at 100 / 200 / 400 M: tools/sort_scale_probe.py); larger clouds were not measured
-  // again after that and keep counting first.  tuning knob sort_spec_max_points moves the limit.)
-  const size_t spec_max_points = (size_t)tuning("sort_spec_max_points", (double)((size_t)1 << 27));
-  // (amhip_ctx_set_dsm_sort_reuse(ctx, 0): no plans are read OR written -- the scan's second pass goes too)
-  const bool spec_mode = p.p3_n1 > 0 && !force_one_level_ && !p.fx_ok && !p.pcl_mode && !dev_values && !split &&
-                         n <= spec_max_points && c->spec_reuse;
-  const unsigned long long geo_sig = spec_signature(p);   // (window geometry + sort plan)
-  const unsigned long long sig = spec_mode ? geo_sig : 0ull;
-  const bool spec = spec_mode && spec_wanted(c, n, sig);
-  // (the regions' head room: count >> room_shift; tuning knob sort_spec_margin_shift, 1 .. 31, experiments)
-  const int room_shift = std::min(31, std::max(1, (int)tuning("sort_spec_margin_shift", 3.0)));
-  // (regions of count + count / 8 + 32 over the previous call's counts)
-  // (reserved from the context's FIRST such call on: growing the two point buffers later means
-  // freeing 2 x 9.6 GB and allocating 2 x 10.8 GB at configs[3]'s size, and the new blocks came back
-  // in small physical fragments -- the first scatter pass, whose writes roam the whole buffer, then
-  // ran at half speed on TLB misses: 9.5 ms instead of 4.6)
-  const size_t spec_basis = std::max(n, spec ? c->spec_n : (size_t)0);
-  const size_t spec_points = spec_mode ? spec_basis + (spec_basis >> room_shift) + spec_basis / 16 +
-                                             32 * (size_t)p.p3_n1 * (size_t)p.p3_n2 + 2048 : 0;
+  const unsigned long long geo_sig = sort_geometry_signature(p);   // (window geometry + sort plan)
   {
     int rc;
-    if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * std::max(n, spec_points)))) return rc;
+    if ((rc = ensure_capacity(&c->sorted, &c->sorted_cap, 3 * n))) return rc;
     if ((rc = ensure_capacity(&c->bin_start, &c->bin_cap, nbins + 4))) return rc;
   }
   c->last_num_bins = (int64_t)nbins;
@@ -1988,7 +1725,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
       if ((rc = ensure_capacity(&c->rec_a, &c->rec_a_cap, (size_t)kRecWords * n + 16))) return rc;
       if ((rc = ensure_capacity(&c->rec_b, &c->rec_b_cap, (size_t)kRecWords * n + 16))) return rc;
       if ((rc = ensure_capacity(&c->zall, &c->zall_cap, 2 * gcount * (kP3CountThreads / 64) + 16))) return rc;
-    } else if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * std::max(n, spec_points)))) {
+    } else if ((rc = ensure_capacity(&c->tmp_points, &c->tmp_points_cap, 3 * n))) {
       return rc;
     }
     double* const zall = rec ? c->zall : nullptr;
@@ -2002,130 +1739,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
     uint32_t* cursor1 = start1 + n1 + 1;
     uint32_t* blk2 = cursor1 + n1;     // n1 + 1
     uint32_t* big_list = blk2 + n1 + 1;  // [count] + up to nk sub-partition ids
-    uint32_t* end1 = big_list + nk + 1;  // n1 (speculative sort: the ends of pass 1's partitions)
-    // The speculative sort's plans live in a buffer of their own (two of them, used alternately:
-    // a call consumes the plan its predecessor's k_dsm_p3_scan wrote and writes its successor's):
-    // [cstart2: nk + 1][cursor2: nk][cstart1: n1 + 1][cursor1: n1] each, then the two overflow words
-    const size_t plan_words = p3_plan_words(nk, n1);
-    uint32_t *plan_use = nullptr, *plan_next = nullptr, *flag_use = nullptr, *flag_next = nullptr;
-    if (spec_mode) {
-      uint32_t* const before = c->spec_plan;
-      if ((rc = ensure_capacity(&c->spec_plan, &c->spec_plan_cap, 2 * plan_words + 16))) return rc;
-      if (c->spec_plan != before && spec) return arg_failure("speculative sort: plan buffer moved");  // (cannot happen: the signature holds nk)
-      if (!c->spec_flag_host) {
-        AMHIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->spec_flag_host), 4 * sizeof(unsigned), 0));
-        c->spec_flag_host[0] = 0u;
-      }
-      const int use = c->spec_parity & 1, next = use ^ 1;
-      plan_use = c->spec_plan + (size_t)use * plan_words;
-      plan_next = c->spec_plan + (size_t)next * plan_words;
-      flag_use = c->spec_plan + 2 * plan_words + use;
-      flag_next = c->spec_plan + 2 * plan_words + next;
-      ++c->spec_calls;
-    }
-    uint32_t* const cstart2 = plan_use;                                                     // nk + 1
-    uint32_t* const cstart1 = plan_use ? plan_use + nk + 1 : nullptr;                       // n1 + 1
-    uint32_t* const cursor2s = plan_use ? plan_use + p3_plan_cursor2_at(nk, n1) : nullptr;  // nk
-    uint32_t* const cursor1s = plan_use ? cursor2s + ((nk + 255) & ~255) : nullptr;         // n1
-    uint32_t* const spec_flag = flag_use;
-    if (spec) {
-      // ---- the speculative sort -----------------------------------------
-      // No count pass: both scatter passes append into regions sized from the PREVIOUS call's
-      // exact (k1, k2) counts on this context (count + count / 8 + 32 each), a run that does not
-      // fit raises a flag instead of being written; the cursors give this call's exact counts,
-      // k_dsm_p3_scan the final positions, and the placement pass moves every sub-partition from
-      // its region to its place.  Behind it the exact pipeline is launched as FIXED grids that
-      // leave at once unless the flag is up (no device-side launch in HIP; a host wait inside a
-      // DSM call is not on offer): a few hundred workgroups each.  A miss costs the wasted
-      // scatters once; the context then counts first for the next eight calls.  It can only hit
-      // when consecutive calls bring similarly distributed clouds.
-      ++c->spec_hits_started;
-      const SortAux no_aux = {nullptr, nullptr, 0};   // (k_p3_spec_mid did it)
-      const size_t g1 = (n + kP3Chunk - 1) / kP3Chunk;
-      const size_t lds_sc = (size_t)kP3Chunk * 28 + (3 * kP3MaxKeys + 32) * sizeof(uint32_t);
-      const size_t lds_cnt = (size_t)nk * sizeof(uint32_t);
-      const size_t lds_pl = (size_t)p.p3_cap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t);
-      const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
-      int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
-      unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
-      p3_rounds_knob(&cap_rounds, &rounds_above, &reg_max);
-      const size_t lds_big = std::max((size_t)kP3BigCap * 24 + ((size_t)p.p3_w + 32) * sizeof(uint32_t),
-                                      (size_t)cap_rounds * 24 + tables);
-      const void* kernels_sc[] = {reinterpret_cast<const void*>(k_dsm_p3_scatter_spec<true>),
-                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_spec<false>),
-                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_pers<true>),
-                                  reinterpret_cast<const void*>(k_dsm_p3_scatter_pers<false>)};
-      for (const void* k : kernels_sc)
-        AMHIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sc));
-      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_count<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cnt));
-      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pl));
-      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_pers),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pl));
-      AMHIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dsm_p3_place_big),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-      {
-        ScopedTimer t(c, AMHIP_K_DSM_SCATTER);
-        hipLaunchKernelGGL(k_dsm_p3_scatter_spec<true>, dim3((unsigned)g1), dim3(kP3Threads), lds_sc, c->stream,
-                           dev_xyz, n, p, cstart1, (const uint32_t*)nullptr, (const uint32_t*)nullptr, cursor1s,
-                           cstart1 + 1, spec_flag, c->sorted, zpart);
-        c->range_parts = (size_t)g1 * (kP3Threads / 64);
-        hipLaunchKernelGGL(k_p3_spec_mid, dim3(1), dim3(1024), 0, c->stream, cstart1, cursor1s, n1, end1, blk2,
-                           (unsigned)kP3Chunk, aux);
-        c->aux_done = true;
-        hipLaunchKernelGGL(k_dsm_p3_scatter_spec<false>, dim3((unsigned)(g1 + n1)), dim3(kP3Threads), lds_sc,
-                           c->stream, c->sorted, n, p, cstart1, end1, blk2, cursor2s, cstart2 + 1, spec_flag,
-                           c->tmp_points, (double*)nullptr);
-      }
-      {
-        ScopedTimer t(c, AMHIP_K_DSM_SCAN);
-        // (this call's exact counts are what pass 2 appended; the same kernel plans the next call)
-        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
-                           start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
-                           (unsigned)kP3Chunk, (const uint32_t*)nullptr, cstart2, cursor2s, plan_next, flag_next, room_shift,
-                           spec_flag, no_aux, (unsigned*)nullptr);
-        hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds_pl, c->stream,
-                           c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, (unsigned)p.p3_cap,
-                           0xFFFFFFFFu, (uint2*)nullptr, cstart2, spec_flag, (const uint32_t*)nullptr, (unsigned*)nullptr);
-        hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                           c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, (uint2*)nullptr,
-                           cap_rounds, rounds_above, reg_max, cstart2, (const uint32_t*)nullptr, spec_flag);
-      }
-      {
-        // ---- the exact pipeline behind it: leaves at once unless spec_flag is up ----
-        ScopedTimer t(c, AMHIP_K_MISC);
-        const HaloParams no_halo = {};
-        hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds_cnt, c->stream,
-                           dev_xyz, n, p, hist_rows, no_halo, (double*)nullptr, (unsigned long long*)nullptr,
-                           (double*)nullptr, spec_flag);
-        hipLaunchKernelGGL(k_dsm_p3_reduce_gated, dim3((unsigned)((nk + 63) / 64)), dim3(256), 0, c->stream,
-                           hist_rows, (int)gcount, nk, cnt, spec_flag);
-        hipLaunchKernelGGL(k_dsm_p3_scan, dim3(plan_next ? 2 : 1), dim3(1024), 0, c->stream, cnt, n1, n2, start2, cursor2,
-                           start1, cursor1, blk2, (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list,
-                           (unsigned)kP3Chunk, spec_flag, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
-                           plan_next, flag_next, room_shift, (const uint32_t*)nullptr, no_aux, (unsigned*)nullptr);
-        hipLaunchKernelGGL(k_dsm_p3_scatter_pers<true>, dim3(512), dim3(kP3Threads), lds_sc, c->stream, dev_xyz,
-                           n, p, start1, blk2, cursor1, c->sorted, spec_flag, (unsigned)g1);
-        hipLaunchKernelGGL(k_dsm_p3_scatter_pers<false>, dim3(512), dim3(kP3Threads), lds_sc, c->stream,
-                           c->sorted, n, p, start1, blk2, cursor2, c->tmp_points, spec_flag,
-                           (unsigned)(g1 + n1));
-        // (every sub-partition, the over-full ones by direct placement: this pass is the rare one)
-        hipLaunchKernelGGL(k_dsm_p3_place_pers, dim3(1024), dim3(kP3PlaceThreads), lds_pl, c->stream,
-                           c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted, 0xFFFFFFFFu,
-                           0xFFFFFFFFu, spec_flag, nk);
-        // this call's overflow word for the host's policy (never waited for)
-        AMHIP_TRY(hipMemcpyAsync(c->spec_flag_host, spec_flag, sizeof(unsigned), hipMemcpyDeviceToHost,
-                                 c->stream));
-        AMHIP_TRY(hipGetLastError());
-      }
-      c->spec_n = n;
-      c->spec_parity ^= 1;  // (the plan this call's scan wrote)
-      c->bin_z_valid = false;
-      return AMHIP_OK;
-    }
     {
-
       ScopedTimer t(c, AMHIP_K_DSM_BIN_COUNT);
       const size_t lds = (size_t)nk * sizeof(uint32_t);
       const size_t lds_halo = (size_t)((nk + 1) & ~1) * sizeof(uint32_t) + sizeof(HaloStage);
@@ -2139,19 +1753,19 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
                                  sizeof(unsigned long long) * split->hp.nd, c->stream));
         hipLaunchKernelGGL(k_dsm_p3_count<true>, dim3((unsigned)g_a), dim3(kP3CountThreads),
                            lds_halo, c->stream, dev_xyz, n_a, p, hist_rows, split->hp, split->halo_out,
-                           split->halo_counts, zall, (const uint32_t*)nullptr);
+                           split->halo_counts, zall);
         AMHIP_TRY(hipGetLastError());
         return AMHIP_OK;  // amhip_dsm_tiled_finish_dev comes back with phase 2
       }
       if (!split)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_a), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz, n_a, p, hist_rows, no_halo, (double*)nullptr,
-                           (unsigned long long*)nullptr, zall, (const uint32_t*)nullptr);
+                           (unsigned long long*)nullptr, zall);
       else if (g_b)
         hipLaunchKernelGGL(k_dsm_p3_count<false>, dim3((unsigned)g_b), dim3(kP3CountThreads), lds,
                            c->stream, dev_xyz + 3 * n_a, n - n_a, p, hist_rows + g_a * (size_t)nk,
                            no_halo, (double*)nullptr, (unsigned long long*)nullptr,
-                           zall ? zall + 2 * g_a * (kP3CountThreads / 64) : nullptr, (const uint32_t*)nullptr);
+                           zall ? zall + 2 * g_a * (kP3CountThreads / 64) : nullptr);
       // (the records' reference height: the middle of the range every count workgroup left --
       // in a tiled call both parts', the second of which may be absent: its rows hold the first
       // call's partials or the initial "empty" pairs)
@@ -2162,15 +1776,9 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
       hipLaunchKernelGGL(k_dsm_p3_reduce_scan, dim3((unsigned)((nk + 63) / 64)), dim3(1024), 0, c->stream,
                          hist_rows, (int)gcount, cnt, n1, n2, start2, cursor2, start1, cursor1, blk2,
                          (unsigned)p.p3_cap, (unsigned)kP3BigCap, big_list, (unsigned)(rec ? kRecChunk : kP3Chunk),
-                         plan_next, flag_next, room_shift, aux, (unsigned*)nullptr, c->dev_tickets);
+                         aux, (unsigned*)nullptr, c->dev_tickets);
       c->aux_done = true;
       AMHIP_TRY(hipGetLastError());
-      if (spec_mode) {  // (the next call on this context may run on the plan the scan just wrote)
-        c->spec_valid = true;
-        c->spec_sig = sig;
-        c->spec_n = n;
-        c->spec_parity ^= 1;
-      }
     }
     if (rec) {
       {
@@ -2256,8 +1864,8 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
       c->sort_stats_sig = geo_sig;
       hipLaunchKernelGGL(k_dsm_p3_place, dim3((unsigned)nk), dim3(kP3PlaceThreads), lds,
                          c->stream, c->tmp_points, p, p.p3_cap, start2, c->bin_start, c->sorted,
-                         want_big ? (unsigned)p.p3_cap : 0xFFFFFFFFu, 0xFFFFFFFFu, bin_z, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)big_list, c->host_sort_stats);
+                         want_big ? (unsigned)p.p3_cap : 0xFFFFFFFFu, 0xFFFFFFFFu, bin_z,
+                         (const uint32_t*)big_list, c->host_sort_stats);
       const size_t tables = (4 * (size_t)p.p3_w + 64) * sizeof(uint32_t);
       int cap_rounds = (int)std::min<size_t>(kP3BigCap, (kLdsMaxBytes - tables) / 24);
       unsigned rounds_above = kP3BigCap, reg_max = 0xFFFFFFFFu;
@@ -2268,8 +1876,7 @@ static int dsm_sort_impl(Ctx* c, const double* dev_xyz, const int32_t* dev_value
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
       if (want_big)
         hipLaunchKernelGGL(k_dsm_p3_place_big, dim3(256), dim3(kP3BigThreads), lds_big, c->stream,
-                           c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+                           c->tmp_points, p, start2, c->bin_start, c->sorted, big_list, bin_z, cap_rounds, rounds_above, reg_max);
       c->bin_z_valid = bin_z != nullptr;
       AMHIP_TRY(hipGetLastError());
     }

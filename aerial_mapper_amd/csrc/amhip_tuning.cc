@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
+#include <atomic>
 #include <mutex>
 #include <string>
 
@@ -17,7 +17,7 @@ namespace {
 const char* const kKeys[] = {
     // sort
     "sort_one_level", "p3_min_points", "p3_target", "p3_cap", "p3_rounds_cap", "p3_rounds_reread",
-    "sort_no_speculation", "sort_spec_max_points", "sort_spec_margin_shift", "no_launch_skips",
+    "no_launch_skips",
     // DSM gather
     "dsm_canon_all", "dsm_no_rough_switch", "dsm_no_subwindow", "eager_reset",
     // mosaic
@@ -30,19 +30,24 @@ const char* const kKeys[] = {
     "gather_tj", "gather_nt", "gather_class_cap0", "gather_class_cap1", "gather_class_cap2", "f32_variant",
     "fx_theta"};
 
-bool known(const std::string& k) {
-  for (const char* s : kKeys)
-    if (k == s) return true;
-  return false;
+constexpr int kNumKeys = (int)(sizeof(kKeys) / sizeof(kKeys[0]));
+
+int key_index(const char* k, size_t len) {
+  for (int i = 0; i < kNumKeys; ++i)
+    if (std::strlen(kKeys[i]) == len && std::memcmp(kKeys[i], k, len) == 0) return i;
+  return -1;
 }
 
+// One atomic slot per key (NaN = not set): a look-up is a string compare over ~30 short keys and one
+// relaxed load -- no lock, no allocation on the per-call host path; the environment is
+// read once.
 struct Store {
-  std::mutex mu;
-  std::map<std::string, double> values;
-  bool env_read = false;
-  void read_env() {  // (mu held)
-    if (env_read) return;
-    env_read = true;
+  std::atomic<double> values[kNumKeys];
+  std::once_flag env_once;
+  Store() {
+    for (auto& v : values) v.store(std::nan(""), std::memory_order_relaxed);
+  }
+  void read_env() {
     const char* e = std::getenv("AMHIP_TUNING");
     if (!e) return;
     std::string s(e);
@@ -57,13 +62,15 @@ struct Store {
       const size_t eq = item.find('=');
       const std::string key = item.substr(0, eq);
       const double v = eq == std::string::npos ? 1.0 : std::atof(item.c_str() + eq + 1);
-      if (!known(key)) {
+      const int k = key_index(key.data(), key.size());
+      if (k < 0) {
         std::fprintf(stderr, "libaerial_mapper_hip: AMHIP_TUNING names an unknown key '%s' (ignored)\n", key.c_str());
         continue;
       }
-      values[key] = v;
+      values[k].store(v, std::memory_order_relaxed);
     }
   }
+  void ensure_env() { std::call_once(env_once, [this] { read_env(); }); }
 };
 
 Store& store() {
@@ -75,19 +82,19 @@ Store& store() {
 
 double tuning(const char* key, double dflt) {
   Store& s = store();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.read_env();
-  const auto it = s.values.find(key);
-  return it == s.values.end() ? dflt : it->second;
+  s.ensure_env();
+  const int k = key ? key_index(key, std::strlen(key)) : -1;
+  if (k < 0) return dflt;
+  const double v = s.values[k].load(std::memory_order_relaxed);
+  return std::isnan(v) ? dflt : v;
 }
 
 bool tuning_set(const char* key, double value) {
-  if (!key || !known(key)) return false;
+  const int k = key ? key_index(key, std::strlen(key)) : -1;
+  if (k < 0) return false;
   Store& s = store();
-  std::lock_guard<std::mutex> lock(s.mu);
-  s.read_env();
-  if (std::isnan(value)) s.values.erase(key);
-  else s.values[key] = value;
+  s.ensure_env();
+  s.values[k].store(value, std::memory_order_relaxed);   // (NaN clears the key)
   return true;
 }
 

@@ -186,7 +186,13 @@ class AerialGridMap(object):
 
     def torch_waits(self):
         """The reverse of wait_for_torch: what this context's kernels wrote must be
-        complete before torch work on ANOTHER stream reads it."""
+        complete before torch work on ANOTHER stream reads it.
+
+        Only torch's CURRENT stream (on this map's device) is ordered behind the call, and the host
+        does not wait: a device-side CHECK (exact hit, alpha <= 0) of a sync=False call is raised by the
+        next synchronize(), not here; an input tensor that is freed or refilled from a THIRD stream
+        before the call has run still races with it -- keep it alive (or record_stream() it) until
+        synchronize()."""
         import torch
         cur = torch.cuda.current_stream(torch.device("cuda", self.device))
         # (handle 0 = the map runs on its OWN stream, which is never torch's: always order)
@@ -229,19 +235,6 @@ class AerialGridMap(object):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int32()
         L.check(self._lib.amhip_ctx_dsm_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"points_binned": a.value, "num_bins": b.value, "bin_cells": c.value}
-
-    def dsm_sort_stats(self):
-        """amhip_ctx_dsm_sort_stats: the speculative sort's bookkeeping on this context."""
-        out = (C.c_int64 * 4)()
-        L.check(self._lib.amhip_ctx_dsm_sort_stats(self._h, out))
-        return {"three_pass_calls": int(out[0]), "speculative": int(out[1]), "overflowed": int(out[2]),
-                "counting_calls_left": int(out[3])}
-
-    def set_dsm_sort_reuse(self, on):
-        """amhip_ctx_set_dsm_sort_reuse: False (the default) = every DSM call counts first (what a
-        context's first call runs: the reference hosts' call pattern, one process() per process);
-        True = a call may size its sort regions from its predecessor's counts (opt-in)."""
-        L.check(self._lib.amhip_ctx_set_dsm_sort_reuse(self._h, 1 if on else 0))
 
     def dsm_gather_stats(self):
         """amhip_ctx_dsm_gather_stats: where the gather tiles of the last DSM call went."""

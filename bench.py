@@ -29,13 +29,13 @@ dsm.cc:160-172).  The opt-in single-precision mode is timed in the same run and 
 the extra object `fast_mode`, with its own parity sample and roofline.
 
 `value` is the call the reference's hosts make (main-dsm.cc:103-107, main-ortho-backward-grid.cc:
-128-141: ONE process() per process): every timed DSM call runs what a context's FIRST call runs
--- the counting sort: the library's default since round 5 (reusing a predecessor's partition plan is
-opt-in, amhip_ctx_set_dsm_sort_reuse(ctx, 1)), so repeating one cloud in the timed loop skips no work.
-The N > 1 ranks run the same pipeline (a tiled call always counts: its count pass selects the
-halo).  What a context that re-processes similar clouds gets on top (the speculative sort,
-amhip_sort.hip) is timed beside it as the extra object `sort`: the same cloud again, and three
-distinct-seed clouds in rotation (a hit there is earned: no call has seen its cloud before).
+128-141: ONE process() per process): every timed DSM call counts, sorts and gathers its cloud from
+scratch -- no data pass is skipped because the cloud repeats (the round-4 plan reuse is gone from
+the library).  The N > 1 ranks run the same pipeline.  The one thing a repeated call still takes
+from its predecessor is a LAUNCH policy: kernels whose work lists were empty last time (the
+capacity-class gathers, the big-sub-partition placement) are not launched; the extra object
+`launch_skips` times the same steps with every such kernel launched (tuning key no_launch_skips:
+what a context's very first call runs) so the difference is on the line.
 
 The parity sample is the WHOLE map by default (--cpu-sample-side 10000: the reference's own
 Dsm::process + OrthoBackwardGrid::process on all 1e8 cells, ~1 min of host time).
@@ -99,10 +99,6 @@ def parse():
                     help="cells per side of the corner sub-tile the reference's CPU path is timed on and "
                          "the GPU layers are compared with (default: the whole 10000 x 10000 map of cfg3, "
                          "~1 min of host time; 4000 for a quick run)")
-    ap.add_argument("--sort-reuse", action="store_true",
-                    help="let the timed steps reuse the previous call's partition plan (the speculative "
-                         "sort: repeated cloud -> no count pass).  Default off: `value` is what a "
-                         "context's first call runs; the reuse is timed beside it (`sort`)")
     ap.add_argument("--colored", action="store_true", help="8UC3 frames / colored_ortho")
     ap.add_argument("--host-path", action="store_true", default=True,
                     help="(default at N = 1) also time ONE pass through the host-buffer (drop-in) "
@@ -689,9 +685,6 @@ def main():
         m.set_dsm_knn(args.knn)
     # the gather's arithmetic in the timed steps (the library's own default is EXACT since round 3)
     m.set_dsm_precision(args.dsm_mode == "exact")
-    # the sort of the timed steps: what a context's FIRST call runs (the reference hosts' call
-    # pattern: one process() per process; the library's default) unless --sort-reuse
-    m.set_dsm_sort_reuse(bool(args.sort_reuse))
     # centre of this rank's window in map coordinates (x decreases with i, y with j)
     tile_center = (ox + Lx / 2.0 - (win[0] + win[2] / 2.0) * res,
                    oy + Ly / 2.0 - (win[1] + win[3] / 2.0) * res)
@@ -751,15 +744,11 @@ def main():
         tiled = tiling.TiledDsm(dsm.settings, m, layout, rank, halo_cap,
                                 comm=tiling.TorchComm(via_host=True) if one_gpu else None)
 
-    ring = {"clouds": [pts], "k": 0}   # (the `sort` extra rotates distinct clouds through here)
-
     def run_dsm():
         if tiled is not None:
             tiled.process(pts_buf, n_pts, sync=False)
         else:
-            cl = ring["clouds"]
-            dsm.process(cl[ring["k"] % len(cl)], m, sync=False)
-            ring["k"] += 1
+            dsm.process(pts, m, sync=False)
 
     if batch:
         # incremental mapping: layers stay resident, every step appends the next batch
@@ -940,12 +929,9 @@ def main():
                                     "exact": "AMHIP_DSM_EXACT (the library's default: FP64, the "
                                              "reference's arithmetic and floats; the opt-in single-"
                                              "precision mode is timed beside it: fast_mode)"}[args.dsm_mode],
-                       "sort_pipeline": ("reuse of the previous call's partition plan allowed (--sort-reuse)"
-                                         if args.sort_reuse and tiled is None else
-                                         "counting sort on every call = what a context's FIRST call runs "
-                                         "(main-dsm.cc:103-107: one process() per process); the same "
-                                         "pipeline at every N (a tiled call always counts: its count pass "
-                                         "selects the halo)"),
+                       "sort_pipeline": "counting sort on every call (count, two scatter passes, placement); "
+                                        "the same pipeline at every N (a tiled call's count pass also "
+                                        "selects the halo)",
                        "cells_per_gpu": cells, "points_per_gpu": N, "frames": F_step,
                        "step": "layers reset (lazy: the fills are fused into the kernels that "
                                "produce the layers; AMHIP_TUNING=eager_reset for plain fills) + "
@@ -1061,51 +1047,28 @@ def main():
                     out["ortho_mismatch_cells_fast_mode"] = (
                         out["parity_sample"] if args.dsm_mode == "fast" else om.get("parity_sample", {})).get(key)
             del refs
-        # What a context that sees similar clouds again gets on top of `value` (the speculative sort,
-        # amhip_sort.hip: dsm_sort -- a call sizes its sort regions from its predecessor's exact counts
-        # and skips the count pass; a region that overflows sends the call through the counting
-        # pipeline launched behind it, same heights either way).  Never the headline: no reference
-        # host calls process() twice on one object's worth of state (main-dsm.cc:103-107).
-        if not batch and not args.knn:
+        # The launch policy a repeated call takes from its predecessor: kernels whose work
+        # lists were empty last time are not launched.  The same steps with every one launched = what
+        # a context's very first call runs.
+        if world == 1 and not batch and not args.knn and tiled is None:
             try:
-                sort_obj = {"timed_steps": "reuse (speculative sort)" if args.sort_reuse else
-                            "counting sort: every call runs what a context's first call runs"}
-                if world == 1 and not args.no_second_mode and args.dsm_mode == "exact" and tiled is None:
-                    k3 = max(3, min(args.steps, 10))
-                    before = m.dsm_sort_stats()
-                    m.set_dsm_sort_reuse(True)
-                    sec, kms = timed_loop(k3, 2)
+                from aerial_mapper_amd import hip_lib as _hl
+                k3 = max(3, min(args.steps, 10))
+                _hl.set_tuning("no_launch_skips", 1)
+                try:
+                    sec, kms = timed_loop(k3, 1)
                     m.synchronize()
-                    mid = m.dsm_sort_stats()
-                    sort_obj["reuse_same_cloud"] = {
-                        "steps": k3, "ms_per_step": round(sec * 1e3, 3),
-                        "Mcells_per_s": round(cells_all / sec / 1e6, 1),
-                        "speculative_calls": mid["speculative"] - before["speculative"],
-                        "overflowed": mid["overflowed"] - before["overflowed"],
-                        "kernels_ms": {k: round(v, 4) for k, v in kms.items()}}
-                    if not wl.get("mt19937_seed"):
-                        # three clouds of the same survey, distinct seeds: no call has seen its cloud
-                        for extra_seed in (1043, 2043):
-                            ring["clouds"].append(synth.make_points_torch(n_pts, half, extra_seed + rank, dev,
-                                                                          center=tile_center))
-                        ring["k"] = 0
-                        sec, kms = timed_loop(max(k3, 6), 3)
-                        m.synchronize()
-                        after = m.dsm_sort_stats()
-                        sort_obj["reuse_rotating_clouds"] = {
-                            "clouds": 3, "steps": max(k3, 6), "ms_per_step": round(sec * 1e3, 3),
-                            "Mcells_per_s": round(cells_all / sec / 1e6, 1),
-                            "speculative_calls": after["speculative"] - mid["speculative"],
-                            "overflowed": after["overflowed"] - mid["overflowed"],
-                            "note": "the layers after these steps are another cloud's: nothing below "
-                                    "compares them"}
-                        del ring["clouds"][1:]
-                    m.set_dsm_sort_reuse(bool(args.sort_reuse))
-                    ring["k"] = 0
-                    timed_loop(1, 0)   # (the layers hold the timed steps' cloud again)
-                out["sort"] = sort_obj
+                finally:
+                    _hl.set_tuning("no_launch_skips", None)
+                out["launch_skips"] = {
+                    "value_uses": "the library's default: empty class / big-list kernels of the previous "
+                                  "call's geometry are not launched",
+                    "all_launched": {"steps": k3, "ms_per_step": round(sec * 1e3, 3),
+                                     "Mcells_per_s": round(cells_all / sec / 1e6, 1)},
+                    "gain_ms": round(sec * 1e3 - out["ms_per_step"], 3)}
+                timed_loop(1, 0)
             except Exception as e:
-                out["sort"] = {"error": repr(e)}
+                out["launch_skips"] = {"error": repr(e)}
         if world == 1 and not fixed and not args.no_rough_terrain and not args.knn and not batch \
                 and not wl.get("mt19937_seed"):
             try:

@@ -583,22 +583,6 @@ int amhip_ctx_dsm_stats(amhip_ctx* ctx, int64_t* points_binned,
  * not used. */
 int amhip_ctx_dsm_gather_stats(amhip_ctx* ctx, int64_t* out8);
 
-/* The speculative sort of the FP64 pipeline (clouds of >= 2^20 points; no reference counterpart:
- * dsm.cc:36-52 builds a kd-tree): a call whose context saw a three-pass DSM call before sizes its
- * sort regions from THAT call's exact counts instead of counting first, with the counting
- * pipeline behind it for the case that a region overflows (same result either way; a miss is
- * followed by eight counting calls, twice as many after every further miss in a row, at most 64).  out4 = three-pass FP64 calls so far, how many of them
- * started speculatively, how many of those overflowed (as far as their overflow words have
- * arrived: synchronise first for an exact figure), counting calls left before the next attempt.
- * Read-only apart from taking note of an overflow word that has arrived (the bookkeeping the next
- * DSM call would do).  OPT-IN since round 5: amhip_ctx_set_dsm_sort_reuse(ctx, 1) switches the reuse
- * on for a context that re-processes one survey (same cloud again: 5.39 against 5.52 ms per
- * cfg3 pass); the default, 0, counts first on every call -- every call then runs what a context's
- * FIRST call runs, which is the call the reference's hosts make (main-dsm.cc:103-107: one
- * process() per process), and what paid on distinct clouds in rotation (5.52 against 5.96 ms). */
-int amhip_ctx_dsm_sort_stats(amhip_ctx* ctx, int64_t* out4);
-int amhip_ctx_set_dsm_sort_reuse(amhip_ctx* ctx, int on);
-
 /* Order `other_stream` (hipStream_t as void*) behind everything the context has enqueued so far: an
  * event recorded on the context's stream, waited for by the other stream -- no host wait.  For
  * callers that feed asynchronous calls (`*_dev` entry points) from buffers another stream refills. */
@@ -628,10 +612,6 @@ int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float low
  *   p3_cap (2048)             points a placement workgroup sorts in its registers / LDS
  *   p3_rounds_cap, p3_rounds_reread   placement in rounds (sub-partitions beyond one LDS image)
  *                             forced at test size: image of n points / re-reading instead of registers
- *   sort_no_speculation       the FP64 pipeline's sort always counts first (see
- *                             amhip_ctx_set_dsm_sort_reuse for the per-context switch)
- *   sort_spec_max_points (2^27), sort_spec_margin_shift (3)   largest cloud the sort reuses a plan
- *                             on / head room of a planned region: count >> shift
  *   no_launch_skips           launch every capacity-class / big-list kernel whatever the previous
  *                             call's counters say
  *   dsm_canon_all             every FP64 quotient goes through the order-independent double-double sums

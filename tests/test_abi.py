@@ -163,6 +163,45 @@ def test_catkin_package_builds_the_same_sources():
             assert f in cm or "*.cc" in cm or "GLOB" in cm, f
 
 
+def test_catkin_package_configures_and_emits_a_sound_hipcc_command(tmp_path):
+    """A real CMake configure of catkin/aerial_mapper_hip (catkin_simple replaced by a three-macro
+    shim: there is no ROS in the image) and a dry run of the Makefile it generates: the hipcc
+    command must reach the shell with nothing for it to mangle (ADVICE r5: an escaped-quote define
+    lost its quotes on the way and broke amhip_build_id.cc)."""
+    import shutil
+    import subprocess
+    if not shutil.which("cmake") or not shutil.which("make"):
+        pytest.skip("cmake / make not available")
+    shim = tmp_path / "catkin_simple"
+    shim.mkdir()
+    (shim / "catkin_simpleConfig.cmake").write_text(
+        "set(CATKIN_DEVEL_PREFIX ${CMAKE_BINARY_DIR}/devel)\n"
+        "set(CATKIN_PACKAGE_LIB_DESTINATION lib)\n"
+        "set(CATKIN_GLOBAL_INCLUDE_DESTINATION include)\n"
+        "file(MAKE_DIRECTORY ${CATKIN_DEVEL_PREFIX}/lib)\n"
+        "macro(catkin_simple)\nendmacro()\n"
+        "macro(cs_add_library name)\n  add_library(${name} SHARED ${ARGN})\nendmacro()\n"
+        "macro(cs_install)\nendmacro()\nmacro(cs_export)\nendmacro()\n")
+    bld = tmp_path / "build"
+    cfg = subprocess.run(["cmake", "-S", os.path.join(ROOT, "catkin", "aerial_mapper_hip"), "-B", str(bld),
+                          "-G", "Unix Makefiles", "-Dcatkin_simple_DIR=%s" % shim,
+                          "-DAERIAL_MAPPER_AMD_ROOT=%s" % ROOT],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert cfg.returncode == 0, cfg.stdout[-3000:]
+    dry = subprocess.run(["make", "-C", str(bld), "-n", "aerial_mapper_hip_kernels"],
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True)
+    assert dry.returncode == 0, dry.stdout[-3000:]
+    cmds = [ln for ln in dry.stdout.splitlines() if "hipcc" in ln and "--offload-arch=gfx950" in ln]
+    assert len(cmds) == 1, dry.stdout[-3000:]
+    cmd = cmds[0]
+    # nothing the shell would re-interpret: no quotes, no backslashes, no defines carrying strings
+    assert '"' not in cmd and "'" not in cmd and "\\" not in cmd, cmd
+    assert "-ffp-contract=off" in cmd and "-DAMHIP_BUILD_ID" not in cmd
+    from aerial_mapper_amd import build
+    for src in build.HIP_SOURCES:
+        assert "/" + src in cmd, src
+
+
 def test_tuning_knobs_go_through_one_door():
     """amhip_set_tuning / AMHIP_TUNING (include/aerial_mapper_hip.h): known keys only, process-wide,
     and the library's own getenv sites stay the documented handful (VERDICT r4 next #9)."""

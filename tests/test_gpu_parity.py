@@ -422,7 +422,6 @@ def test_dsm_class_launches_skipped_after_a_uniform_call_still_serve_an_uneven_c
     tol = 1e-6 if _EXACT else 1e-4
     with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, lx, ly, res)) as m:
         m.set_dsm_precision(_EXACT)
-        m.set_dsm_sort_reuse(False)
         dsm = A.Dsm(A.DsmSettings(), m)
         for _ in range(2):                   # (the second call reads the first one's counters: all zero)
             m.reset()

@@ -43,9 +43,7 @@ BUDGETS = [
     ("k_dsm_p3_scatterILb0E", 4, 0),
     ("k_dsm_p3_scatterILb1E", 4, 0),
     ("14k_dsm_p3_placeE", 4, 0),
-    ("k_dsm_p3_scatter_specILb0E", 4, 0),                 # the speculative sort's passes (FP64 pipeline)
-    ("k_dsm_p3_scatter_specILb1E", 4, 0),
-    ("13k_dsm_p3_scanE", 4, 0),                           # (one workgroup of 1024 threads: 128 registers at most, none spilled)
+    ("20k_dsm_p3_reduce_scanE", 4, 0),                    # (one workgroup of 1024 threads scans: 128 registers at most, none spilled)
     ("k_dsm_p3_scatter_recILb0E", 4, 0),                  # the record pipeline (single-precision mode)
     ("k_dsm_p3_scatter_recILb1E", 4, 0),
     ("18k_dsm_p3_place_recE", 4, 0),

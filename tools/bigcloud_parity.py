@@ -61,16 +61,15 @@ def run(n, side, res=0.25, s=600):
         for mode in ("exact", "fast"):
             m.set_dsm_precision(mode == "exact")
             m.reset()
-            dsm.process(pts, m)              # (first call: counting sort)
+            dsm.process(pts, m)              # (warm-up)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             m.reset()
-            dsm.process(pts, m)              # (second call: the plan of the first, where the sort reuses one)
+            dsm.process(pts, m)
             dt = time.perf_counter() - t0
             st = m.dsm_stats()
-            sort = m.dsm_sort_stats()
             elev = m.as_torch("elevation")
-            e = {"ms_per_call": round(dt * 1e3, 2), "points_binned": st["points_binned"], "sort": sort, "windows": []}
+            e = {"ms_per_call": round(dt * 1e3, 2), "points_binned": st["points_binned"], "windows": []}
             for (i0, j0), (want, _) in zip(wins, refs):
                 got = elev[j0:j0 + s, i0:i0 + s].cpu().numpy()
                 ok = ~np.isnan(want)
