@@ -60,6 +60,17 @@ struct LayerSync {
   Hash128 device;
   bool host_known = false;
   Hash128 host;
+  // sync_in found (or put) the device layer in its lazily-reset initial state AND the host matrix
+  // holds that constant: once a kernel has materialised the layer, sync_out downloads it without
+  // waiting for its content sum (the sum then runs on a second stream beside the download)
+  bool fresh_in = false;
+};
+
+// Where the last host-buffer call spent its time (amhip_session_last_profile; window 0's view):
+// wall-clock phases on the host, HIP-event times for what the stream did.
+struct CallProfile {
+  double total_ms = 0, h2d_ms = 0, host_sum_ms = 0, kernel_ms = 0, dev_sum_wait_ms = 0, d2h_ms = 0;
+  double up_bytes = 0, down_bytes = 0;
 };
 
 struct Session {
@@ -81,10 +92,16 @@ struct Session {
   std::vector<double*> cloud;
   std::vector<size_t> cloud_cap;               // doubles
   std::vector<unsigned long long*> dev_hash;   // device scratch: two u64 per layer
+  std::vector<unsigned long long*> pin_hash;   // its pinned host mirror
   std::vector<float*> pin;                     // pinned host staging of partial downloads
   std::vector<size_t> pin_cap;                 // floats
   bool verify_partial = false;                 // tuning knob session_verify_partial: re-sum the host matrix
   std::atomic<unsigned long long> up_bytes{0}, down_bytes{0};  // layer traffic (amhip_session_transfer_stats)
+  // per window: a second stream for the content sums that run beside a download, and the events
+  // that time a call's kernels / downloads (CallProfile)
+  std::vector<hipStream_t> aux_stream;
+  std::vector<hipEvent_t> ev_k0, ev_k1, ev_s1, ev_d1;
+  CallProfile prof;
   int W() const { return (int)ctx.size(); }
 };
 
@@ -274,14 +291,18 @@ static int sync_in(Session& s, int k, int layer, const float* host, const Hash12
   if (rc) return rc;
   st.host = host_hash;
   st.host_known = !s.always_copy;
+  st.fresh_in = false;
   bool have = false;
   if (!s.always_copy) {
+    const bool host_is_const = host_hash == s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + layer];
     if (st.device_valid && st.device == host_hash) {
       have = true;  // the device holds exactly this
-    } else if (host_hash == s.const_hash[(size_t)k * AMHIP_NUM_LAYERS + layer]) {
+      st.fresh_in = host_is_const && ctx_layer_is_initial(c, layer);
+    } else if (host_is_const) {
       // (any matrix with these sums is taken for the initial constant: 2^-128)
       if ((rc = ctx_layer_set_initial(c, layer))) return rc;
       have = true;
+      st.fresh_in = ctx_layer_is_initial(c, layer);
     }
   }
   if (!have) {
@@ -339,9 +360,39 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
               rect[0] + rect[2] <= w.rows && rect[1] + rect[3] <= w.cols &&
               2 * (size_t)rect[2] * (size_t)rect[3] <= (size_t)w.rows * (size_t)w.cols;
   }
+  AMHIP_TRY(hipEventRecord(s.ev_k1[k], c->stream));  // (the call's kernels end here)
   clock.mark("kernels (wait)", c->stream, true);
+  // A download is asynchronous: until the stream has synchronised without an error the host
+  // matrix may be stale or half written, so the layers being downloaded are marked "host
+  // unknown" FIRST and "host == device sum" only after the wait (ADVICE r3: a failed copy must
+  // not leave the session believing the host holds h[q] -- the next call would skip it).
+  bool copied[AMHIP_NUM_LAYERS] = {};
+  bool packed[AMHIP_NUM_LAYERS] = {};
+  bool early[AMHIP_NUM_LAYERS] = {};
+  bool any = false;
+  const auto wall0 = std::chrono::steady_clock::now();
+  // (1) "fresh" layers -- the host holds the initial constant, the device layer was lazily initial
+  // when the call began and a kernel has materialised it since: their download starts NOW, on the
+  // context's stream, and their content sums (which only decide what LATER calls may skip) run
+  // beside it on the second stream.  A layer whose every written cell happens to equal the
+  // constant is downloaded for nothing; nothing else changes.
+  if (!s.always_copy && !partial && !tuning_on("session_serial_sums")) {
+    for (int q = 0; q < nl; ++q) {
+      if (!hosts[q]) continue;
+      const LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layers[q]];
+      early[q] = st.fresh_in && st.host_known && !ctx_layer_is_initial(c, layers[q]);
+      any = any || early[q];
+    }
+  }
+  const bool beside = any;
+  unsigned long long* const got = s.pin_hash[k];   // (pinned: the copy below must not block the host)
   if (!s.always_copy) {
-    AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS, c->stream));
+    hipStream_t hs = c->stream;
+    if (beside) {  // (beside the downloads; ordered behind the kernels by their end event)
+      hs = s.aux_stream[k];
+      AMHIP_TRY(hipStreamWaitEvent(hs, s.ev_k1[k], 0));
+    }
+    AMHIP_TRY(hipMemsetAsync(s.dev_hash[k], 0, sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS, hs));
     for (int q = 0; q < nl; ++q) {
       if (!hosts[q]) continue;
       const int l = layers[q];
@@ -350,12 +401,25 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
         continue;
       }
       run[q] = true;
-      hipLaunchKernelGGL(k_layer_hash, dim3(2048), dim3(256), 0, c->stream, c->layers[l], 0.0f, w.rows,
+      hipLaunchKernelGGL(k_layer_hash, dim3(2048), dim3(256), 0, hs, c->layers[l], 0.0f, w.rows,
                          w.cols, w.i0, w.j0, s.grid.rows, s.dev_hash[k] + 2 * q);
     }
-    unsigned long long got[2 * AMHIP_NUM_LAYERS];
-    AMHIP_TRY(hipMemcpyAsync(got, s.dev_hash[k], sizeof(got), hipMemcpyDeviceToHost, c->stream));
-    AMHIP_TRY(hipStreamSynchronize(c->stream));
+    AMHIP_TRY(hipMemcpyAsync(got, s.dev_hash[k], sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS,
+                             hipMemcpyDeviceToHost, hs));
+    // (a download into pageable memory keeps the calling thread until it is done: the sums are
+    // already running on the second stream by then)
+    for (int q = 0; q < nl; ++q) {
+      if (!early[q]) continue;
+      LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layers[q]];
+      st.host_known = false;
+      AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[layers[q]], s, w, true, c->stream));
+      s.down_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
+      s.prof.down_bytes += (double)w.rows * (double)w.cols * 4.0;
+      copied[q] = true;
+    }
+    // (the downloads' own start, where the sums ran in front of them on the same stream)
+    AMHIP_TRY(hipEventRecord(s.ev_s1[k], c->stream));
+    AMHIP_TRY(hipStreamSynchronize(hs));
     for (int q = 0; q < nl; ++q)
       if (run[q]) {
         h[q].a = got[2 * q];
@@ -363,13 +427,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
       }
   }
   clock.mark("device content sums");
-  // A download is asynchronous: until the stream has synchronised without an error the host
-  // matrix may be stale or half written, so the layers being downloaded are marked "host
-  // unknown" FIRST and "host == device sum" only after the wait (ADVICE r3: a failed copy must
-  // not leave the session believing the host holds h[q] -- the next call would skip it).
-  bool copied[AMHIP_NUM_LAYERS] = {};
-  bool packed[AMHIP_NUM_LAYERS] = {};
-  bool any = false;
+  const auto wall1 = std::chrono::steady_clock::now();
   const size_t block = (size_t)rect[2] * (size_t)rect[3];
   if (partial) {  // (staging for every layer of the call, at most 1 GiB: beyond, the plain way)
     const size_t need = block * (size_t)nl;
@@ -388,6 +446,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
       }
     }
   }
+  // (2) every other layer: downloaded where the device's sum differs from what the host holds
   for (int q = 0; q < nl; ++q) {
     if (!hosts[q]) continue;
     const int l = layers[q];
@@ -397,6 +456,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
     const bool host_is_before = !s.always_copy && st.host_known && st.host == st.device;
     st.device_valid = !s.always_copy;
     st.device = h[q];
+    if (early[q]) continue;
     if (!host_has_it) {
       st.host_known = false;
       if ((rc = ctx_materialize(c, l))) return rc;
@@ -407,14 +467,17 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
                                    hipMemcpyDeviceToHost, c->stream));
         packed[q] = true;
         s.down_bytes += (unsigned long long)block * 4ull;
+        s.prof.down_bytes += (double)block * 4.0;
       } else {
         AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
         s.down_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
+        s.prof.down_bytes += (double)w.rows * (double)w.cols * 4.0;
       }
       copied[q] = true;
       any = true;
     }
   }
+  AMHIP_TRY(hipEventRecord(s.ev_d1[k], c->stream));
   if (any) AMHIP_TRY(hipStreamSynchronize(c->stream));
   clock.mark("downloads");
   for (int q = 0; q < nl; ++q)
@@ -437,6 +500,16 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
     LayerSync& st = s.sync[(size_t)k * AMHIP_NUM_LAYERS + layers[q]];
     st.host_known = !s.always_copy;
     st.host = h[q];
+  }
+  if (k == 0) {  // (the call's profile: window 0's view)
+    AMHIP_TRY(hipEventSynchronize(s.ev_d1[k]));
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, s.ev_k0[k], s.ev_k1[k]) == hipSuccess) s.prof.kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, beside || s.always_copy ? s.ev_k1[k] : s.ev_s1[k], s.ev_d1[k]) == hipSuccess)
+      s.prof.d2h_ms = ms;
+    (void)hipGetLastError();
+    // (the sums' share of the wall clock: the whole wait when nothing was downloaded beside them)
+    s.prof.dev_sum_wait_ms = beside ? 0.0 : std::chrono::duration<double, std::milli>(wall1 - wall0).count();
   }
   return AMHIP_OK;
 }
@@ -523,6 +596,7 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
     s.ctx.push_back(c);
     s.win.push_back(w);
     s.dev.push_back(d);
+    if ((rc = ctx_use_device(&c->impl))) break;
     unsigned long long* dh = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&dh), sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS) !=
         hipSuccess) {
@@ -530,6 +604,28 @@ int amhip_session_create(const amhip_grid_desc* grid, int tiles_i, int tiles_j,
       break;
     }
     s.dev_hash.push_back(dh);
+    unsigned long long* ph = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ph), sizeof(unsigned long long) * 2 * AMHIP_NUM_LAYERS,
+                      hipHostMallocDefault) != hipSuccess) {
+      rc = hip_fail(hipGetLastError(), "hipHostMalloc(session scratch)", __FILE__, __LINE__);
+      break;
+    }
+    s.pin_hash.push_back(ph);
+    hipStream_t aux = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+        hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess || hipEventCreate(&e3) != hipSuccess) {
+      rc = hip_fail(hipGetLastError(), "session: second stream / timing events", __FILE__, __LINE__);
+      if (aux) (void)hipStreamDestroy(aux);
+      for (hipEvent_t e : {e0, e1, e2, e3})
+        if (e) (void)hipEventDestroy(e);
+      break;
+    }
+    s.aux_stream.push_back(aux);
+    s.ev_k0.push_back(e0);
+    s.ev_k1.push_back(e1);
+    s.ev_d1.push_back(e2);
+    s.ev_s1.push_back(e3);
   }
   if (rc) {
     amhip_session_destroy(h);
@@ -600,6 +696,10 @@ void amhip_session_destroy(amhip_session* h) {
       if (k < s.cloud.size() && s.cloud[k]) (void)hipFree(s.cloud[k]);
       if (k < s.dev_hash.size() && s.dev_hash[k]) (void)hipFree(s.dev_hash[k]);
       if (k < s.pin.size() && s.pin[k]) (void)hipHostFree(s.pin[k]);
+      if (k < s.pin_hash.size() && s.pin_hash[k]) (void)hipHostFree(s.pin_hash[k]);
+      if (k < s.aux_stream.size() && s.aux_stream[k]) (void)hipStreamDestroy(s.aux_stream[k]);
+      for (auto* v : {&s.ev_k0, &s.ev_k1, &s.ev_s1, &s.ev_d1})
+        if (k < v->size() && (*v)[k]) (void)hipEventDestroy((*v)[k]);
       amhip_ctx_destroy(s.ctx[k]);
     }
   }
@@ -639,6 +739,20 @@ int amhip_session_transfer_stats(const amhip_session* h, uint64_t* uploaded_byte
   return AMHIP_OK;
 }
 
+int amhip_session_last_profile(const amhip_session* h, double* out8) {
+  if (!h || !out8) return arg_failure("amhip_session_last_profile: null argument");
+  const CallProfile& p = h->impl.prof;
+  out8[0] = p.total_ms;
+  out8[1] = p.h2d_ms;
+  out8[2] = p.host_sum_ms;
+  out8[3] = p.kernel_ms;
+  out8[4] = p.dev_sum_wait_ms;
+  out8[5] = p.d2h_ms;
+  out8[6] = p.up_bytes;
+  out8[7] = p.down_bytes;
+  return AMHIP_OK;
+}
+
 int amhip_session_set_dsm_precision(amhip_session* h, int mode) {
   if (!h) return arg_failure("null session");
   for (amhip_ctx* c : h->impl.ctx) {
@@ -663,6 +777,12 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   std::vector<Hash128> hh;
   const float* mats[1] = {elevation};
   int rc;
+  const auto call0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
+  s.prof = CallProfile();
+  s.prof.up_bytes = (double)n * 24.0;
   if (W == 1) {
     PhaseClock clock("dsm");
     Ctx* c = &s.ctx[0]->impl;
@@ -671,17 +791,23 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     if ((rc = ensure_capacity(&c->stage_points, &c->stage_points_cap, 3 * n))) return rc;
     // (a pageable source makes this call return only once the data is staged; the sums run
     // in a second thread meanwhile)
+    double sum_ms = 0.0;
     std::thread hasher([&]() {
+      const auto t = std::chrono::steady_clock::now();
       if (!s.always_copy) host_hashes(s, mats, 1, &hh);
       else hh.assign(1, Hash128());
+      sum_ms = ms_since(t);
     });
     hipError_t e = hipMemcpyAsync(c->stage_points, host_xyz, 3 * n * sizeof(double),
                                   hipMemcpyHostToDevice, c->stream);
+    s.prof.h2d_ms = ms_since(call0);
     clock.mark("cloud enqueued");
     hasher.join();
+    s.prof.host_sum_ms = sum_ms;
     clock.mark("host content sum");
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(cloud)", __FILE__, __LINE__);
     if ((rc = sync_in(s, 0, AMHIP_LAYER_ELEVATION, elevation, hh[0], true))) return rc;
+    AMHIP_TRY(hipEventRecord(s.ev_k0[0], c->stream));
     if ((rc = amhip_dsm_process_dev(s.ctx[0], c->stage_points, n, radius_sq, center_easting,
                                     center_northing)))
       return rc;
@@ -689,7 +815,9 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     const int lay[1] = {AMHIP_LAYER_ELEVATION};
     float* outs[1] = {elevation};
     if ((rc = sync_out(s, 0, lay, outs, 1, true))) return rc;
-    return ctx_fetch_status(c);
+    rc = ctx_fetch_status(c);
+    s.prof.total_ms = ms_since(call0);
+    return rc;
   }
 
   if (!s.always_copy) host_hashes(s, mats, 1, &hh);
@@ -801,9 +929,12 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
                                        c->stream));
         off += cnt;
       }
+      AMHIP_TRY(hipEventRecord(s.ev_k0[d], c->stream));
       if ((r = amhip_dsm_process_dev(s.ctx[d], s.cloud[d], total, radius_sq, center_easting,
                                      center_northing)))
         return r;
+    } else {
+      AMHIP_TRY(hipEventRecord(s.ev_k0[d], c->stream));
     }
     const int lay[1] = {AMHIP_LAYER_ELEVATION};
     float* outs[1] = {elevation};
@@ -812,6 +943,7 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
   });
   // (a later call may overwrite route_out[k] while a slower peer still reads it: every window
   // finished its copies before its own sync_out returned, and all threads were joined)
+  s.prof.total_ms = ms_since(call0);
   return rc;
 }
 
@@ -861,22 +993,32 @@ int amhip_session_ortho_backward_process(
   };
   // the frames go up while host threads hash the six matrices
   PhaseClock clock("ortho_backward");
+  const auto call0 = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+  };
+  s.prof = CallProfile();
+  s.prof.up_bytes = (double)frame * (double)F;
   int rc_up = AMHIP_OK;
   std::string up_msg;
+  double up_ms = 0.0;
   std::thread uploader([&]() {
     rc_up = for_windows(s, upload_frames);
     if (rc_up) up_msg = amhip_last_error();
+    up_ms = ms_since(call0);
   });
   if (!s.always_copy) host_hashes(s, ins, AMHIP_NUM_LAYERS, &hh);
   else hh.assign((size_t)AMHIP_NUM_LAYERS * W, Hash128());
+  s.prof.host_sum_ms = ms_since(call0);
   clock.mark("host content sums");
   uploader.join();
+  s.prof.h2d_ms = up_ms;
   clock.mark("frames enqueued");
   if (rc_up) {
     set_last_error(up_msg);
     return rc_up;
   }
-  return for_windows(s, [&](int k) -> int {
+  const int rc_all = for_windows(s, [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
     if (r) return r;
@@ -885,6 +1027,7 @@ int amhip_session_ortho_backward_process(
       if (ins[l] && (r = sync_in(s, k, l, ins[l], hh[(size_t)l * W + k], l != AMHIP_LAYER_ELEVATION)))
         return r;
     if (k == 0) clock.mark("sync_in");
+    AMHIP_TRY(hipEventRecord(s.ev_k0[k], c->stream));
     if ((r = amhip_ortho_backward_process_dev(s.ctx[k], cam, host_T_G_C, F, c->stage_frames, frame,
                                               row, channels, colored)))
       return r;
@@ -896,6 +1039,8 @@ int amhip_session_ortho_backward_process(
     if ((r = sync_out(s, k, lay, outs, 5, true))) return r;
     return ctx_fetch_status(c);
   });
+  s.prof.total_ms = ms_since(call0);
+  return rc_all;
 }
 
 // ortho::OrthoFromPcl::process (ortho-from-pcl.cc:20-113) on host buffers: `ortho` = the
@@ -925,6 +1070,7 @@ int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xy
                              hipMemcpyHostToDevice, c->stream));
     AMHIP_TRY(hipMemcpyAsync(c->stage_values, host_intensities, n * sizeof(int32_t),
                              hipMemcpyHostToDevice, c->stream));
+    AMHIP_TRY(hipEventRecord(s.ev_k0[k], c->stream));
     if ((r = amhip_ortho_from_pcl_process_dev(s.ctx[k], c->stage_points, c->stage_values, n,
                                               radius_sq, adaptive)))
       return r;

@@ -25,7 +25,7 @@ const char* const kKeys[] = {
     "no_distorted_cull", "no_distorted_prune", "distorted_square_cull",
     // session
     "session_always_copy", "session_threads", "session_scalar_sums", "session_no_partial",
-    "session_verify_partial", "session_trace",
+    "session_verify_partial", "session_trace", "session_serial_sums",
     // lab builds (-DAMHIP_TIMING_PROBES) only
     "gather_tj", "gather_nt", "gather_class_cap0", "gather_class_cap1", "gather_class_cap2", "f32_variant",
     "fx_theta"};

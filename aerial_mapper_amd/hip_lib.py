@@ -45,7 +45,7 @@ EXPORTS = [
     "amhip_densify_dev", "amhip_rectify_stereo_pair_dev", "amhip_halo_select_dev", "amhip_dsm_tiled_begin_dev",
     "amhip_dsm_tiled_finish_dev", "amhip_compose_T_G_C", "amhip_ortho_backward_process_dev",
     "amhip_ortho_backward_process", "amhip_ctx_enable_timing", "amhip_ctx_timing_reset",
-    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats", "amhip_ctx_dsm_gather_stats", "amhip_ctx_order_after", "amhip_build_id", "amhip_set_tuning", "amhip_get_tuning", "amhip_default_dsm_precision",
+    "amhip_ctx_kernel_time", "amhip_kernel_name", "amhip_ctx_dsm_stats", "amhip_ctx_dsm_gather_stats", "amhip_ctx_order_after", "amhip_session_last_profile", "amhip_build_id", "amhip_set_tuning", "amhip_get_tuning", "amhip_default_dsm_precision",
     "amhip_mosaic_create", "amhip_mosaic_destroy", "amhip_mosaic_set_stream",
     "amhip_mosaic_synchronize", "amhip_mosaic_reset", "amhip_mosaic_batch",
     "amhip_mosaic_batch_dev", "amhip_mosaic_update", "amhip_mosaic_update_dev",
@@ -167,6 +167,7 @@ def load():
     lib.amhip_session_set_dsm_precision.argtypes = [vp, C.c_int]
     lib.amhip_ctx_order_after.argtypes = [vp, vp]
     lib.amhip_session_transfer_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.amhip_session_last_profile.argtypes = [vp, C.POINTER(C.c_double)]
     lib.amhip_session_dsm_process.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_double, C.c_double, vp]
     lib.amhip_session_ortho_from_pcl_process.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]
     lib.amhip_session_ortho_backward_process.argtypes = [

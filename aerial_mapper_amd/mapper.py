@@ -499,6 +499,14 @@ class HostSession(object):
         L.check(self._lib.amhip_session_transfer_stats(self._h, C.byref(up), C.byref(down)))
         return int(up.value), int(down.value)
 
+    def last_profile(self):
+        """amhip_session_last_profile: where the last host-buffer call spent its time (ms / bytes)."""
+        out = (C.c_double * 8)()
+        L.check(self._lib.amhip_session_last_profile(self._h, out))
+        keys = ("total_ms", "h2d_ms", "host_sum_ms", "kernel_ms", "dev_sum_wait_ms", "d2h_ms", "bytes_up",
+                "bytes_down")
+        return {k: (round(float(v), 3) if k.endswith("_ms") else int(v)) for k, v in zip(keys, out)}
+
     def dsm_process(self, dsm_settings, points):
         pts = np.ascontiguousarray(points, np.float64).reshape(-1, 3)
         s = dsm_settings

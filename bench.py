@@ -455,23 +455,37 @@ def session_route(args, A, st, tiles, devices, dsm_settings, ncam, mosaic_settin
             torch.cuda.synchronize(d)
         t0h = time.perf_counter()
         hs.dsm_process(dsm_settings, h_pts)
-        t1h = time.perf_counter()
+        dsm_s = time.perf_counter() - t0h
+        prof = {"dsm": hs.last_profile()}        # (the read-outs are outside both timed calls)
+        mosaic_s = 0.0
         if F:
+            t1m = time.perf_counter()
             hs.ortho_process(ncam, mosaic_settings, poses, h_frames)
-        t2h = time.perf_counter()
+            mosaic_s = time.perf_counter() - t1m
+            prof["mosaic"] = hs.last_profile()
         # a second pass over the SAME map (incremental mapping: the layers are resident,
         # the matrices unchanged since the session wrote them)
-        hs.dsm_process(dsm_settings, h_pts)
         t3h = time.perf_counter()
+        hs.dsm_process(dsm_settings, h_pts)
         if F:
             hs.ortho_process(ncam, mosaic_settings, poses, h_frames)
-        t4h = time.perf_counter()
+        second_s = time.perf_counter() - t3h
         nwin = hs.num_windows
     bytes_up = h_pts.nbytes + (sum(f.nbytes for f in h_frames) * len(set(devices)) if F else 0)
     bytes_down = 4.0 * cells_total * (4 if F else 1)
-    return {"ms": round((t2h - t0h) * 1e3, 1), "dsm_ms": round((t1h - t0h) * 1e3, 1),
-            "Mcells_per_s": round(cells_total / (t2h - t0h) / 1e6, 1),
-            "second_pass_ms": round((t4h - t2h) * 1e3, 1),
+    first_ms = (dsm_s + mosaic_s) * 1e3
+    tot = lambda key: round(sum(c[key] for c in prof.values()), 3)
+    return {"ms": round(first_ms, 1), "dsm_ms": round(dsm_s * 1e3, 1),
+            "Mcells_per_s": round(cells_total / (first_ms * 1e-3) / 1e6, 1),
+            # where the first pass went (amhip_session_last_profile, per call and summed): h2d = wall
+            # clock until the call's inputs were handed to the copy engine (pageable sources block
+            # that long), host_sum = host content sums (beside the upload: only their excess over
+            # h2d is on the critical path), kernel / d2h = HIP events on the map's stream,
+            # dev_sum_wait = device content sums that could not run beside a download
+            "breakdown": {"h2d_ms": tot("h2d_ms"), "host_sum_ms": tot("host_sum_ms"),
+                          "kernel_ms": tot("kernel_ms"), "dev_sum_wait_ms": tot("dev_sum_wait_ms"),
+                          "d2h_ms": tot("d2h_ms"), "calls": prof},
+            "second_pass_ms": round(second_s * 1e3, 1),
             "windows": nwin, "devices": [int(d) for d in devices],
             "bytes_up": bytes_up, "bytes_down": bytes_down,
             "link_floor_ms": round((bytes_up + bytes_down) / 56e9 / len(set(devices)) * 1e3, 1),

@@ -543,6 +543,14 @@ int amhip_session_set_always_copy(amhip_session* s, int on);
 int amhip_session_set_dsm_precision(amhip_session* s, int mode);  /* AMHIP_DSM_FAST / _EXACT */
 int amhip_session_transfer_stats(const amhip_session* s, uint64_t* uploaded_bytes,
                                  uint64_t* downloaded_bytes);
+/* Where the LAST host-buffer call on this session (DSM / backward mosaic / OrthoFromPcl) spent its
+ * time, window 0's view: out8 = { total_ms, h2d_ms (wall clock until the call's inputs -- cloud or
+ * frames -- were handed to the copy engine; pageable sources block that long), host_sum_ms (host
+ * content sums, running beside the upload), kernel_ms (HIP events around the call's kernels),
+ * dev_sum_wait_ms (wall clock spent waiting for device content sums that could not run beside a
+ * download), d2h_ms (HIP events around the downloads), bytes uploaded as inputs, layer bytes
+ * downloaded }. */
+int amhip_session_last_profile(const amhip_session* s, double* out8);
 /* dsm::Dsm::process (dsm.cc:186-201): `elevation` = the GridMap's matrix (map rows x cols,
  * column-major), read and written like the reference does. */
 int amhip_session_dsm_process(amhip_session* s, const double* host_xyz, size_t n, int radius_sq,
@@ -624,6 +632,7 @@ int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float low
  *                             dispatch every tile of a large map instead of a list of visible ones
  *   no_distorted_cull, no_distorted_prune, distorted_square_cull   cameras with a distortion model
  *   session_always_copy, session_threads, session_scalar_sums, session_no_partial,
+ *   session_serial_sums       device content sums always before the downloads (round 5's order)
  *   session_verify_partial, session_trace          amhip_session: every matrix both ways on every
  *                             call / host threads of the content sums / scalar sums / whole-window
  *                             downloads / re-sum partial downloads / phase timings on stderr

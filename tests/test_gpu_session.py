@@ -278,3 +278,42 @@ def test_session_downloads_only_the_rectangle_a_small_call_wrote(tuning, tiles):
     if tiles == (1, 1):                                               # (half a map has < 16 K tiles: dense launches, whole windows)
         assert down_full["mosaic"] >= 3 * window                      # >= one frame's three layers, whole
         assert 0 < down_part["mosaic"] < down_full["mosaic"] // 20
+
+
+@pytest.mark.parametrize("tiles", [(1, 1), (2, 2)])
+def test_session_downloads_fresh_layers_beside_their_content_sums(tuning, tiles):
+    """Round 6: a layer that was lazily initial when the call began (host matrix = the initial
+    constant) and that a kernel has materialised is downloaded at once, its content sum runs on a
+    second stream beside the download (tuning knob session_serial_sums: round 5's order, sums
+    first).  Same matrices, same residency bookkeeping afterwards (a repeated call moves nothing),
+    and amhip_session_last_profile accounts for the call."""
+    import aerial_mapper_amd as A
+    sc = S.Scene(160.0, 128.0, 0.5, 120000, seed=411, num_frames=10)
+    want = _oracle(sc)
+    got = {}
+    for serial in (False, True):
+        tuning(session_serial_sums=1 if serial else None)
+        with A.HostSession(_settings(A, sc.grid), tiles=tiles) as hs:
+            hs.set_dsm_precision(True)
+            hs.dsm_process(A.DsmSettings(1), sc.points)
+            p = hs.last_profile()
+            cells4 = sc.grid.rows * sc.grid.cols * 4
+            assert p["bytes_up"] == sc.points.nbytes and p["total_ms"] > 0.0
+            if tiles == (1, 1):
+                assert p["bytes_down"] == cells4 and p["d2h_ms"] > 0.0 and p["kernel_ms"] > 0.0, (p, cells4)
+                # (sums beside the download: nothing waited for; round 5's order: the wait is on the clock)
+                assert (p["dev_sum_wait_ms"] > 0.0) == serial, p
+            hs.ortho_process(_ncam(A, sc), A.OrthoSettings(), sc.poses, sc.frames)
+            p = hs.last_profile()
+            if tiles == (1, 1):
+                assert p["bytes_down"] == 3 * cells4 and p["bytes_up"] == sum(f.nbytes for f in sc.frames), p
+            got[serial] = {k: v.copy() for k, v in hs.layers.items()}
+            up0, down0 = hs.transfer_stats()
+            hs.dsm_process(A.DsmSettings(1), sc.points)
+            hs.ortho_process(_ncam(A, sc), A.OrthoSettings(), sc.poses, sc.frames)
+            assert hs.transfer_stats() == (up0, down0)      # resident and known: no layer moves
+            S.assert_layers_equal(hs.layers, got[serial], ["elevation"] + ORTHO_LAYERS)
+    S.assert_layers_equal(got[False], got[True], ["elevation"] + ORTHO_LAYERS)
+    S.assert_dsm_close(got[False]["elevation"], want["elevation"], tol=1e-6)
+    if np.array_equal(got[False]["elevation"].view(np.uint32), want["elevation"].view(np.uint32)):
+        S.assert_layers_equal(got[False], want, ORTHO_LAYERS)
