@@ -82,6 +82,10 @@ WORKLOADS = {
                  desc="incremental mosaic: 2000 frames of a 10 km lawn-mower flight appended in "
                       "64-frame batches onto the resident layers of the 40000x40000 @0.25m map "
                       "(DSM of the 400M-point cloud built once, untimed); a step = one batch"),
+    "small5": dict(side=4096, res=0.25, points=4_000_000, frames=160, batch=64, W=1920, H=1080,
+                   f=1400.0, altitude=700.0, fixed_map=True,
+                   desc="incremental mosaic like cfg5 at test size: 160 frames appended in 64-frame batches "
+                        "(64 + 64 + 32) onto the resident layers of a 4096x4096 @0.25m map"),
     "small4": dict(side=4096, res=0.25, points=4_000_000, frames=0, W=1920, H=1080,
                    f=1400.0, altitude=700.0, fixed_map=True,
                    desc="4M pts -> 4096x4096 @0.25m DSM, tiled like cfg4 (test size)"),
@@ -683,6 +687,13 @@ def main():
     if args.session_child:
         # (internal) the whole map of an N-rank run through ONE amhip_session with one window per
         # device: prints the `session_route` object and nothing else
+        # (tests/test_gpu_bench_multirank.py: AMHIP_BENCH_SESSION_CHILD_FAULT=exit | hang rehearses the
+        # parent's two failure paths -- the ranks' line must be printed either way)
+        fault = os.environ.get("AMHIP_BENCH_SESSION_CHILD_FAULT")
+        if fault == "exit":
+            raise SystemExit("session child: injected failure")
+        if fault == "hang":
+            time.sleep(3600)
         F = wl["frames"]
         ch = 3 if args.colored else 1
         ncam = A.NCamera(wl["f"], wl["f"], (wl["W"] - 1) / 2.0, (wl["H"] - 1) / 2.0, wl["W"], wl["H"]) if F else None
@@ -1109,15 +1120,17 @@ def main():
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                       "TORCHELASTIC_RUN_ID", "MASTER_PORT"):
                 env.pop(k, None)
+            limit = float(os.environ.get("AMHIP_BENCH_SESSION_TIMEOUT", "420"))
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                                   universal_newlines=True, timeout=420)
+                                   universal_newlines=True, timeout=limit)
                 lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
                 out["session_route"] = json.loads(lines[-1]) if lines else {
                     "error": "child exit %d: %s" % (r.returncode, r.stderr[-400:])}
             except subprocess.TimeoutExpired:
                 out["session_route"] = {"error": "the one-process session over %d devices did not finish in "
-                                                 "420 s (killed); the ranks' numbers above are unaffected" % world}
+                                                 "%.0f s (killed); the ranks' numbers above are unaffected"
+                                                 % (world, limit)}
             except Exception as e:
                 out["session_route"] = {"error": repr(e)}
         print(json.dumps(out))

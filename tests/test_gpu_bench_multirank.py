@@ -53,6 +53,56 @@ def test_four_ranks_two_by_two_windows_with_diagonal_neighbours():
     assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("one map, 2 x 2 windows")
 
 
+def test_eight_ranks_two_by_four_windows_like_the_drivers_node():
+    """ the shape of the driver's 8-GPU run -- 2 x 4 windows, interior windows with
+    eight neighbours (edges AND diagonals), uneven window edges (4096 cells over 4 columns of windows
+    on 32-cell multiples, over 2 rows on 64-cell multiples) -- as eight real processes on the one GPU
+    of the test box: preflight and verify against ONE full-map DSM."""
+    d = _run(8, "small4")
+    assert d["n_gpus"] == 8 and "REHEARSAL" in d["data"]
+    assert d["scaling"] == "strong" and d["config"]["parallelism"].startswith("one map, 2 x 4 windows")
+    r = d["ranks"]
+    assert r["world_size_reported"] == 8 and sorted(x["rank"] for x in r["ranks"]) == list(range(8))
+    p, v = d["preflight"], d["verify"]
+    assert p["pass"] and p["windows"] == 8 and p["nan_pattern_equal"], p
+    assert len(p["neighbours_of_rank0"]) == 3          # (a corner window: two edges + one diagonal)
+    assert v["windows"] == 8 and v["pass"], v
+
+
+def test_eight_ranks_incremental_mosaic_like_configs_4():
+    """BASELINE configs[4] at test size (--workload small5): the DSM built once over 2 x 4 windows, then
+    the flight's frames appended in 64-frame batches onto the resident layers of every window."""
+    d = _run(8, "small5", extra=("--no-preflight",))
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"].startswith("one map, 2 x 4 windows")
+    assert d["verify"]["pass"] and d["verify"]["windows"] == 8, d["verify"]
+    assert d["config"]["frames"] == 64 and d["value"] > 0
+
+
+@pytest.mark.parametrize("fault", ["exit", "hang"])
+def test_a_failing_session_child_does_not_cost_the_ranks_line(fault):
+    """N > 1 without a launcher: rank 0 times the one-process route in a CHILD with a time limit.
+    Whatever the child does -- exits with an error, never returns -- the ranks' measured line is
+    printed, with the failure recorded under `session_route`."""
+    env_extra = {"AMHIP_BENCH_SESSION_CHILD_FAULT": fault, "AMHIP_BENCH_SESSION_TIMEOUT": "8"}
+    old = {k: os.environ.get(k) for k in env_extra}
+    os.environ.update(env_extra)
+    try:
+        r = _run_plain(2, "small", ["--verify"])
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["verify"]["pass"] and d["preflight"]["pass"]
+    assert "error" in d["session_route"], d["session_route"]
+    assert ("did not finish" if fault == "hang" else "child exit") in d["session_route"]["error"]
+
+
 def test_the_line_identifies_its_ranks_and_carries_the_preflight():
     """ the N > 1 line proves by itself who took part: the backend, the world
     size torch.distributed reports, every rank's device, and a small verified tiled step in front

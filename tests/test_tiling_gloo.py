@@ -75,7 +75,7 @@ def _worker(rank, world, port, tiles, assume_owned, via_host, ret):
 
 @pytest.mark.parametrize("world,tiles,assume_owned,via_host",
                          [(2, (2, 1), True, False), (2, (1, 2), False, False), (4, (2, 2), True, False),
-                          (2, (2, 1), True, True)])
+                          (2, (2, 1), True, True), (8, (2, 4), True, False)])   # (8: the driver node's 2 x 4)
 def test_route_points_gloo(world, tiles, assume_owned, via_host):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -169,7 +169,7 @@ def _worker_neighbours(rank, world, port, tiles, ret):
 
 
 @pytest.mark.parametrize("world,tiles,max_nbrs", [(2, (2, 1), 1), (4, (2, 2), 3), (6, (3, 2), 5),
-                                                  (4, (4, 1), 2)])
+                                                  (4, (4, 1), 2), (8, (2, 4), 5)])
 def test_neighbour_only_exchange_gloo(world, tiles, max_nbrs):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
