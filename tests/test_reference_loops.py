@@ -1,9 +1,10 @@
-"""The restated oracle (oracle/amo_*.cc) against the reference's OWN loops: dsm.cc,
-ortho-backward-grid.cc and ortho-from-pcl.cc compiled unchanged from /root/reference against
-the stand-in headers of oracle/refkit/ (oracle/Makefile target `loops`,
-oracle/_ref/libref_loops_*.so).  Everything the reference's own code does is pinned by
-these comparisons -- bit for bit, every layer; what stays a definition is the arithmetic
-inside the external libraries' calls (oracle/refkit/refkit.h)."""
+"""CONSISTENCY CHECK of the restated oracle (oracle/amo_*.cc): the text of the reference's dsm.cc,
+ortho-backward-grid.cc and ortho-from-pcl.cc, compiled unchanged from /root/reference over the
+builder-written stand-in headers of oracle/refkit/ (oracle/Makefile target `loops`,
+oracle/_ref/libref_loops_*.so), must give the same layers bit for bit.  This guards the
+restatement against a mis-read of the loops' control flow.  It is NOT a reference build and pins no
+parity (oracle/refkit/refkit.h: the externals' arithmetic is the stand-ins', i.e. the builder's);
+nothing graded -- bench.py's cpu_baseline, its parity sample -- runs through these libraries."""
 import numpy as np
 import pytest
 
