@@ -18,11 +18,16 @@
 //                   correctly rounded; the rare undecidable inputs -- more than
 //                   19 significant digits straddling a rounding boundary -- are
 //                   flagged and re-done with strtod on the host)
+//   k_io_tail       ONE lane, from the first record whose tokens are not each consumed whole by
+//                   their field's extraction: the iostream loop itself, character by character
+//                   (libstdc++'s num_get: what a double / an int extraction accepts, where it
+//                   stops, where the NEXT extraction resumes -- "4.7" read as an int leaves ".7"
+//                   for the next double; "1-2-3-4" is a whole record)
 //   k_io_keep_count / k_io_keep_emit     z > -100 filter, file order kept
-// The stream semantics are the reference's for well-formed files: tokens are
-// taken four at a time, reading stops at the first token that is not a number
-// (an intensity with a valid integer prefix still completes its record, as
-// `>> int` would), an incomplete last record is dropped.
+// The stream semantics are the reference's for EVERY input: while every whitespace-delimited token
+// is consumed whole by its field (any well-formed file), tokens map to extractions one to one and
+// are parsed in parallel; from the first one that is not, the sequential kernel takes over until
+// the stream fails or ends.  An incomplete last record is dropped, as `while (infile >> ...)` does.
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -199,6 +204,45 @@ __device__ __forceinline__ AdjMant eisel_lemire(int64_t q, uint64_t w,
 
 enum : int { kTokOk = 0, kTokSlow = 1, kTokBad = 2, kTokOkThenStop = 3 };
 
+// ---- what libstdc++'s num_get ACCEPTS from a character sequence (locale_facets.tcc, "C" locale:
+// no grouping, '.' the decimal point).  Returns the number of characters taken; the conversion of
+// exactly those characters (strtod / the integer rules) then succeeds or sets failbit.
+// _M_extract_float: [+-] 0* then { digit | '.' once, not after the exponent | (e|E) once, only after
+// a mantissa digit, followed by an optional sign }.
+__device__ size_t accept_float(const unsigned char* s, size_t room) {
+  size_t i = 0;
+  if (i < room && (s[i] == '+' || s[i] == '-')) ++i;
+  bool mantissa = false, dec = false, sci = false;
+  while (i < room && s[i] == '0') {
+    mantissa = true;
+    ++i;
+  }
+  while (i < room) {
+    const unsigned char c = s[i];
+    if (c >= '0' && c <= '9') {
+      mantissa = true;
+      ++i;
+    } else if (c == '.' && !dec && !sci) {
+      dec = true;
+      ++i;
+    } else if ((c == 'e' || c == 'E') && !sci && mantissa) {
+      sci = true;
+      ++i;
+      if (i < room && (s[i] == '+' || s[i] == '-')) ++i;
+    } else {
+      break;
+    }
+  }
+  return i;
+}
+// _M_extract_int (base 10): [+-] digits, every digit taken even past an overflow
+__device__ size_t accept_int(const unsigned char* s, size_t room) {
+  size_t i = 0;
+  if (i < room && (s[i] == '+' || s[i] == '-')) ++i;
+  while (i < room && s[i] >= '0' && s[i] <= '9') ++i;
+  return i;
+}
+
 // libstdc++ num_get<...>::do_get(double&): [+-] digits [. digits] [(e|E) [+-] digits]
 __device__ int parse_double(const unsigned char* s, int len,
                             const uint64_t (*__restrict__ T)[2], double* out) {
@@ -297,7 +341,7 @@ k_io_parse(const unsigned char* __restrict__ text, size_t len, const uint64_t* _
            size_t ntok, const uint64_t (*__restrict__ T)[2], double* __restrict__ xyz,
            int32_t* __restrict__ inten, unsigned long long* __restrict__ first_bad,
            unsigned long long* __restrict__ slow_count, uint64_t* __restrict__ slow_list,
-           size_t slow_cap) {
+           size_t slow_cap, size_t nrec_cap) {
   const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= ntok) return;
   const size_t start = tok[t];
@@ -308,22 +352,84 @@ k_io_parse(const unsigned char* __restrict__ text, size_t len, const uint64_t* _
   const bool too_long = n == kMaxTokenLen && (size_t)n < room && !io_space(s[n]);
   const int field = (int)(t & 3);
   const size_t rec = t >> 2;
+  // (tokens of an incomplete last record are only CHECKED: an anomaly among them still hands the
+  // stream to k_io_tail, which may find a whole record in them)
+  const bool store = rec < nrec_cap;
   int st;
   if (field < 3) {
     double v = 0.0;
-    st = too_long ? kTokSlow : parse_double(s, n, T, &v);
-    if (st == kTokOk) xyz[3 * rec + field] = v;
+    st = too_long ? kTokBad : parse_double(s, n, T, &v);
+    if (st == kTokOk && store) xyz[3 * rec + field] = v;
   } else {
     int32_t v = 0;
     st = too_long ? kTokBad : parse_int(s, n, &v);
-    if (st == kTokOk || st == kTokOkThenStop) inten[rec] = v;
+    if (st == kTokOk && store) inten[rec] = v;
+    if (st == kTokOkThenStop) st = kTokBad;   // (what follows the digits is the next extraction's)
   }
+  // an ANOMALY: the extraction does not consume this token whole (or fails on it) -- from this
+  // token's record on the sequential kernel reads the stream
   if (st == kTokBad) atomicMin(first_bad, (unsigned long long)t);
-  if (st == kTokOkThenStop) atomicMin(first_bad, (unsigned long long)t + 1ull);
-  if (st == kTokSlow) {
+  if (st == kTokSlow && store) {
     const unsigned long long k = atomicAdd(slow_count, 1ull);
-    if (k < slow_cap) slow_list[k] = t;
+    if (k < slow_cap) {
+      slow_list[3 * k + 0] = start;
+      slow_list[3 * k + 1] = (uint64_t)n;
+      slow_list[3 * k + 2] = 3 * rec + (uint64_t)field;
+    }
   }
+}
+
+// The iostream loop of aerial-mapper-io.cc:316-323 / :337-345 itself, on ONE lane, from byte `pos`
+// (where record `rec0`'s first extraction begins) until an extraction fails or the text ends:
+//   while (infile >> x >> y >> z >> intensity) { push; if (infile.eof()) break; }
+// Records rec0, rec0 + 1, ... are stored while they fit `cap`; *nrec_out = records the loop
+// completed in all (the caller enlarges the buffers and runs it again if that exceeds cap).
+__global__ void k_io_tail(const unsigned char* __restrict__ text, size_t len, size_t pos, size_t rec0,
+                          size_t cap, const uint64_t (*__restrict__ T)[2], double* __restrict__ xyz,
+                          int32_t* __restrict__ inten, unsigned long long* __restrict__ nrec_out,
+                          unsigned long long* __restrict__ slow_count, uint64_t* __restrict__ slow_list,
+                          size_t slow_cap) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  size_t rec = rec0;
+  for (;;) {
+    double v[3] = {0.0, 0.0, 0.0};
+    size_t slow_at[3] = {0, 0, 0}, slow_len[3] = {0, 0, 0};
+    bool ok = true;
+    for (int f = 0; f < 3 && ok; ++f) {
+      while (pos < len && io_space(text[pos])) ++pos;   // (the sentry: skipws)
+      const size_t span = accept_float(text + pos, len - pos);
+      const int st = span <= 0x7FFFFFFFull ? parse_double(text + pos, (int)span, T, &v[f]) : kTokBad;
+      if (st == kTokBad) ok = false;   // (nothing accepted, strtod would stop early, or overflow: failbit)
+      if (st == kTokSlow) {
+        slow_at[f] = pos;
+        slow_len[f] = span;
+      }
+      pos += span;
+    }
+    if (!ok) break;
+    while (pos < len && io_space(text[pos])) ++pos;
+    const size_t span = accept_int(text + pos, len - pos);
+    int32_t iv = 0;
+    const int st = span <= 0x7FFFFFFFull ? parse_int(text + pos, (int)span, &iv) : kTokBad;
+    if (st != kTokOk) break;           // (no digit, or outside int: failbit)
+    pos += span;
+    if (rec < cap) {
+      for (int f = 0; f < 3; ++f) {
+        xyz[3 * rec + f] = v[f];
+        if (slow_len[f]) {
+          const unsigned long long k = atomicAdd(slow_count, 1ull);
+          if (k < slow_cap) {
+            slow_list[3 * k + 0] = slow_at[f];
+            slow_list[3 * k + 1] = slow_len[f];
+            slow_list[3 * k + 2] = 3 * rec + (uint64_t)f;
+          }
+        }
+      }
+      inten[rec] = iv;
+    }
+    ++rec;
+  }
+  *nrec_out = rec;
 }
 
 // ---- z > -100, in file order -------------------------------------------------------
@@ -425,57 +531,93 @@ int io_parse_point_cloud(int device, const char* host_text, size_t len, double**
   AMHIP_TRY(hipStreamSynchronize(stream));
   if (ntok >= 0xFFFFFFFFull) return io_fail("amhip_io: more than 2^32 tokens in one call");
   const size_t nrec_all = (size_t)(ntok / 4);
-  if (nrec_all == 0) return AMHIP_OK;
+  if (ntok == 0) return AMHIP_OK;
 
   DevBuf tok, raw_xyz, raw_int, slow;
   const size_t slow_cap = 1 << 20;
+  size_t rec_cap = nrec_all + 1;
   if ((rc = tok.alloc((size_t)ntok * sizeof(uint64_t)))) return rc;
-  if ((rc = raw_xyz.alloc((nrec_all + 1) * 3 * sizeof(double)))) return rc;
-  if ((rc = raw_int.alloc((nrec_all + 1) * sizeof(int32_t)))) return rc;
-  if ((rc = slow.alloc(slow_cap * sizeof(uint64_t)))) return rc;
-  unsigned long long init[2] = {~0ull, 0ull};  // first_bad, slow_count
+  if ((rc = raw_xyz.alloc(rec_cap * 3 * sizeof(double)))) return rc;
+  if ((rc = raw_int.alloc(rec_cap * sizeof(int32_t)))) return rc;
+  if ((rc = slow.alloc(3 * slow_cap * sizeof(uint64_t)))) return rc;
+  unsigned long long init[3] = {~0ull, 0ull, 0ull};  // first anomaly, slow_count, the tail's record count
   unsigned long long* ctl = total.as<unsigned long long>() + 1;
   AMHIP_TRY(hipMemcpyAsync(ctl, init, sizeof(init), hipMemcpyHostToDevice, stream));
   hipLaunchKernelGGL(k_io_token_emit, dim3((unsigned)nblk), dim3(kIoThreads), 0, stream, dtext, len,
                      counts.as<uint32_t>(), tok.as<uint64_t>());
-  // an incomplete last record never reaches the vectors: parse whole records only
-  const size_t ntok_used = nrec_all * 4;
-  hipLaunchKernelGGL(k_io_parse, dim3((unsigned)((ntok_used + 255) / 256)), dim3(256), 0, stream,
-                     dtext, len, tok.as<uint64_t>(), ntok_used,
+  // every token is checked; the tokens of whole records are stored (an incomplete last record
+  // never reaches the vectors)
+  hipLaunchKernelGGL(k_io_parse, dim3((unsigned)((ntok + 255) / 256)), dim3(256), 0, stream,
+                     dtext, len, tok.as<uint64_t>(), (size_t)ntok,
                      reinterpret_cast<const uint64_t(*)[2]>(table.p), raw_xyz.as<double>(),
-                     raw_int.as<int32_t>(), ctl, ctl + 1, slow.as<uint64_t>(), slow_cap);
+                     raw_int.as<int32_t>(), ctl, ctl + 1, slow.as<uint64_t>(), slow_cap, nrec_all);
   AMHIP_TRY(hipGetLastError());
-  unsigned long long res[2];
+  unsigned long long res[3];
   AMHIP_TRY(hipMemcpyAsync(res, ctl, sizeof(res), hipMemcpyDeviceToHost, stream));
   AMHIP_TRY(hipStreamSynchronize(stream));
   size_t nrec = nrec_all;
-  if (res[0] != ~0ull && (size_t)(res[0] / 4) < nrec) nrec = (size_t)(res[0] / 4);
-  // ---- slow path: the host re-does the flagged tokens with strtod -------------------
+  // (numbers the PARALLEL pass filed for strtod; those of records the tail re-reads are dropped)
+  const unsigned long long nslow_parallel = res[1];
+  size_t tail_from = ~size_t(0);
+  if (res[0] != ~0ull) {
+    // ---- the first token its extraction does not consume whole: from its record on, the
+    // iostream loop itself (k_io_tail) ------------------------------------------------------
+    const size_t rec0 = (size_t)(res[0] / 4);
+    tail_from = rec0;
+    uint64_t off0 = 0;
+    AMHIP_TRY(hipMemcpy(&off0, tok.as<uint64_t>() + 4 * rec0, sizeof(off0), hipMemcpyDeviceToHost));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      // (the tail files its own strtod entries behind the parallel pass's)
+      AMHIP_TRY(hipMemcpyAsync(ctl + 1, &nslow_parallel, sizeof(nslow_parallel), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL(k_io_tail, dim3(1), dim3(1), 0, stream, dtext, len, (size_t)off0, rec0, rec_cap,
+                         reinterpret_cast<const uint64_t(*)[2]>(table.p), raw_xyz.as<double>(),
+                         raw_int.as<int32_t>(), ctl + 2, ctl + 1, slow.as<uint64_t>(), slow_cap);
+      AMHIP_TRY(hipGetLastError());
+      AMHIP_TRY(hipMemcpyAsync(res, ctl, sizeof(res), hipMemcpyDeviceToHost, stream));
+      AMHIP_TRY(hipStreamSynchronize(stream));
+      nrec = (size_t)res[2];
+      if (nrec <= rec_cap) break;
+      if (attempt == 1) return io_fail("amhip_io: internal: the sequential reader's record count changed");
+      // more records than tokens / 4 (tokens that hold several numbers): larger buffers, the
+      // records in front of rec0 carried over, once more
+      DevBuf big_xyz, big_int;
+      if ((rc = big_xyz.alloc((nrec + 1) * 3 * sizeof(double)))) return rc;
+      if ((rc = big_int.alloc((nrec + 1) * sizeof(int32_t)))) return rc;
+      if (rec0) {
+        AMHIP_TRY(hipMemcpyAsync(big_xyz.p, raw_xyz.p, rec0 * 3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        AMHIP_TRY(hipMemcpyAsync(big_int.p, raw_int.p, rec0 * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+      }
+      AMHIP_TRY(hipStreamSynchronize(stream));
+      std::swap(raw_xyz.p, big_xyz.p);
+      std::swap(raw_int.p, big_int.p);
+      rec_cap = nrec + 1;
+    }
+  }
+  // ---- slow path: the host re-does the flagged numbers with strtod -------------------
+  // (more than 19 significant digits straddling a rounding boundary; syntactically valid by
+  // construction.  Entries of records the stream never completed are ignored.)
   size_t nslow = (size_t)res[1];
   if (nslow > slow_cap) return io_fail("amhip_io: too many tokens need the strtod path");
   if (nslow) {
-    std::vector<uint64_t> list(nslow), offs(nslow);
-    AMHIP_TRY(hipMemcpy(list.data(), slow.p, nslow * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    size_t first_bad_tok = ~size_t(0);
+    std::vector<uint64_t> list(3 * nslow);
+    AMHIP_TRY(hipMemcpy(list.data(), slow.p, 3 * nslow * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    size_t first_bad_rec = ~size_t(0);
     for (size_t k = 0; k < nslow; ++k) {
-      uint64_t off = 0;
-      AMHIP_TRY(hipMemcpy(&off, tok.as<uint64_t>() + list[k], sizeof(off), hipMemcpyDeviceToHost));
-      size_t e = off;
-      while (e < len && !(host_text[e] == ' ' || (host_text[e] >= 9 && host_text[e] <= 13))) ++e;
-      const std::string s(host_text + off, e - off);
+      const size_t off = (size_t)list[3 * k], n = (size_t)list[3 * k + 1], dest = (size_t)list[3 * k + 2];
+      if (dest / 3 >= nrec) continue;
+      if (k < (size_t)nslow_parallel && dest / 3 >= tail_from) continue;   // (re-read by the tail)
+      const std::string str(host_text + off, n);
       char* endp = nullptr;
       errno = 0;
-      const double v = std::strtod(s.c_str(), &endp);
-      const bool bad = endp == s.c_str() || *endp != '\0' || v == HUGE_VAL || v == -HUGE_VAL;
-      if (bad) {
-        if (list[k] < first_bad_tok) first_bad_tok = list[k];
+      const double v = std::strtod(str.c_str(), &endp);
+      const bool bad = endp == str.c_str() || *endp != '\0' || v == HUGE_VAL || v == -HUGE_VAL;
+      if (bad) {   // (overflow: failbit -- the stream ends in this record)
+        first_bad_rec = std::min(first_bad_rec, dest / 3);
         continue;
       }
-      const size_t rec = list[k] >> 2, field = list[k] & 3;
-      AMHIP_TRY(hipMemcpy(raw_xyz.as<double>() + 3 * rec + field, &v, sizeof(v),
-                          hipMemcpyHostToDevice));
+      AMHIP_TRY(hipMemcpy(raw_xyz.as<double>() + dest, &v, sizeof(v), hipMemcpyHostToDevice));
     }
-    if (first_bad_tok != ~size_t(0) && first_bad_tok / 4 < nrec) nrec = first_bad_tok / 4;
+    if (first_bad_rec < nrec) nrec = first_bad_rec;
   }
   if (out_slow) *out_slow = nslow;
   if (nrec == 0) return AMHIP_OK;

@@ -124,6 +124,13 @@ def parse():
     ap.add_argument("--no-second-mode", action="store_true", help="skip the other mode's loop")
     ap.add_argument("--no-rough-terrain", action="store_true",
                     help="skip the rough-terrain extra (N = 1: 25 m steps in 20 %% of the gather tiles)")
+    ap.add_argument("--window-parity", action="store_true",
+                    help="N = 1, one fixed survey (cfg4 / small4): after the timed steps compare four "
+                         "600 x 600-cell windows of the elevation layer (three corners and the middle) "
+                         "with the CPU oracle's DSM of those windows")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="default run (cfg3, N = 1): skip the child runs of the other BASELINE configs "
+                         "(`other_workloads`)")
     ap.add_argument("--no-preflight", action="store_true",
                     help="N > 1: skip the small verified step in front of the timed ones")
     ap.add_argument("--route", default="auto", choices=["auto", "ranks", "session"],
@@ -446,6 +453,89 @@ def preflight_verify(args, A, tiling, synth, dist, one_gpu, dev, local_rank, ran
     v["halo_rows_per_neighbour"] = cap
     v["map"] = "%dx%d cells, %d points, %d x %d windows" % (side, side, n_all, tiles_i, tiles_j)
     return v
+
+
+def window_parity(map_, pts_dev, side, res, L, origin, exact, s=600):
+    """Four s x s-cell windows of the resident elevation layer against the CPU oracle's DSM of the
+    same cells (a grid of its own per window whose cell centres are the big map's: everything is
+    dyadic, hence exact).  The big-cloud paths -- placement in rounds, clouds beyond 2^27 points --
+    at full size, where a whole-map oracle run does not fit the host."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    which = "ref" if O.have_ref() else "port"
+    s = min(s, side)
+    wins = [(0, 0), ((side - s) // 2, (side - s) // 2), (side - s, side - s), (0, side - s)]
+    elev = map_.as_torch("elevation")
+    out = {"oracle": which, "window_cells": s * s, "windows": []}
+    for i0, j0 in wins:
+        sub_len = s * res
+        cx = origin[0] + L / 2.0 - (i0 + s / 2.0) * res
+        cy = origin[1] + L / 2.0 - (j0 + s / 2.0) * res
+        g = O.make_grid(sub_len, sub_len, res, cx, cy, which=which)
+        assert (g.rows, g.cols) == (s, s)
+        halo = 3.0
+        x, y = pts_dev[:, 0], pts_dev[:, 1]
+        keep = (x > cx - sub_len / 2 - halo) & (x < cx + sub_len / 2 + halo) & \
+               (y > cy - sub_len / 2 - halo) & (y < cy + sub_len / 2 + halo)
+        sub = pts_dev[keep].cpu().numpy()
+        rc, want, _ = O.dsm_process(sub, g, 1, 0.0, 0.0, which=which)
+        assert rc == 0
+        got = elev[j0:j0 + s, i0:i0 + s].cpu().numpy()
+        ok = ~np.isnan(want)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & ~ok)
+        out["windows"].append({
+            "cells": "[%d, %d) x [%d, %d)" % (i0, i0 + s, j0, j0 + s), "points": int(sub.shape[0]),
+            "nan_pattern_equal": bool(np.array_equal(np.isnan(got), ~ok)),
+            "max_abs_err_m": float(np.abs(got[ok].astype(np.float64) - want[ok]).max()) if ok.any() else 0.0,
+            "bit_identical_frac": round(float(same.mean()), 9)})
+    tol = 1e-6 if exact else 1e-4
+    out["pass"] = all(w["nan_pattern_equal"] and w["max_abs_err_m"] <= tol for w in out["windows"])
+    return out
+
+
+def other_workloads(args):
+    """The other BASELINE configs on this GPU, each a CHILD `python bench.py --workload ...` of a few
+    steps (its own process: its own contexts and memory, and nothing it does can cost the parent's
+    line).  What DESIGN.md quotes beside the headline comes from here, keyed by the library's build."""
+    import subprocess
+    common = ["--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-host-path", "--no-second-mode",
+              "--no-rough-terrain", "--no-other-workloads", "--dsm-mode", args.dsm_mode]
+    runs = [("cfg2 (configs[1]: DSM alone)", ["--workload", "cfg2"]),
+            ("cfg2 --knn 4 (configs[1]'s optional 'IDW k = 4' cap: not a reference code path)",
+             ["--workload", "cfg2", "--knn", "4"]),
+            ("cfg3 --colored (8UC3 frames, colored_ortho)", ["--workload", "cfg3", "--colored"]),
+            ("cfg4 at N = 1 (configs[3]'s whole 400M-point / 40000^2 map on one GPU)",
+             ["--workload", "cfg4", "--window-parity"]),
+            ("cfg5 at N = 1 (configs[4]: 64-frame batches onto the resident 40000^2 map)",
+             ["--workload", "cfg5"])]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = {}
+    for name, extra in runs:
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + common + extra, env=env,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                               timeout=240)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if not lines:
+                out[name] = {"error": "child exit %d: %s" % (r.returncode, r.stderr[-300:])}
+                continue
+            d = json.loads(lines[-1])
+            e = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"],
+                 "library_build_id": d.get("library_build_id"),
+                 "kernels_ms": {k: v.get("ms_per_step") for k, v in d.get("kernels", {}).items()},
+                 "child_wall_s": round(time.perf_counter() - t0, 1)}
+            if "window_parity" in d:
+                e["window_parity"] = d["window_parity"]
+            out[name] = e
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "did not finish in 240 s (killed)"}
+        except Exception as e:
+            out[name] = {"error": repr(e)}
+    return out
 
 
 def session_route(args, A, st, tiles, devices, dsm_settings, ncam, mosaic_settings, h_pts, poses, h_frames,
@@ -1106,6 +1196,11 @@ def main():
                 out["rough_terrain"] = rough_terrain(args, A, m, pts, dsm, side, res, tile_center, L)
             except Exception as e:
                 out["rough_terrain"] = {"error": repr(e)}
+        if world == 1 and fixed and args.window_parity and not args.knn:
+            try:
+                out["window_parity"] = window_parity(m, pts, side, res, L, (ox, oy), args.dsm_mode == "exact")
+            except Exception as e:
+                out["window_parity"] = {"error": repr(e)}
         if world == 1 and args.host_path and not fixed and args.route != "ranks":
             h_pts = pts.cpu().numpy()
             h_frames = [f for f in frames.cpu().numpy()] if F else None
@@ -1113,6 +1208,17 @@ def main():
                                                   mosaic.settings if F else None, h_pts, poses, h_frames,
                                                   cells, res, (ox, oy))
             out["pcie_inclusive"]["route"] = "session (--route session at N = 1 is this object)"
+        if world == 1 and args.workload == "cfg3" and not args.no_other_workloads and not args.knn \
+                and not args.colored and not args.no_cpu_baseline:
+            # (after everything of this process: the children need the GPU's memory -- cfg4 / cfg5 hold
+            # a 40000^2 map -- so this process's buffers go first)
+            try:
+                del frames, pts, pts_buf
+                m.close()
+                torch.cuda.empty_cache()
+            except Exception:
+                pass
+            out["other_workloads"] = other_workloads(args)
         if world > 1 and args.route != "ranks" and not batch:
             # In a CHILD process with a time limit: one host process driving all N devices has never
             # run next to N live ranks on real hardware -- whatever it does (fail, hang), this

@@ -511,11 +511,15 @@ class ReferenceForwardMosaic(object):
 def io_load_point_cloud(text, with_intensities=True, which="port"):
     """io::AerialMapperIO::loadPointCloudFromFile on an in-memory file (bytes)."""
     cap = text.count(b"\n") + text.count(b" ") // 3 + 8
-    xyz = np.empty((cap, 3), np.float64)
-    inten = np.empty(cap, np.int32)
-    n = lib(which).amo_io_load_point_cloud(text, len(text), C.c_void_p(xyz.ctypes.data),
-                                           C.c_void_p(inten.ctypes.data) if with_intensities else None,
-                                           cap)
+    for _ in range(2):
+        xyz = np.empty((cap, 3), np.float64)
+        inten = np.empty(cap, np.int32)
+        n = lib(which).amo_io_load_point_cloud(text, len(text), C.c_void_p(xyz.ctypes.data),
+                                               C.c_void_p(inten.ctypes.data) if with_intensities else None,
+                                               cap)
+        if n <= cap:
+            break
+        cap = n            # (tokens that hold several numbers: "1-2-3-4" is a whole record)
     assert n <= cap
     return xyz[:n].copy(), inten[:n].copy()
 

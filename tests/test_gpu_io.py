@@ -36,6 +36,36 @@ def test_semantics_of_the_extraction_loop():
         _same(t)
 
 
+def test_adversarial_tokens_follow_the_iostream_loop():
+    """ the tokens a hand-written parser gets wrong.  The oracle IS the C++ library's
+    own `infile >> x >> y >> z >> intensity` (oracle/amo_io.cc runs aerial-mapper-io.cc:309-347's loop
+    on a stream over the buffer): nothing about number syntax is restated there.  aerial-mapper-io.cc
+    itself needs GDAL, OpenCV, aslam and glog headers -- not in the image, so it is not compiled."""
+    for t in [b"nan 2 3 4\n5 6 7 8\n", b"1 2 inf 4\n", b"1 NaN 3 4\n", b"-inf 2 3 4\n", b"1 2 infinity 4\n",
+              b"0x10 2 3 4\n", b"1 2 3 0x1F\n", b"1 2 3 010\n",            # (no hex; a leading 0 is decimal)
+              b"1 2 3 1e5\n6 7 8 9\n", b"1 2 3 4.7 5 6 7 8\n",              # (an int stops at 'e' / '.')
+              b"1 2 -100 4\n5 6 -100.00000000000001 7\n8 9 -99.99999999999999 1\n",   # (z > -100, strictly)
+              b"1,5 2 3 4\n", b"1..2 3 4 5\n", b"1e+ 2 3 4\n", b"1e+5e3 2 3 4\n", b"--1 2 3 4\n",
+              b"+-1 2 3 4\n", b"1 2 3 4\n5 6 7", b"1 2 3 4\n5 6 7 8 ", b"1 2 3 4\n5 6 7 8\n\n\n",
+              b"1 2 3 4\x00 5 6 7 8\n", b"1 2 3 4\n# comment\n5 6 7 8\n", b"1 2 3 4;\n5 6 7 8\n",
+              b"1e5 +3 .5 7\n", b"1E+05 -3. 5.e-1 -7\n", b".e5 2 3 4\n", b". 2 3 4\n", b"e5 2 3 4\n",
+              b"1e0000000000000000000005 2 3 4\n", b"1e-0000000000000000000005 2 3 4\n",
+              b"00000000000000000000000000000000000001 2 3 4\n",
+              b"1 2 3 2147483648\n5 6 7 8\n", b"1 2 3 -2147483649\n5 6 7 8\n",   # (int overflow: failbit)
+              b"1 2 3 +5\n", b"1 2 3 -0\n", b"1 2 3 - 5\n",
+              "١ 2 3 4\n".encode(), b"\xef\xbb\xbf1 2 3 4\n",                 # (non-ASCII digits, a BOM)
+              b"1\n2\n3\n4\n5\n6\n7\n8\n", b"1 2 3 4 5 6 7 8 9 10 11\n",
+              # one whitespace-delimited token, several extractions: the next one resumes where the last stopped
+              b"1-2-3-4\n", b"1-2-3-4-5-6-7-8\n", b"1.5.25 3 4\n", b"1e5-3+2 7\n", b"1 2 3.5-4\n",
+              b"1 2 3 4-5 6 7 8\n", b"1 2 3 4+5 6 7 8\n", b"1 2 3 4.5 6 7 8.9 1 2 3\n",
+              b"0x10 2 3 4\n", b"1 2 3 4\n5.5.5.5 6\n7 8 9 1\n", b"1 2 3 4e5 6 7 8\n",
+              b"-.5-.5-.5-5\n" * 3, (b"1-2-3-4" * 50) + b"\n",
+              b"1 2 3 4\n" * 100 + b"5 6 7 8.5 6 7 8\n" + b"1 2 3 4\n" * 100,
+              b"9" * 1000 + b" 2 3 4\n", b"1 2 3 4\n" + b"0" * 2000 + b".5 2 3 4\n5 6 7 8\n",
+              b"1." + b"9" * 900 + b".5 3 4\n"]:
+        _same(t)
+
+
 def test_hard_decimal_to_double_cases():
     hard = ["0.1", "0.2", "0.3", "1e23", "8.5e-1", "9007199254740993", "9007199254740992",
             "9007199254740991", "4.9e-324", "2.4703282292062327e-324", "2.4703282292062328e-324",
