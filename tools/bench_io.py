@@ -68,9 +68,9 @@ def main():
         "note": "includes the pageable host->device copy of the text; tokens that needed the "
                 "host strtod path: %d" % cloud.strtod_tokens,
         "cpu_baseline": {"value": round(nb / tc / 1e6, 3), "unit": "Mpoints/s", "cores": 1,
-                         "kind": "reference",
-                         "sample": "the reference's `infile >> x >> y >> z >> intensity` loop "
-                                   "(oracle/amo_io.cc) on the first %d points: %.2f s" % (nb, tc)},
+                         "kind": "port",
+                         "sample": "the loop of aerial-mapper-io.cc:316-323 restated over the C++ library's "
+                                   "own operator>> (oracle/amo_io.cc) on the first %d points: %.2f s" % (nb, tc)},
         "parity_sample": {"points": nb,
                           "xyz_mismatch": int((got_xyz.view(np.uint64) != want_xyz.view(np.uint64)).sum()),
                           "intensity_mismatch": int((got_int != want_int).sum())},
