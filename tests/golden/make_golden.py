@@ -1,17 +1,13 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz -- small input/output vectors of the hot path.
 
-The reference has no tests or fixtures of its own, so
-these are produced HERE by the strongest checker available in the build
-container: the reference's OWN translation units compiled unchanged from
-/root/reference against oracle/refkit/ (oracle/_ref/libref_loops_*.so), falling
-back to oracle/_ref/liboracle_ref.so = the reference's VENDORED nanoflann
-driven by the restated dsm.cc / ortho-backward-grid.cc loops (the two agree bit
-for bit, tests/test_reference_loops.py).  The fixtures
-travel to the GPU box, where /root/reference does not exist.
-tests/test_reference_loops.py checks that the reference's OWN loops (dsm.cc,
-ortho-backward-grid.cc, ortho-from-pcl.cc compiled unchanged against
-oracle/refkit/) reproduce every dsm_ / ortho_ / pcl_ fixture bit for bit.
+The reference has no tests or fixtures of its own and its translation units
+cannot be built in this image, so these vectors are the ORACLE's: produced by the restated loops
+over the reference's vendored nanoflann (oracle/_ref/liboracle_ref.so) -- or, identically bit for
+bit (tests/test_reference_loops.py), by the consistency-check libraries of oracle/refkit/ where they
+are built.  They pin the GPU path and the oracle against each other across rounds and on the GPU
+box (where /root/reference does not exist); they are NOT reference outputs: parity stays
+"unpinned" in the task's sense.
 
     python tests/golden/make_golden.py        (needs /root/reference)
 
