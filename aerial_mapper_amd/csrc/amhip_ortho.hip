@@ -876,12 +876,6 @@ __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per
 k_ortho_backward(AMHIP_ORTHO_KERNEL_ARGS) {
   AMHIP_ORTHO_KERNEL_BODY(false, 16)
 }
-// margin-guarded fold, four cells per lane, registers as they come (3 waves per SIMD):
-// tuning knob ortho_fast_waves=3 (A-B knob)
-__global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(3)))
-k_ortho_backward_fast(AMHIP_ORTHO_KERNEL_ARGS) {
-  AMHIP_ORTHO_KERNEL_BODY(true, 16)
-}
 // margin-guarded fold, two cells per lane, held to 128 VGPRs (4 waves per SIMD): the default
 __global__ void __launch_bounds__(kOrthoThreads) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_ortho_backward_fast4(AMHIP_ORTHO_KERNEL_ARGS) {
@@ -975,9 +969,7 @@ int ortho_run(Ctx* c, const OrthoParams& p, const FramePose* dev_poses, const Fr
             (unsigned)((p.cols + kTileJ - 1) / kTileJ));
   float* out = p.colored ? c->layers[AMHIP_LAYER_COLORED_ORTHO]
                          : c->layers[AMHIP_LAYER_ORTHO];
-  const int fast_waves = (int)tuning("ortho_fast_waves", 4.0);  // (A-B knob)
-  auto kernel = !p.fast ? k_ortho_backward
-                        : (fast_waves == 3 ? k_ortho_backward_fast : k_ortho_backward_fast4);
+  auto kernel = !p.fast ? k_ortho_backward : k_ortho_backward_fast4;
   c->dirty_on_device = false;  // (a dense launch can write anywhere in the window)
   c->dirty[0] = c->dirty[1] = 0;
   c->dirty[2] = c->win_rows;

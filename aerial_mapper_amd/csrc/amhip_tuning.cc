@@ -21,7 +21,7 @@ const char* const kKeys[] = {
     // DSM gather
     "dsm_canon_all", "dsm_no_rough_switch", "dsm_no_subwindow", "eager_reset",
     // mosaic
-    "ortho_exact_fold", "ortho_no_prune", "ortho_fast_waves", "no_coarse_cull", "ortho_no_tile_list",
+    "ortho_exact_fold", "ortho_no_prune", "no_coarse_cull", "ortho_no_tile_list",
     "no_distorted_cull", "no_distorted_prune", "distorted_square_cull",
     // session
     "session_always_copy", "session_threads", "session_scalar_sums", "session_no_partial",

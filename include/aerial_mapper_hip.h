@@ -626,10 +626,10 @@ int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float low
  *   dsm_no_rough_switch       the single-precision mode stays in its own pipeline on rough scenes
  *   dsm_no_subwindow          small clouds onto large maps are binned over the whole window
  *   eager_reset               amhip_layers_reset fills the layers at once (default: fused into producers)
- *   ortho_exact_fold, ortho_no_prune, ortho_fast_waves (4), no_coarse_cull, ortho_no_tile_list
+ *   ortho_exact_fold, ortho_no_prune, no_coarse_cull, ortho_no_tile_list
  *                             mosaic: every pair in the reference's arithmetic / keep dominated frames /
- *                             3- or 4-waves build of the guarded kernel / no small-batch pre-cull /
- *                             dispatch every tile of a large map instead of a list of visible ones
+ *                             no small-batch pre-cull / dispatch every tile of a large map instead of a
+ *                             list of visible ones
  *   no_distorted_cull, no_distorted_prune, distorted_square_cull   cameras with a distortion model
  *   session_always_copy, session_threads, session_scalar_sums, session_no_partial,
  *   session_serial_sums       device content sums always before the downloads (round 5's order)

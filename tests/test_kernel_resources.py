@@ -47,7 +47,6 @@ BUDGETS = [
     ("k_dsm_p3_scatter_recILb0E", 4, 0),                  # the record pipeline (single-precision mode)
     ("k_dsm_p3_scatter_recILb1E", 4, 0),
     ("18k_dsm_p3_place_recE", 4, 0),
-    ("21k_ortho_backward_fastE", 3, 4),                   # (the A-B variant: 4 cells per lane carry 4 pixel registers across a slab)
     ("22k_ortho_backward_fast4E", 4, 12),                 # the default mosaic kernel (two cells per lane)
     # denser clouds in single precision: 4096-point images run two workgroups per CU (4 waves per
     # SIMD), the wave-per-block kernel three waves per SIMD

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Bench lines under different environments on ONE box.  Usage:
-#   gpurun -- bash tools/gpu_env_ab.sh "" "AMHIP_TUNING=ortho_fast_waves=3" ...   (one run per argument)
+#   gpurun -- bash tools/gpu_env_ab.sh "" "AMHIP_TUNING=ortho_no_prune=1" ...   (one run per argument)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/gpurun_out"
 n=0
