@@ -2306,6 +2306,7 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       const int nt = (int)tuning("gather_nt", 512.0);
 #else
       constexpr int nt = 512;
+      (void)nt;
 #endif
       auto with_cap = [&](int cap) {
         DsmParams q = p;
@@ -2455,7 +2456,9 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       if (p.tile_j == 16 && cap0 == 1024) {
         if (f32) AMHIP_LAUNCH_F32(16, 1024);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 16, 1024, 0, 8192);
+#ifdef AMHIP_TIMING_PROBES
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 16, 1024);
+#endif
         else AMHIP_LAUNCH_DENSE(512, 16, 1024);
       } else if (p.tile_j == 16 && cap0 > 2048) {
         // (make_dsm_params picks 4096 / 7680 only for the single-precision mode)
@@ -2469,8 +2472,10 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       } else {
         if (f32) AMHIP_LAUNCH_F32(32, 2048);
         else if (sparse) AMHIP_LAUNCH_LIST(512, 32, 2048, 0, 8192);
+#ifdef AMHIP_TIMING_PROBES
         else if (nt == 256) AMHIP_LAUNCH_DENSE(256, 32, 2048);
         else if (nt == 1024) AMHIP_LAUNCH_DENSE(1024, 32, 2048);
+#endif
         else AMHIP_LAUNCH_DENSE(512, 32, 2048);
       }
       if (skip_classes) {
