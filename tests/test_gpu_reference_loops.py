@@ -1,8 +1,10 @@
-"""GPU against the reference's OWN code: dsm.cc, ortho-backward-grid.cc and ortho-from-pcl.cc
-compiled unchanged against oracle/refkit/ (oracle/_ref/libref_loops_*.so -- built where
-/root/reference exists, they travel to the GPU box with the other built libraries).  The
-same bars as against the restated oracle: DSM heights within 1e-4 m with the same NaN
-pattern, mosaic layers bit for bit."""
+"""GPU against the CONSISTENCY-CHECK build of the reference's loop sources: the text of dsm.cc,
+ortho-backward-grid.cc and ortho-from-pcl.cc compiled unchanged over the builder-written stand-in
+headers of oracle/refkit/ (oracle/_ref/libref_loops_*.so -- built where /root/reference exists, they
+travel to the GPU box with the other built libraries).  NOT a reference build (oracle/refkit/refkit.h)
+and no pin: one more route by which a mis-read loop in the restated oracle AND in the kernels
+would show.  The same bars as against the restated oracle: DSM heights within 1e-4 m with the same
+NaN pattern, mosaic layers bit for bit."""
 import numpy as np
 import pytest
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Oracle-checked run of the big-cloud paths at FULL size: the sort's placement
 in rounds (sub-partitions beyond one LDS image, registers and re-read forms -- contexts beyond
-~130 M points) and clouds beyond 2^27 points, against the reference's own compiled dsm.cc
-(oracle/_ref/libref_loops_dsm.so; the restated oracle where that was not built) on 600 x 600-cell
+~130 M points) and clouds beyond 2^27 points, against the CPU oracle (the restated loops over the reference's
+vendored nanoflann, oracle/_ref/liboracle_ref.so) on 600 x 600-cell
 windows -- a corner, the middle, the far corner -- in both gather modes.  dsm.cc:36-52 has no size
 regime; neither may the drop-in.
 
@@ -47,13 +47,12 @@ def run(n, side, res=0.25, s=600):
     from aerial_mapper_amd import synth
     dev = torch.device("cuda", 0)
     L = side * res
-    which = "loops" if O.have_loops() else ("ref" if O.have_ref() else "port")
+    which = "ref" if O.have_ref() else "port"   # (the oracle: restated loops over the vendored nanoflann)
     pts = synth.make_points_torch(n, L / 2.0 + 4.0, 45, dev)
     wins = [(0, 0), ((side - s) // 2, (side - s) // 2), (side - s, side - s), (0, side - s)]
     refs = [window_reference(O, pts, res, L, i0, j0, s, which) for i0, j0 in wins]
     out = {"points": n, "cells": side * side, "map": "%d x %d @ %.2f m" % (side, side, res),
-           "reference": {"loops": "dsm.cc compiled unchanged (oracle/refkit)", "ref": "vendored nanoflann under "
-                         "restated loops", "port": "restated loops"}[which],
+           "oracle": {"ref": "vendored nanoflann under restated loops", "port": "restated loops"}[which],
            "windows": ["cells [%d, %d) x [%d, %d), %d points incl. 3 m halo" % (i0, i0 + s, j0, j0 + s, r[1])
                        for (i0, j0), r in zip(wins, refs)], "modes": {}}
     with A.AerialGridMap(A.GridMapSettings(0.0, 0.0, L, L, res)) as m:
