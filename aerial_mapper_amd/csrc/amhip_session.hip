@@ -102,6 +102,7 @@ struct Session {
   std::vector<hipStream_t> aux_stream;
   std::vector<hipEvent_t> ev_k0, ev_k1, ev_s1, ev_d1;
   CallProfile prof;
+  std::atomic<unsigned long long> prof_down{0};   // (the windows' threads add to it: the call's downloads)
   int W() const { return (int)ctx.size(); }
 };
 
@@ -414,7 +415,7 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
       st.host_known = false;
       AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[layers[q]], s, w, true, c->stream));
       s.down_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
-      s.prof.down_bytes += (double)w.rows * (double)w.cols * 4.0;
+      s.prof_down += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
       copied[q] = true;
     }
     // (the downloads' own start, where the sums ran in front of them on the same stream)
@@ -467,11 +468,11 @@ static int sync_out(Session& s, int k, const int* layers, float* const* hosts, i
                                    hipMemcpyDeviceToHost, c->stream));
         packed[q] = true;
         s.down_bytes += (unsigned long long)block * 4ull;
-        s.prof.down_bytes += (double)block * 4.0;
+        s.prof_down += (unsigned long long)block * 4ull;
       } else {
         AMHIP_TRY(copy_window(map_at(hosts[q], s, w), c->layers[l], s, w, true, c->stream));
         s.down_bytes += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
-        s.prof.down_bytes += (double)w.rows * (double)w.cols * 4.0;
+        s.prof_down += (unsigned long long)w.rows * (unsigned long long)w.cols * 4ull;
       }
       copied[q] = true;
       any = true;
@@ -749,7 +750,7 @@ int amhip_session_last_profile(const amhip_session* h, double* out8) {
   out8[4] = p.dev_sum_wait_ms;
   out8[5] = p.d2h_ms;
   out8[6] = p.up_bytes;
-  out8[7] = p.down_bytes;
+  out8[7] = (double)h->impl.prof_down.load();
   return AMHIP_OK;
 }
 
@@ -782,6 +783,7 @@ int amhip_session_dsm_process(amhip_session* h, const double* host_xyz, size_t n
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
   s.prof = CallProfile();
+  s.prof_down = 0;
   s.prof.up_bytes = (double)n * 24.0;
   if (W == 1) {
     PhaseClock clock("dsm");
@@ -998,6 +1000,7 @@ int amhip_session_ortho_backward_process(
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
   s.prof = CallProfile();
+  s.prof_down = 0;
   s.prof.up_bytes = (double)frame * (double)F;
   int rc_up = AMHIP_OK;
   std::string up_msg;
@@ -1057,9 +1060,14 @@ int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xy
   Session& s = h->impl;
   std::vector<Hash128> hh;
   const float* mats[1] = {ortho};
+  const auto call0 = std::chrono::steady_clock::now();
+  s.prof = CallProfile();
+  s.prof_down = 0;
+  s.prof.up_bytes = (double)n * 28.0 * (double)s.W();   // (every window gets the whole cloud)
   if (!s.always_copy) host_hashes(s, mats, 1, &hh);
   else hh.assign(s.W(), Hash128());
-  return for_windows(s, [&](int k) -> int {
+  s.prof.host_sum_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call0).count();
+  const int rc_all = for_windows(s, [&](int k) -> int {
     Ctx* c = &s.ctx[k]->impl;
     int r = ctx_use_device(c);
     if (r) return r;
@@ -1079,6 +1087,8 @@ int amhip_session_ortho_from_pcl_process(amhip_session* h, const double* host_xy
     if ((r = sync_out(s, k, lay, outs, 1))) return r;
     return ctx_fetch_status(c);
   });
+  s.prof.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - call0).count();
+  return rc_all;
 }
 
 // ---- what leaves the map (formats: amhip_export.hip) ---------------
