@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Fill DESIGN.md's @@...@@ placeholders of section 4.4 from a bench line (profiles/rNN_bench_cfg3_n1.json).
+"""Regenerate DESIGN.md's section 4.4 from docs/design_4_4.template.md (its @@...@@ placeholders) and a
+bench line (profiles/rNN_bench_cfg3_n1.json).
     python tools/fill_design_numbers.py profiles/r06_bench_cfg3_n1.json [profiles/r06_exact_pmc_traffic.json]"""
 import json
 import os
@@ -42,8 +43,11 @@ rep = {
 }
 p = os.path.join(ROOT, "DESIGN.md")
 s = open(p).read()
+sec = open(os.path.join(ROOT, "docs", "design_4_4.template.md")).read()
 for key, val in rep.items():
-    s = s.replace("@@%s@@" % key, val)
-left = [w for w in s.split("@@")[1::2]]
+    sec = sec.replace("@@%s@@" % key, val)
+left = [w for w in sec.split("@@")[1::2]]
+i, j = s.index("### 4.4 Measurements"), s.index("### 4.5 The other kernels")
+s = s[:i] + sec + s[j:]
 open(p, "w").write(s)
 print("filled; build", d.get("library_build_id"), "placeholders left:", left)
