@@ -470,7 +470,9 @@ static int make_dsm_params(const Ctx& c, int radius_sq,
   // Only for dsm::Dsm (heights): OrthoFromPcl interpolates 8-bit intensities whose spread
   // (up to 255) leaves no room under the error bound.
   p.knn_k = mode == 0 ? c.dsm_knn : 0;
-  if (p.knn_k) p.lds_ok = 0;  // (capped mode: one lane per cell on the global bins)
+  // (capped mode: the LDS-tiled gather's own build, k_dsm_gather_tiled_knn; tuning knob knn_global_bins:
+  // one lane per cell on the global bins, the round-1 kernel)
+  if (p.knn_k && tuning_on("knn_global_bins")) p.lds_ok = 0;
   p.fx_ok = 0;
   if (p.lds_ok && mode == 0 && !c.dsm_exact && !c.dsm_exact_now && rec_fits) {
     int S = 28;

@@ -334,18 +334,23 @@ __device__ __forceinline__ bool cell_fallback_global(const DsmParams& p,
 // (nanoflann::KNNResultSet::addPoint, nanoflann.hpp:100-125: a later arrival never
 // displaces an equal distance).
 constexpr int kMaxKnn = 8;
-struct KnnSet {
-  double d2[kMaxKnn], z[kMaxKnn];
-  int n;
+template <int K>
+struct KnnSetT {
+  double d2[K], z[K];
+  double worst;   // d2 of the k-th entry once the set is full, +inf before: what a candidate has to beat
+  int n;          // (a scalar of its own: s->d2[k - 1] with a run-time k would move the arrays to scratch memory)
 };
+typedef KnnSetT<kMaxKnn> KnnSet;
 
-__device__ __forceinline__ void knn_add(KnnSet* s, int k, double d2, double z) {
-  if (s->n == k && !(d2 < s->d2[k - 1])) return;
+// (K: the registers the set takes, k <= K the cap in force)
+template <int K>
+__device__ __forceinline__ void knn_add(KnnSetT<K>* s, int k, double d2, double z) {
+  if (!(d2 < s->worst)) return;
   // shift the strictly greater entries up (static indices only: the set lives in registers)
   double cd = d2, cz = z;
   bool inserted = false;  // from the insertion point on every entry moves up by one
 #pragma unroll
-  for (int q = 0; q < kMaxKnn; ++q) {
+  for (int q = 0; q < K; ++q) {
     if (q < k) {
       const bool here = inserted || q >= s->n || cd < s->d2[q];
       const double od = s->d2[q], oz = s->z[q];
@@ -359,6 +364,19 @@ __device__ __forceinline__ void knn_add(KnnSet* s, int k, double d2, double z) {
     }
   }
   if (s->n < k) ++s->n;
+  if (s->n == k) {
+#pragma unroll
+    for (int q = 0; q < K; ++q)
+      if (q == k - 1) s->worst = s->d2[q];
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void knn_init(KnnSetT<K>* s) {
+  s->n = 0;
+  s->worst = __builtin_huge_val();
+#pragma unroll
+  for (int q = 0; q < K; ++q) s->d2[q] = s->z[q] = 0.0;
 }
 
 __device__ __forceinline__ void knn_scan(const DsmParams& p, const uint32_t* __restrict__ start,
@@ -386,9 +404,7 @@ __device__ __forceinline__ void cell_global_knn(const DsmParams& p,
   const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
   const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
   KnnSet s;
-  s.n = 0;
-#pragma unroll
-  for (int q = 0; q < kMaxKnn; ++q) s.d2[q] = s.z[q] = 0.0;
+  knn_init(&s);
   knn_scan(p, start, P, qx, qy, i, j, p.w[0], p.T[0], &s);
   if (s.n == 0 && p.nlevels > 1) {  // the ladder of dsm.cc:133-144, as in cell_fallback_global
     Accum acc = {0.0, 0.0, 0u, false, 0.0};
@@ -845,7 +861,11 @@ __device__ __forceinline__ bool exponent_far_from_one(double v) {
   return (e - 691u) > 664u;
 }
 
-template <int NT, int kTileJ, int kCap>
+// kKnn: the OPTIONAL capped mode (amhip_ctx_set_dsm_knn) on the same LDS image -- per cell the k
+// nearest of the first search's points, summed in ascending distance with true divisions like
+// cell_global_knn(); cells without a first-level neighbour, tiles beyond the image and exact hits
+// take cell_global_knn() itself.
+template <int NT, int kTileJ, int kCap, int kKnn = 0 /* 0: off; else the capped mode's set size, 4 or 8 */>
 __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* __restrict__ start,
                                             const Pts P,
                                             const uint8_t* __restrict__ tile_occ, const CellOut& o,
@@ -947,7 +967,10 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     // not fit this launch's LDS image: one lane per cell on the global bins
     for (int c = 0; c < kCellsPerLane; ++c) {
       const int i = i0 + lane, j = j0 + wid * kCellsPerLane + c;
-      if (i <= i_hi && j <= j_hi) cell_global(p, start, P, i, j, o);
+      if (i <= i_hi && j <= j_hi) {
+        if constexpr (kKnn > 0) cell_global_knn(p, start, P, i, j, o);
+        else cell_global(p, start, P, i, j, o);
+      }
     }
     return;
   }
@@ -1054,6 +1077,62 @@ __device__ __forceinline__ void gather_tile(const DsmParams& p, const uint32_t* 
     }
   }
   __syncthreads();
+  if constexpr (kKnn > 0) {
+    // ---- capped mode: lane = row index i, one cell at a time (the set of k lives in registers) ----
+    const int i = i0 + lane;
+    if (i <= i_hi) {
+      const double qx = p.base_x + p.res * (-(double)(i + p.i_off));
+      const int ci = i + p.M - ox;
+      const double T0k = p.T[0];
+      for (int c = 0; c < kCellsPerLane; ++c) {
+        const int j = j0 + wid * kCellsPerLane + c;
+        if (j > j_hi) break;
+        const double qy = p.base_y + p.res * (-(double)(j + p.j_off));
+        // (the row pairs of the cell PAIR this cell belongs to: they cover both cells' windows, the
+        // exact test drops what lies beyond this one's)
+        const int cjp = (j0 + wid * kCellsPerLane + (c & ~1)) + p.M - oy;
+        const uint32_t* orow = s_off + ((cjp - w0 + sh) >> 1) * RW2 + 2 * ci;
+        KnnSetT<(kKnn > 0 ? kKnn : 1)> ks;
+        knn_init(&ks);
+        for (int r = 0; r <= w0; ++r) {
+          const int w = p.wrp[r];
+          const uint32_t kb = orow[-2 * w], ke = orow[2 * w + 2];
+          orow += RW2;
+          uint32_t k = kb;
+          for (; k < ke; ++k) {
+            const double2 xy = s_xy[k];
+            const double dx = qx - xy.x;
+            const double dy = qy - xy.y;
+            double d2 = dx * dx;
+            d2 = d2 + dy * dy;
+            if (d2 < T0k) knn_add(&ks, p.knn_k, d2, s_z[k]);
+          }
+        }
+        bool again = ks.n == 0;      // no first-level neighbour: the ladder, on the global bins
+        double num = 0.0, den = 0.0;
+#pragma unroll
+        for (int q = 0; q < kKnn; ++q)
+          if (q < ks.n) {
+            if (!(ks.d2[q] > 0.0)) again = true;   // (exact hit: cell_global_knn raises the CHECK)
+            num += ks.z[q] / ks.d2[q];
+            den += 1.0 / ks.d2[q];
+          }
+        if (again) {
+          const uint32_t slot = atomicAdd(&s_ctl[1], 1u);
+          s_flag[slot] = (uint16_t)((wid * kCellsPerLane + c) * kTileI + lane);
+        } else {
+          emit_value(p, o, i, j, num / den);
+        }
+      }
+    }
+    __syncthreads();
+    const int nflag_k = (int)s_ctl[1];
+    for (int f = tid; f < nflag_k; f += NT) {
+      const int code = s_flag[f] & 0x3FFF;
+      cell_global_knn(p, start, P, i0 + (code % kTileI), j0 + (code / kTileI), o);
+    }
+    return;
+  }
   // (max |z| of the call's points: round_is_certain's bound, loaded here, used after the loop.
   // The bound's n is the lane's own candidate count: a tile-wide n -- the image's 860 points,
   // a wave-uniform bound in scalar registers -- sends 1000 cells per 1e8 to the redo instead of
@@ -1966,6 +2045,20 @@ k_dsm_gather_tiled(DsmParams p, const uint32_t* __restrict__ start,
   gather_tile<NT, kTileJ, kCap>(p, start, P, tile_occ, o, tile, smem, my_class);
 }
 
+// The capped mode's dense launch (every capacity class: a tile beyond the image takes the global bins).
+template <int NT, int kTileJ, int kCap, int kSet>
+__global__ void __launch_bounds__(NT)
+k_dsm_gather_tiled_knn(DsmParams p, const uint32_t* __restrict__ start, const Pts P,
+                       const uint8_t* __restrict__ tile_occ, CellOut o) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ntiles = p.tiles_i * p.tiles_j;
+  const int b = blockIdx.x;
+  const int xcd = b & 7, k = b >> 3;
+  const int q = ntiles >> 3, r = ntiles & 7;
+  const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  gather_tile<NT, kTileJ, kCap, kSet>(p, start, P, tile_occ, o, tile, smem, -1);
+}
+
 // List launch: a fixed grid walks a list of tiles -- the occupied tiles of a
 // sparse call (a small cloud on a large map, e.g. one stereo pair of an
 // incremental mapping run) or the tiles of one capacity class.
@@ -2301,6 +2394,29 @@ int dsm_run(Ctx* c, const double* dev_xyz, const int32_t* dev_values, size_t n,
       hipLaunchKernelGGL(k_dsm_tile_occupancy, dim3(pp.nocc + pp.nrange), dim3(256), 0, c->stream,
                          p, p.tile_j, c->bin_start, c->tile_occ, lists, sparse ? 1 : 0, ccap0, ccap1, ccap2,
                          bin_z, rej_own ? 1 : 0, cap2, rej_dense ? 1 : 0, pts_view.zref, pp);
+      if (p.knn_k > 0) {
+        // the capped mode: one dense launch over the same LDS image (no capacity classes: a
+        // denser tile takes the global bins cell by cell)
+#define AMHIP_LAUNCH_KNN_(TJ_, CAP_, SET_)                                                       \
+  do {                                                                                        \
+    AMHIP_TRY(hipFuncSetAttribute(                                                            \
+        reinterpret_cast<const void*>(k_dsm_gather_tiled_knn<512, TJ_, CAP_, SET_>),          \
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));                       \
+    hipLaunchKernelGGL((k_dsm_gather_tiled_knn<512, TJ_, CAP_, SET_>), dim3(ntiles), dim3(512), \
+                       p.lds_bytes, c->stream, p, c->bin_start, pts_view, c->tile_occ,       \
+                       cell_out);                                                             \
+  } while (0)
+  // (a set of 4 registers for k <= 4 measured the same as the set of 8: the shift's cost follows k)
+#define AMHIP_LAUNCH_KNN(TJ_, CAP_) AMHIP_LAUNCH_KNN_(TJ_, CAP_, kMaxKnn)
+        if (p.tile_j == 16 && cap0 == 1024) AMHIP_LAUNCH_KNN(16, 1024);
+        else if (p.tile_j == 16 && cap0 == 2048) AMHIP_LAUNCH_KNN(16, 2048);
+        else if (p.tile_j == 32 && cap0 == 2048) AMHIP_LAUNCH_KNN(32, 2048);
+        else return arg_failure("internal: no capped-mode gather for this tile shape");
+#undef AMHIP_LAUNCH_KNN
+#undef AMHIP_LAUNCH_KNN_
+        AMHIP_TRY(hipGetLastError());
+        return AMHIP_OK;
+      }
       // tuning knob gather_nt: threads per gather workgroup (tuning knob; 512 measured best)
 #ifdef AMHIP_TIMING_PROBES
       const int nt = (int)tuning("gather_nt", 512.0);

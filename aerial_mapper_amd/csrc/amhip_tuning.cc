@@ -19,7 +19,7 @@ const char* const kKeys[] = {
     "sort_one_level", "p3_min_points", "p3_target", "p3_cap", "p3_rounds_cap", "p3_rounds_reread",
     "no_launch_skips",
     // DSM gather
-    "dsm_canon_all", "dsm_no_rough_switch", "dsm_no_subwindow", "eager_reset",
+    "dsm_canon_all", "knn_global_bins", "dsm_no_rough_switch", "dsm_no_subwindow", "eager_reset",
     // mosaic
     "ortho_exact_fold", "ortho_no_prune", "no_coarse_cull", "ortho_no_tile_list",
     "no_distorted_cull", "no_distorted_prune", "distorted_square_cull",

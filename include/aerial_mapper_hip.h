@@ -623,6 +623,7 @@ int amhip_session_layer_to_image(amhip_session* s, int layer, int bgr, float low
  *   no_launch_skips           launch every capacity-class / big-list kernel whatever the previous
  *                             call's counters say
  *   dsm_canon_all             every FP64 quotient goes through the order-independent double-double sums
+ *   knn_global_bins           the optional k-cap mode on the plain global-bins kernel (default: LDS-tiled)
  *   dsm_no_rough_switch       the single-precision mode stays in its own pipeline on rough scenes
  *   dsm_no_subwindow          small clouds onto large maps are binned over the whole window
  *   eager_reset               amhip_layers_reset fills the layers at once (default: fused into producers)

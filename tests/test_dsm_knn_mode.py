@@ -83,3 +83,39 @@ def test_gpu_capped_mode_equals_the_oracle(k):
     assert np.abs(got[~gn].astype(np.float64) - want[~wn]).max() <= 1e-4
     rc, ref_full, _ = O.dsm_process(sc.points, sc.grid)
     S.assert_dsm_close(uncapped, ref_full)      # switching the cap off restores the graded mode
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,res,density", [(4, 0.25, 8.0), (1, 0.5, 4.0), (8, 0.25, 16.0)])
+def test_gpu_capped_mode_lds_tiled_equals_the_oracle_and_the_global_bins_kernel(tuning, k, res, density):
+    """Round 6: the capped mode runs on the LDS-tiled gather's image (k_dsm_gather_tiled_knn) instead
+    of one lane per cell on the global bins (tuning knob knn_global_bins: that kernel).  Same sets,
+    same ascending sums: identical floats except where an exact distance tie at the k-th place meets
+    a different arrival order; holes (ladder) and an empty corner included."""
+    import aerial_mapper_amd as A
+    lx, ly = 200.0, 150.0
+    sc = S.Scene(lx, ly, res, int(density * (lx + 8) * (ly + 8)), seed=511, point_extent=max(lx, ly) / 2 + 4)
+    x, y = sc.points[:, 0], sc.points[:, 1]
+    keep = ~((np.abs(x - 5.0) < 3.0) & (np.abs(y) < 40.0)) & ~((x > 80.0) & (y > 55.0))
+    pts = np.ascontiguousarray(sc.points[keep])
+    which = "ref" if O.have_ref() else "port"
+    rc, want = O.dsm_process_knn(pts, sc.grid, k, which=which)
+    assert rc == O.OK
+    g = sc.grid
+    got = {}
+    for knob in (None, 1):
+        tuning(knn_global_bins=knob)
+        with A.AerialGridMap(A.GridMapSettings(g.pos_x, g.pos_y, g.length_x, g.length_y, g.resolution)) as m:
+            m.set_dsm_knn(k)
+            A.Dsm(A.DsmSettings(1), m).process(pts, m)
+            got[knob] = m.get("elevation")
+            if knob is None:
+                st = m.dsm_gather_stats()
+                assert st["tiles"] > 0, st          # (the LDS-tiled path took the call)
+    wn = np.isnan(want)
+    assert wn.any() and (~wn).any()
+    for knob, e in got.items():
+        assert np.array_equal(np.isnan(e), wn), knob
+        assert (e[~wn].view(np.uint32) == want[~wn].view(np.uint32)).mean() > 0.9999, knob
+        assert np.abs(e[~wn].astype(np.float64) - want[~wn]).max() <= 1e-4, knob
+    assert (got[None][~wn].view(np.uint32) == got[1][~wn].view(np.uint32)).mean() > 0.9999
