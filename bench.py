@@ -300,9 +300,9 @@ def parity_against(refs, args, map_, poses, ncam, F):
                 b = layers2[name]
                 eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
                 parity[name + "_mismatch_cells_on_equal_heights"] = int((~eq).sum())
-            parity["note"] = ("*_mismatch_cells: GPU DSM + mosaic against reference DSM + mosaic (the "
+            parity["note"] = ("*_mismatch_cells: GPU DSM + mosaic against the oracle's DSM + mosaic (the "
                               "heights differ by <= dsm_max_abs_err_m); *_on_equal_heights: the "
-                              "reference's mosaic loop fed the GPU's heights")
+                              "oracle's mosaic loop fed the GPU's heights")
     return parity
 
 
